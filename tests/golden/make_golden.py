@@ -1,0 +1,548 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+TEST INFRASTRUCTURE ONLY.  Run from the repo root:  python tests/golden/make_golden.py [group ...]
+
+The reference (``/root/reference``) is imported through ``_refharness`` (inert stand-ins for
+numba / pygame / gymnasium / rvo2 / socialforce); only *data* (inputs and the outputs the
+reference produced) is written to the ``.npz`` fixtures.  Groups:
+
+  g1_direct   single ``update_humans_parallel`` call on dense synthetic states (all 9 types,
+              walls / robot row / per-agent params / NaN-padded goals / goal switches)
+  g1_episode  single calls captured mid-episode through ``MotionModelManager.update_humans``
+  g2_block    20 consecutive substeps through ``MotionModelManager.update_humans``
+              (circular crossing, parallel traffic with respawn, static obstacles, walls)
+  g3_gym      ``SocialNavGym.reset``/``step`` loops with scripted actions
+  g4_peek     ``get_next_human_observable_states``
+  g5_reward   ``collision_detection_and_reaching_goal`` + ``compute_reward_and_infos``
+  g6_generators  scenario generator outputs for fixed seeds
+  g7_respawn  parallel-traffic respawn (state just before / after)
+"""
+from __future__ import annotations
+
+import configparser
+import math
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refharness  # noqa: E402
+from golden_io import save_cases  # noqa: E402
+
+SFMS = ["sfm_helbing", "sfm_guo", "sfm_moussaid", "hsfm_farina", "hsfm_guo", "hsfm_moussaid",
+        "hsfm_new", "hsfm_new_guo", "hsfm_new_moussaid"]
+DT = 0.0125
+
+ns = _refharness.import_reference()
+
+
+# ----------------------------------------------------------------------------- helpers
+def default_params(model: str) -> np.ndarray:
+    game = types.SimpleNamespace(real_size=15, display_to_real_ratio=1000 / 15)
+    from social_gym.src.human_agent import HumanAgent
+
+    h = HumanAgent(game, 0, model, [0.0, 0.0], 0.0, [[1.0, 1.0]])
+    return h.get_parameters(model)
+
+
+def my_walls(rng) -> list:
+    """Three polygons (3, 4, 5 vertices, CCW) placed around the origin; our own shapes."""
+    out = []
+    for k, nv in enumerate((3, 4, 5)):
+        c = np.array([math.cos(2.1 * k + 0.3), math.sin(2.1 * k + 0.3)]) * (2.0 + 0.7 * k)
+        rad = 0.5 + 0.25 * k
+        ang0 = rng.uniform(0, 2 * math.pi)
+        verts = []
+        for v in range(nv):
+            a = ang0 + 2 * math.pi * v / nv
+            rr = rad * (0.8 + 0.4 * rng.random())
+            verts.append([float(c[0] + rr * math.cos(a)), float(c[1] + rr * math.sin(a))])
+        out.append(verts)
+    return out
+
+
+def walls_to_array(walls: list) -> np.ndarray:
+    smax = max(len(w) for w in walls)
+    arr = np.full((len(walls), smax, 2, 2), np.nan)
+    for i, w in enumerate(walls):
+        for j in range(len(w)):
+            a, b = w[j], w[(j + 1) % len(w)]
+            arr[i, j, 0], arr[i, j, 1] = min(a, b), max(a, b)
+    return arr
+
+
+def sample_positions(rng, n, half, min_sep):
+    pts = []
+    tries = 0
+    while len(pts) < n:
+        p = rng.uniform(-half, half, size=2)
+        tries += 1
+        if all(np.linalg.norm(p - q) >= min_sep for q in pts) or tries > 20000:
+            pts.append(p)
+    return np.array(pts)
+
+
+# ----------------------------------------------------------------------------- G1 direct
+def gen_g1_direct():
+    cases = []
+    seed = 0
+    for t, model in enumerate(SFMS):
+        base = default_params(model)
+        for n in (5, 10, 25, 50):
+            combos = [(w, r, h) for w in (0, 1) for r in (0, 1) for h in (0, 1)]
+            if n == 50:
+                combos = [(0, 0, 0), (1, 1, 1)]
+            for walls_on, robot_on, hetero in combos:
+                seed += 1
+                rng = np.random.default_rng(10_000 + seed)
+                rows = n + robot_on
+                half = 0.42 * math.sqrt(rows) + 0.4
+                S = np.zeros((rows, 13))
+                S[:, 0:2] = sample_positions(rng, rows, half, 0.18)
+                S[:, 2] = rng.uniform(-math.pi, math.pi, rows)
+                S[:, 3:5] = rng.normal(0, 0.6, (rows, 2))
+                S[:, 5:7] = rng.normal(0, 0.6, (rows, 2))
+                S[:, 7] = rng.normal(0, 0.8, rows)
+                S[:, 8] = rng.uniform(0.2, 0.5, rows)
+                S[:, 9] = rng.uniform(60, 90, rows)
+                S[:, 12] = rng.uniform(0.5, 1.5, rows)
+                if seed % 3 == 0:  # consistent rows, as produced by a previous headed step
+                    c, s = np.cos(S[:, 2]), np.sin(S[:, 2])
+                    S[:, 3] = c * S[:, 5] - s * S[:, 6]
+                    S[:, 4] = s * S[:, 5] + c * S[:, 6]
+                G = 3 if seed % 2 else 2
+                goals = np.full((n, G, 2), np.nan)
+                for i in range(n):
+                    k = int(rng.integers(1, G + 1))
+                    goals[i, :k] = rng.uniform(-half - 3, half + 3, (k, 2))
+                    if rng.random() < 0.25:  # goal inside the radius -> goal switch
+                        ang = rng.uniform(0, 2 * math.pi)
+                        goals[i, 0] = S[i, 0:2] + 0.7 * S[i, 8] * rng.random() * np.array([math.cos(ang), math.sin(ang)])
+                S[:n, 10:12] = goals[:, 0]
+                if robot_on:
+                    S[n, 10:12] = rng.uniform(-5, 5, 2)
+                P = np.tile(base, (n, 1))
+                if hetero:
+                    nz = base != 0
+                    P = P * np.where(nz, rng.uniform(0.8, 1.25, P.shape), 1.0)
+                safety = np.zeros(rows) if seed % 4 else np.full(rows, 0.01 + 0.15)
+                obstacles = walls_to_array(my_walls(rng)) if walls_on else None
+                all_eq = not hetero
+                S_in, goals_in = S.copy(), goals.copy()
+                out = ns.fp.update_humans_parallel(t, S, goals, obstacles, P, DT, safety, all_eq, bool(robot_on))
+                case = dict(type=t, n=n, dt=DT, all_params_equal=all_eq, last_is_robot=bool(robot_on),
+                            state_in=S_in, goals_in=goals_in, params=P, safety=safety,
+                            state_out=out, goals_out=goals.copy(), state_in_after=S.copy())
+                if obstacles is not None:
+                    case["obstacles"] = obstacles
+                cases.append(case)
+    print("g1_direct:", len(cases), "cases ->", save_cases("g1_direct", cases))
+
+
+# ----------------------------------------------------------------------------- sims
+def crossing_config(rng, model, n, radius, walls=None, robot=None, robot_visible=False, attrs=False):
+    humans = {}
+    pts = []
+    for i in range(n):
+        while True:
+            ang = rng.uniform(0, 2 * math.pi)
+            p = radius * np.array([math.cos(ang), math.sin(ang)]) + rng.uniform(-0.5, 0.5, 2)
+            if all(np.linalg.norm(p - q) > 0.9 for q in pts):
+                break
+        pts.append(p)
+        humans[i] = {"pos": [float(p[0]), float(p[1])], "yaw": float(ns.utils.bound_angle(math.pi + ang)),
+                     "goals": [[float(-p[0]), float(-p[1])], [float(p[0]), float(p[1])]],
+                     "des_speed": float(rng.uniform(0.6, 1.4)) if attrs else 1.0,
+                     "radius": float(rng.uniform(0.25, 0.45)) if attrs else 0.3}
+    data = {"headless": True, "motion_model": model, "runge_kutta": False, "robot_visible": robot_visible,
+            "grid": False, "humans": humans, "walls": walls or []}
+    if robot is not None:
+        data["robot"] = robot
+    return data
+
+
+def record_calls(mm_module):
+    """Wrap the array seam so every call's inputs/outputs are captured."""
+    rec = []
+    orig = ns.fp.update_humans_parallel
+
+    def wrapper(t, S, goals, obstacles, P, dt, safety, all_params_equal=False, last_is_robot=False):
+        item = dict(type=int(t), n=int(len(S) - int(last_is_robot)), dt=float(dt),
+                    all_params_equal=bool(all_params_equal), last_is_robot=bool(last_is_robot),
+                    state_in=S.copy(), goals_in=goals.copy(), params=P.copy(), safety=safety.copy())
+        if obstacles is not None:
+            item["obstacles"] = obstacles.copy()
+        out = orig(t, S, goals, obstacles, P, dt, safety, all_params_equal, last_is_robot)
+        item["state_out"] = out.copy()
+        item["goals_out"] = goals.copy()
+        item["state_in_after"] = S.copy()
+        rec.append(item)
+        return out
+
+    mm_module.update_humans_parallel = wrapper
+    return rec, lambda: setattr(mm_module, "update_humans_parallel", orig)
+
+
+def gen_g1_episode():
+    cases = []
+    rec, restore = record_calls(ns.mmm)
+    seed = 0
+    try:
+        for t, model in enumerate(SFMS):
+            for n, radius, nsteps in ((5, 2.0, 110), (10, 2.6, 130), (25, 3.6, 150)):
+                for walls_on, robot_on in ((0, 0), (1, 1)):
+                    seed += 1
+                    rng = np.random.default_rng(20_000 + seed)
+                    robot = {"pos": [0.3, -0.4], "yaw": 0.3, "radius": 0.3, "goals": [[0.0, 4.0]]} if robot_on else None
+                    cfg = crossing_config(rng, model, n, radius, walls=my_walls(rng) if walls_on else None,
+                                          robot=robot, robot_visible=bool(robot_on), attrs=bool(seed % 2))
+                    sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=True)
+                    mm = sim.motion_model_manager
+                    if seed % 3 == 0:
+                        mm.set_safety_space(0.15)
+                    rec.clear()
+                    for k in range(nsteps):
+                        if robot_on:  # robot drifts with a constant velocity, as robot.step does
+                            sim.robot.position = sim.robot.position + np.array([0.2, 0.5]) * DT
+                            sim.robot.linear_velocity = np.array([0.2, 0.5])
+                        mm.update_humans(k * DT, DT)
+                    for idx in (nsteps // 2, nsteps - 1):
+                        c = dict(rec[idx])
+                        c["model"] = model
+                        cases.append(c)
+    finally:
+        restore()
+    print("g1_episode:", len(cases), "cases ->", save_cases("g1_episode", cases))
+
+
+def mm_snapshot(mm):
+    d = dict(states=mm.states.copy(), goals=mm.goals.copy(), params=mm.params.copy(),
+             safety=mm.safety_space.copy())
+    if mm.obstacles is not None:
+        d["obstacles"] = mm.obstacles.copy()
+    return d
+
+
+def gen_g2_block():
+    cases = []
+    seed = 0
+    # (a) custom crossings (with/without walls)
+    for t, model in enumerate(SFMS):
+        for n, radius, warm in ((5, 2.2, 60), (25, 3.8, 90)):
+            seed += 1
+            rng = np.random.default_rng(30_000 + seed)
+            walls = my_walls(rng) if seed % 2 else None
+            cfg = crossing_config(rng, model, n, radius, walls=walls)
+            sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=True)
+            mm = sim.motion_model_manager
+            for k in range(warm):
+                mm.update_humans(0, DT)
+            before = mm_snapshot(mm)
+            for k in range(20):
+                mm.update_humans(0, DT)
+            after = mm_snapshot(mm)
+            cases.append(dict(kind="crossing", model=model, type=t, n=n, dt=DT, n_substeps=20,
+                              all_params_equal=bool(mm.all_equal_humans), respawn=False,
+                              **{f"in_{k}": v for k, v in before.items()},
+                              out_states=after["states"], out_goals=after["goals"]))
+    # (b) reference generators: parallel traffic (respawn) and static obstacles
+    for t, model in enumerate(SFMS):
+        for scen in ("parallel_traffic", "circular_crossing_with_static_obstacles"):
+            seed += 1
+            np.random.seed(1000 + seed)
+            n = 8
+            kw = {"insert_robot": False, "human_policy": model, "headless": True, "runge_kutta": False,
+                  "n_actors": n}
+            if scen == "parallel_traffic":
+                kw.update(traffic_length=14, traffic_height=3)
+            else:
+                kw.update(circle_radius=7)
+            sim = ns.sim.SocialNavSim(kw, scenario=scen, parallelize_humans=True)
+            mm = sim.motion_model_manager
+            warm = 40 if scen == "parallel_traffic" else 200
+            for k in range(warm):
+                mm.update_humans(0, DT)
+            if scen == "parallel_traffic":
+                # push two humans close to their goal so that the 20-step window contains respawns
+                for i in (1, 4):
+                    mm.states[i, 0] = mm.goals[i, 0, 0] + 3.0 + 0.05 * (i + 1)
+                    mm.humans[i].set_state(mm.states[i, 0:8])
+            before = mm_snapshot(mm)
+            for k in range(20):
+                mm.update_humans(0, DT)
+            after = mm_snapshot(mm)
+            c = dict(kind=scen, model=model, type=t, n=n, dt=DT, n_substeps=20,
+                     all_params_equal=bool(mm.all_equal_humans),
+                     respawn=bool(mm.parallel_traffic_humans_respawn),
+                     **{f"in_{k}": v for k, v in before.items()},
+                     out_states=after["states"], out_goals=after["goals"])
+            if mm.parallel_traffic_humans_respawn:
+                c["respawn_bounds"] = [float(x) for x in mm.respawn_bounds]
+            cases.append(c)
+            sim.parallel_traffic_humans_respawn = False
+    print("g2_block:", len(cases), "cases ->", save_cases("g2_block", cases))
+
+
+# ----------------------------------------------------------------------------- Gym level
+class FakePolicy:
+    """Only the attributes SocialNavGym reads (social_nav_gym.py:102,131,139)."""
+
+    def __init__(self, kinematics="holonomic", headed_obs=False):
+        self.multiagent_training = True
+        self.with_theta_and_omega_visible = headed_obs
+        self.kinematics = kinematics
+        self.name = "fake"
+        self.query_env = True
+        self.time_step = None
+
+
+def make_env(human_policy, scenario, human_num, robot_visible, headed_obs=False, kinematics="holonomic",
+             time_step=0.0125, robot_time_step=0.25, randomize=False, circle_radius=7.0):
+    cfg = configparser.RawConfigParser()
+    cfg.read_dict({
+        "env": {"time_limit": 50, "time_step": time_step, "robot_time_step": robot_time_step, "val_size": 100,
+                "test_size": 500, "randomize_attributes": str(randomize).lower()},
+        "reward": {"success_reward": 1, "collision_penalty": -0.25, "discomfort_dist": 0.2,
+                   "discomfort_penalty_factor": 0.5},
+        "sim": {"train_val_sim": scenario, "test_sim": scenario, "traffic_length": 14, "traffic_height": 3,
+                "circle_radius": circle_radius, "human_num": human_num},
+        "humans": {"visible": "true", "policy": human_policy, "radius": 0.3, "v_pref": 1.0,
+                   "sensor": "coordinates"},
+        "robot": {"visible": str(robot_visible).lower(), "policy": "none", "radius": 0.3, "v_pref": 1.0,
+                  "sensor": "coordinates"},
+    })
+    env = ns.gym.SocialNavGym()
+    env.configure(cfg)
+    robot = ns.robot_agent.RobotAgent(env)
+    robot.visible = robot_visible
+    robot.desired_speed = 1.0
+    robot.radius = 0.3
+    robot.sensor = "coordinates"
+    robot.policy = FakePolicy(kinematics, headed_obs)
+    robot.kinematics = kinematics
+    env.set_robot(robot)
+    return env, cfg
+
+
+def ob_to_array(ob):
+    rows = []
+    for o in ob:
+        row = [o.px, o.py, o.vx, o.vy, o.radius]
+        if hasattr(o, "theta"):
+            row += [o.theta, o.omega]
+        rows.append(row)
+    return np.array(rows, dtype=np.float64)
+
+
+def gen_g3_gym():
+    cases = []
+    seed = 0
+    scenarios = ["circle_crossing", "parallel_traffic", "circular_crossing_with_static_obstacles", "hybrid_scenario"]
+    for model in ("sfm_helbing", "hsfm_farina", "hsfm_new_guo", "sfm_moussaid"):
+        for scen in scenarios:
+            for robot_visible in (False, True):
+                seed += 1
+                rng = np.random.default_rng(40_000 + seed)
+                phase = ("test", "val", "train")[seed % 3]
+                test_case = int(rng.integers(0, 90))
+                headed_obs = bool(seed % 2) and model.startswith("hsfm")
+                # unicycle actions cannot go through the reference's step(): it reads robot.theta,
+                # which is None/absent (social_nav_sim.py:973) -> only holonomic is recordable
+                kin = "holonomic"
+                # static-obstacle generator needs n >= 6 (n = 5 puts obstacles 0 and 2 at the same
+                # angle and its rejection loop never ends, social_nav_sim.py:391-392)
+                hn = 6 if scen == "circular_crossing_with_static_obstacles" else 5
+                env, _ = make_env(model, scen, hn, robot_visible, headed_obs, kin)
+                if seed % 4 == 0:
+                    env.set_safety_space(0.15)
+                ob, info = env.reset(phase=phase, test_case=test_case)
+                obs = [ob_to_array(ob)]
+                actions, rewards, terms, truncs, infos, dmins = [], [], [], [], [], []
+                mm_states = [env.motion_model_manager.states.copy()]
+                robot_states = [np.array([*env.robot.position, env.robot.yaw, *env.robot.linear_velocity])]
+                nsteps = 10
+                for k in range(nsteps):
+                    if kin == "holonomic":
+                        g = env.robot.get_goal_position() - env.robot.position
+                        a = g / max(np.linalg.norm(g), 1e-9) * 0.8 + rng.normal(0, 0.15, 2)
+                        action = ns.action.ActionXY(float(a[0]), float(a[1]))
+                        actions.append([action.vx, action.vy])
+                    else:
+                        action = ns.action.ActionRot(float(rng.uniform(0.3, 1.0)), float(rng.uniform(-0.05, 0.05)))
+                        actions.append([action.v, action.r])
+                    ob, r, term, trunc, info = env.step(action)
+                    obs.append(ob_to_array(ob))
+                    rewards.append(float(r)); terms.append(bool(term)); truncs.append(bool(trunc))
+                    infos.append(type(info[0]).__name__)
+                    dmins.append(float(getattr(info[0], "min_dist", np.nan)))
+                    mm_states.append(env.motion_model_manager.states.copy())
+                    robot_states.append(np.array([*env.robot.position, env.robot.yaw, *env.robot.linear_velocity]))
+                mm = env.motion_model_manager
+                cases.append(dict(model=model, scenario=scen, robot_visible=robot_visible, phase=phase,
+                                  test_case=test_case, headed_obs=headed_obs, kinematics=kin, human_num=hn,
+                                  safety_space=float(env.safety_space),
+                                  respawn=bool(mm.parallel_traffic_humans_respawn),
+                                  obs=np.array(obs), actions=np.array(actions), rewards=np.array(rewards),
+                                  terminated=np.array(terms), truncated=np.array(truncs), infos=infos,
+                                  dmins=np.array(dmins), mm_states=np.array(mm_states),
+                                  robot_states=np.array(robot_states), global_time=float(env.global_time)))
+                env.parallel_traffic_humans_respawn = False
+    print("g3_gym:", len(cases), "cases ->", save_cases("g3_gym", cases))
+
+
+def gen_g4_peek():
+    cases = []
+    seed = 0
+    for model in ("sfm_helbing", "sfm_guo", "hsfm_farina", "hsfm_new_moussaid"):
+        for scen in ("circle_crossing", "parallel_traffic"):
+            for robot_visible in (False, True):
+                seed += 1
+                env, _ = make_env(model, scen, 6, robot_visible)
+                env.reset(phase="test", test_case=seed)
+                for k in range(4):
+                    env.step(ns.action.ActionXY(0.3, 0.6))
+                mm = env.motion_model_manager
+                before = mm.states.copy()
+                goals_before = mm.goals.copy()
+                nxt4 = mm.get_next_human_observable_states(0.25)
+                mid = mm.states.copy()
+                nxt8 = mm.get_next_human_observable_states(0.25, theta_and_omega_visible=True)
+                cases.append(dict(model=model, scenario=scen, robot_visible=robot_visible, test_case=seed,
+                                  dt=0.25, states_before=before, goals_before=goals_before,
+                                  params=mm.params.copy(), safety=mm.safety_space.copy(),
+                                  all_params_equal=bool(mm.all_equal_humans), type=int(mm.sfm_type),
+                                  next4=nxt4, next8=nxt8, states_after=mm.states.copy(), states_mid=mid,
+                                  goals_after=mm.goals.copy()))
+                env.parallel_traffic_humans_respawn = False
+    print("g4_peek:", len(cases), "cases ->", save_cases("g4_peek", cases))
+
+
+def gen_g5_reward():
+    rng = np.random.default_rng(50_000)
+    env, _ = make_env("sfm_helbing", "circle_crossing", 5, False)
+    env.reset(phase="test", test_case=0)
+    cases = []
+    for k in range(200):
+        n = 5
+        hp = rng.uniform(-2, 2, (n, 2)) * (0.4 if k % 3 == 0 else 1.0)
+        hv = rng.normal(0, 0.7, (n, 2))
+        hr = rng.uniform(0.2, 0.5, n)
+        rp = rng.uniform(-1, 1, 2)
+        rg = rp + rng.uniform(-1, 1, 2) * (0.3 if k % 4 == 0 else 3.0)
+        rr = float(rng.uniform(0.2, 0.4))
+        a = rng.normal(0, 0.8, 2)
+        T = 0.25
+        gt = float(rng.choice([0.0, 10.0, 48.9, 49.0, 49.2]))
+        for i, h in enumerate(env.humans):
+            h.position = hp[i].copy(); h.linear_velocity = hv[i].copy(); h.radius = float(hr[i])
+        env.robot.position = rp.copy(); env.robot.radius = rr
+        env.robot.goals = [[float(rg[0]), float(rg[1])]]
+        col, dmin, reach = env.collision_detection_and_reaching_goal(ns.action.ActionXY(float(a[0]), float(a[1])), T)
+        reward, term, trunc, info = env.compute_reward_and_infos(col, dmin, reach, gt, T)
+        cases.append(dict(hp=hp, hv=hv, hr=hr, rp=rp, rg=rg, rr=rr, action=a, T=T, global_time=gt,
+                          time_limit=50, collision=bool(col), dmin=float(dmin), reaching_goal=bool(reach),
+                          reward=float(reward), terminated=bool(term), truncated=bool(trunc),
+                          info=type(info).__name__))
+    print("g5_reward:", len(cases), "cases ->", save_cases("g5_reward", cases))
+
+
+def cfg_to_arrays(data):
+    hs = data["humans"]
+    n = len(hs)
+    gmax = max(len(hs[i]["goals"]) for i in range(n))
+    goals = np.full((n, gmax, 2), np.nan)
+    for i in range(n):
+        goals[i, :len(hs[i]["goals"])] = np.array(hs[i]["goals"])
+    d = dict(pos=np.array([hs[i]["pos"] for i in range(n)]), yaw=np.array([hs[i]["yaw"] for i in range(n)]),
+             goals=goals, des_speed=np.array([hs[i]["des_speed"] for i in range(n)]),
+             radius=np.array([hs[i]["radius"] for i in range(n)]))
+    if "robot" in data:
+        d["robot_pos"] = np.array(data["robot"]["pos"], dtype=float)
+        d["robot_goals"] = np.array(data["robot"]["goals"], dtype=float)
+        d["robot_yaw"] = float(data["robot"]["yaw"])
+    return d
+
+
+def gen_g6_generators():
+    cases = []
+    host = types.SimpleNamespace()
+    gens = {"circular_crossing": ns.sim.SocialNavSim.generate_circular_crossing_setting,
+            "parallel_traffic": ns.sim.SocialNavSim.generate_parallel_traffic_scenario,
+            "circular_crossing_with_static_obstacles": ns.sim.SocialNavSim.generate_circular_crossing_with_static_obstacles}
+    for seed in list(range(0, 4)) + list(range(1000, 1004)) + list(range(2000, 2004)):
+        for name, fn in gens.items():
+            for insert_robot in (False, True):
+                for attrs in (False, True):
+                    if name == "circular_crossing_with_static_obstacles" and attrs:
+                        continue
+                    n = 7 if seed % 2 else 5
+                    if name == "circular_crossing_with_static_obstacles":
+                        n = 7 if seed % 2 else 6  # n = 5 never terminates in the reference
+                    np.random.seed(seed)
+                    kw = dict(insert_robot=insert_robot, human_policy="sfm_helbing", headless=True, runge_kutta=False,
+                              robot_visible=False, robot_radius=0.3, n_actors=n, randomize_human_attributes=attrs)
+                    if name == "parallel_traffic":
+                        kw.update(traffic_length=14, traffic_height=3)
+                    else:
+                        kw.update(circle_radius=7, randomize_human_positions=True)
+                    data = fn(host, **kw)
+                    cases.append(dict(generator=name, seed=seed, n=n, insert_robot=insert_robot,
+                                      randomize_attributes=attrs, **cfg_to_arrays(data)))
+    # hybrid choice for a range of seeds (np.random.choice on a 2-list after seeding)
+    choice = []
+    for seed in range(0, 64):
+        np.random.seed(seed)
+        choice.append(str(np.random.choice(["circle_crossing", "parallel_traffic"])))
+    cases.append(dict(generator="hybrid_choice", seeds=list(range(0, 64)), choice=choice))
+    # non-random circular crossing (rand=False)
+    for insert_robot in (False, True):
+        data = gens["circular_crossing"](host, insert_robot=insert_robot, human_policy="sfm_helbing", headless=True,
+                                         n_actors=6, circle_radius=7, randomize_human_positions=False)
+        cases.append(dict(generator="circular_crossing_fixed", seed=-1, n=6, insert_robot=insert_robot,
+                          randomize_attributes=False, **cfg_to_arrays(data)))
+    print("g6_generators:", len(cases), "cases ->", save_cases("g6_generators", cases))
+
+
+def gen_g7_respawn():
+    cases = []
+    seed = 0
+    for model in ("sfm_helbing", "hsfm_farina", "sfm_guo"):
+        for robot_visible in (False, True):
+            seed += 1
+            env, _ = make_env(model, "parallel_traffic", 6, robot_visible)
+            if seed % 2 == 0:
+                env.set_safety_space(0.1)
+            env.reset(phase="test", test_case=10 + seed)
+            mm = env.motion_model_manager
+            for k in range(3):
+                env.step(ns.action.ActionXY(0.5, 0.0))
+            # move three humans next to their goal so several respawn in the same call (sequential rule)
+            for i in (0, 2, 5):
+                mm.states[i, 0] = mm.goals[i, 0, 0] + 3.0 + 0.004 * (i + 1)
+                mm.humans[i].set_state(mm.states[i, 0:8])
+            before = mm_snapshot(mm)
+            robot_before = np.array([*env.robot.position, env.robot.radius, env.robot.safety_space])
+            mm.update_humans(0.0, DT)
+            after = mm_snapshot(mm)
+            cases.append(dict(model=model, type=int(mm.sfm_type), robot_visible=robot_visible, dt=DT,
+                              all_params_equal=bool(mm.all_equal_humans),
+                              respawn_bounds=[float(x) for x in mm.respawn_bounds], robot=robot_before,
+                              human_safety=np.array([h.safety_space for h in mm.humans], dtype=float),
+                              **{f"in_{k}": v for k, v in before.items()},
+                              out_states=after["states"], out_goals=after["goals"]))
+            env.parallel_traffic_humans_respawn = False
+    print("g7_respawn:", len(cases), "cases ->", save_cases("g7_respawn", cases))
+
+
+GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
+              g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
+              g7_respawn=gen_g7_respawn)
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(GROUPS)
+    for g in todo:
+        GROUPS[g]()
