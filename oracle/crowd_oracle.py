@@ -1,0 +1,157 @@
+"""ctypes front-end of the C oracle (TEST INFRASTRUCTURE ONLY).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  It is the checker, never the product: the shipped package has no dependency on it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".inc"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _ptr(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _suffix(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float64:
+        return "f64", C.c_double
+    if dtype == np.float32:
+        return "f32", C.c_float
+    raise TypeError(dtype)
+
+
+def update_humans(type_, S, goals, obstacles, P, dt, safety, all_params_equal=False, last_is_robot=False,
+                  dtype=np.float64):
+    """Same call shape as the reference's update_humans_parallel (forces_parallel.py:185).
+
+    S and goals are converted to `dtype` copies; returns (out, S_after, goals_after)."""
+    sfx, ct = _suffix(dtype)
+    S = np.ascontiguousarray(S, dtype=dtype).copy()
+    goals = np.ascontiguousarray(goals, dtype=dtype).copy()
+    P = np.ascontiguousarray(P, dtype=dtype)
+    safety = np.ascontiguousarray(safety, dtype=dtype)
+    rows = S.shape[0]
+    G = goals.shape[1]
+    if obstacles is not None:
+        obstacles = np.ascontiguousarray(obstacles, dtype=dtype)
+        O, Smax = obstacles.shape[0], obstacles.shape[1]
+    else:
+        O, Smax = 0, 0
+    out = np.empty_like(S)
+    scratch = np.empty(rows * 2 + O * 2 + 8, dtype=dtype)
+    fn = getattr(lib(), f"orc_update_humans_{sfx}")
+    fn.restype = C.c_int
+    rc = fn(C.c_int(type_), _ptr(S, ct), _ptr(goals, ct), C.c_int(G), _ptr(obstacles, ct), C.c_int(O),
+            C.c_int(Smax), _ptr(P, ct), ct(dt), _ptr(safety, ct), C.c_int(int(all_params_equal)),
+            C.c_int(int(last_is_robot)), C.c_int(rows), _ptr(out, ct), _ptr(scratch, ct))
+    if rc != 0:
+        raise ValueError(f"Type {type_} does not exist for this implementation")
+    return out, S, goals
+
+
+def step_block(type_, S, goals, obstacles, P, dt, n_substeps, safety, all_params_equal, robot_visible=False,
+               robot=None, action=None, kinematics=0, respawn=False, respawn_par=(0.0, 0.0, 0.0),
+               dtype=np.float64, threads=0):
+    """Batched ([W, rows, 13] ...) or single-world ([rows, 13]) block of substeps; returns
+    (S, goals, robot) after the block."""
+    sfx, ct = _suffix(dtype)
+    S = np.ascontiguousarray(S, dtype=dtype).copy()
+    single = S.ndim == 2
+    if single:
+        S = S[None]
+    W, rows = S.shape[0], S.shape[1]
+    n = rows - int(robot_visible)
+    goals = np.ascontiguousarray(goals, dtype=dtype).copy().reshape(W, n, -1, 2)
+    G = goals.shape[2]
+    P = np.ascontiguousarray(P, dtype=dtype)
+    if P.ndim == 2:
+        P = np.broadcast_to(P, (W,) + P.shape).copy()
+    safety = np.ascontiguousarray(np.broadcast_to(np.asarray(safety, dtype=dtype), (W, rows)))
+    obs_stride = 0
+    if obstacles is not None:
+        obstacles = np.ascontiguousarray(obstacles, dtype=dtype)
+        if obstacles.ndim == 5:
+            obs_stride = int(np.prod(obstacles.shape[1:]))
+            O, Smax = obstacles.shape[1], obstacles.shape[2]
+        else:
+            O, Smax = obstacles.shape[0], obstacles.shape[1]
+    else:
+        O, Smax = 0, 0
+    if robot is not None:
+        robot = np.ascontiguousarray(robot, dtype=dtype).copy().reshape(W, 13)
+    if action is not None:
+        action = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=dtype), (W, 2)))
+    rp = np.asarray(respawn_par, dtype=dtype)
+    fn = getattr(lib(), f"orc_step_block_batched_{sfx}")
+    fn.restype = C.c_int
+    rc = fn(C.c_int(W), C.c_int(type_), _ptr(S, ct), _ptr(goals, ct), C.c_int(G), _ptr(obstacles, ct),
+            C.c_size_t(obs_stride), C.c_int(O), C.c_int(Smax), _ptr(P, ct), C.c_size_t(n * 20), ct(dt),
+            C.c_int(n_substeps), _ptr(safety, ct), C.c_int(int(all_params_equal)), C.c_int(int(robot_visible)),
+            C.c_int(rows), _ptr(robot, ct), _ptr(action, ct), C.c_int(kinematics), C.c_int(int(respawn)),
+            _ptr(rp, ct), C.c_int(threads))
+    if rc != 0:
+        raise ValueError(f"oracle step_block failed rc={rc}")
+    if single:
+        return S[0], goals[0], (robot[0] if robot is not None else None)
+    return S, goals, robot
+
+
+def respawn(S, goals, safety, robot, bound_x, bound_y, dtype=np.float64):
+    sfx, ct = _suffix(dtype)
+    S = np.ascontiguousarray(S, dtype=dtype).copy()
+    goals = np.ascontiguousarray(goals, dtype=dtype).copy()
+    safety = np.ascontiguousarray(safety, dtype=dtype)
+    n, G = goals.shape[0], goals.shape[1]
+    rb = None if robot is None else np.asarray(robot, dtype=dtype)
+    fn = getattr(lib(), f"orc_respawn_{sfx}")
+    fn.restype = None
+    fn(_ptr(S, ct), _ptr(goals, ct), C.c_int(G), C.c_int(n), _ptr(safety, ct), _ptr(rb, ct), ct(bound_x), ct(bound_y))
+    return S, goals
+
+
+INFO_NAMES = ["Nothing", "Danger", "ReachGoal", "Collision", "Timeout"]
+
+
+def collision_reward(hp, hv, hr, rp, rr, rgoal, act, T, global_time, time_limit=50.0, success_reward=1.0,
+                     collision_penalty=-0.25, discomfort_dist=0.2, discomfort_factor=0.5, dtype=np.float64):
+    sfx, ct = _suffix(dtype)
+    hp = np.ascontiguousarray(hp, dtype=dtype); hv = np.ascontiguousarray(hv, dtype=dtype)
+    hr = np.ascontiguousarray(hr, dtype=dtype); rp = np.ascontiguousarray(rp, dtype=dtype)
+    rgoal = np.ascontiguousarray(rgoal, dtype=dtype); act = np.ascontiguousarray(act, dtype=dtype)
+    out = np.zeros(7, dtype=dtype)
+    fn = getattr(lib(), f"orc_collision_reward_{sfx}")
+    fn.restype = None
+    fn(C.c_int(len(hr)), _ptr(hp, ct), _ptr(hv, ct), _ptr(hr, ct), _ptr(rp, ct), ct(rr), _ptr(rgoal, ct),
+       _ptr(act, ct), ct(T), ct(global_time), ct(time_limit), ct(success_reward), ct(collision_penalty),
+       ct(discomfort_dist), ct(discomfort_factor), _ptr(out, ct))
+    return dict(collision=bool(out[0]), dmin=float(out[1]), reaching_goal=bool(out[2]), reward=float(out[3]),
+                terminated=bool(out[4]), truncated=bool(out[5]), info=INFO_NAMES[int(out[6])])
+
+
+def num_threads() -> int:
+    f = lib().orc_num_threads
+    f.restype = C.c_int
+    return int(f())

@@ -269,7 +269,7 @@ def gen_g2_block():
             if scen == "parallel_traffic":
                 # push two humans close to their goal so that the 20-step window contains respawns
                 for i in (1, 4):
-                    mm.states[i, 0] = mm.goals[i, 0, 0] + 3.0 + 0.05 * (i + 1)
+                    mm.states[i, 0] = mm.goals[i, 0, 0] + 3.0 + 0.02 * (i + 1)
                     mm.humans[i].set_state(mm.states[i, 0:8])
             before = mm_snapshot(mm)
             for k in range(20):
@@ -522,7 +522,7 @@ def gen_g7_respawn():
                 env.step(ns.action.ActionXY(0.5, 0.0))
             # move three humans next to their goal so several respawn in the same call (sequential rule)
             for i in (0, 2, 5):
-                mm.states[i, 0] = mm.goals[i, 0, 0] + 3.0 + 0.004 * (i + 1)
+                mm.states[i, 0] = mm.goals[i, 0, 0] + 2.9 + 0.01 * (i + 1)
                 mm.humans[i].set_state(mm.states[i, 0:8])
             before = mm_snapshot(mm)
             robot_before = np.array([*env.robot.position, env.robot.radius, env.robot.safety_space])
