@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the crowd-step hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch: ONE Gym step (= `substeps` fused Euler substeps
+of dt = 0.0125 s, social_nav_gym.py:240-245 / env.config:2-4) of every world resident on the GPU,
+i.e. one cs_step launch.  Workload at N=1 = BASELINE.json configs[2] (the config the metric names):
+4096 worlds x 25-agent Headed-SFM (hsfm_farina) hybrid scenario (half circular crossing R=7, half
+14x3 m parallel traffic with respawn), synthetic random-goal crowds, state resident in HBM.
+Worlds are independent: each rank owns its own 4096 worlds (weak scaling, no collective on the data
+path); the only collectives are the timing barrier and the MAX over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (algorithmic
+bytes per launch / average kernel duration measured with HIP events on the launch stream, against
+the 8 TB/s HBM3E peak) and `cpu_baseline` (the C oracle timed on the host cores of this box).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per agent-substep, f32 (SURVEY.md §8d / BASELINE.md §4)
+ALG_BYTES = {"sfm": 52, "hsfm": 76, "orca": 48}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
+    ap.add_argument("--agents", type=int, default=25)
+    ap.add_argument("--model", default="hsfm_farina")
+    ap.add_argument("--scenario", default="hybrid", choices=["hybrid", "circle", "traffic"])
+    ap.add_argument("--substeps", type=int, default=20)
+    ap.add_argument("--dt", type=float, default=0.0125)
+    ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
+    ap.add_argument("--walls", action="store_true", help="add 3 shared polygon walls")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def build_worlds(args, rank):
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n = args.worlds, args.agents
+    seed0 = 1000 + rank * 7919
+    respawn_bounds = None
+    respawn_worlds = None
+    if args.scenario == "hybrid":
+        S, goals, P, respawn_bounds = sc.hybrid_worlds(W, n, args.model, seed0=seed0)
+        respawn_worlds = (np.arange(W) % 2 == 1).astype(np.int32)
+    elif args.scenario == "circle":
+        radius = 7.0 if n <= 30 else 7.0 * n / 25.0
+        pos, yaw, g = sc.circular_crossing(W, n, radius, seed0)
+        S, goals = sc.make_states(pos, yaw, g), g
+        P = np.tile(sc.default_params(args.model), (n, 1))
+    else:
+        pos, yaw, g = sc.parallel_traffic(W, n, seed0=seed0)
+        S, goals = sc.make_states(pos, yaw, g), g
+        P = np.tile(sc.default_params(args.model), (n, 1))
+        respawn_bounds = (7.0, 1.5)
+    walls = sc.polygon_walls() if args.walls else None
+    cw = CrowdWorlds(S, goals, P, None, walls, type=args.model, all_params_equal=True,
+                     respawn_bounds=respawn_bounds, respawn_worlds=respawn_worlds, layout=args.layout)
+    host = dict(S=S, goals=goals, P=P, walls=walls, respawn_bounds=respawn_bounds, respawn_worlds=respawn_worlds)
+    return cw, host
+
+
+def cpu_baseline(args, host, type_id):
+    """The C oracle (port of the reference's f64 array kernel) on this box's host cores, on a bounded
+    sample of the same workload: the first `sample_worlds` worlds, blocks of `substeps` substeps."""
+    from oracle import crowd_oracle as orc
+
+    orc.build()
+    cores = orc.num_threads()
+    sample_worlds = min(args.worlds, 64 * max(1, cores))
+    idx = np.arange(sample_worlds)
+    S = host["S"][idx].astype(np.float64)
+    goals = host["goals"][idx].astype(np.float64)
+    respawn = host["respawn_bounds"] is not None
+    rp = (host["respawn_bounds"][0], host["respawn_bounds"][1], 0.0) if respawn else (0.0, 0.0, 0.0)
+    # the oracle has one respawn switch per call: run traffic and crossing worlds as two groups
+    groups = [(idx, respawn)] if host["respawn_worlds"] is None else \
+        [(idx[host["respawn_worlds"][idx] == 1], True), (idx[host["respawn_worlds"][idx] == 0], False)]
+    safety = np.zeros((sample_worlds, S.shape[1]))
+    done = 0
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        for sel, rs in groups:
+            if sel.size == 0:
+                continue
+            s2, g2, _ = orc.step_block(type_id, S[sel], goals[sel], host["walls"], host["P"].astype(np.float64),
+                                       args.dt, args.substeps, safety[sel], True, respawn=rs, respawn_par=rp,
+                                       dtype=np.float64, threads=cores)
+            S[sel], goals[sel] = s2, g2
+            done += sel.size * args.substeps
+        reps += 1
+        if time.perf_counter() - t0 >= args.cpu_seconds:
+            break
+    el = time.perf_counter() - t0
+    return {"value": done * args.agents / el, "unit": "agent-substeps/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_worlds} worlds x {args.agents} agents x {reps * args.substeps} substeps "
+                      f"(f64 C oracle, OpenMP over worlds, {el:.1f} s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    from social_navigation_pyenvs_amd import _lib
+    from social_navigation_pyenvs_amd.batched import SFMS
+
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    _lib.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world_size and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world_size}", file=sys.stderr)
+
+    cw, host = build_worlds(args, rank)
+    stream = _lib.stream_create()
+    cw.stream = stream
+    n_sub = args.substeps
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        cw.step(args.dt, n_sub)
+    barrier()
+    starts = [_lib.Event() for _ in range(args.steps)]
+    stops = [_lib.Event() for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        starts[k].record(stream)
+        cw.step(args.dt, n_sub)
+        stops[k].record(stream)
+    _lib.stream_sync(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = np.array([starts[k].elapsed_ms(stops[k]) for k in range(args.steps)])
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the state is finite and moved
+    S_end = cw.get_states()
+    finite = float(np.mean(np.isfinite(S_end[..., :8])))
+
+    if rank == 0:
+        agent_substeps = world_size * args.worlds * args.agents * n_sub * args.steps
+        value = agent_substeps / elapsed
+        family = "hsfm" if args.model.startswith("hsfm") else "sfm"
+        alg_bytes_launch = ALG_BYTES[family] * args.worlds * args.agents * n_sub
+        if args.walls:
+            alg_bytes_launch += 16 * 15 * 0  # walls are shared by all worlds: 0 B per world-substep
+        k_avg = float(np.mean(kernel_ms))
+        achieved = alg_bytes_launch / (k_avg * 1e-3) / 1e9
+        g, b, wpb = cw.launch_geometry()
+        out = {
+            "metric": "env-steps/sec (worlds x agents) for HSFM 25-agent crowd",
+            "value": value,
+            "unit": "agent-substeps/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.worlds} worlds/GPU x {args.agents}-agent {args.model} {args.scenario} scenario"
+                            f"{' + 3 polygon walls' if args.walls else ''}, {n_sub} fused substeps of "
+                            f"{args.dt} s per step (one Gym step), state resident in HBM ({args.layout})",
+                "worlds_per_gpu": args.worlds, "agents": args.agents, "substeps_per_step": n_sub,
+                "model": args.model, "scenario": args.scenario, "parallelism": f"worlds sharded x{world_size}, no collective",
+                "launch": {"grid": g, "block": b, "worlds_per_block": wpb},
+            },
+            "world_substeps_per_s": value / args.agents,
+            "gym_steps_per_s": value / args.agents / n_sub,
+            "finite_fraction": finite,
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_sfm_step", "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kernel_ms)),
+                "algorithmic_bytes_per_launch": alg_bytes_launch,
+                "bytes_per_agent_substep": ALG_BYTES[family],
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))
+            out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * crowdstep.h -- C ABI of libcrowdstep.so, the MI355X (gfx950) batched crowd-stepper.
+ *
+ * The reference (TommasoVandermeer/Social-Navigation-PyEnvs) has no FFI: its seam for this path is
+ * the pure-array Python function  update_humans_parallel()  (social_gym/src/forces_parallel.py:185,
+ * called from exactly one site, social_gym/src/motion_model_manager.py:360) plus the rvo2
+ * PyRVOSimulator object API for ORCA (motion_model_manager.py:237-246, 386-394).  Every entry point
+ * below names the reference interface it replaces.  All of them are batched over W independent
+ * worlds; W = 1 with the reference's [N,13] arrays is the drop-in case.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Pointers named d_* are DEVICE
+ *     pointers (hipMalloc / cs_malloc / torch.Tensor.data_ptr()); h_* are host pointers.
+ *   - return 0 (CS_OK) or a negative cs_status; cs_last_error() gives the message (thread-local).
+ *     Nothing throws or aborts across the ABI.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream unless stated otherwise.
+ *   - arithmetic type: float32 ("f32").  Array layouts are the reference's row layouts:
+ *       state row  S[13]  = px,py,theta,vx,vy,bvx,bvy,omega,r,m,gx,gy,vd       (agent.py:256-258)
+ *       param row  P[20]  = relax_t,Ai,Aw,Bi,Bw,Ci,Cw,Di,Dw,Ei,k1,k2,lambda,gamma,ns,ns1,ko,kd,
+ *                           alpha,k_lambda                                      (agent.py:268-388)
+ *       goals [n][G][2] NaN padded; obstacles [O][Smax][2][2] NaN padded
+ *   - a world has n humans (+1 trailing robot row when `robot_row` is set) = `rows` rows.
+ */
+#ifndef CROWDSTEP_H
+#define CROWDSTEP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cs_status {
+    CS_OK = 0,
+    CS_ERR_ARG = -1,      /* bad shape / null pointer / unsupported size                       */
+    CS_ERR_TYPE = -2,     /* model type outside 0..8 (the reference raises ValueError, :211)    */
+    CS_ERR_HIP = -3,      /* HIP runtime error, message in cs_last_error()                      */
+    CS_ERR_NO_DEVICE = -4 /* no gfx950 device visible                                           */
+} cs_status;
+
+/* model ids = index into the reference's SFMS list (motion_model_manager.py:15-17) */
+enum {
+    CS_SFM_HELBING = 0, CS_SFM_GUO = 1, CS_SFM_MOUSSAID = 2,
+    CS_HSFM_FARINA = 3, CS_HSFM_GUO = 4, CS_HSFM_MOUSSAID = 5,
+    CS_HSFM_NEW = 6, CS_HSFM_NEW_GUO = 7, CS_HSFM_NEW_MOUSSAID = 8,
+    CS_ORCA = 9 /* HUMAN_MODELS[9] (social_nav_gym.py:11-12); only cs_step / cs_peek accept it */
+};
+
+/* memory layout of a state array: element (world w, row a, field f) lives at
+ *   base[(w*rows + a) * agent_stride + f * field_stride]
+ * CS_LAYOUT_AOS: the reference's [W][rows][13]   (agent_stride 13, field_stride 1)
+ * CS_LAYOUT_SOA: 13 planes [13][W*rows]          (agent_stride 1,  field_stride W*rows) */
+enum { CS_LAYOUT_AOS = 0, CS_LAYOUT_SOA = 1 };
+
+/* flag bits of cs_worlds.flags */
+enum {
+    CS_ALL_PARAMS_EQUAL = 1 << 0, /* update_humans_parallel(all_params_equal=True): pair forces use P[0]  */
+    CS_ROBOT_ROW        = 1 << 1, /* last_is_robot=True: last row is the robot, never updated by the model */
+    CS_PARAMS_SHARED    = 1 << 2, /* d_params is one [n][20] block shared by all worlds                    */
+    CS_OBSTACLES_SHARED = 1 << 3, /* d_obstacles is one [O][Smax][2][2] block shared by all worlds         */
+    CS_RESPAWN          = 1 << 4, /* parallel-traffic respawn after every substep (mmm.py:407-422)         */
+    CS_ROBOT_UNICYCLE   = 1 << 5  /* d_action rows are (v, r) instead of (vx, vy) (robot_agent.py:119-136) */
+};
+
+/* Descriptor of W resident worlds; every pointer is a caller-owned device buffer. */
+typedef struct cs_worlds {
+    int32_t W;          /* worlds                                                                */
+    int32_t n;          /* humans per world                                                      */
+    int32_t G;          /* goal slots per human                                                  */
+    int32_t O;          /* polygons (0 = no walls)                                               */
+    int32_t Smax;       /* segment slots per polygon                                             */
+    int32_t type;       /* 0..8                                                                  */
+    int32_t flags;      /* CS_* bits                                                             */
+    int32_t layout;     /* CS_LAYOUT_*  of d_state                                               */
+    float*  d_state;    /* [W][rows][13] (or SoA planes)  in/out                                 */
+    float*  d_goals;    /* [W][n][G][2]                   in/out (rotated on goal switch)        */
+    const float* d_params;    /* [W][n][20] or [n][20]                                           */
+    const float* d_safety;    /* [W][rows]                                                       */
+    const float* d_obstacles; /* [W][O][Smax][2][2] or shared, NULL when O == 0                  */
+    float*  d_robot;    /* [W][13] robot safe-state rows or NULL.  With CS_ROBOT_ROW it is the
+                           source of the last row before every substep (mmm.py:359)             */
+    const int32_t* d_world_flags; /* optional [W]: bit0 = respawn enabled in this world (NULL: the
+                           CS_RESPAWN bit applies to every world; hybrid batches mix both kinds)   */
+    float   respawn_bound_x, respawn_bound_y; /* respawn_bounds (social_nav_sim.py:360)           */
+    /* ORCA only (type == CS_ORCA): ORCA_DEFAULTS of motion_model_manager.py:14 */
+    float   orca_neighbor_dist, orca_time_horizon, orca_time_horizon_obst;
+    int32_t orca_max_neighbors;
+} cs_worlds;
+
+/* ---------------------------------------------------------------- runtime / memory helpers */
+const char* cs_last_error(void);
+int cs_abi_version(void);
+int cs_device_count(int* count);
+int cs_set_device(int device);
+int cs_device_name(int device, char* buf, size_t buflen);
+int cs_malloc(void** d_ptr, size_t bytes);
+int cs_free(void* d_ptr);
+int cs_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int cs_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int cs_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
+int cs_memset(void* d_ptr, int value, size_t bytes, void* stream);
+int cs_stream_create(void** stream);
+int cs_stream_destroy(void* stream);
+int cs_stream_sync(void* stream);
+/* HIP events on the launch stream (bench.py times kernels with these) */
+int cs_event_create(void** event);
+int cs_event_destroy(void* event);
+int cs_event_record(void* event, void* stream);
+int cs_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+
+/* ---------------------------------------------------------------- the hot path
+ *
+ * cs_update_humans_parallel  replaces  update_humans_parallel(type, agents_state, goals, obstacles,
+ *   agents_params, dt, safety_space, all_params_equal, last_is_robot) -> updated_state
+ *   (forces_parallel.py:185-284), for W worlds at once, one Euler substep.
+ *   d_state is read and mutated exactly like `agents_state` (goal columns on a goal switch and, for
+ *   headed types, columns 3:5 = R(theta)*bv); d_goals is rotated in place; d_out receives the
+ *   returned copy (robot row copied through).  d_out may equal w->d_state (in-place update, what
+ *   `self.states = update_humans_parallel(...)` amounts to, motion_model_manager.py:360).
+ *   w->d_robot is ignored here (the last row of d_state IS the robot row).
+ */
+int cs_update_humans_parallel(const cs_worlds* w, float dt, float* d_out, void* stream);
+
+/*
+ * cs_step  replaces the substep loop of SocialNavGym.step (social_nav_gym.py:240-245) /
+ *   MotionModelManager.update_humans (motion_model_manager.py:354-367, 407-422), fused in ONE
+ *   launch:  n_substeps x { robot.step(action, dt) ; states[-1] = robot row ; update_humans ;
+ *   respawn }.  State is updated in place.
+ *   d_action: [W][2] robot action held for the whole block, or NULL (robot does not move).
+ */
+int cs_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action, void* stream);
+
+/*
+ * cs_peek  replaces MotionModelManager.get_next_human_observable_states(dt, theta_and_omega_visible)
+ *   (motion_model_manager.py:691-709): one Euler step of size dt WITHOUT committing it.
+ *   d_next: [W][n][8] rows  x, y, yaw, Vx, Vy, Omega, Gx, Gy  (get_human_states(include_goal=True,
+ *   headed=False), :294-298); the caller slices [0,1,3,4] for the 4-column form.
+ */
+int cs_peek(const cs_worlds* w, float dt, float* d_next, void* stream);
+
+/*
+ * cs_collision_reward  replaces SocialNavSim.collision_detection_and_reaching_goal
+ *   (social_nav_sim.py:949-984) + compute_reward_and_infos (:986-1029) for W worlds.
+ *   Reads humans from w->d_state and the robot from w->d_robot (position, radius, goal).
+ *   d_action [W][2] holonomic (vx, vy).  d_global_time [W].
+ *   reward_cfg = {time_limit, success_reward, collision_penalty, discomfort_dist,
+ *                 discomfort_penalty_factor}
+ *   d_out [W][7] = collision, dmin, reaching_goal, reward, terminated, truncated, info_code
+ *   (info_code: 0 Nothing, 1 Danger, 2 ReachGoal, 3 Collision, 4 Timeout; social_gym/src/info.py)
+ */
+int cs_collision_reward(const cs_worlds* w, const float* d_action, float T, const float* d_global_time,
+                        const float* reward_cfg /* host, 5 floats */, float* d_out, void* stream);
+
+/* layout conversion of a state array between the reference's AoS rows and SoA planes */
+int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
+int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);
+
+/* kernel launch geometry the library would use for `w` (diagnostics / DESIGN.md numbers) */
+int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_per_block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROWDSTEP_H */

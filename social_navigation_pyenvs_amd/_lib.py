@@ -1,0 +1,186 @@
+"""ctypes binding of libcrowdstep.so (the C ABI declared in include/crowdstep.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, every compute entry
+point raises ``CrowdstepError``.  Loading the library (symbol table) works without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcrowdstep.so")
+
+CS_OK = 0
+CS_ERR_ARG, CS_ERR_TYPE, CS_ERR_HIP, CS_ERR_NO_DEVICE = -1, -2, -3, -4
+CS_LAYOUT_AOS, CS_LAYOUT_SOA = 0, 1
+CS_ALL_PARAMS_EQUAL = 1 << 0
+CS_ROBOT_ROW = 1 << 1
+CS_PARAMS_SHARED = 1 << 2
+CS_OBSTACLES_SHARED = 1 << 3
+CS_RESPAWN = 1 << 4
+CS_ROBOT_UNICYCLE = 1 << 5
+CS_ORCA = 9
+
+# every symbol include/crowdstep.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "cs_last_error", "cs_abi_version", "cs_device_count", "cs_set_device", "cs_device_name", "cs_malloc",
+    "cs_free", "cs_memcpy_h2d", "cs_memcpy_d2h", "cs_memcpy_d2d", "cs_memset", "cs_stream_create",
+    "cs_stream_destroy", "cs_stream_sync", "cs_event_create", "cs_event_destroy", "cs_event_record",
+    "cs_event_elapsed_ms", "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
+    "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry",
+]
+
+
+class CrowdstepError(RuntimeError):
+    pass
+
+
+class cs_worlds(C.Structure):
+    _fields_ = [
+        ("W", C.c_int32), ("n", C.c_int32), ("G", C.c_int32), ("O", C.c_int32), ("Smax", C.c_int32),
+        ("type", C.c_int32), ("flags", C.c_int32), ("layout", C.c_int32),
+        ("d_state", C.c_void_p), ("d_goals", C.c_void_p), ("d_params", C.c_void_p), ("d_safety", C.c_void_p),
+        ("d_obstacles", C.c_void_p), ("d_robot", C.c_void_p), ("d_world_flags", C.c_void_p),
+        ("respawn_bound_x", C.c_float), ("respawn_bound_y", C.c_float),
+        ("orca_neighbor_dist", C.c_float), ("orca_time_horizon", C.c_float), ("orca_time_horizon_obst", C.c_float),
+        ("orca_max_neighbors", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for this); raises if it was never built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrowdstepError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the crowd stepper.")
+    lib = C.CDLL(LIB_PATH)
+    lib.cs_last_error.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        if name != "cs_last_error" and hasattr(lib, name):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc == CS_OK:
+        return
+    msg = load().cs_last_error().decode(errors="replace")
+    if rc == CS_ERR_TYPE:
+        raise ValueError(msg)  # the reference raises ValueError for a bad type (forces_parallel.py:211)
+    if rc == CS_ERR_ARG:
+        raise ValueError(f"crowdstep: {msg}")
+    raise CrowdstepError(f"crowdstep rc={rc}: {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().cs_device_count(C.byref(n))
+    return n.value if rc == CS_OK else 0
+
+
+def require_gpu() -> None:
+    if device_count() < 1:
+        raise CrowdstepError("no MI355X / HIP device visible: the crowd stepper has no CPU path")
+
+
+def set_device(device: int) -> None:
+    check(load().cs_set_device(C.c_int(device)))
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    check(load().cs_device_name(C.c_int(device), buf, C.c_size_t(256)))
+    return buf.value.decode()
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer owned through the C ABI (numpy in / numpy out, no torch needed)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(load().cs_malloc(C.byref(p), C.c_size_t(max(self.nbytes, 4))))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, arr, dtype=np.float32, stream=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        buf = cls(arr.shape, dtype)
+        buf.upload(arr, stream)
+        return buf
+
+    def upload(self, arr, stream=None):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        if arr.nbytes != self.nbytes:
+            raise ValueError(f"upload size mismatch {arr.shape} vs {self.shape}")
+        check(load().cs_memcpy_h2d(C.c_void_p(self.ptr), arr.ctypes.data_as(C.c_void_p), C.c_size_t(self.nbytes),
+                                   C.c_void_p(stream)))
+        if stream:
+            check(load().cs_stream_sync(C.c_void_p(stream)))
+
+    def download(self, stream=None) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(load().cs_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr), C.c_size_t(self.nbytes),
+                                   C.c_void_p(stream)))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            try:
+                load().cs_free(C.c_void_p(self.ptr))
+            finally:
+                self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        p = C.c_void_p()
+        check(load().cs_event_create(C.byref(p)))
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        check(load().cs_event_record(C.c_void_p(self.ptr), C.c_void_p(stream)))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        check(load().cs_event_elapsed_ms(C.c_void_p(self.ptr), C.c_void_p(stop.ptr), C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().cs_event_destroy(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def stream_create() -> int:
+    p = C.c_void_p()
+    check(load().cs_stream_create(C.byref(p)))
+    return p.value
+
+
+def stream_sync(stream=None) -> None:
+    check(load().cs_stream_sync(C.c_void_p(stream)))
+
+
+def stream_destroy(stream) -> None:
+    check(load().cs_stream_destroy(C.c_void_p(stream)))

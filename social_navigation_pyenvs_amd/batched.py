@@ -1,0 +1,223 @@
+"""Device-resident batch of W independent crowd worlds driven through the C ABI.
+
+This is the array-level host API above ``libcrowdstep.so``: the batched counterpart of the arrays a
+reference ``MotionModelManager`` owns (``states [N,13]``, ``goals [N,G,2]``, ``params [N,20]``,
+``obstacles [O,S,2,2]``, ``safety_space [N]``; motion_model_manager.py:253-276) with a leading world
+axis W.  Buffers are either owned here (hipMalloc through the ABI) or borrowed from the caller
+(``torch.Tensor`` / raw device pointers), so a learner can keep observations on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceBuffer, check, cs_worlds
+
+SFMS = ["sfm_helbing", "sfm_guo", "sfm_moussaid", "hsfm_farina", "hsfm_guo", "hsfm_moussaid",
+        "hsfm_new", "hsfm_new_guo", "hsfm_new_moussaid"]  # motion_model_manager.py:15-17
+
+
+def _ptr(x) -> int | None:
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):  # torch.Tensor on the GPU
+        if not x.is_cuda or not x.is_contiguous():
+            raise ValueError("device tensors handed to crowdstep must be contiguous CUDA/HIP tensors")
+        return int(x.data_ptr())
+    raise TypeError(f"cannot take a device pointer from {type(x)}")
+
+
+class CrowdWorlds:
+    """W worlds x n humans (+ optional robot row) resident in HBM.
+
+    Parameters mirror ``update_humans_parallel`` (forces_parallel.py:185): ``type`` 0..8,
+    ``all_params_equal``, ``last_is_robot`` (here ``robot_row``)."""
+
+    def __init__(self, states, goals, params, safety=None, obstacles=None, *, type, all_params_equal=False,
+                 robot_row=False, robot=None, respawn_bounds=None, respawn_worlds=None, layout="aos", device=None,
+                 stream=None):
+        _lib.require_gpu()
+        if device is not None:
+            _lib.set_device(device)
+        if isinstance(type, str):
+            type = SFMS.index(type)
+        if type < 0 or type > 8:
+            raise ValueError(f"Type {type} does not exist for this implementation")
+        self.type = int(type)
+        self.stream = stream
+        states = np.asarray(states, dtype=np.float32)
+        if states.ndim == 2:
+            states = states[None]
+        self.W, self.rows = states.shape[0], states.shape[1]
+        self.robot_row = bool(robot_row)
+        self.n = self.rows - int(self.robot_row)
+        goals = np.asarray(goals, dtype=np.float32)
+        if goals.ndim == 3:
+            goals = goals[None]
+        if goals.shape[0] != self.W or goals.shape[1] != self.n:
+            raise ValueError(f"goals shape {goals.shape} does not match W={self.W}, n={self.n}")
+        self.G = goals.shape[2]
+        params = np.asarray(params, dtype=np.float32)
+        self.params_shared = params.ndim == 2
+        if params.shape[-2:] != (self.n, 20):
+            raise ValueError(f"params must be [..., {self.n}, 20], got {params.shape}")
+        if safety is None:
+            safety = np.zeros((self.W, self.rows), dtype=np.float32)
+        safety = np.ascontiguousarray(np.broadcast_to(np.asarray(safety, dtype=np.float32), (self.W, self.rows)))
+        self.layout = layout
+        self.all_params_equal = bool(all_params_equal)
+        self.respawn_bounds = respawn_bounds
+        # ---- device buffers -------------------------------------------------------------
+        if layout == "soa":
+            st = np.ascontiguousarray(states.reshape(self.W * self.rows, 13).T)
+        else:
+            st = states
+        self.d_state = DeviceBuffer.from_numpy(st)
+        self.d_goals = DeviceBuffer.from_numpy(goals)
+        self.d_params = DeviceBuffer.from_numpy(params)
+        self.d_safety = DeviceBuffer.from_numpy(safety)
+        self.O = self.Smax = 0
+        self.d_obstacles = None
+        self.obstacles_shared = True
+        if obstacles is not None:
+            obstacles = np.asarray(obstacles, dtype=np.float32)
+            self.obstacles_shared = obstacles.ndim == 4
+            self.O, self.Smax = obstacles.shape[-4], obstacles.shape[-3]
+            self.d_obstacles = DeviceBuffer.from_numpy(obstacles)
+        self.d_robot = None
+        if robot is not None:
+            robot = np.ascontiguousarray(np.broadcast_to(np.asarray(robot, dtype=np.float32), (self.W, 13)))
+            self.d_robot = DeviceBuffer.from_numpy(robot)
+        self.d_world_flags = None
+        if respawn_worlds is not None:  # per-world respawn switch (hybrid batches)
+            wf = np.ascontiguousarray(np.broadcast_to(np.asarray(respawn_worlds), (self.W,)).astype(np.int32) & 1)
+            self.d_world_flags = DeviceBuffer.from_numpy(wf, dtype=np.int32)
+        self.unicycle = False
+        self._keep = []
+
+    # ------------------------------------------------------------------ descriptor
+    def _flags(self, respawn=None) -> int:
+        f = 0
+        if self.all_params_equal:
+            f |= _lib.CS_ALL_PARAMS_EQUAL
+        if self.robot_row:
+            f |= _lib.CS_ROBOT_ROW
+        if self.params_shared:
+            f |= _lib.CS_PARAMS_SHARED
+        if self.obstacles_shared:
+            f |= _lib.CS_OBSTACLES_SHARED
+        if (self.respawn_bounds is not None) if respawn is None else respawn:
+            f |= _lib.CS_RESPAWN
+        if self.unicycle:
+            f |= _lib.CS_ROBOT_UNICYCLE
+        return f
+
+    def descriptor(self, respawn=None) -> cs_worlds:
+        d = cs_worlds()
+        d.W, d.n, d.G, d.O, d.Smax = self.W, self.n, self.G, self.O, self.Smax
+        d.type = self.type
+        d.flags = self._flags(respawn)
+        d.layout = _lib.CS_LAYOUT_SOA if self.layout == "soa" else _lib.CS_LAYOUT_AOS
+        d.d_state = _ptr(self.d_state)
+        d.d_goals = _ptr(self.d_goals)
+        d.d_params = _ptr(self.d_params)
+        d.d_safety = _ptr(self.d_safety)
+        d.d_obstacles = _ptr(self.d_obstacles)
+        d.d_robot = _ptr(self.d_robot)
+        d.d_world_flags = _ptr(self.d_world_flags)
+        bx, by = self.respawn_bounds if self.respawn_bounds is not None else (0.0, 0.0)
+        d.respawn_bound_x, d.respawn_bound_y = float(bx), float(by)
+        return d
+
+    # ------------------------------------------------------------------ hot path
+    def update_humans_parallel(self, dt: float, in_place: bool = True):
+        """One substep, semantics of forces_parallel.py:185.  Returns the device buffer holding the
+        updated rows (the state buffer itself when ``in_place``)."""
+        d = self.descriptor(respawn=False)
+        out = self.d_state if in_place else DeviceBuffer(self.d_state.shape)
+        check(_lib.load().cs_update_humans_parallel(C.byref(d), C.c_float(dt), C.c_void_p(_ptr(out)),
+                                                    C.c_void_p(self.stream)))
+        return out
+
+    def step(self, dt: float, n_substeps: int = 1, action=None) -> None:
+        """n_substeps fused substeps (robot move + update_humans + respawn), in place."""
+        d = self.descriptor()
+        a_ptr = None
+        if action is not None:
+            if isinstance(action, np.ndarray) or isinstance(action, (list, tuple)):
+                act = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=np.float32), (self.W, 2)))
+                buf = DeviceBuffer.from_numpy(act)
+                self._keep = [buf]
+                a_ptr = buf.ptr
+            else:
+                a_ptr = _ptr(action)
+        check(_lib.load().cs_step(C.byref(d), C.c_float(dt), C.c_int(n_substeps), C.c_void_p(a_ptr),
+                                  C.c_void_p(self.stream)))
+
+    def peek(self, dt: float) -> np.ndarray:
+        """[W, n, 8] rows x, y, yaw, Vx, Vy, Omega, Gx, Gy of the next state; nothing is committed."""
+        d = self.descriptor(respawn=False)
+        out = DeviceBuffer((self.W, self.n, 8))
+        check(_lib.load().cs_peek(C.byref(d), C.c_float(dt), C.c_void_p(out.ptr), C.c_void_p(self.stream)))
+        return out.download(self.stream)
+
+    def collision_reward(self, action, T: float, global_time, reward_cfg=(50.0, 1.0, -0.25, 0.2, 0.5)) -> np.ndarray:
+        """[W, 7] = collision, dmin, reaching_goal, reward, terminated, truncated, info_code."""
+        if self.d_robot is None:
+            raise ValueError("collision_reward needs the robot rows")
+        d = self.descriptor()
+        act = DeviceBuffer.from_numpy(np.broadcast_to(np.asarray(action, dtype=np.float32), (self.W, 2)))
+        gt = DeviceBuffer.from_numpy(np.broadcast_to(np.asarray(global_time, dtype=np.float32), (self.W,)))
+        out = DeviceBuffer((self.W, 7))
+        cfg = (C.c_float * 5)(*[float(x) for x in reward_cfg])
+        check(_lib.load().cs_collision_reward(C.byref(d), C.c_void_p(act.ptr), C.c_float(T), C.c_void_p(gt.ptr),
+                                              cfg, C.c_void_p(out.ptr), C.c_void_p(self.stream)))
+        return out.download(self.stream)
+
+    # ------------------------------------------------------------------ state access
+    def sync(self):
+        _lib.stream_sync(self.stream)
+
+    def get_states(self, buf=None) -> np.ndarray:
+        arr = (buf or self.d_state).download(self.stream)
+        if self.layout == "soa":
+            arr = arr.reshape(13, self.W * self.rows).T
+        return np.ascontiguousarray(arr).reshape(self.W, self.rows, 13)
+
+    def set_states(self, states) -> None:
+        states = np.asarray(states, dtype=np.float32).reshape(self.W, self.rows, 13)
+        if self.layout == "soa":
+            states = np.ascontiguousarray(states.reshape(self.W * self.rows, 13).T)
+        self.d_state.upload(states, self.stream)
+
+    def get_goals(self) -> np.ndarray:
+        return self.d_goals.download(self.stream)
+
+    def set_goals(self, goals) -> None:
+        self.d_goals.upload(np.asarray(goals, dtype=np.float32).reshape(self.W, self.n, self.G, 2), self.stream)
+
+    def get_robot(self) -> np.ndarray:
+        return self.d_robot.download(self.stream)
+
+    def set_robot(self, robot) -> None:
+        robot = np.ascontiguousarray(np.broadcast_to(np.asarray(robot, dtype=np.float32), (self.W, 13)))
+        if self.d_robot is None:
+            self.d_robot = DeviceBuffer.from_numpy(robot)
+        else:
+            self.d_robot.upload(robot, self.stream)
+
+    def set_safety(self, safety) -> None:
+        safety = np.ascontiguousarray(np.broadcast_to(np.asarray(safety, dtype=np.float32), (self.W, self.rows)))
+        self.d_safety.upload(safety, self.stream)
+
+    def launch_geometry(self):
+        d = self.descriptor()
+        g, b, wpb = C.c_int(), C.c_int(), C.c_int()
+        check(_lib.load().cs_launch_geometry(C.byref(d), C.byref(g), C.byref(b), C.byref(wpb)))
+        return g.value, b.value, wpb.value

@@ -1,0 +1,45 @@
+"""Build libcrowdstep.so (HIP, gfx950) in-tree with hipcc.  No CPU fallback is ever built."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+CSRC = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(CSRC)
+ROOT = os.path.dirname(PKG)
+LIB_PATH = os.path.join(PKG, "libcrowdstep.so")
+SOURCES = ["crowdstep.hip", "orca.hip"]
+ARCH = "gfx950"
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the crowd stepper only exists as a HIP library for gfx950")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in os.listdir(CSRC) if s.endswith((".hip", ".h", ".hpp"))]
+    deps.append(os.path.join(ROOT, "include", "crowdstep.h"))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
+    if not force and not needs_build():
+        return LIB_PATH
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + srcs + (extra_flags or [])
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,47 @@
+"""CPU suite: the C-ABI library loads without a GPU and exports every symbol include/crowdstep.h declares."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__ as g
+
+    g.build()
+    from social_navigation_pyenvs_amd import _lib
+
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "crowdstep.h")).read()
+    declared = set(re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cs_status"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libcrowdstep.so does not export {name}"
+    assert set(_lib.ABI_SYMBOLS) == declared
+    assert lib.cs_abi_version() >= 1
+
+
+def test_struct_layout_matches_header():
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd._lib import cs_worlds
+
+    # 8 int32 + 7 pointers + 5 floats + 1 int32, natural alignment
+    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 4
+    assert cs_worlds.d_state.offset == 32
+
+
+def test_product_fails_loudly_without_gpu():
+    from social_navigation_pyenvs_amd import _lib
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import numpy as np
+
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    with pytest.raises(_lib.CrowdstepError):
+        CrowdWorlds(np.zeros((1, 2, 13)), np.zeros((1, 2, 1, 2)), np.zeros((2, 20)), type=0)
