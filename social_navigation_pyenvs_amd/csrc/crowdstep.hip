@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 
 #include "crowdstep.h"
 
@@ -64,9 +65,59 @@ struct KArgs {
     float* peek_out;
     const int* world_flags;
     float bx, by;
+    unsigned long long* stamps; // diagnostic build only
 };
 
-__device__ __forceinline__ float norm2(float x, float y) { return sqrtf(x * x + y * y); }
+// ---- math: gfx950 single-instruction transcendentals (1 ulp each) ---------------------------
+// The parity bar is 1e-5 absolute on positions/velocities against the f64 reference; v_rsq_f32 /
+// v_rcp_f32 / v_sqrt_f32 / v_exp_f32 (<= 1 ulp) stay two orders of magnitude inside it, while the
+// IEEE-exact divide / sqrt / libm exp sequences cost 10-15 VALU slots each in an O(N^2) loop.
+// Diagnostic build only (-DCS_STAMPS): per-section cycle shares via s_memtime, written to a debug
+// buffer that nothing else reads (cdna_hip_programming.md §7 "In-kernel stamps").
+#ifdef CS_STAMPS
+#define STAMP(k)                                                                             \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long t__;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        st_acc[k] += t__ - st_last;                                                          \
+        st_last = t__;                                                                       \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int PADR = 8;  // partner rows are read in groups of 8: readable (finite) padding behind each buffer
+
+__device__ __forceinline__ float norm2(float x, float y) { return sqrt_fast(fmaf(x, x, y * y)); }
+
+// sin and cos together: Cody-Waite reduction by pi/2 + degree-7/8 minimax polynomials; abs error
+// < 1e-7 for |x| < 50 (theta is kept in [-pi, pi] by bound_angle)
+__device__ __forceinline__ void sincos_fast(float x, float& s, float& c)
+{
+    const float k = rintf(x * 0.6366197723675814f);
+    const int q = (int)k;
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.371139000186241e-08f, r);
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    float ss = (q & 1) ? cp : sp;
+    float cc = (q & 1) ? sp : cp;
+    if (q & 2) ss = -ss;
+    if ((q + 1) & 2) cc = -cc;
+    s = ss; c = cc;
+}
 
 // social_gym/src/utils.py:7-13 (Python % == fmod for the operand signs reaching each branch)
 __device__ __forceinline__ float bound_angle(float a)
@@ -80,54 +131,54 @@ __device__ __forceinline__ float bound_angle(float a)
     return a;
 }
 
-// Social-force parameters used inside the pair loop (subset of the 20-vector, agent.py:268-388)
+// Social-force parameters used inside the pair loop (subset of the 20-vector, agent.py:268-388),
+// with the exponent scales pre-multiplied: exp(x / B) = exp2(x * (log2(e) / B))
 struct SocP {
-    float Ai, Bi, Ci, Di, Ei, k1, k2, lam, gam, ns, ns1;
+    float Ai, cB, Ci, cD, Ei, k1, k2, lam, gam, ns, ns1;
+    float lA, sA, lC, sC; // A * exp(x/B) = sA * exp2(x * cB + lA),  lA = log2|A|  (A = 0 -> exp2(-inf) = 0)
 };
 
 __device__ __forceinline__ SocP load_socp(const float* P)
 {
     SocP s;
-    s.Ai = P[1]; s.Bi = P[3]; s.Ci = P[5]; s.Di = P[7]; s.Ei = P[9];
+    s.Ai = P[1]; s.cB = LOG2E / P[3]; s.Ci = P[5]; s.cD = LOG2E / P[7]; s.Ei = P[9];
     s.k1 = P[10]; s.k2 = P[11]; s.lam = P[12]; s.gam = P[13]; s.ns = P[14]; s.ns1 = P[15];
+    s.lA = log2f(fabsf(s.Ai)); s.sA = copysignf(1.0f, s.Ai);
+    s.lC = log2f(fabsf(s.Ci)); s.sC = copysignf(1.0f, s.Ci);
     return s;
 }
 
-// forces_parallel.py:109-130 / :60-83 -- force on (pi, vi) from (pj, vj); rij = r_i+r_j+safety_i+safety_j
-template <int SOC>
-__device__ __forceinline__ void pair_force(const SocP& p, float pix, float piy, float vix, float viy,
-                                           float pjx, float pjy, float vjx, float vjy, float rij,
-                                           float& fx, float& fy)
+// forces_parallel.py:120-130 / :72-83 -- Moussaid force on (pi, vi) from (pj, vj); `skip` marks the
+// lane's own row / padding.  rij = r_i + r_j + safety_i + safety_j.
+__device__ __forceinline__ void pair_force_moussaid(const SocP& p, float pix, float piy, float vix, float viy,
+                                                    float pjx, float pjy, float vjx, float vjy, float rij,
+                                                    bool skip, float& fx, float& fy)
 {
     const float dx = pix - pjx, dy = piy - pjy;
-    const float dist = norm2(dx, dy);
-    const float nx = dx / dist, ny = dy / dist;
+    const float d2 = skip ? 1.0f : fmaf(dx, dx, dy * dy);
+    const float inv = rsq_fast(d2);
+    const float dist = d2 * inv;
+    const float nx = dx * inv, ny = dy * inv;
     const float rd = rij - dist;
     const float m0 = fmaxf(0.0f, rd);
-    if constexpr (SOC < 2) {
-        const float tx = -ny, ty = nx;
-        const float dv = (vjx - vix) * tx + (vjy - viy) * ty;
-        const float fn = p.Ai * expf(rd / p.Bi) + p.k1 * m0;
-        float ft = p.k2 * m0 * dv;
-        if constexpr (SOC == 1) ft += p.Ci * expf(rd / p.Di);
-        fx += fn * nx + ft * tx;
-        fy += fn * ny + ft * ty;
-    } else {
-        const float vdx = vix - vjx, vdy = viy - vjy;
-        const float ivx = p.lam * vdx - nx, ivy = p.lam * vdy - ny;
-        const float inorm = norm2(ivx, ivy);
-        const float ix = ivx / inorm, iy = ivy / inorm;
-        const float th = bound_angle(atan2f(ny, nx) - atan2f(iy, ix) + 3.141592653589793f);
-        const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
-        const float hx = -iy, hy = ix;
-        const float F = p.gam * inorm;
-        const float dv = (-vdx) * hx + (-vdy) * hy;
-        const float e0 = p.Ei * expf(-dist / F);
-        const float a1 = p.ns1 * F * th, a2 = p.ns * F * th;
-        const float e1 = expf(-(a1 * a1)), e2 = expf(-(a2 * a2));
-        fx -= e0 * (e1 * ix + k * e2 * hx) + p.k1 * m0 * ix + p.k2 * m0 * dv * hx;
-        fy -= e0 * (e1 * iy + k * e2 * hy) + p.k1 * m0 * iy + p.k2 * m0 * dv * hy;
-    }
+    const float vdx = vix - vjx, vdy = viy - vjy;
+    const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);
+    const float i2 = fmaxf(fmaf(ivx, ivx, ivy * ivy), 1e-30f);
+    const float iinv = rsq_fast(i2);
+    const float inorm = i2 * iinv;
+    const float ix = ivx * iinv, iy = ivy * iinv;
+    const float th = bound_angle(atan2f(ny, nx) - atan2f(iy, ix) + 3.141592653589793f);
+    const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
+    const float hx = -iy, hy = ix;
+    const float F = p.gam * inorm;
+    const float dv = -(vdx * hx + vdy * hy);
+    const float e0 = p.Ei * exp2_fast(-dist * rcp_fast(F) * LOG2E);
+    const float a1 = p.ns1 * F * th, a2 = p.ns * F * th;
+    const float e1 = exp2_fast(-(a1 * a1) * LOG2E), e2 = exp2_fast(-(a2 * a2) * LOG2E);
+    const float sel = skip ? 0.0f : 1.0f;
+    const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
+    fx -= sel * (e0 * (e1 * ix + k * e2 * hx) + kk * ix + kt * hx);
+    fy -= sel * (e0 * (e1 * iy + k * e2 * hy) + kk * iy + kt * hy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -142,10 +193,14 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int T = blockDim.x;
-    float4* lds_pv = reinterpret_cast<float4*>(smem_raw);          // [2][T] x,y,vx,vy (stored velocity)
-    float2* lds_vr = reinterpret_cast<float2*>(lds_pv + 2 * T);    // [2][T] velocity as refreshed in-place
-    float* lds_rs = reinterpret_cast<float*>(lds_vr + 2 * T);      // [T] radius + safety
-    float* lds_g0x = lds_rs + T;                                   // [T] respawn scratch
+    // Every world's rows are stored TWICE, back to back ([w][2][rows]): lane i then reads its partners
+    // i+1 .. i+rows-1 at constant offsets from one base address -- no own-row slot, no modulo, no
+    // per-partner compare (v_cmp + v_cndmask costs as much as a transcendental on this SIMD).
+    const int TP = 2 * T + PADR;                                   // rows per position buffer (+ finite padding)
+    float4* lds_p = reinterpret_cast<float4*>(smem_raw);           // [2][TP] x, y, radius+safety, -
+    float2* lds_v = reinterpret_cast<float2*>(lds_p + 2 * TP);     // [2][T] stored linear velocity
+    float2* lds_vr = lds_v + 2 * T;                                // [2][T] velocity as refreshed in-place
+    float* lds_g0x = reinterpret_cast<float*>(lds_vr + 2 * T);     // [T] respawn scratch
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);           // [T] respawn scratch
 
     const int tid = threadIdx.x;
@@ -157,7 +212,8 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     const bool robot_row = (a.flags & CS_ROBOT_ROW) != 0;
     const bool human = valid && row < n;
     const bool is_robot = valid && robot_row && row == n;
-    const int base = lw * rows;
+    const int base = lw * rows;        // first row of my world in the per-row arrays (lds_v, lds_vr, ...)
+    const int pbase = 2 * base;        // first row of my world in the doubled position buffers
     const float dt = a.dt;
     const int obs_type = (a.type == 1 || a.type == 4 || a.type == 7) ? 1 : 0;
 
@@ -181,19 +237,26 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     }
     // parameters: my own row of P for the single-agent forces; P[0] of my world for the pair loop
     // when all_params_equal (forces_parallel.py:220), else my own row (:261)
-    float relax_t = 1, Aw = 0, Bw = 1, Cw = 0, Dw = 1, k1 = 0, k2 = 0, ko = 0, kd = 0, alpha = 1, klam = 0;
+    float m_tau = 0, Aw = 0, cBw = 0, Cw = 0, cDw = 0, k1 = 0, k2 = 0, ko = 0, kd = 0, alpha = 1, klam = 0;
+    float dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0;
     SocP sp = {};
     float g0x = gx, g0y = gy;
     float* gi = nullptr;
     if (human) {
         const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20;
         const float* P = a.params + pw + (long)row * 20;
-        relax_t = P[0]; Aw = P[2]; Bw = P[4]; Cw = P[6]; Dw = P[8]; k1 = P[10]; k2 = P[11];
+        m_tau = m / P[0];                       // m / relax_t              (:39)
+        Aw = P[2]; cBw = LOG2E / P[4]; Cw = P[6]; cDw = LOG2E / P[8]; k1 = P[10]; k2 = P[11];
         ko = P[16]; kd = P[17]; alpha = P[18]; klam = P[19];
+        dt_m = a.dt / m;                        // (F / m) * dt             (:277,:282)
+        inv_alpha = 1.0f / alpha;
+        inertia = 0.5f * m * r * r;             // :265
+        dt_inertia = a.dt / inertia;            // (torque / I) * dt        (:279)
         sp = load_socp(PEQ ? (a.params + pw) : P);
         gi = a.goals + ((long)w * n + row) * a.G * 2;
         g0x = gi[0]; g0y = gi[1];
     }
+    const float inv_O = a.O > 0 ? 1.0f / (float)a.O : 0.0f;
     const float* obst = nullptr;
     if (a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
 
@@ -205,37 +268,56 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     if (valid && robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
     auto robot_step = [&]() { // robot_agent.py:114-136
         if (a.flags & CS_ROBOT_UNICYCLE) {
-            const float c = cosf(th + ay), s = sinf(th + ay);
+            float c, s;
+            sincos_fast(th + ay, s, c);
             px += c * ax * dt; py += s * ax * dt;
             th = fmodf(th + ay, 6.283185307179586f);
             if (th < 0) th += 6.283185307179586f;
-            vx = cosf(th) * ax; vy = sinf(th) * ax;
+            sincos_fast(th, s, c);
+            vx = c * ax; vy = s * ax;
         } else {
             px += ax * dt; py += ay * dt; vx = ax; vy = ay;
         }
     };
 
+    float cs = 1.0f, sn = 0.0f; // cos / sin of my theta, carried from one substep to the next
+
     // ---- prologue: publish substep-0 rows ----------------------------------------------
     if (is_robot && robot_moves) robot_step();
+    const float my_rs = r + safety;
+    for (int i = tid; i < 2 * TP; i += T) lds_p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // padding stays finite
+    __syncthreads();
+    auto publish = [&](int buf) {      // my row, both copies
+        const float4 me = make_float4(px, py, my_rs, 0.0f);
+        lds_p[buf * TP + pbase + row] = me;
+        lds_p[buf * TP + pbase + rows + row] = me;
+    };
     if (valid) {
-        lds_pv[tid] = make_float4(px, py, vx, vy);
+        publish(0);
+        lds_v[tid] = make_float2(vx, vy);
         float rvx = vx, rvy = vy;
         if (HEADED > 0 && human) {
-            const float c = cosf(th), s = sinf(th);
-            rvx = c * bvx + (-s) * bvy;
-            rvy = s * bvx + c * bvy;
+            sincos_fast(th, sn, cs);
+            rvx = cs * bvx + (-sn) * bvy;
+            rvy = sn * bvx + cs * bvy;
         }
         lds_vr[tid] = make_float2(rvx, rvy);
-        lds_rs[tid] = r + safety;
     }
     __syncthreads();
 
+#ifdef CS_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
     int cur = 0;
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
+        STAMP(7);
         if (human) {
             // -- goal switch, forces_parallel.py:226-234 (on the incoming position)
-            if (norm2(g0x - px, g0y - py) <= r) {
+            const float gdx = g0x - px, gdy = g0y - py;
+            if (fmaf(gdx, gdx, gdy * gdy) <= r * r) { // |goals[i][0] - p| <= r ; rare, divergent
                 int k = a.G;
                 for (int g = 0; g < a.G; ++g)
                     if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) { k = g; break; }
@@ -249,10 +331,11 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 }
                 gx = g0x; gy = g0y;
             }
+            STAMP(0);
             // -- rotation matrix and refreshed linear velocity, :254-256
-            float c = 1.0f, s = 0.0f, cvx = vx, cvy = vy;
+            const float c = cs, s = sn;
+            float cvx = vx, cvy = vy;
             if constexpr (HEADED > 0) {
-                c = cosf(th); s = sinf(th);
                 cvx = c * bvx + (-s) * bvy;
                 cvy = s * bvx + c * bvy;
             }
@@ -260,85 +343,145 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
             float fdx = 0.0f, fdy = 0.0f;
             {
                 const float dx = gx - px, dy = gy - py;
-                const float dist = norm2(dx, dy);
-                if (dist > r) {
-                    const float ex = dx / dist, ey = dy / dist;
-                    fdx = m * (ex * vd - cvx) / relax_t;
-                    fdy = m * (ey * vd - cvy) / relax_t;
+                const float d2 = fmaf(dx, dx, dy * dy);
+                const float inv = rsq_fast(fmaxf(d2, 1e-30f));
+                if (d2 * inv > r) {
+                    fdx = m_tau * (dx * inv * vd - cvx);
+                    fdy = m_tau * (dy * inv * vd - cvy);
                 }
             }
             // -- obstacle force: closest point per polygon :236-252, then :136-162
             float fox = 0.0f, foy = 0.0f;
             if (obst != nullptr) {
                 for (int o = 0; o < a.O; ++o) {
-                    float best = 0.0f, bxp = 0.0f, byp = 0.0f;
+                    // first argmin over the polygon's segments, on squared distances (same order)
+                    float best = 0.0f, bdx = 0.0f, bdy = 0.0f;
                     bool have = false;
                     for (int sg = 0; sg < a.Smax; ++sg) {
                         const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)o * a.Smax + sg) * 4);
-                        float d, hx = 0.0f, hy = 0.0f;
+                        float d, ddx = 0.0f, ddy = 0.0f;
                         if (isnan(seg.x)) {
-                            d = 9223372036854775807.0f;
+                            d = 3.0e38f; // the reference stores iinfo(int64).max as the distance (:247)
                         } else {
                             const float ex = seg.z - seg.x, ey = seg.w - seg.y;
-                            const float len = norm2(ex, ey);
-                            const float t = ((px - seg.x) * ex + (py - seg.y) * ey) / (len * len);
-                            float ts = t > 0.0f ? t : 0.0f;
-                            ts = ts < 1.0f ? ts : 1.0f;
-                            hx = seg.x + ts * ex; hy = seg.y + ts * ey;
-                            d = norm2(hx - px, hy - py);
+                            const float t = ((px - seg.x) * ex + (py - seg.y) * ey) * rcp_fast(fmaf(ex, ex, ey * ey));
+                            const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                            ddx = px - fmaf(ts, ex, seg.x); ddy = py - fmaf(ts, ey, seg.y);
+                            d = fmaf(ddx, ddx, ddy * ddy);
                         }
-                        if (!have || d < best) { best = d; bxp = hx; byp = hy; have = true; }
+                        if (!have || d < best) { best = d; bdx = ddx; bdy = ddy; have = true; }
                     }
-                    const float dx = px - bxp, dy = py - byp;
-                    const float dist = norm2(dx, dy);
-                    const float nx = dx / dist, ny = dy / dist;
-                    const float tx = -ny, ty = nx;
-                    const float dv = -(cvx * tx + cvy * ty);
+                    const float inv = rsq_fast(fmaxf(best, 1e-30f));
+                    const float dist = best * inv;
+                    const float nx = bdx * inv, ny = bdy * inv;
+                    const float dv = -(cvy * nx - cvx * ny);                 // -(v . t), t = (-ny, nx)
                     const float rd = r - dist + safety;
                     const float m0 = fmaxf(0.0f, rd);
-                    const float fn = Aw * expf(rd / Bw) + k1 * m0;
-                    if (obs_type == 0) {
-                        const float ft = k2 * m0 * dv;
-                        fox += fn * nx - ft * tx;
-                        foy += fn * ny - ft * ty;
-                    } else {
-                        const float ft = (-Cw * expf(rd / Dw) - k2 * m0) * dv;
-                        fox += fn * nx + ft * tx;
-                        foy += fn * ny + ft * ty;
-                    }
+                    const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
+                    float ft;                                                 // coefficient of t
+                    if (obs_type == 0) ft = -(k2 * m0) * dv;
+                    else ft = (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
+                    fox += fn * nx - ft * ny;
+                    foy += fn * ny + ft * nx;
                 }
-                fox /= (float)a.O; foy /= (float)a.O;
+                fox *= inv_O; foy *= inv_O;
             }
+            STAMP(1);
             // -- social force: O(N) partners broadcast from LDS, :87-133 / :43-84
             float fsx = 0.0f, fsy = 0.0f;
             {
-                const float my_rs = r + safety;
                 // all_params_equal: every row's stored velocity (the reference evaluates all pairs
                 // before any in-place refresh); else: my refreshed velocity, partner j<i refreshed,
                 // j>i stored (prange == range order; identical from the 2nd fused substep on)
                 const float vix = PEQ ? vx : cvx, viy = PEQ ? vy : cvy;
-                const float4* pv = lds_pv + cur * T + base;
+                const float4* pp = lds_p + cur * TP + pbase;
+                const float2* pvel = lds_v + cur * T + base;
                 const float2* vr = lds_vr + cur * T + base;
-                const float* rs = lds_rs + base;
-                for (int j = 0; j < rows; ++j) {
-                    if (j == row) continue;
-                    const float4 q = pv[j];
-                    float vjx = q.z, vjy = q.w;
-                    if constexpr (!PEQ && HEADED > 0) {
-                        if (j < row) { const float2 t2 = vr[j]; vjx = t2.x; vjy = t2.y; }
+                auto partner_vel = [&](int j) {
+                    float2 v2 = pvel[j];
+                    if constexpr (!PEQ && HEADED > 0) { if (j < row) v2 = vr[j]; }
+                    return v2;
+                };
+                if constexpr (SOC == 2) {
+                    for (int j = 0; j < rows; ++j) {
+                        const float4 q = pp[j];
+                        const float2 vj = partner_vel(j);
+                        pair_force_moussaid(sp, px, py, vix, viy, q.x, q.y, vj.x, vj.y, my_rs + q.z, j == row, fsx, fsy);
                     }
-                    pair_force<SOC>(sp, px, py, vix, viy, q.x, q.y, vjx, vjy, my_rs + rs[j], fsx, fsy);
+                } else {
+                    // Helbing / Guo (:117-118).  Per partner the force is
+                    //   [A e^{rd/B} + k1 max(0,rd)] n + [C e^{rd/D} + k2 max(0,rd) dv] t      (C = 0: Helbing)
+                    // Main loop: the exponential parts for every partner, branch-free (one ds_read_b128,
+                    // ~13 VALU + 2 transcendental ops each; A and C folded into the exponent; the next group
+                    // of four is fetched from LDS while the current one is evaluated).  The k1 / k2 contact
+                    // parts are exact zeros unless rd > 0: they are added by a second pass that a wavefront
+                    // runs only when one of its lanes touched a partner in this substep.
+                    float eax = 0.0f, eay = 0.0f, ecx = 0.0f, ecy = 0.0f, rdmax = -1.0f;
+                    constexpr int U = 8;                  // partners in flight per lane (independent rsq -> exp chains)
+                    const float4* rp = pp + row + 1;      // partner k of mine = row (i + 1 + k) mod rows, k = 0 .. rows-2
+                    const int np = rows - 1;
+                    auto group = [&](const float4 (&q)[U], int rem, auto tail_tag) {
+                        constexpr bool TAIL = decltype(tail_tag)::value;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const float dx = px - q[u].x, dy = py - q[u].y;
+                            float d2 = fmaf(dx, dx, dy * dy);
+                            if constexpr (TAIL) d2 = (u >= rem) ? 1.0e30f : d2; // padding slot (wave-uniform): dist 1e15 -> 0
+                            const float inv = rsq_fast(d2);
+                            const float rd = fmaf(-d2, inv, my_rs + q[u].z);          // rij - dist
+                            const float ga = exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv; // |A| e^{rd/B} / dist
+                            eax = fmaf(ga, dx, eax); eay = fmaf(ga, dy, eay);
+                            if constexpr (SOC == 1) {
+                                const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * inv; // |C| e^{rd/D} / dist
+                                ecx = fmaf(-gc, dy, ecx); ecy = fmaf(gc, dx, ecy);       // along t = (-ny, nx)
+                            }
+                            rdmax = fmaxf(rdmax, rd);
+                        }
+                    };
+                    float4 qn[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) qn[u] = rp[u];
+                    for (int k0 = 0; k0 < np; k0 += U) {
+                        float4 q[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) q[u] = qn[u];
+                        if (k0 + U < np) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) qn[u] = rp[k0 + U + u]; // next group; rows past np are finite padding
+                        }
+                        asm volatile("" ::: "memory"); // keep the prefetch above the arithmetic (no re-load at use)
+                        const int rem = np - k0;
+                        if (rem >= U) group(q, U, std::false_type{});
+                        else group(q, rem, std::true_type{});
+                    }
+                    fsx = sp.sA * eax; fsy = sp.sA * eay;
+                    if constexpr (SOC == 1) { fsx = fmaf(sp.sC, ecx, fsx); fsy = fmaf(sp.sC, ecy, fsy); }
+                    if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
+                        for (int j = 0; j < rows; ++j) {
+                            const float4 q = pp[j];
+                            const float2 vj = partner_vel(j);
+                            const float dx = px - q.x, dy = py - q.y;
+                            const float d2 = (j == row) ? 1.0e30f : fmaf(dx, dx, dy * dy);
+                            const float inv = rsq_fast(d2);
+                            const float m0 = fmaxf(0.0f, fmaf(-d2, inv, my_rs + q.z));
+                            const float nx = dx * inv, ny = dy * inv;
+                            const float dv = (vj.y - viy) * nx - (vj.x - vix) * ny;     // (v_j - v_i) . t
+                            const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;
+                            fsx += fn * nx - ft * ny;
+                            fsy += fn * ny + ft * nx;
+                        }
+                    }
                 }
             }
+            STAMP(2);
             // -- total force, body frame, torque  :262-271, :165-182
             const float fix = fdx + fox + fsx, fiy = fdy + foy + fsy;
-            float gfx = fix, gfy = fiy, torque = 0.0f, inertia = 1.0f;
+            float gfx = fix, gfy = fiy, torque = 0.0f;
             if constexpr (HEADED > 0) {
-                inertia = 0.5f * m * r * r;
                 const float drx = (HEADED == 1) ? fdx : fix, dry = (HEADED == 1) ? fdy : fiy;
-                const float fnorm = norm2(drx, dry);
-                const float k_theta = inertia * klam * fnorm;
-                const float k_omega = inertia * (1.0f + alpha) * sqrtf((klam * fnorm) / alpha);
+                const float kf = klam * norm2(drx, dry);
+                const float k_theta = inertia * kf;
+                const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf * inv_alpha);
                 torque = -k_theta * bound_angle(th - atan2f(dry, drx)) - k_omega * om;
                 gfx = fix * c + fiy * s;
                 gfy = ko * ((fox + fsx) * (-s) + (foy + fsy) * c) - kd * bvy;
@@ -348,62 +491,73 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
             px += vx * dt; py += vy * dt;
             if constexpr (HEADED > 0) {
                 th = bound_angle(th + om * dt);
-                bvx += (gfx / m) * dt; bvy += (gfy / m) * dt;
-                const float nb = norm2(bvx, bvy);
-                if (nb > vd) { bvx = (bvx / nb) * vd; bvy = (bvy / nb) * vd; }
-                om += (torque / inertia) * dt;
-                const float c2 = cosf(th), s2 = sinf(th);
-                vx = c2 * bvx + (-s2) * bvy;
-                vy = s2 * bvx + c2 * bvy;
+                bvx = fmaf(gfx, dt_m, bvx); bvy = fmaf(gfy, dt_m, bvy);
+                const float nb2 = fmaf(bvx, bvx, bvy * bvy);
+                const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
+                if (nb2 * ninv > vd) { const float sc = vd * ninv; bvx *= sc; bvy *= sc; }
+                om = fmaf(torque, dt_inertia, om);
+                sincos_fast(th, sn, cs);
+                vx = cs * bvx + (-sn) * bvy;
+                vy = sn * bvx + cs * bvy;
             } else {
-                vx += (gfx / m) * dt; vy += (gfy / m) * dt;
-                const float nb = norm2(vx, vy);
-                if (nb > vd) { vx = (vx / nb) * vd; vy = (vy / nb) * vd; }
+                vx = fmaf(gfx, dt_m, vx); vy = fmaf(gfy, dt_m, vy);
+                const float nb2 = fmaf(vx, vx, vy * vy);
+                const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
+                if (nb2 * ninv > vd) { const float sc = vd * ninv; vx *= sc; vy *= sc; }
             }
             if ((a.mode & M_MUTATE_INPUT) && sub == 0) {
                 float* si = a.Sin + sidx * a.in_as;
                 if (HEADED > 0) { si[3 * a.in_fs] = in_vx; si[4 * a.in_fs] = in_vy; }
                 si[10 * a.in_fs] = gx; si[11 * a.in_fs] = gy;
             }
-            lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
-            lds_vr[nxt * T + tid] = make_float2(vx, vy);
+            publish(nxt);
+            lds_v[nxt * T + tid] = make_float2(vx, vy);
+            if constexpr (!PEQ && HEADED > 0) lds_vr[nxt * T + tid] = make_float2(vx, vy);
+            STAMP(3);
         } else if (is_robot) {
             // the robot's move of the NEXT substep happens before that substep's update_humans
             if (robot_moves && sub + 1 < a.nsub) robot_step();
-            lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
-            lds_vr[nxt * T + tid] = make_float2(vx, vy);
+            publish(nxt);
+            lds_v[nxt * T + tid] = make_float2(vx, vy);
+            if constexpr (!PEQ && HEADED > 0) lds_vr[nxt * T + tid] = make_float2(vx, vy);
         }
         __syncthreads();
+        STAMP(4);
         // -- parallel-traffic respawn, motion_model_manager.py:407-422 (sequential inside a world)
         if (a.flags & CS_RESPAWN) {
-            const int flag = (human && respawn_here && norm2(px - g0x, py - g0y) < 3.0f) ? 1 : 0;
-            if (__syncthreads_or(flag)) {
+            const float rdx = px - g0x, rdy = py - g0y;
+            const int flag = (human && respawn_here && fmaf(rdx, rdx, rdy * rdy) < 9.0f) ? 1 : 0; // |p - g| < 3
+            bool any_flag;
+            if constexpr (MAXT == 64) any_flag = __builtin_amdgcn_ballot_w64(flag != 0) != 0; // one wave per block
+            else any_flag = __syncthreads_or(flag) != 0;
+            if (any_flag) {
                 lds_flag[tid] = flag;
                 lds_g0x[tid] = g0x;
                 __syncthreads();
                 if (valid && row == 0) {
-                    float4* pvn = lds_pv + nxt * T + base;
-                    const float* rs = lds_rs + base;
+                    float4* pvn = lds_p + nxt * TP + pbase;
                     for (int i = 0; i < n; ++i) {
                         if (!lds_flag[base + i]) continue;
-                        float mx = pvn[0].x, mr = rs[0];
+                        float mx = pvn[0].x, mr = pvn[0].z;
                         for (int j = 1; j < n; ++j) {
                             mx = fmaxf(mx, pvn[j].x);
-                            mr = fmaxf(mr, rs[j]);
+                            mr = fmaxf(mr, pvn[j].z);
                         }
                         if (robot_row) { // consider_robot: the robot where it stands in THIS substep
-                            mx = fmaxf(mx, lds_pv[cur * T + base + n].x);
-                            mr = fmaxf(mr, rs[n]);
+                            const float4 qr = lds_p[cur * TP + pbase + n];
+                            mx = fmaxf(mx, qr.x);
+                            mr = fmaxf(mr, qr.z);
                         }
                         float4 q = pvn[i];
                         q.x = fmaxf(mx + mr * 2.0f, a.bx);
                         q.y = (q.y >= 0.0f) ? fminf(q.y, a.by) : fmaxf(q.y, -a.by);
                         pvn[i] = q;
+                        pvn[rows + i] = q;
                     }
                 }
                 __syncthreads();
                 if (flag) {
-                    const float4 q = lds_pv[nxt * T + tid];
+                    const float4 q = lds_p[nxt * TP + pbase + row];
                     px = q.x; py = q.y;
                     g0y = py;               // human.set_goals([[goals[0][0], position[1]]])   :418
                     bvy = g0x; om = g0y;    // states[i,6:8] = goal  (reference writes cols 6:8) :421
@@ -411,14 +565,22 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 }
             }
         }
+        STAMP(5);
         cur = nxt;
     }
+#ifdef CS_STAMPS
+    if (a.stamps != nullptr && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+    }
+#endif
 
     // ---- epilogue ---------------------------------------------------------------------------
     if (a.mode & M_PEEK) {
         if (human) {
             float* o = a.peek_out + ((long)w * n + row) * 8;
-            o[0] = px; o[1] = py; o[2] = th; o[3] = vx; o[4] = vy; o[5] = om; o[6] = gx; o[7] = gy;
+            o[0] = px; o[1] = py; o[2] = th; o[3] = vx; o[4] = vy; o[5] = om;
+            o[6] = g0x; o[7] = g0y; // human.goals[0] (the goals array), not the state's goal columns (:297)
         }
         return;
     }
@@ -529,6 +691,10 @@ kfn pick_kernel(int type, bool peq)
     return nullptr;
 }
 
+#ifdef CS_STAMPS
+unsigned long long* g_stamp_buf = nullptr;
+#endif
+
 struct Geometry { int grid, block, wpb; };
 
 int geometry(const cs_worlds* w, Geometry& g)
@@ -578,9 +744,15 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.robot = w->d_robot; a.action = d_action; a.peek_out = d_peek;
     a.bx = w->respawn_bound_x; a.by = w->respawn_bound_y;
     a.world_flags = w->d_world_flags;
+#ifdef CS_STAMPS
+    a.stamps = g_stamp_buf;
+#endif
     const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
     kfn fn = (g.block == 64) ? pick_kernel<64>(w->type, peq) : pick_kernel<1024>(w->type, peq);
-    const size_t shmem = (size_t)g.block * (2 * sizeof(float4) + 2 * sizeof(float2) + 3 * sizeof(float));
+    const size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float)) +
+                         2 * PADR * sizeof(float4);
+    if (shmem > 64 * 1024) // one world per block with > ~600 rows
+        HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(fn, dim3(g.grid), dim3(g.block), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -706,6 +878,10 @@ int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void*
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
+
+#ifdef CS_STAMPS
+int cs_debug_set_stamp_buffer(void* d_buf) { g_stamp_buf = (unsigned long long*)d_buf; return CS_OK; }
+#endif
 
 int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_per_block)
 {

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Diagnostic: build libcrowdstep_stamps.so with -DCS_STAMPS and print the share of wave cycles
+each section of k_sfm_step takes (never shipped, never timed for throughput)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from social_navigation_pyenvs_amd import _lib, scenarios as sc  # noqa: E402
+from social_navigation_pyenvs_amd.csrc import build as hb  # noqa: E402
+
+so = os.path.join(ROOT, "gpurun_out", "libcrowdstep_stamps.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCS_STAMPS",
+                       "-I", os.path.join(ROOT, "include"), "-o", so,
+                       os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "crowdstep.hip")])
+_lib.LIB_PATH = so
+_lib._lib = None
+from social_navigation_pyenvs_amd.batched import CrowdWorlds  # noqa: E402
+
+W, n = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 25
+model = sys.argv[2] if len(sys.argv) > 2 else "hsfm_farina"
+S, goals, P, rb = sc.hybrid_worlds(W, n, model)
+cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
+                 respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), layout="soa")
+g, b, wpb = cw.launch_geometry()
+buf = _lib.DeviceBuffer((g * (b // 64), 8), np.uint64)
+lib = _lib.load()
+lib.cs_debug_set_stamp_buffer(C.c_void_p(buf.ptr))
+for _ in range(5):
+    cw.step(0.0125, 20)
+cw.sync()
+st = buf.download().astype(np.float64)
+names = ["goal switch", "rot+desired+walls", "pair loop", "torque+euler+lds write", "barrier", "respawn check", "-", "loop top"]
+tot = st.sum(1).mean()
+print(f"N={n} {model}: mean wave cycles in loop = {tot:.0f} (per substep {tot / 20:.0f})")
+for k, nm in enumerate(names):
+    print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")

@@ -1,0 +1,72 @@
+// Diagnostic microbenchmark: SIMD issue cost of the VALU ops the pair loop is made of (gfx950).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <int OP>
+__global__ __launch_bounds__(64) void k(float* out, int iters, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, c = {1.0001f, 0.9999f}, d = {1e-6f, -1e-6f};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (OP == 0) { // 8 independent v_fma_f32
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a1 = __builtin_fmaf(a1, 1.0001f, 1e-6f); a2 = __builtin_fmaf(a2, 1.0001f, 1e-6f); a3 = __builtin_fmaf(a3, 1.0001f, 1e-6f);
+                a4 = __builtin_fmaf(a4, 1.0001f, 1e-6f); a5 = __builtin_fmaf(a5, 1.0001f, 1e-6f); a6 = __builtin_fmaf(a6, 1.0001f, 1e-6f); a7 = __builtin_fmaf(a7, 1.0001f, 1e-6f);
+            } else if (OP == 1) { // 4 independent v_pk_fma_f32 (= 8 fma)
+                p0 = __builtin_elementwise_fma(p0, c, d); p1 = __builtin_elementwise_fma(p1, c, d); p2 = __builtin_elementwise_fma(p2, c, d); p3 = __builtin_elementwise_fma(p3, c, d);
+            } else if (OP == 2) { // 8 independent v_exp_f32
+                a0 = __builtin_amdgcn_exp2f(a0); a1 = __builtin_amdgcn_exp2f(a1); a2 = __builtin_amdgcn_exp2f(a2); a3 = __builtin_amdgcn_exp2f(a3);
+                a4 = __builtin_amdgcn_exp2f(a4); a5 = __builtin_amdgcn_exp2f(a5); a6 = __builtin_amdgcn_exp2f(a6); a7 = __builtin_amdgcn_exp2f(a7);
+            } else if (OP == 3) { // 8 independent v_rsq_f32
+                a0 = __builtin_amdgcn_rsqf(a0); a1 = __builtin_amdgcn_rsqf(a1); a2 = __builtin_amdgcn_rsqf(a2); a3 = __builtin_amdgcn_rsqf(a3);
+                a4 = __builtin_amdgcn_rsqf(a4); a5 = __builtin_amdgcn_rsqf(a5); a6 = __builtin_amdgcn_rsqf(a6); a7 = __builtin_amdgcn_rsqf(a7);
+            } else if (OP == 4) { // 8 independent v_cndmask (select)
+                a0 = a0 > 1.0f ? a1 : a0; a2 = a2 > 1.0f ? a3 : a2; a4 = a4 > 1.0f ? a5 : a4; a6 = a6 > 1.0f ? a7 : a6;
+                a1 = a1 > 2.0f ? a0 : a1; a3 = a3 > 2.0f ? a2 : a3; a5 = a5 > 2.0f ? a4 : a5; a7 = a7 > 2.0f ? a6 : a7;
+            } else if (OP == 5) { // one dependent chain of fma
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f);
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f);
+            } else if (OP == 6) { // 8 v_mul_f32 (plain, not fma)
+                a0 *= 1.0001f; a1 *= 1.0001f; a2 *= 1.0001f; a3 *= 1.0001f; a4 *= 1.0001f; a5 *= 1.0001f; a6 *= 1.0001f; a7 *= 1.0001f;
+            }
+        }
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+}
+
+template <int OP>
+void run(const char* name, int waves_per_simd, float* d_out)
+{
+    const int iters = 4096;
+    const int blocks = 256 * 4 * waves_per_simd; // one wave per block
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d_out, iters, 1.0f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d_out, iters, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double n_inst = (double)iters * 8 * (OP == 1 ? 4 : 8);  // wave-instructions per wave
+    // SIMD cycles per wave-instruction at 2.4 GHz nominal, all waves of a SIMD sharing it
+    const double cyc = ms * 1e-3 * 2.4e9 / (n_inst * waves_per_simd);
+    printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f SIMD-cycles per wave-instruction (at 2.4 GHz)\n", name, waves_per_simd, ms, cyc);
+}
+
+int main()
+{
+    float* d_out; hipMalloc(&d_out, 256 * 4 * 8 * 64 * sizeof(float));
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_fma_f32 x8 indep", w, d_out);
+        run<1>("v_pk_fma_f32 x4 indep", w, d_out);
+        run<6>("v_mul_f32 x8 indep", w, d_out);
+        run<2>("v_exp_f32 x8 indep", w, d_out);
+        run<3>("v_rsq_f32 x8 indep", w, d_out);
+        run<4>("v_cmp+v_cndmask x8", w, d_out);
+        run<5>("v_fma_f32 dependent chain", w, d_out);
+    }
+    return 0;
+}
