@@ -33,7 +33,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | N
     if not force and not needs_build():
         return LIB_PATH
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: v_pk_*_f32 has no throughput advantage over two scalar ops on gfx950 (measured,
+    # tools/valu_microbench.hip) and packing costs ~2 v_mov per partner in the pair loop
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + srcs + (extra_flags or [])
     if verbose:
         print(" ".join(cmd))

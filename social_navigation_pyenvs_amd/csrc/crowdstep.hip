@@ -112,11 +112,11 @@ __device__ __forceinline__ void sincos_fast(float x, float& s, float& c)
     float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
     cp = fmaf(cp, r2, 4.166664568298827e-2f);
     cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
-    float ss = (q & 1) ? cp : sp;
-    float cc = (q & 1) ? sp : cp;
-    if (q & 2) ss = -ss;
-    if ((q + 1) & 2) cc = -cc;
-    s = ss; c = cc;
+    const bool odd = (q & 1) != 0;
+    const float ss = odd ? cp : sp;
+    const float cc = odd ? sp : cp;
+    s = __uint_as_float(__float_as_uint(ss) ^ ((unsigned)(q & 2) << 30));        // quadrants 2,3: -sin
+    c = __uint_as_float(__float_as_uint(cc) ^ ((unsigned)((q + 1) & 2) << 30));  // quadrants 1,2: -cos
 }
 
 // social_gym/src/utils.py:7-13 (Python % == fmod for the operand signs reaching each branch)
@@ -129,6 +129,37 @@ __device__ __forceinline__ float bound_angle(float a)
     if (a > pi) a -= two_pi;
     if (a < -pi) a += two_pi;
     return a;
+}
+
+// bound_angle for the heading update: identical to the branches above for |a| < 2 pi (k = rint(a / 2 pi)
+// is 1 above pi, -1 below -pi, 0 between; ties at exactly +-pi stay, as in the reference); the fmod
+// branch for |a| >= 2 pi is wave-uniformly skipped.
+__device__ __forceinline__ float wrap_angle(float a)
+{
+    const float two_pi = 6.283185307179586f;
+    if (fabsf(a) >= two_pi) a = fmodf(a, two_pi);
+    return fmaf(-two_pi, rintf(a * 0.15915494309189535f), a);
+}
+
+// atan2 with |error| < 2e-7 rad (degree-7 minimax in a^2 on [0,1], a = min/max); atan2(0, 0) = 0
+__device__ __forceinline__ float atan2_fast(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+    const float a = mn * rcp_fast(mx);
+    const float s = a * a;
+    float r = -0.004054529592394829f;
+    r = fmaf(r, s, 0.021862812340259552f);
+    r = fmaf(r, s, -0.05591210350394249f);
+    r = fmaf(r, s, 0.09642179310321808f);
+    r = fmaf(r, s, -0.13908621668815613f);
+    r = fmaf(r, s, 0.19946563243865967f);
+    r = fmaf(r, s, -0.33329859375953674f);
+    r = fmaf(r, s, 0.9999993443489075f);
+    r *= a;
+    if (ay > ax) r = 1.5707963267948966f - r;
+    if (x < 0.0f) r = 3.141592653589793f - r;
+    return copysignf(r, y);
 }
 
 // Social-force parameters used inside the pair loop (subset of the 20-vector, agent.py:268-388),
@@ -422,6 +453,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                     const int np = rows - 1;
                     auto group = [&](const float4 (&q)[U], int rem, auto tail_tag) {
                         constexpr bool TAIL = decltype(tail_tag)::value;
+                        float rdk[U];
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
                             const float dx = px - q[u].x, dy = py - q[u].y;
@@ -435,24 +467,34 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                                 const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * inv; // |C| e^{rd/D} / dist
                                 ecx = fmaf(-gc, dy, ecx); ecy = fmaf(gc, dx, ecy);       // along t = (-ny, nx)
                             }
-                            rdmax = fmaxf(rdmax, rd);
+                            rdk[u] = rd;
                         }
+#pragma unroll
+                        for (int u = 0; u < U; u += 2) rdmax = fmaxf(fmaxf(rdmax, rdk[u]), rdk[u + 1]); // v_max3_f32
                     };
-                    float4 qn[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) qn[u] = rp[u];
-                    for (int k0 = 0; k0 < np; k0 += U) {
-                        float4 q[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) q[u] = qn[u];
-                        if (k0 + U < np) {
-#pragma unroll
-                            for (int u = 0; u < U; ++u) qn[u] = rp[k0 + U + u]; // next group; rows past np are finite padding
-                        }
-                        asm volatile("" ::: "memory"); // keep the prefetch above the arithmetic (no re-load at use)
-                        const int rem = np - k0;
+                    auto run = [&](const float4 (&q)[U], int rem) {
                         if (rem >= U) group(q, U, std::false_type{});
                         else group(q, rem, std::true_type{});
+                    };
+                    // two register sets, filled alternately: the next group's LDS reads are in flight
+                    // while the current one is evaluated (no copies, no re-load at the point of use)
+                    float4 qa[U], qb[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) qa[u] = rp[u];
+                    for (int k0 = 0; k0 < np; k0 += 2 * U) {
+                        if (k0 + U < np) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) qb[u] = rp[k0 + U + u]; // rows past np are finite padding
+                        }
+                        asm volatile("" ::: "memory");
+                        run(qa, np - k0);
+                        if (k0 + U >= np) break;
+                        if (k0 + 2 * U < np) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) qa[u] = rp[k0 + 2 * U + u];
+                        }
+                        asm volatile("" ::: "memory");
+                        run(qb, np - k0 - U);
                     }
                     fsx = sp.sA * eax; fsy = sp.sA * eay;
                     if constexpr (SOC == 1) { fsx = fmaf(sp.sC, ecx, fsx); fsy = fmaf(sp.sC, ecy, fsy); }
@@ -482,7 +524,10 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 const float kf = klam * norm2(drx, dry);
                 const float k_theta = inertia * kf;
                 const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf * inv_alpha);
-                torque = -k_theta * bound_angle(th - atan2f(dry, drx)) - k_omega * om;
+                // bound_angle(theta - atan2(Fy, Fx)) is the signed angle from F to the heading:
+                // atan2(|F| sin(theta - phi), |F| cos(theta - phi)) -- one atan2, no wrap needed
+                const float delta = atan2_fast(s * drx - c * dry, c * drx + s * dry);
+                torque = -k_theta * delta - k_omega * om;
                 gfx = fix * c + fiy * s;
                 gfy = ko * ((fox + fsx) * (-s) + (foy + fsy) * c) - kd * bvy;
             }
@@ -490,7 +535,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
             const float in_vx = cvx, in_vy = cvy; // what the reference leaves in agents_state[i,3:5]
             px += vx * dt; py += vy * dt;
             if constexpr (HEADED > 0) {
-                th = bound_angle(th + om * dt);
+                th = wrap_angle(fmaf(om, dt, th));
                 bvx = fmaf(gfx, dt_m, bvx); bvy = fmaf(gfy, dt_m, bvy);
                 const float nb2 = fmaf(bvx, bvx, bvy * bvy);
                 const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));

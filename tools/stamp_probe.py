@@ -15,7 +15,7 @@ from social_navigation_pyenvs_amd.csrc import build as hb  # noqa: E402
 
 so = os.path.join(ROOT, "gpurun_out", "libcrowdstep_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCS_STAMPS",
+subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-DCS_STAMPS",
                        "-I", os.path.join(ROOT, "include"), "-o", so,
                        os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "crowdstep.hip")])
 _lib.LIB_PATH = so
