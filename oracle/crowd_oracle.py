@@ -151,6 +151,55 @@ def collision_reward(hp, hv, hr, rp, rr, rgoal, act, T, global_time, time_limit=
                 terminated=bool(out[4]), truncated=bool(out[5]), info=INFO_NAMES[int(out[6])])
 
 
+def orca_new_velocities(pos, vel, pref, radius, maxspeed, neighbor_dist=10.0, max_nb=10, time_horizon=5.0,
+                        time_step=0.25, return_lines=False):
+    """One RVO2 doStep velocity solve for one world (float32, PARITY UNPINNED)."""
+    f = np.float32
+    pos = np.ascontiguousarray(pos, dtype=f); vel = np.ascontiguousarray(vel, dtype=f)
+    pref = np.ascontiguousarray(pref, dtype=f); radius = np.ascontiguousarray(radius, dtype=f)
+    maxspeed = np.ascontiguousarray(maxspeed, dtype=f)
+    na = pos.shape[0]
+    out = np.zeros((na, 2), dtype=f)
+    lines = np.zeros((na, max(max_nb, 1), 4), dtype=f)
+    nl = np.zeros(na, dtype=np.int32)
+    fn = lib().orc_orca_new_velocities
+    fn.restype = None
+    fn(C.c_int(na), _ptr(pos, C.c_float), _ptr(vel, C.c_float), _ptr(pref, C.c_float), _ptr(radius, C.c_float),
+       _ptr(maxspeed, C.c_float), C.c_float(neighbor_dist), C.c_int(max_nb), C.c_float(time_horizon),
+       C.c_float(time_step), _ptr(out, C.c_float), lines.ctypes.data_as(C.c_void_p) if return_lines else None,
+       nl.ctypes.data_as(C.POINTER(C.c_int)) if return_lines else None)
+    return (out, lines, nl) if return_lines else out
+
+
+def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot=None, action=None,
+                    neighbor_dist=10.0, max_nb=10, time_horizon=5.0, respawn=False, bounds=(0.0, 0.0), threads=0):
+    """Batched ([W, rows, 13]) or single-world block of ORCA substeps on the shared row layout
+    (cols 5:7 = preferred velocity).  Returns (S, goals, robot)."""
+    f = np.float32
+    S = np.ascontiguousarray(S, dtype=f).copy()
+    single = S.ndim == 2
+    if single:
+        S = S[None]
+    W, rows = S.shape[0], S.shape[1]
+    n = rows - int(robot_visible)
+    goals = np.ascontiguousarray(goals, dtype=f).copy().reshape(W, n, -1, 2)
+    G = goals.shape[2]
+    margin = np.ascontiguousarray(np.broadcast_to(np.asarray(margin, dtype=f), (W, rows)))
+    if robot is not None:
+        robot = np.ascontiguousarray(robot, dtype=f).copy().reshape(W, 13)
+    if action is not None:
+        action = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=f), (W, 2)))
+    fn = lib().orc_orca_step_block_batched
+    fn.restype = None
+    fn(C.c_int(W), _ptr(S, C.c_float), _ptr(goals, C.c_float), C.c_int(G), C.c_int(rows), C.c_int(int(robot_visible)),
+       _ptr(margin, C.c_float), _ptr(robot, C.c_float), _ptr(action, C.c_float), C.c_float(dt), C.c_int(n_substeps),
+       C.c_float(neighbor_dist), C.c_int(max_nb), C.c_float(time_horizon), C.c_int(int(respawn)),
+       C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_int(threads))
+    if single:
+        return S[0], goals[0], (robot[0] if robot is not None else None)
+    return S, goals, robot
+
+
 def num_threads() -> int:
     f = lib().orc_num_threads
     f.restype = C.c_int

@@ -255,11 +255,12 @@ void orc_orca_step_block(float* S, float* goals, int G, int rows, int robot_visi
                 float* gi = goals + (size_t)i * G * 2;
                 const float ddx = r[0] - gi[0], ddy = r[1] - gi[1];
                 if (sqrtf(ddx * ddx + ddy * ddy) < 3.0f) {
-                    float mx = S[0], mr = S[8] + (margin[0] - 0.01f);
+                    /* h.radius + h.safety_space: set_safety_space() only resizes the RVO agents for ORCA
+                       (mmm.py:154-158), the humans' safety_space attribute stays 0 -> plain radii */
+                    float mx = S[0], mr = S[8];
                     for (int j = 1; j < n; ++j) {
                         if (S[13 * j] > mx) mx = S[13 * j];
-                        const float rr = S[13 * j + 8] + (margin[j] - 0.01f);
-                        if (rr > mr) mr = rr;
+                        if (S[13 * j + 8] > mr) mr = S[13 * j + 8];
                     }
                     if (robot_visible && robot) {
                         if (robot[0] > mx) mx = robot[0];

@@ -17,6 +17,9 @@ from ._lib import DeviceBuffer, check, cs_worlds
 
 SFMS = ["sfm_helbing", "sfm_guo", "sfm_moussaid", "hsfm_farina", "hsfm_guo", "hsfm_moussaid",
         "hsfm_new", "hsfm_new_guo", "hsfm_new_moussaid"]  # motion_model_manager.py:15-17
+HUMAN_MODELS = SFMS + ["orca"]  # social_nav_gym.py:11-12
+# motion_model_manager.py:14  neighbor_dist, max_neighbors, time_horizon, time_horizon_obstacles
+ORCA_DEFAULTS = dict(neighbor_dist=10.0, max_neighbors=10, time_horizon=5.0, time_horizon_obst=5.0)
 
 
 def _ptr(x) -> int | None:
@@ -46,10 +49,12 @@ class CrowdWorlds:
         if device is not None:
             _lib.set_device(device)
         if isinstance(type, str):
-            type = SFMS.index(type)
-        if type < 0 or type > 8:
+            type = HUMAN_MODELS.index(type)
+        if type < 0 or type > 9:
             raise ValueError(f"Type {type} does not exist for this implementation")
         self.type = int(type)
+        self.orca = self.type == _lib.CS_ORCA
+        self.orca_params = dict(ORCA_DEFAULTS)
         self.stream = stream
         states = np.asarray(states, dtype=np.float32)
         if states.ndim == 2:
@@ -63,6 +68,10 @@ class CrowdWorlds:
         if goals.shape[0] != self.W or goals.shape[1] != self.n:
             raise ValueError(f"goals shape {goals.shape} does not match W={self.W}, n={self.n}")
         self.G = goals.shape[2]
+        if params is None:
+            if not self.orca:
+                raise ValueError("params are required for the SFM / HSFM models")
+            params = np.zeros((self.n, 20), dtype=np.float32)
         params = np.asarray(params, dtype=np.float32)
         self.params_shared = params.ndim == 2
         if params.shape[-2:] != (self.n, 20):
@@ -133,6 +142,10 @@ class CrowdWorlds:
         d.d_world_flags = _ptr(self.d_world_flags)
         bx, by = self.respawn_bounds if self.respawn_bounds is not None else (0.0, 0.0)
         d.respawn_bound_x, d.respawn_bound_y = float(bx), float(by)
+        d.orca_neighbor_dist = float(self.orca_params["neighbor_dist"])
+        d.orca_max_neighbors = int(self.orca_params["max_neighbors"])
+        d.orca_time_horizon = float(self.orca_params["time_horizon"])
+        d.orca_time_horizon_obst = float(self.orca_params["time_horizon_obst"])
         return d
 
     # ------------------------------------------------------------------ hot path

@@ -1,0 +1,29 @@
+// Shared host-side helpers of libcrowdstep.so (error reporting across the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "crowdstep.h"
+
+namespace csimpl {
+
+extern thread_local std::string g_err;
+
+inline int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+// ORCA branch (orca.hip)
+int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);
+
+} // namespace csimpl
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return ::csimpl::fail(CS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));      \
+    } while (0)

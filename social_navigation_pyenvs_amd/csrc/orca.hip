@@ -1,0 +1,376 @@
+// orca.hip -- ORCA (RVO2) crowd step for gfx950: the ORCA branch of MotionModelManager.update_humans
+//   /root/reference/social_gym/src/motion_model_manager.py:385-394  (setTimeStep; doStep; read back; update_goals_orca)
+//   :125-133 (goal rotation + preferred velocity), :105-114 (robot agent overwritten after the step),
+//   :407-422 (respawn), :14 ORCA_DEFAULTS, :237-246 (agent radius = radius + 0.01 [+ safety space]).
+// The arithmetic of doStep lives in the third-party RVO2 library (un-vendored, un-pinned, absent in the
+// build image): it is restated here from the published algorithm -- Agent::computeNeighbors (brute force
+// in index order instead of the kd-tree; same neighbour set), computeNewVelocity (ORCA half-planes),
+// linearProgram1/2/3, update -- in float32 like RVO2.  PARITY UNPINNED (see oracle/orca_oracle.c).
+//
+// Mapping: lane = agent row, floor(64/rows) worlds per wavefront, the rows' (x, y, vx, vy, radius) in LDS,
+// every lane's neighbour list / ORCA lines / LP3 projection lines in per-lane LDS columns (the 2-D
+// linear programme is divergent by nature; lanes walk their own constraints).  n_substeps are fused in
+// one launch.  IEEE divide / sqrt and no FMA contraction, to follow the CPU restatement op for op.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+using csimpl::fail;
+
+constexpr float RVO_EPSILON = 0.00001f;
+constexpr int KMAX = 16; // max_neighbors supported (ORCA_DEFAULTS uses 10)
+
+struct OArgs {
+    int W, n, rows, G, flags, nsub, wpb, K;
+    float dt, neighbor_dist, time_horizon, bx, by;
+    float* S; long as, fs;
+    float* goals;
+    const float* margin;
+    float* robot;
+    const float* action;
+    float* peek_out;
+    const int* world_flags;
+};
+
+__device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+
+// per-lane column views into LDS: element i of lane tid lives at base[i * T + tid]
+struct Lines {
+    float4* p;
+    int T, tid;
+    __device__ __forceinline__ float4 get(int i) const { return p[i * T + tid]; }
+    __device__ __forceinline__ void set(int i, float4 v) const { p[i * T + tid] = v; }
+};
+
+// RVO2 linearProgram1
+__device__ bool lp1(const Lines& L, int lineNo, float radius, float ox, float oy, bool dirOpt, float& rx, float& ry)
+{
+    const float4 ln = L.get(lineNo); // x,y = point ; z,w = direction
+    const float dot = ln.x * ln.z + ln.y * ln.w;
+    const float disc = dot * dot + radius * radius - (ln.x * ln.x + ln.y * ln.y);
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    float tL = -dot - sq, tR = -dot + sq;
+    for (int i = 0; i < lineNo; ++i) {
+        const float4 li = L.get(i);
+        const float den = det2(ln.z, ln.w, li.z, li.w);
+        const float num = det2(li.z, li.w, ln.x - li.x, ln.y - li.y);
+        if (fabsf(den) <= RVO_EPSILON) {
+            if (num < 0.0f) return false;
+            continue;
+        }
+        const float t = num / den;
+        if (den >= 0.0f) tR = fminf(tR, t); else tL = fmaxf(tL, t);
+        if (tL > tR) return false;
+    }
+    float t;
+    if (dirOpt) {
+        t = (ox * ln.z + oy * ln.w > 0.0f) ? tR : tL;
+    } else {
+        t = ln.z * (ox - ln.x) + ln.w * (oy - ln.y);
+        if (t < tL) t = tL; else if (t > tR) t = tR;
+    }
+    rx = ln.x + t * ln.z;
+    ry = ln.y + t * ln.w;
+    return true;
+}
+
+// RVO2 linearProgram2
+__device__ int lp2(const Lines& L, int nl, float radius, float ox, float oy, bool dirOpt, float& rx, float& ry)
+{
+    if (dirOpt) { rx = ox * radius; ry = oy * radius; }
+    else if (ox * ox + oy * oy > radius * radius) {
+        const float nrm = sqrtf(ox * ox + oy * oy);
+        rx = ox / nrm * radius; ry = oy / nrm * radius;
+    } else { rx = ox; ry = oy; }
+    for (int i = 0; i < nl; ++i) {
+        const float4 li = L.get(i);
+        if (det2(li.z, li.w, li.x - rx, li.y - ry) > 0.0f) {
+            const float tx = rx, ty = ry;
+            if (!lp1(L, i, radius, ox, oy, dirOpt, rx, ry)) { rx = tx; ry = ty; return i; }
+        }
+    }
+    return nl;
+}
+
+// RVO2 linearProgram3 (no obstacle lines)
+__device__ void lp3(const Lines& L, const Lines& P, int nl, int begin, float radius, float& rx, float& ry)
+{
+    float distance = 0.0f;
+    for (int i = begin; i < nl; ++i) {
+        const float4 li = L.get(i);
+        if (det2(li.z, li.w, li.x - rx, li.y - ry) > distance) {
+            int np = 0;
+            for (int j = 0; j < i; ++j) {
+                const float4 lj = L.get(j);
+                float4 ln;
+                const float d = det2(li.z, li.w, lj.z, lj.w);
+                if (fabsf(d) <= RVO_EPSILON) {
+                    if (li.z * lj.z + li.w * lj.w > 0.0f) continue;
+                    ln.x = 0.5f * (li.x + lj.x); ln.y = 0.5f * (li.y + lj.y);
+                } else {
+                    const float s = det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
+                    ln.x = li.x + s * li.z; ln.y = li.y + s * li.w;
+                }
+                const float ex = lj.z - li.z, ey = lj.w - li.w;
+                const float en = sqrtf(ex * ex + ey * ey);
+                ln.z = ex / en; ln.w = ey / en;
+                P.set(np++, ln);
+            }
+            const float tx = rx, ty = ry;
+            if (lp2(P, np, radius, -li.w, li.z, true, rx, ry) < np) { rx = tx; ry = ty; }
+            distance = det2(li.z, li.w, li.x - rx, li.y - ry);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int T = blockDim.x;
+    const int K = a.K;
+    float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [2][T] x, y, vx, vy
+    float4* lds_L = lds_pv + 2 * T;                                  // [K][T] ORCA lines
+    float4* lds_P = lds_L + K * T;                                   // [K][T] LP3 projection lines
+    float* lds_r = reinterpret_cast<float*>(lds_P + K * T);          // [T] radius + margin
+    float* lds_nd = lds_r + T;                                       // [K][T] neighbour distSq
+    int* lds_ni = reinterpret_cast<int*>(lds_nd + K * T);            // [K][T] neighbour row
+    float* lds_rp = reinterpret_cast<float*>(lds_ni + K * T);        // [T] plain radius (respawn rule)
+    float* lds_g0x = lds_rp + T;                                     // [T] respawn scratch
+    int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);             // [T] respawn scratch
+
+    const int tid = threadIdx.x;
+    const int rows = a.rows, n = a.n;
+    const int lw = tid / rows, row = tid - lw * rows;
+    const int w = blockIdx.x * a.wpb + lw;
+    const bool valid = (lw < a.wpb) && (w < a.W);
+    const bool robot_row = (a.flags & CS_ROBOT_ROW) != 0;
+    const bool human = valid && row < n;
+    const bool is_robot = valid && robot_row && row == n;
+    const int base = lw * rows;
+    const float dt = a.dt;
+    const bool respawn_here = valid && (a.world_flags == nullptr || (a.world_flags[w] & 1));
+
+    float px = 0, py = 0, vx = 0, vy = 0, pvx = 0, pvy = 0, r = 0, vmax = 0, margin = 0;
+    float th = 0, om = 0;
+    const long sidx = (long)w * rows + row;
+    float* srow = nullptr;
+    if (valid) {
+        srow = a.S + sidx * a.as;
+        const long fs = a.fs;
+        px = srow[0]; py = srow[fs]; th = srow[2 * fs]; vx = srow[3 * fs]; vy = srow[4 * fs];
+        pvx = srow[5 * fs]; pvy = srow[6 * fs]; om = srow[7 * fs]; r = srow[8 * fs]; vmax = srow[12 * fs];
+        margin = a.margin[sidx];
+    }
+    float* gi = nullptr;
+    float g0x = 0, g0y = 0;
+    if (human) { gi = a.goals + ((long)w * n + row) * a.G * 2; g0x = gi[0]; g0y = gi[1]; }
+
+    // the true robot (moves with the action); the simulator's copy is the state row
+    const bool robot_moves = a.action != nullptr && a.robot != nullptr;
+    float rbx = 0, rby = 0, rbvx = 0, rbvy = 0, ax = 0, ay = 0;
+    if (valid && robot_moves) {
+        const float* rb = a.robot + (long)w * 13;
+        rbx = rb[0]; rby = rb[1]; rbvx = rb[3]; rbvy = rb[4];
+        ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1];
+    }
+
+    if (valid) { lds_pv[tid] = make_float4(px, py, vx, vy); lds_r[tid] = r + margin; lds_rp[tid] = r; }
+    __syncthreads();
+
+    const Lines L{lds_L, T, tid}, P{lds_P, T, tid};
+    int cur = 0;
+    for (int sub = 0; sub < a.nsub; ++sub) {
+        const int nxt = cur ^ 1;
+        if (valid && robot_moves && (is_robot || (!robot_row && row == 0))) { // robot.step(action, dt) (holonomic)
+            rbx += ax * dt; rby += ay * dt; rbvx = ax; rbvy = ay;
+        }
+        if (human) {
+            const float4* pv = lds_pv + cur * T + base;
+            const float* rr = lds_r + base;
+            // ---- Agent::computeNeighbors / insertAgentNeighbor (index order; strict <, ties keep order)
+            int cnt = 0;
+            float rangeSq = a.neighbor_dist * a.neighbor_dist;
+            if (K > 0) {
+                for (int b = 0; b < rows; ++b) {
+                    if (b == row) continue;
+                    const float4 q = pv[b];
+                    const float ddx = px - q.x, ddy = py - q.y;
+                    const float dsq = ddx * ddx + ddy * ddy;
+                    if (dsq < rangeSq) {
+                        if (cnt < K) ++cnt;
+                        int i = cnt - 1;
+                        while (i != 0 && dsq < lds_nd[(i - 1) * T + tid]) {
+                            lds_nd[i * T + tid] = lds_nd[(i - 1) * T + tid];
+                            lds_ni[i * T + tid] = lds_ni[(i - 1) * T + tid];
+                            --i;
+                        }
+                        lds_nd[i * T + tid] = dsq;
+                        lds_ni[i * T + tid] = b;
+                        if (cnt == K) rangeSq = lds_nd[(cnt - 1) * T + tid];
+                    }
+                }
+            }
+            // ---- Agent::computeNewVelocity: one ORCA half-plane per neighbour
+            const float invT = 1.0f / a.time_horizon;
+            for (int k = 0; k < cnt; ++k) {
+                const int b = lds_ni[k * T + tid];
+                const float4 q = pv[b];
+                const float rpx = q.x - px, rpy = q.y - py;
+                const float rvx = vx - q.z, rvy = vy - q.w;
+                const float distSq = rpx * rpx + rpy * rpy;
+                const float R = (r + margin) + rr[b];
+                const float RSq = R * R;
+                float dx, dy, ux, uy;
+                if (distSq > RSq) {
+                    const float wx = rvx - invT * rpx, wy = rvy - invT * rpy;
+                    const float wLenSq = wx * wx + wy * wy;
+                    const float dot1 = wx * rpx + wy * rpy;
+                    if (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq) {
+                        const float wLen = sqrtf(wLenSq);
+                        const float uwx = wx / wLen, uwy = wy / wLen;
+                        dx = uwy; dy = -uwx;
+                        const float s = R * invT - wLen;
+                        ux = s * uwx; uy = s * uwy;
+                    } else {
+                        const float leg = sqrtf(distSq - RSq);
+                        if (det2(rpx, rpy, wx, wy) > 0.0f) {
+                            dx = (rpx * leg - rpy * R) / distSq; dy = (rpx * R + rpy * leg) / distSq;
+                        } else {
+                            dx = -(rpx * leg + rpy * R) / distSq; dy = -(-rpx * R + rpy * leg) / distSq;
+                        }
+                        const float dot2 = rvx * dx + rvy * dy;
+                        ux = dot2 * dx - rvx; uy = dot2 * dy - rvy;
+                    }
+                } else {
+                    const float invDt = 1.0f / dt;
+                    const float wx = rvx - invDt * rpx, wy = rvy - invDt * rpy;
+                    const float wLen = sqrtf(wx * wx + wy * wy);
+                    const float uwx = wx / wLen, uwy = wy / wLen;
+                    dx = uwy; dy = -uwx;
+                    const float s = R * invDt - wLen;
+                    ux = s * uwx; uy = s * uwy;
+                }
+                L.set(k, make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy));
+            }
+            float nvx, nvy;
+            const int failed = lp2(L, cnt, vmax, pvx, pvy, false, nvx, nvy);
+            if (failed < cnt) lp3(L, P, cnt, failed, vmax, nvx, nvy);
+            // ---- Agent::update, then the reference's read-back + update_goals_orca (:390-394, :125-133)
+            vx = nvx; vy = nvy;
+            px += vx * dt; py += vy * dt;
+            float ddx = g0x - px, ddy = g0y - py;
+            if (sqrtf(ddx * ddx + ddy * ddy) < r) { // update_goals: strict <  (:66-70)
+                int k = a.G;
+                for (int g = 0; g < a.G; ++g) if (isnan(gi[2 * g])) { k = g; break; }
+                if (a.peek_out == nullptr) {
+                    const float r0 = gi[0], r1 = gi[1];
+                    for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
+                    if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
+                    g0x = gi[0]; g0y = gi[1];
+                } else if (k > 1) { g0x = gi[2]; g0y = gi[3]; }
+                ddx = g0x - px; ddy = g0y - py;
+            }
+            const float nrm = sqrtf(ddx * ddx + ddy * ddy);
+            if (nrm > vmax) { pvx = ddx / nrm; pvy = ddy / nrm; } else { pvx = ddx; pvy = ddy; }
+            lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
+        } else if (is_robot) {
+            // set_state_orca(robot) AFTER doStep (:389): the simulator's robot agent takes the true state
+            if (robot_moves) { px = rbx; py = rby; vx = rbvx; vy = rbvy; }
+            lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
+        }
+        __syncthreads();
+        if (a.flags & CS_RESPAWN) { // motion_model_manager.py:407-422, sequential inside a world
+            const float rdx = px - g0x, rdy = py - g0y;
+            const int flag = (human && respawn_here && sqrtf(rdx * rdx + rdy * rdy) < 3.0f) ? 1 : 0;
+            if (__builtin_amdgcn_ballot_w64(flag != 0) != 0) {
+                lds_flag[tid] = flag;
+                lds_g0x[tid] = g0x;
+                __syncthreads();
+                if (valid && row == 0) {
+                    float4* pvn = lds_pv + nxt * T + base;
+                    const float* rp = lds_rp + base;
+                    for (int i = 0; i < n; ++i) {
+                        if (!lds_flag[base + i]) continue;
+                        // h.radius + h.safety_space with safety_space == 0 for ORCA humans (mmm.py:154-158)
+                        float mx = pvn[0].x, mr = rp[0];
+                        for (int j = 1; j < n; ++j) { mx = fmaxf(mx, pvn[j].x); mr = fmaxf(mr, rp[j]); }
+                        if (robot_row) { mx = fmaxf(mx, pvn[n].x); mr = fmaxf(mr, rp[n]); }
+                        float4 q = pvn[i];
+                        q.x = fmaxf(mx + mr * 2.0f, a.bx);
+                        q.y = (q.y >= 0.0f) ? fminf(q.y, a.by) : fmaxf(q.y, -a.by);
+                        pvn[i] = q;
+                    }
+                }
+                __syncthreads();
+                if (flag) {
+                    const float4 q = lds_pv[nxt * T + tid];
+                    px = q.x; py = q.y; g0y = py;
+                    if (a.peek_out == nullptr) for (int g = 0; g < a.G; ++g) { gi[2 * g] = g0x; gi[2 * g + 1] = g0y; }
+                }
+            }
+        }
+        cur = nxt;
+    }
+
+    if (a.peek_out != nullptr) { // get_human_states(include_goal=True, headed=False) of the next state
+        if (human) {
+            float* o = a.peek_out + ((long)w * n + row) * 8;
+            o[0] = px; o[1] = py; o[2] = th; o[3] = vx; o[4] = vy; o[5] = om; o[6] = g0x; o[7] = g0y;
+        }
+        return;
+    }
+    if (valid) {
+        const long fs = a.fs;
+        srow[0] = px; srow[fs] = py; srow[3 * fs] = vx; srow[4 * fs] = vy;
+        if (human) { srow[5 * fs] = pvx; srow[6 * fs] = pvy; srow[10 * fs] = g0x; srow[11 * fs] = g0y; }
+        if (robot_moves && (is_robot || (!robot_row && row == 0))) {
+            float* rb = a.robot + (long)w * 13;
+            rb[0] = rbx; rb[1] = rby; rb[3] = rbvx; rb[4] = rbvy;
+        }
+    }
+}
+
+} // namespace
+
+namespace csimpl {
+
+int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream)
+{
+    if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
+    if (w->W <= 0 || w->n <= 0 || w->G <= 0) return fail(CS_ERR_ARG, "W, n, G must be positive");
+    if (!w->d_state || !w->d_goals || !w->d_safety) return fail(CS_ERR_ARG, "null device buffer in cs_worlds");
+    if (w->O != 0) return fail(CS_ERR_ARG, "ORCA static obstacles are not implemented (no Gym scenario has walls)");
+    if (w->flags & CS_ROBOT_UNICYCLE) return fail(CS_ERR_ARG, "ORCA step supports holonomic robot actions only");
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    if (rows > 64) return fail(CS_ERR_ARG, "ORCA step supports up to 64 rows per world");
+    if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
+    if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
+    OArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = w->W; a.n = w->n; a.rows = rows; a.G = w->G; a.flags = w->flags; a.nsub = n_substeps;
+    a.wpb = 64 / rows; a.K = w->orca_max_neighbors;
+    a.dt = dt; a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
+    a.bx = w->respawn_bound_x; a.by = w->respawn_bound_y;
+    a.S = w->d_state;
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * rows; }
+    a.goals = w->d_goals; a.margin = w->d_safety; a.robot = w->d_robot; a.action = d_action;
+    a.peek_out = d_peek; a.world_flags = w->d_world_flags;
+    if (d_peek) a.flags &= ~CS_RESPAWN;
+    const int T = 64;
+    const int grid = (w->W + a.wpb - 1) / a.wpb;
+    const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
+                         (size_t)a.K * T * (2 * sizeof(float4) + 2 * sizeof(float));
+    hipLaunchKernelGGL(k_orca_step, dim3(grid), dim3(T), shmem, stream, a);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+} // namespace csimpl

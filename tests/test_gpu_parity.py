@@ -232,4 +232,4 @@ def test_bad_type_raises_value_error():
 
     c = load_cases("g1_episode")[0]
     with pytest.raises(ValueError):
-        CrowdWorlds(f32(c["state_in"]), f32(c["goals_in"]), f32(c["params"]), type=9)
+        CrowdWorlds(f32(c["state_in"]), f32(c["goals_in"]), f32(c["params"]), type=10)
