@@ -1,0 +1,322 @@
+"""SocialNavGym -- the drop-in Gym boundary (reference: social_gym/social_nav_gym.py:14-277).
+
+``configure(config)``, ``set_robot(robot)``, ``set_safety_space(s)``, ``reset(phase, test_case)``,
+``step(action)``, ``render()`` and the attributes CrowdNav reads (``global_time, time_limit, time_step,
+robot_time_step, case_size, case_counter, humans, robot, motion_model, states, updated,
+motion_model_manager``) keep the reference's names, argument meaning, return shapes and error
+behaviour (``AttributeError`` without a robot, ``ValueError`` for a robot time step that is not a
+multiple of the time step, ``NotImplementedError`` for an unknown human policy).
+
+What differs underneath: the ``time_step_factor`` substeps of ``step()`` (robot move + ``update_humans``
++ respawn, :240-245) are ONE fused kernel launch on the MI355X; PyGame is gone (``render`` is a no-op as
+with the reference's ``HEADLESS = True``); gymnasium is optional (the class subclasses ``gym.Env`` when
+the package is importable).  ``BatchedSocialNavGym`` below runs W such worlds in lock-step.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from .. import _lib
+from ..batched import CrowdWorlds, HUMAN_MODELS as _MODELS
+from .social_nav_sim import SocialNavSim
+from .src.info import INFO_BY_CODE, Collision, Danger, Nothing, ReachGoal, Timeout  # noqa: F401
+from .src.utils import is_multiple
+
+try:  # optional: register / subclass when gymnasium exists (it is not part of this image)
+    import gymnasium as gym
+
+    _EnvBase = gym.Env
+except Exception:  # pragma: no cover
+    gym = None
+
+    class _EnvBase:  # minimal stand-in so isinstance checks on the API shape still work
+        pass
+
+HEADLESS = True
+PARALLELIZE_ROBOT = True
+PARALLELIZE_HUMANS = True
+HUMAN_MODELS = list(_MODELS)
+
+
+class SocialNavGym(_EnvBase, SocialNavSim):
+    def __init__(self):
+        # the reference builds a throw-away 10-human world here (:25); an empty shell is enough
+        self.config_data = {"humans": {}, "walls": [], "headless": True}
+        self.humans = []
+        self.walls = []
+        self.mode = "circular_crossing"
+        self.parallelize_robot = PARALLELIZE_ROBOT
+        self.parallelize_humans = PARALLELIZE_HUMANS
+        self.sampling_time = 1 / 60
+        self.robot_sampling_time = 1 / 4
+        self.real_size = 15
+        self.display_to_real_ratio = 1.0
+        self.updated = True
+        self.sim_t = 0.0
+        self.time_limit = None
+        self.time_step = None
+        self.robot = None
+        self.global_time = None
+        self.human_times = None
+        self.success_reward = None
+        self.collision_penalty = None
+        self.discomfort_dist = None
+        self.discomfort_penalty_factor = None
+        self.config = None
+        self.case_capacity = None
+        self.case_size = None
+        self.case_counter = None
+        self.randomize_attributes = None
+        self.train_val_sim = None
+        self.test_sim = None
+        self.square_width = None
+        self.circle_radius = None
+        self.human_num = None
+        self.safety_space = 0
+        self.states = None
+        self.action_values = None
+        self.attention_weights = None
+        self.action_space = gym.spaces.Discrete(1) if gym is not None else None
+        self.observation_space = gym.spaces.Discrete(1) if gym is not None else None
+
+    # ------------------------------------------------------------------ configuration (:59-98)
+    def configure(self, config):
+        self.config = config
+        self.time_limit = config.getint("env", "time_limit")
+        self.time_step = config.getfloat("env", "time_step")
+        self.robot_time_step = config.getfloat("env", "robot_time_step")
+        if not is_multiple(self.robot_time_step, self.time_step):
+            raise ValueError("Robot time step must be a multiple of time step")
+        self.time_step_factor = int(self.robot_time_step / self.time_step)
+        self.randomize_attributes = config.getboolean("env", "randomize_attributes")
+        self.success_reward = config.getfloat("reward", "success_reward")
+        self.collision_penalty = config.getfloat("reward", "collision_penalty")
+        self.discomfort_dist = config.getfloat("reward", "discomfort_dist")
+        self.discomfort_penalty_factor = config.getfloat("reward", "discomfort_penalty_factor")
+        self.human_policy = config.get("humans", "policy")
+        self.robot_radius = config.getfloat("robot", "radius")
+        if self.human_policy not in HUMAN_MODELS:
+            raise NotImplementedError
+        u32 = np.iinfo(np.uint32).max
+        self.case_capacity = {"train": u32 - 2000, "val": 1000, "test": 1000}
+        self.case_size = {"train": u32 - 2000, "val": config.getint("env", "val_size"), "test": config.getint("env", "test_size")}
+        self.train_val_sim = config.get("sim", "train_val_sim")
+        self.test_sim = config.get("sim", "test_sim")
+        self.traffic_height = config.getfloat("sim", "traffic_height")
+        self.traffic_length = config.getfloat("sim", "traffic_length")
+        self.circle_radius = config.getfloat("sim", "circle_radius")
+        self.human_num = config.getint("sim", "human_num")
+        self.case_counter = {"train": 0, "test": 0, "val": 0}
+        logging.info("human number: {}".format(self.human_num))
+        logging.info("Human policy: {}".format(self.human_policy))
+
+    def set_safety_space(self, safety_space: float):
+        self.safety_space = safety_space
+
+    def set_robot(self, robot):
+        self.robot = robot
+        if PARALLELIZE_ROBOT:
+            self.robot.parallelize = True
+
+    def compute_humans_observable_state(self):
+        if self.robot.sensor == "coordinates":
+            headed = self.robot.policy.with_theta_and_omega_visible
+            return [h.get_observable_state(visible_theta_and_omega=True) if headed else h.get_observable_state() for h in self.humans]
+        raise NotImplementedError
+
+    def check_actual_collisions_and_goal(self):
+        dmin, collision = 10000.0, False
+        for h in self.humans:
+            d = np.linalg.norm(h.position - self.robot.position) - h.radius - self.robot.radius
+            dmin = d if d < dmin else dmin
+            if dmin <= 0:
+                collision = True
+        reaching_goal = np.linalg.norm(self.robot.position - self.robot.get_goal_position()) < self.robot.radius
+        return collision, dmin, reaching_goal
+
+    # ------------------------------------------------------------------ reset (:120-225)
+    def _generate(self, scenario, human_num):
+        kw = dict(insert_robot=True, human_policy=self.human_policy, headless=HEADLESS, runge_kutta=False,
+                  robot_visible=self.robot.visible, robot_radius=self.robot_radius, n_actors=human_num,
+                  randomize_human_attributes=self.randomize_attributes)
+        if scenario == "circle_crossing":
+            self.generate_circular_crossing_setting(circle_radius=self.circle_radius, randomize_human_positions=True, **kw)
+        elif scenario == "parallel_traffic":
+            self.generate_parallel_traffic_scenario(traffic_length=self.traffic_length, traffic_height=self.traffic_height, **kw)
+        elif scenario == "circular_crossing_with_static_obstacles":
+            self.generate_circular_crossing_with_static_obstacles(circle_radius=self.circle_radius, randomize_human_positions=True, **kw)
+        # any other name: the reference falls through its elif chain and keeps the previous config_data
+
+    def reset(self, phase="test", test_case=None):
+        if self.robot is None:
+            raise AttributeError("robot has to be set!")
+        assert phase in ["train", "val", "test"]
+        if test_case is not None:
+            self.case_counter[phase] = test_case
+        if self.robot.parallelize:
+            self.robot.policy.parallelize = True
+        self.global_time = 0
+        multi = self.robot.policy.multiagent_training
+        self.human_times = [0] * (self.human_num if (phase == "test" or multi) else 1)
+        if self.config.get("humans", "policy") == "trajnet":
+            raise NotImplementedError
+        counter_offset = {"train": self.case_capacity["val"] + self.case_capacity["test"], "val": 0, "test": self.case_capacity["val"]}
+        if self.case_counter[phase] >= 0:
+            seed = counter_offset[phase] + self.case_counter[phase]
+            np.random.seed(seed)
+            if phase in ["train", "val"]:
+                human_num = self.human_num if multi else 1
+                scenario = self.train_val_sim
+            else:
+                human_num = self.human_num
+                scenario = self.test_sim
+            if scenario == "hybrid_scenario":
+                scenario = np.random.choice(["circle_crossing", "parallel_traffic"])
+                np.random.seed(seed)  # the choice draw is discarded: the generator restarts the stream (:156-157)
+            self._generate(str(scenario), human_num)
+            self.case_counter[phase] = (self.case_counter[phase] + 1) % self.case_size[phase]
+        else:
+            assert phase == "test"
+            if self.case_counter[phase] == -1:  # the reference's debugging case (:199-209)
+                self.human_num = 3
+                humans = {0: {"pos": [0, -6], "yaw": np.pi / 2, "goals": [[0, 5], [0, -6]]},
+                          1: {"pos": [-5, -5], "yaw": np.pi / 2, "goals": [[-5, 5], [-5, -5]]},
+                          2: {"pos": [5, -5], "yaw": np.pi / 2, "goals": [[5, 5], [5, -5]]}}
+                robot = {"pos": [7.5, 7.5], "yaw": 0.0, "radius": 0.25, "goals": [[7.5, 7.5]]}
+                self.config_data = {"headless": False, "motion_model": "sfm_helbing", "runge_kutta": False, "insert_robot": True,
+                                    "grid": True, "humans": humans, "walls": [], "robot": robot}
+            else:
+                raise NotImplementedError
+        self.robot.set_radius_and_update_graphics(self.robot_radius)
+        r = self.config_data["robot"]
+        self.robot.set(r["pos"][0], r["pos"][1], r["goals"][0][0], r["goals"][0][1], 0, 0, r["yaw"], w=0)
+        self.reset_sim(reset_robot=False)
+        if self.safety_space > 0:
+            self.motion_model_manager.set_safety_space(self.safety_space)
+        self.set_time_step(self.time_step)
+        self.set_robot_time_step(self.robot_time_step)
+        self.states = list()
+        if hasattr(self.robot.policy, "action_values"):
+            self.action_values = list()
+        if hasattr(self.robot.policy, "get_attention_weights"):
+            self.attention_weights = list()
+        return self.compute_humans_observable_state(), {0: Nothing()}
+
+    # ------------------------------------------------------------------ step (:227-250)
+    def step(self, action):
+        collision, dmin, reaching_goal = self.collision_detection_and_reaching_goal(action, self.robot_time_step)
+        reward, terminated, truncated, info = self.compute_reward_and_infos(collision, dmin, reaching_goal, self.global_time,
+                                                                            self.robot_time_step)
+        self.states.append([self.robot.get_full_state(), [h.get_full_state() for h in self.humans]])
+        if hasattr(self.robot.policy, "action_values"):
+            self.action_values.append(self.robot.policy.action_values)
+        if hasattr(self.robot.policy, "get_attention_weights"):
+            self.attention_weights.append(self.robot.policy.get_attention_weights())
+        # time_step_factor x { robot.step(action, dt) ; update_humans(t, dt) } -> one fused launch
+        self.robot.check_validity(action)
+        unicycle = self.robot.kinematics != "holonomic"
+        act = (action.v, action.r) if unicycle else (action.vx, action.vy)
+        self.motion_model_manager.update_humans_block(self.time_step, self.time_step_factor, act, unicycle=unicycle)
+        for _ in range(self.time_step_factor):
+            self.global_time += self.time_step
+        self.updated = True
+        return self.compute_humans_observable_state(), reward, terminated, truncated, {0: info}
+
+    def imitation_learning_step(self):
+        raise NotImplementedError("imitation learning drives the robot with a human motion model (motion_model_manager.py:"
+                                  "615-653), which is outside the crowd-step hot path of this build")
+
+    def set_human_motion_model_as_robot_policy(self, *a, **k):
+        raise NotImplementedError("see imitation_learning_step")
+
+    def render(self):
+        return None
+
+
+class BatchedSocialNavGym:
+    """W independent SocialNavGym worlds advanced in lock-step on one GPU.
+
+    Same episode logic as ``SocialNavGym.step`` -- reward / termination from the swept collision test on the
+    CURRENT state (cs_collision_reward), then ``time_step_factor`` fused substeps (cs_step) -- with arrays
+    instead of object lists: observations ``[W, N, 5]`` (px, py, vx, vy, radius) or ``[W, N, 7]`` (+ theta,
+    omega), rewards ``[W]``, terminated / truncated ``[W]`` bool, ``info_code [W]`` (index into
+    ``social_gym.src.info.INFO_BY_CODE``).  Worlds are generated by the exact reference generators from
+    seeds ``offset[phase] + case`` (one per world) through a scratch ``SocialNavGym``; every world needs the
+    same human count and goal-slot count (a hybrid batch pads traffic goals with NaN).
+    """
+
+    def __init__(self, config, n_worlds: int, robot_visible=False, robot_radius=None, headed_obs=False):
+        self.W = int(n_worlds)
+        self.headed_obs = bool(headed_obs)
+        self._proto = SocialNavGym()
+        self._proto.configure(config)
+        self.config = config
+        self.time_step = self._proto.time_step
+        self.robot_time_step = self._proto.robot_time_step
+        self.time_step_factor = self._proto.time_step_factor
+        self.time_limit = self._proto.time_limit
+        self.robot_visible = bool(robot_visible)
+        self.reward_cfg = (float(self.time_limit), self._proto.success_reward, self._proto.collision_penalty,
+                           self._proto.discomfort_dist, self._proto.discomfort_penalty_factor)
+        self.global_time = None
+        self.cw = None
+
+    def reset(self, phase="test", first_case=0, safety_space=0.0):
+        from .src.agent import RobotAgent
+        from types import SimpleNamespace
+
+        proto = self._proto
+        rows_s, rows_g, rows_p, rows_r, respawn = [], [], [], [], []
+        model = proto.human_policy
+        for w in range(self.W):
+            robot = RobotAgent(proto)
+            robot.visible, robot.sensor, robot.kinematics = self.robot_visible, "coordinates", "holonomic"
+            robot.policy = SimpleNamespace(multiagent_training=True, with_theta_and_omega_visible=self.headed_obs, kinematics="holonomic")
+            proto.parallel_traffic_humans_respawn = False  # one fresh env per world: no sticky respawn flag
+            proto.set_robot(robot)
+            proto.reset(phase=phase, test_case=first_case + w)
+            mm = proto.motion_model_manager
+            rows_s.append(mm.states.copy())
+            rows_g.append(mm.goals.copy())
+            rows_p.append(None if mm.params is None else mm.params.copy())
+            rows_r.append(robot.get_safe_state())
+            respawn.append(1 if mm.parallel_traffic_humans_respawn else 0)
+            bounds = mm.respawn_bounds if mm.parallel_traffic_humans_respawn else None
+            if bounds is not None:
+                self._bounds = bounds
+        gmax = max(g.shape[1] for g in rows_g)
+        n = rows_g[0].shape[0]
+        goals = np.full((self.W, n, gmax, 2), np.nan)
+        for w, g in enumerate(rows_g):
+            goals[w, :, :g.shape[1]] = g
+        S = np.stack(rows_s)
+        P = None if rows_p[0] is None else np.stack(rows_p)
+        self.n = n
+        self.radius = S[:, :n, 8].astype(np.float32)
+        margin = np.zeros((self.W, S.shape[1]))
+        if model == "orca":
+            margin += 0.01 + safety_space
+        elif safety_space > 0:
+            margin[:, :n] = 0.01 + safety_space
+        any_respawn = any(respawn)
+        self.cw = CrowdWorlds(S, goals, P, margin, None, type=model, all_params_equal=True, robot_row=self.robot_visible,
+                              robot=np.stack(rows_r), respawn_bounds=self._bounds if any_respawn else None,
+                              respawn_worlds=np.array(respawn, np.int32) if any_respawn else None)
+        self.global_time = np.zeros(self.W, np.float32)
+        return self.observe()
+
+    def observe(self):
+        S = self.cw.get_states()[:, :self.n]
+        cols = [0, 1, 3, 4, 8] + ([2, 7] if self.headed_obs else [])
+        return S[:, :, cols]
+
+    def step(self, actions):
+        """actions [W, 2] holonomic (vx, vy).  Returns (obs, reward [W], terminated [W], truncated [W], info_code [W])."""
+        actions = np.ascontiguousarray(np.broadcast_to(np.asarray(actions, np.float32), (self.W, 2)))
+        out = self.cw.collision_reward(actions, self.robot_time_step, self.global_time, self.reward_cfg)
+        self.cw.step(self.time_step, self.time_step_factor, actions)
+        for _ in range(self.time_step_factor):
+            self.global_time += np.float32(self.time_step)
+        return self.observe(), out[:, 3].copy(), out[:, 4] > 0, out[:, 5] > 0, out[:, 6].astype(np.int32)

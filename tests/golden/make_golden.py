@@ -363,6 +363,7 @@ def gen_g3_gym():
                 obs = [ob_to_array(ob)]
                 actions, rewards, terms, truncs, infos, dmins = [], [], [], [], [], []
                 mm_states = [env.motion_model_manager.states.copy()]
+                mm_goals = [env.motion_model_manager.goals.copy()]
                 robot_states = [np.array([*env.robot.position, env.robot.yaw, *env.robot.linear_velocity])]
                 nsteps = 10
                 for k in range(nsteps):
@@ -380,6 +381,7 @@ def gen_g3_gym():
                     infos.append(type(info[0]).__name__)
                     dmins.append(float(getattr(info[0], "min_dist", np.nan)))
                     mm_states.append(env.motion_model_manager.states.copy())
+                    mm_goals.append(env.motion_model_manager.goals.copy())
                     robot_states.append(np.array([*env.robot.position, env.robot.yaw, *env.robot.linear_velocity]))
                 mm = env.motion_model_manager
                 cases.append(dict(model=model, scenario=scen, robot_visible=robot_visible, phase=phase,
@@ -388,7 +390,8 @@ def gen_g3_gym():
                                   respawn=bool(mm.parallel_traffic_humans_respawn),
                                   obs=np.array(obs), actions=np.array(actions), rewards=np.array(rewards),
                                   terminated=np.array(terms), truncated=np.array(truncs), infos=infos,
-                                  dmins=np.array(dmins), mm_states=np.array(mm_states),
+                                  dmins=np.array(dmins), mm_states=np.array(mm_states), mm_goals=np.array(mm_goals),
+                                  mm_safety=mm.safety_space.copy(), all_params_equal=bool(mm.all_equal_humans),
                                   robot_states=np.array(robot_states), global_time=float(env.global_time)))
                 env.parallel_traffic_humans_respawn = False
     print("g3_gym:", len(cases), "cases ->", save_cases("g3_gym", cases))
