@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per agent-substep, f32 (SURVEY.md §8d / BASELINE.md §4)
 ALG_BYTES = {"sfm": 52, "hsfm": 76, "orca": 48}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+# HBM-side bytes per agent per LAUNCH from rocprofv3 PMC passes of this very command (profiles/r1c_pmc_traffic.md):
+# (FETCH_SIZE 5550.0 KB + WRITE_SIZE 4505.9 KB) / (4096 x 25 agents); independent of the number of fused substeps.
+# FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950 (reads 0.87x the 64 B/agent the code loads).
+MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH = {("hsfm_farina", "hybrid", False): (5550.04 + 4505.90) * 1024 / (4096 * 25)}
 
 
 def parse():
@@ -56,8 +60,11 @@ def build_worlds(args, rank):
     from social_navigation_pyenvs_amd import scenarios as sc
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
+    from social_navigation_pyenvs_amd.sharding import shard_seed, world_shard
+
     W, n = args.worlds, args.agents
-    seed0 = 1000 + rank * 7919
+    first, _ = world_shard(rank, int(os.environ.get("WORLD_SIZE", "1")), W)
+    seed0 = shard_seed(first)
     respawn_bounds = None
     respawn_worlds = None
     if args.scenario == "hybrid":
@@ -82,40 +89,42 @@ def build_worlds(args, rank):
 
 def cpu_baseline(args, host, type_id):
     """The C oracle (port of the reference's f64 array kernel) on this box's host cores, on a bounded
-    sample of the same workload: the first `sample_worlds` worlds, blocks of `substeps` substeps."""
+    sample of the same workload: the first `sample_worlds` worlds, blocks of `substeps` substeps, stepped in
+    place (no host copies in the timed loop).  Run on all cores (OpenMP over worlds) and on one."""
     from oracle import crowd_oracle as orc
 
     orc.build()
     cores = orc.num_threads()
-    sample_worlds = min(args.worlds, 64 * max(1, cores))
-    idx = np.arange(sample_worlds)
-    S = host["S"][idx].astype(np.float64)
-    goals = host["goals"][idx].astype(np.float64)
     respawn = host["respawn_bounds"] is not None
     rp = (host["respawn_bounds"][0], host["respawn_bounds"][1], 0.0) if respawn else (0.0, 0.0, 0.0)
-    # the oracle has one respawn switch per call: run traffic and crossing worlds as two groups
-    groups = [(idx, respawn)] if host["respawn_worlds"] is None else \
-        [(idx[host["respawn_worlds"][idx] == 1], True), (idx[host["respawn_worlds"][idx] == 0], False)]
-    safety = np.zeros((sample_worlds, S.shape[1]))
-    done = 0
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        for sel, rs in groups:
-            if sel.size == 0:
-                continue
-            s2, g2, _ = orc.step_block(type_id, S[sel], goals[sel], host["walls"], host["P"].astype(np.float64),
-                                       args.dt, args.substeps, safety[sel], True, respawn=rs, respawn_par=rp,
-                                       dtype=np.float64, threads=cores)
-            S[sel], goals[sel] = s2, g2
-            done += sel.size * args.substeps
-        reps += 1
-        if time.perf_counter() - t0 >= args.cpu_seconds:
-            break
-    el = time.perf_counter() - t0
-    return {"value": done * args.agents / el, "unit": "agent-substeps/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_worlds} worlds x {args.agents} agents x {reps * args.substeps} substeps "
-                      f"(f64 C oracle, OpenMP over worlds, {el:.1f} s)"}
+
+    def timed(sample_worlds, threads, seconds):
+        idx = np.arange(sample_worlds)
+        groups = [(idx, respawn)] if host["respawn_worlds"] is None else \
+            [(idx[host["respawn_worlds"][idx] == 1], True), (idx[host["respawn_worlds"][idx] == 0], False)]
+        runners = [orc.StepBlockRunner(type_id, host["S"][sel], host["goals"][sel], host["walls"], host["P"],
+                                       np.zeros((sel.size, host["S"].shape[1])), True, respawn=rs, respawn_par=rp,
+                                       dtype=np.float64, threads=threads) for sel, rs in groups if sel.size]
+        done, reps = 0, 0
+        t0 = time.perf_counter()
+        while True:
+            for r in runners:
+                r.run(args.dt, args.substeps)
+                done += r.W * args.substeps
+            reps += 1
+            if time.perf_counter() - t0 >= seconds:
+                break
+        el = time.perf_counter() - t0
+        return done * args.agents / el, reps, el
+
+    sw_all = min(args.worlds, 32 * max(1, cores))
+    v_all, reps, el = timed(sw_all, cores, args.cpu_seconds)
+    v_one, reps1, el1 = timed(min(args.worlds, 64), 1, min(4.0, args.cpu_seconds))
+    return {"value": v_all, "unit": "agent-substeps/s", "cores": cores, "kind": "port",
+            "single_core_value": v_one,
+            "sample": f"{sw_all} worlds x {args.agents} agents x {reps * args.substeps} substeps, f64 C oracle "
+                      f"(oracle/), OpenMP over worlds on {cores} threads, {el:.1f} s; single-core leg: 64 worlds x "
+                      f"{reps1 * args.substeps} substeps, {el1:.1f} s"}
 
 
 def main():
@@ -165,10 +174,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = np.array([starts[k].elapsed_ms(stops[k]) for k in range(args.steps)])
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from social_navigation_pyenvs_amd.sharding import max_over_ranks
+
+    elapsed = max_over_ranks(elapsed, dist, device="cuda")
 
     # sanity: the state is finite and moved
     S_end = cw.get_states()
@@ -210,7 +218,10 @@ def main():
             "finite_fraction": finite,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": (MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH[(args.model, args.scenario, args.walls)] * args.worlds * args.agents
+                            if (args.model, args.scenario, args.walls) in MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH else None),
+                "traffic_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)",
                 "kernel": "k_sfm_step", "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kernel_ms)),
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "bytes_per_agent_substep": ALG_BYTES[family],

@@ -119,6 +119,40 @@ def step_block(type_, S, goals, obstacles, P, dt, n_substeps, safety, all_params
     return S, goals, robot
 
 
+class StepBlockRunner:
+    """In-place, copy-free repeated calls of orc_step_block_batched (for timing the CPU baseline)."""
+
+    def __init__(self, type_, S, goals, obstacles, P, safety, all_params_equal, respawn=False,
+                 respawn_par=(0.0, 0.0, 0.0), dtype=np.float64, threads=0):
+        self.sfx, self.ct = _suffix(dtype)
+        self.S = np.ascontiguousarray(S, dtype=dtype).copy()
+        self.W, self.rows = self.S.shape[0], self.S.shape[1]
+        self.n = self.rows
+        self.goals = np.ascontiguousarray(goals, dtype=dtype).copy().reshape(self.W, self.n, -1, 2)
+        self.G = self.goals.shape[2]
+        P = np.ascontiguousarray(P, dtype=dtype)
+        self.P = np.broadcast_to(P, (self.W,) + P.shape[-2:]).copy() if P.ndim == 2 else P
+        self.safety = np.ascontiguousarray(np.broadcast_to(np.asarray(safety, dtype=dtype), (self.W, self.rows)))
+        self.obs = None if obstacles is None else np.ascontiguousarray(obstacles, dtype=dtype)
+        self.O, self.Smax = (0, 0) if self.obs is None else (self.obs.shape[-4], self.obs.shape[-3])
+        self.obs_stride = 0 if (self.obs is None or self.obs.ndim == 4) else int(np.prod(self.obs.shape[1:]))
+        self.type_, self.peq, self.respawn = type_, all_params_equal, respawn
+        self.rp = np.asarray(respawn_par, dtype=dtype)
+        self.threads = threads
+        self.fn = getattr(lib(), f"orc_step_block_batched_{self.sfx}")
+        self.fn.restype = C.c_int
+
+    def run(self, dt, n_substeps):
+        ct = self.ct
+        rc = self.fn(C.c_int(self.W), C.c_int(self.type_), _ptr(self.S, ct), _ptr(self.goals, ct), C.c_int(self.G),
+                     _ptr(self.obs, ct), C.c_size_t(self.obs_stride), C.c_int(self.O), C.c_int(self.Smax),
+                     _ptr(self.P, ct), C.c_size_t(self.n * 20), ct(dt), C.c_int(n_substeps), _ptr(self.safety, ct),
+                     C.c_int(int(self.peq)), C.c_int(0), C.c_int(self.rows), None, None, C.c_int(0),
+                     C.c_int(int(self.respawn)), _ptr(self.rp, ct), C.c_int(self.threads))
+        if rc != 0:
+            raise ValueError(f"oracle step_block failed rc={rc}")
+
+
 def respawn(S, goals, safety, robot, bound_x, bound_y, dtype=np.float64):
     sfx, ct = _suffix(dtype)
     S = np.ascontiguousarray(S, dtype=dtype).copy()
