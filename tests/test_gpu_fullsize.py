@@ -1,0 +1,83 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties: batch composition must not
+change any world (bitwise "checksum of checksums"), speeds respect the clamp, sampled worlds equal the oracle."""
+import numpy as np
+import pytest
+
+from oracle import crowd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _worlds(cfg):
+    from social_navigation_pyenvs_amd import scenarios as sc
+
+    if cfg == "cfg2":      # 4096 worlds x 10-agent SFM circle crossing
+        W, n, model = 4096, 10, "sfm_helbing"
+        pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
+        S, goals, P, rb, rw, walls = sc.make_states(pos, yaw, g), g, np.tile(sc.default_params(model), (n, 1)), None, None, None
+    elif cfg == "cfg3":    # 4096 worlds x 25-agent HSFM hybrid scenario
+        W, n, model = 4096, 25, "hsfm_farina"
+        S, goals, P, rb = sc.hybrid_worlds(W, n, model)
+        rw, walls = (np.arange(W) % 2 == 1).astype(np.int32), None
+    else:                  # one GPU's shard of cfg5: 8192 worlds x 50-agent HSFM + static obstacles (both flavours)
+        W, n, model = 8192, 50, "hsfm_farina"  # (hsfm_new* blows up |omega| to 1e108 in the f64 reference itself here)
+        pos, yaw, g = sc.circular_crossing(W, n, 14.0, 1000)
+        S, goals = sc.make_states(pos, yaw, g), g
+        S[:, :3, 12] = 0.0                      # three immobile "obstacle" humans, larger radius, goal = own position
+        S[:, :3, 8] = 0.8
+        goals[:, :3, 0] = S[:, :3, 0:2]; goals[:, :3, 1] = S[:, :3, 0:2]; S[:, :3, 10:12] = S[:, :3, 0:2]
+        P, rb, rw, walls = np.tile(sc.default_params(model), (n, 1)), None, None, sc.polygon_walls()
+    return W, n, model, S.astype(np.float32), goals.astype(np.float32), P.astype(np.float32), rb, rw, walls
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5shard"])
+def test_full_size_properties(cfg):
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    W, n, model, S, goals, P, rb, rw, walls = _worlds(cfg)
+    peq = True
+
+    def run(sel, nsub=20, steps=3):
+        cw = CrowdWorlds(S[sel], goals[sel], P, None, walls, type=model, all_params_equal=peq, respawn_bounds=rb,
+                         respawn_worlds=None if rw is None else rw[sel], layout="soa")
+        for _ in range(steps):
+            cw.step(0.0125, nsub)
+        return cw.get_states(), cw.get_goals()
+
+    full, gfull = run(np.arange(W))
+    assert np.all(np.isfinite(full[..., :8]))
+    # (1) composition invariance, bitwise: a permuted half-batch gives the same rows for the same worlds
+    rng = np.random.default_rng(0)
+    sel = rng.permutation(W)[: W // 2 + 3]
+    part, gpart = run(sel)
+    np.testing.assert_array_equal(part, full[sel])
+    np.testing.assert_array_equal(gpart, gfull[sel])
+    # (2) the speed clamp holds for every agent (body speed for HSFM == |v| after R(theta))
+    sp = np.linalg.norm(full[..., 3:5], axis=-1)
+    assert np.all(sp <= S[..., 12] * (1 + 1e-5) + 1e-6)
+    # (3) things that must not change: radius, mass, desired speed
+    np.testing.assert_array_equal(full[..., [8, 9, 12]], S[..., [8, 9, 12]])
+    # (4) sampled worlds against the f64 oracle, one substep from the evolved state
+    cw = CrowdWorlds(full, gfull, P, None, walls, type=model, all_params_equal=peq, layout="aos")
+    out = cw.get_states(cw.update_humans_parallel(0.0125, in_place=False))
+    for w in rng.choice(W, 12, replace=False):
+        ref, _, _ = orc.update_humans(SFMS.index(model), full[w].astype(np.float64), gfull[w].astype(np.float64),
+                                      None if walls is None else walls.astype(np.float32).astype(np.float64),
+                                      P.astype(np.float64), 0.0125, np.zeros(n), peq, False)
+        err = np.max(np.abs(out[w][:, [0, 1, 3, 4]] - ref[:, [0, 1, 3, 4]]))
+        assert err < 1e-5, (cfg, int(w), err)
+
+
+def test_fused_block_equals_repeated_single_substeps_bitwise():
+    """n fused substeps == n launches of one substep (same arithmetic, state round-trips through HBM)."""
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n, model, S, goals, P, rb, rw, walls = _worlds("cfg3")
+    sel = np.arange(512)
+    a = CrowdWorlds(S[sel], goals[sel], P, None, None, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw[sel])
+    b = CrowdWorlds(S[sel], goals[sel], P, None, None, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw[sel])
+    a.step(0.0125, 20)
+    for _ in range(20):
+        b.step(0.0125, 1)
+    np.testing.assert_array_equal(a.get_states(), b.get_states())
+    np.testing.assert_array_equal(a.get_goals(), b.get_goals())
