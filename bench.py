@@ -68,20 +68,26 @@ def build_worlds(args, rank):
     respawn_bounds = None
     respawn_worlds = None
     if args.scenario == "hybrid":
-        S, goals, P, respawn_bounds = sc.hybrid_worlds(W, n, args.model, seed0=seed0)
+        S, goals, P, respawn_bounds = sc.hybrid_worlds(W, n, "sfm_helbing" if args.model == "orca" else args.model, seed0=seed0)
         respawn_worlds = (np.arange(W) % 2 == 1).astype(np.int32)
     elif args.scenario == "circle":
         radius = 7.0 if n <= 30 else 7.0 * n / 25.0
         pos, yaw, g = sc.circular_crossing(W, n, radius, seed0)
         S, goals = sc.make_states(pos, yaw, g), g
-        P = np.tile(sc.default_params(args.model), (n, 1))
+        P = None if args.model == "orca" else np.tile(sc.default_params(args.model), (n, 1))
     else:
         pos, yaw, g = sc.parallel_traffic(W, n, seed0=seed0)
         S, goals = sc.make_states(pos, yaw, g), g
-        P = np.tile(sc.default_params(args.model), (n, 1))
+        P = None if args.model == "orca" else np.tile(sc.default_params(args.model), (n, 1))
         respawn_bounds = (7.0, 1.5)
     walls = sc.polygon_walls() if args.walls else None
-    cw = CrowdWorlds(S, goals, P, None, walls, type=args.model, all_params_equal=True,
+    margin = None
+    if args.model == "orca":  # cfg4: RVO2 agents, radius + 0.01, preferred velocity in columns 5:7 (unit vector to the goal)
+        P = None
+        d = goals[:, :, 0] - S[:, :, 0:2]
+        S[:, :, 5:7] = d / np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
+        margin = np.full(S.shape[:2], 0.01)
+    cw = CrowdWorlds(S, goals, P, margin, walls, type=args.model, all_params_equal=True,
                      respawn_bounds=respawn_bounds, respawn_worlds=respawn_worlds, layout=args.layout)
     host = dict(S=S, goals=goals, P=P, walls=walls, respawn_bounds=respawn_bounds, respawn_worlds=respawn_worlds)
     return cw, host
@@ -135,7 +141,7 @@ def main():
     import torch
 
     from social_navigation_pyenvs_amd import _lib
-    from social_navigation_pyenvs_amd.batched import SFMS
+    from social_navigation_pyenvs_amd.batched import HUMAN_MODELS as SFMS
 
     _lib.require_gpu()
     torch.cuda.set_device(local_rank)
@@ -185,7 +191,7 @@ def main():
     if rank == 0:
         agent_substeps = world_size * args.worlds * args.agents * n_sub * args.steps
         value = agent_substeps / elapsed
-        family = "hsfm" if args.model.startswith("hsfm") else "sfm"
+        family = "orca" if args.model == "orca" else ("hsfm" if args.model.startswith("hsfm") else "sfm")
         alg_bytes_launch = ALG_BYTES[family] * args.worlds * args.agents * n_sub
         if args.walls:
             alg_bytes_launch += 16 * 15 * 0  # walls are shared by all worlds: 0 B per world-substep
@@ -222,12 +228,12 @@ def main():
                 "traffic": (MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH[(args.model, args.scenario, args.walls)] * args.worlds * args.agents
                             if (args.model, args.scenario, args.walls) in MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH else None),
                 "traffic_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)",
-                "kernel": "k_sfm_step", "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kernel_ms)),
+                "kernel": "k_orca_step" if args.model == "orca" else "k_sfm_step", "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kernel_ms)),
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "bytes_per_agent_substep": ALG_BYTES[family],
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.model != "orca":
             out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
         print(json.dumps(out))

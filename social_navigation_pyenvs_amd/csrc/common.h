@@ -16,6 +16,10 @@ inline int fail(int code, const std::string& msg)
     return code;
 }
 
+#ifdef CS_STAMPS
+extern unsigned long long* g_stamp_buf; // diagnostic build only (tools/stamp_probe.py)
+#endif
+
 // ORCA branch (orca.hip)
 int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);
 

@@ -24,6 +24,9 @@
 
 namespace csimpl {
 thread_local std::string g_err;
+#ifdef CS_STAMPS
+unsigned long long* g_stamp_buf = nullptr;
+#endif
 }
 
 namespace {
@@ -730,7 +733,7 @@ kfn pick_kernel(int type, bool peq)
 }
 
 #ifdef CS_STAMPS
-unsigned long long* g_stamp_buf = nullptr;
+using csimpl::g_stamp_buf;
 #endif
 
 struct Geometry { int grid, block, wpb; };

@@ -20,6 +20,20 @@
 
 #pragma clang fp contract(off)
 
+#ifdef CS_STAMPS
+#define OSTAMP(k)                                                                            \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long t__;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if (g_ost) { g_ost[k] += t__ - g_ost_last; }                                         \
+        g_ost_last = t__;                                                                    \
+    } while (0)
+#else
+#define OSTAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 using csimpl::fail;
@@ -37,9 +51,12 @@ struct OArgs {
     const float* action;
     float* peek_out;
     const int* world_flags;
+    unsigned long long* stamps;
 };
 
 __device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+// IEEE divide / sqrt are kept on purpose: with v_rcp_f32 / v_sqrt_f32 the kernel ran 1.3x faster but left the
+// 1e-5 band around the C restatement (the LP's branch decisions amplify ulp-level differences).
 
 // per-lane column views into LDS: element i of lane tid lives at base[i * T + tid]
 struct Lines {
@@ -131,6 +148,145 @@ __device__ void lp3(const Lines& L, const Lines& P, int nl, int begin, float rad
     }
 }
 
+// One ORCA half-plane (RVO2 Agent::computeNewVelocity, agent part): q = (x, y, vx, vy) of the neighbour,
+// R = combined radius.  Returns (point.x, point.y, direction.x, direction.y).
+__device__ __forceinline__ float4 orca_line(float px, float py, float vx, float vy, const float4 q, float R, float invT, float dt)
+{
+    const float rpx = q.x - px, rpy = q.y - py;
+    const float rvx = vx - q.z, rvy = vy - q.w;
+    const float distSq = rpx * rpx + rpy * rpy;
+    const float RSq = R * R;
+    float dx, dy, ux, uy;
+    if (distSq > RSq) {
+        const float wx = rvx - invT * rpx, wy = rvy - invT * rpy;
+        const float wLenSq = wx * wx + wy * wy;
+        const float dot1 = wx * rpx + wy * rpy;
+        if (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq) {
+            const float wLen = sqrtf(wLenSq);
+            const float uwx = wx / wLen, uwy = wy / wLen;
+            dx = uwy; dy = -uwx;
+            const float s = R * invT - wLen;
+            ux = s * uwx; uy = s * uwy;
+        } else {
+            const float leg = sqrtf(distSq - RSq);
+            if (det2(rpx, rpy, wx, wy) > 0.0f) {
+                dx = (rpx * leg - rpy * R) / distSq; dy = (rpx * R + rpy * leg) / distSq;
+            } else {
+                dx = -(rpx * leg + rpy * R) / distSq; dy = -(-rpx * R + rpy * leg) / distSq;
+            }
+            const float dot2 = rvx * dx + rvy * dy;
+            ux = dot2 * dx - rvx; uy = dot2 * dy - rvy;
+        }
+    } else {
+        const float invDt = 1.0f / dt;
+        const float wx = rvx - invDt * rpx, wy = rvy - invDt * rpy;
+        const float wLen = sqrtf(wx * wx + wy * wy);
+        const float uwx = wx / wLen, uwy = wy / wLen;
+        dx = uwy; dy = -uwx;
+        const float s = R * invDt - wLen;
+        ux = s * uwx; uy = s * uwy;
+    }
+    return make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
+}
+
+// Register-resident solve for maxNeighbors = 10 (ORCA_DEFAULTS): same arithmetic and the same order of
+// operations as the generic path, organised for the SIMD:
+//  * neighbours: the 10 smallest (distSq, row) pairs in lexicographic order -- what RVO2's insertion with
+//    strict '<' produces -- kept sorted in ten 64-bit keys (high word = float bits of distSq, low word = row)
+//    that order like positive doubles, so one insertion is ten v_min_f64 / v_max_f64 compare-exchanges;
+//  * ORCA lines in registers; linearProgram2 / linearProgram1 statically unrolled over the (line, earlier
+//    line) triangle, each line's LP1 skipped wave-uniformly when no lane violates that line;
+//  * linearProgram3 (infeasible programme, rare) spills the lines to the per-lane LDS columns and runs the
+//    generic code.
+__device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
+                                     float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
+                                     float time_horizon, float dt, const Lines& L, const Lines& P, float& nvx, float& nvy,
+                                     unsigned long long* g_ost, unsigned long long& g_ost_last)
+{
+    constexpr int KF = 10;
+    OSTAMP(0);
+    const double sentinel = __hiloint2double(0x7F7FFFFF, (int)0xFFFFFFFFu);
+    double key[KF];
+#pragma unroll
+    for (int s = 0; s < KF; ++s) key[s] = sentinel;
+    const float range2 = neighbor_dist * neighbor_dist;
+    for (int b = 0; b < rows; ++b) {
+        const float4 q = pv[b];
+        const float ddx = px - q.x, ddy = py - q.y;
+        const float dsq = ddx * ddx + ddy * ddy;
+        const bool in = (dsq < range2) && (b != row);
+        double x = in ? __hiloint2double((int)__float_as_uint(dsq), b) : sentinel;
+#pragma unroll
+        for (int s = 0; s < KF; ++s) {
+            const double lo = fmin(key[s], x);
+            x = fmax(key[s], x);
+            key[s] = lo;
+        }
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int s = 0; s < KF; ++s) cnt += (__double2hiint(key[s]) != 0x7F7FFFFF) ? 1 : 0;
+    OSTAMP(1);
+
+    const float invT = 1.0f / time_horizon;
+    float4 Lr[KF];
+#pragma unroll
+    for (int k = 0; k < KF; ++k) {
+        const int b = (k < cnt) ? __double2loint(key[k]) : row; // unused slots read my own row (finite, never used)
+        Lr[k] = orca_line(px, py, vx, vy, pv[b], my_r + rr[b], invT, dt);
+    }
+
+    OSTAMP(2);
+    // linearProgram2(lines, maxSpeed, prefVelocity, directionOpt = false)
+    float rx, ry;
+    if (pvx * pvx + pvy * pvy > vmax * vmax) {
+        const float nrm = sqrtf(pvx * pvx + pvy * pvy);
+        rx = pvx / nrm * vmax; ry = pvy / nrm * vmax;
+    } else { rx = pvx; ry = pvy; }
+    int failed = cnt;
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < KF; ++i) {
+        const float4 ln = Lr[i];
+        const bool viol = !done && (i < cnt) && (det2(ln.z, ln.w, ln.x - rx, ln.y - ry) > 0.0f);
+        if (__builtin_amdgcn_ballot_w64(viol) != 0) { // linearProgram1(i) for the lanes that violate line i
+            const float dot = ln.x * ln.z + ln.y * ln.w;
+            const float disc = dot * dot + vmax * vmax - (ln.x * ln.x + ln.y * ln.y);
+            bool ok = !(disc < 0.0f);
+            const float sq = sqrtf(fmaxf(disc, 0.0f));
+            float tL = -dot - sq, tR = -dot + sq;
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const float4 lj = Lr[j];
+                const float den = det2(ln.z, ln.w, lj.z, lj.w);
+                const float num = det2(lj.z, lj.w, ln.x - lj.x, ln.y - lj.y);
+                if (fabsf(den) <= RVO_EPSILON) {
+                    if (num < 0.0f) ok = false;          // parallel and on the wrong side: infeasible
+                } else if (ok) {                         // (after a failure RVO2 has already returned)
+                    const float t = num / den;
+                    if (den >= 0.0f) tR = fminf(tR, t); else tL = fmaxf(tL, t);
+                    if (tL > tR) ok = false;
+                }
+            }
+            float t = ln.z * (pvx - ln.x) + ln.w * (pvy - ln.y);
+            if (t < tL) t = tL; else if (t > tR) t = tR;
+            if (viol) {
+                if (ok) { rx = ln.x + t * ln.z; ry = ln.y + t * ln.w; }
+                else { failed = i; done = true; }
+            }
+        }
+    }
+    OSTAMP(3);
+    if (__builtin_amdgcn_ballot_w64(failed < cnt) != 0) { // some lane's programme is infeasible: linearProgram3
+#pragma unroll
+        for (int k = 0; k < KF; ++k) L.set(k, Lr[k]);
+        if (failed < cnt) lp3(L, P, cnt, failed, vmax, rx, ry);
+    }
+    OSTAMP(4);
+    nvx = rx; nvy = ry;
+}
+
+template <bool FAST10>
 __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -186,6 +342,13 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
     __syncthreads();
 
     const Lines L{lds_L, T, tid}, P{lds_P, T, tid};
+    unsigned long long ost_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long* g_ost = nullptr;
+    unsigned long long g_ost_last = 0;
+#ifdef CS_STAMPS
+    g_ost = ost_acc;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g_ost_last)::"memory");
+#endif
     int cur = 0;
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
@@ -195,74 +358,43 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
         if (human) {
             const float4* pv = lds_pv + cur * T + base;
             const float* rr = lds_r + base;
-            // ---- Agent::computeNeighbors / insertAgentNeighbor (index order; strict <, ties keep order)
-            int cnt = 0;
-            float rangeSq = a.neighbor_dist * a.neighbor_dist;
-            if (K > 0) {
-                for (int b = 0; b < rows; ++b) {
-                    if (b == row) continue;
-                    const float4 q = pv[b];
-                    const float ddx = px - q.x, ddy = py - q.y;
-                    const float dsq = ddx * ddx + ddy * ddy;
-                    if (dsq < rangeSq) {
-                        if (cnt < K) ++cnt;
-                        int i = cnt - 1;
-                        while (i != 0 && dsq < lds_nd[(i - 1) * T + tid]) {
-                            lds_nd[i * T + tid] = lds_nd[(i - 1) * T + tid];
-                            lds_ni[i * T + tid] = lds_ni[(i - 1) * T + tid];
-                            --i;
-                        }
-                        lds_nd[i * T + tid] = dsq;
-                        lds_ni[i * T + tid] = b;
-                        if (cnt == K) rangeSq = lds_nd[(cnt - 1) * T + tid];
-                    }
-                }
-            }
-            // ---- Agent::computeNewVelocity: one ORCA half-plane per neighbour
-            const float invT = 1.0f / a.time_horizon;
-            for (int k = 0; k < cnt; ++k) {
-                const int b = lds_ni[k * T + tid];
-                const float4 q = pv[b];
-                const float rpx = q.x - px, rpy = q.y - py;
-                const float rvx = vx - q.z, rvy = vy - q.w;
-                const float distSq = rpx * rpx + rpy * rpy;
-                const float R = (r + margin) + rr[b];
-                const float RSq = R * R;
-                float dx, dy, ux, uy;
-                if (distSq > RSq) {
-                    const float wx = rvx - invT * rpx, wy = rvy - invT * rpy;
-                    const float wLenSq = wx * wx + wy * wy;
-                    const float dot1 = wx * rpx + wy * rpy;
-                    if (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq) {
-                        const float wLen = sqrtf(wLenSq);
-                        const float uwx = wx / wLen, uwy = wy / wLen;
-                        dx = uwy; dy = -uwx;
-                        const float s = R * invT - wLen;
-                        ux = s * uwx; uy = s * uwy;
-                    } else {
-                        const float leg = sqrtf(distSq - RSq);
-                        if (det2(rpx, rpy, wx, wy) > 0.0f) {
-                            dx = (rpx * leg - rpy * R) / distSq; dy = (rpx * R + rpy * leg) / distSq;
-                        } else {
-                            dx = -(rpx * leg + rpy * R) / distSq; dy = -(-rpx * R + rpy * leg) / distSq;
-                        }
-                        const float dot2 = rvx * dx + rvy * dy;
-                        ux = dot2 * dx - rvx; uy = dot2 * dy - rvy;
-                    }
-                } else {
-                    const float invDt = 1.0f / dt;
-                    const float wx = rvx - invDt * rpx, wy = rvy - invDt * rpy;
-                    const float wLen = sqrtf(wx * wx + wy * wy);
-                    const float uwx = wx / wLen, uwy = wy / wLen;
-                    dx = uwy; dy = -uwx;
-                    const float s = R * invDt - wLen;
-                    ux = s * uwx; uy = s * uwy;
-                }
-                L.set(k, make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy));
-            }
             float nvx, nvy;
-            const int failed = lp2(L, cnt, vmax, pvx, pvy, false, nvx, nvy);
-            if (failed < cnt) lp3(L, P, cnt, failed, vmax, nvx, nvy);
+            if constexpr (FAST10) {
+                orca_velocity_fast10(pv, rr, rows, row, px, py, vx, vy, r + margin, vmax, pvx, pvy, a.neighbor_dist,
+                                     a.time_horizon, dt, L, P, nvx, nvy, g_ost, g_ost_last);
+            } else {
+                // ---- Agent::computeNeighbors / insertAgentNeighbor (index order; strict <, ties keep order)
+                int cnt = 0;
+                float rangeSq = a.neighbor_dist * a.neighbor_dist;
+                if (K > 0) {
+                    for (int b = 0; b < rows; ++b) {
+                        if (b == row) continue;
+                        const float4 q = pv[b];
+                        const float ddx = px - q.x, ddy = py - q.y;
+                        const float dsq = ddx * ddx + ddy * ddy;
+                        if (dsq < rangeSq) {
+                            if (cnt < K) ++cnt;
+                            int i = cnt - 1;
+                            while (i != 0 && dsq < lds_nd[(i - 1) * T + tid]) {
+                                lds_nd[i * T + tid] = lds_nd[(i - 1) * T + tid];
+                                lds_ni[i * T + tid] = lds_ni[(i - 1) * T + tid];
+                                --i;
+                            }
+                            lds_nd[i * T + tid] = dsq;
+                            lds_ni[i * T + tid] = b;
+                            if (cnt == K) rangeSq = lds_nd[(cnt - 1) * T + tid];
+                        }
+                    }
+                }
+                // ---- Agent::computeNewVelocity: one ORCA half-plane per neighbour
+                const float invT = 1.0f / a.time_horizon;
+                for (int k = 0; k < cnt; ++k) {
+                    const int b = lds_ni[k * T + tid];
+                    L.set(k, orca_line(px, py, vx, vy, pv[b], (r + margin) + rr[b], invT, dt));
+                }
+                const int failed = lp2(L, cnt, vmax, pvx, pvy, false, nvx, nvy);
+                if (failed < cnt) lp3(L, P, cnt, failed, vmax, nvx, nvy);
+            }
             // ---- Agent::update, then the reference's read-back + update_goals_orca (:390-394, :125-133)
             vx = nvx; vy = nvy;
             px += vx * dt; py += vy * dt;
@@ -317,8 +449,13 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
                 }
             }
         }
+        OSTAMP(5);
         cur = nxt;
     }
+#ifdef CS_STAMPS
+    if (a.stamps && (threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) a.stamps[(size_t)blockIdx.x * 8 + k] = ost_acc[k];
+#endif
 
     if (a.peek_out != nullptr) { // get_human_states(include_goal=True, headed=False) of the next state
         if (human) {
@@ -363,12 +500,16 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * rows; }
     a.goals = w->d_goals; a.margin = w->d_safety; a.robot = w->d_robot; a.action = d_action;
     a.peek_out = d_peek; a.world_flags = w->d_world_flags;
+#ifdef CS_STAMPS
+    a.stamps = g_stamp_buf;
+#endif
     if (d_peek) a.flags &= ~CS_RESPAWN;
     const int T = 64;
     const int grid = (w->W + a.wpb - 1) / a.wpb;
     const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
                          (size_t)a.K * T * (2 * sizeof(float4) + 2 * sizeof(float));
-    hipLaunchKernelGGL(k_orca_step, dim3(grid), dim3(T), shmem, stream, a);
+    if (a.K == 10) hipLaunchKernelGGL(k_orca_step<true>, dim3(grid), dim3(T), shmem, stream, a);
+    else hipLaunchKernelGGL(k_orca_step<false>, dim3(grid), dim3(T), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

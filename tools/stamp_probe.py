@@ -17,13 +17,33 @@ so = os.path.join(ROOT, "gpurun_out", "libcrowdstep_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-DCS_STAMPS",
                        "-I", os.path.join(ROOT, "include"), "-o", so,
-                       os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "crowdstep.hip")])
+                       os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "crowdstep.hip"),
+                       os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "orca.hip")])
 _lib.LIB_PATH = so
 _lib._lib = None
 from social_navigation_pyenvs_amd.batched import CrowdWorlds  # noqa: E402
 
 W, n = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 25
 model = sys.argv[2] if len(sys.argv) > 2 else "hsfm_farina"
+if model == "orca":
+    pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
+    S = sc.make_states(pos, yaw, g)
+    d = g[:, :, 0] - S[:, :, 0:2]
+    S[:, :, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    cw = CrowdWorlds(S, g, None, np.full((W, n), 0.01), None, type="orca", layout="soa")
+    gg, b, wpb = cw.launch_geometry() if False else ((W + (64 // n) - 1) // (64 // n), 64, 64 // n)
+    buf = _lib.DeviceBuffer((gg, 8), np.uint64)
+    _lib.load().cs_debug_set_stamp_buffer(C.c_void_p(buf.ptr))
+    for _ in range(3):
+        cw.step(0.0125, 20)
+    cw.sync()
+    st = buf.download().astype(np.float64)
+    names = ["pre (robot/loads)", "neighbour selection", "ORCA lines", "LP2 (+LP1)", "LP3", "update+goal+respawn", "-", "-"]
+    tot = st.sum(1).mean()
+    print(f"ORCA N={n}: mean wave cycles = {tot:.0f} (per substep {tot / 20:.0f})")
+    for k, nm in enumerate(names):
+        print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
+    sys.exit(0)
 S, goals, P, rb = sc.hybrid_worlds(W, n, model)
 cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
                  respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), layout="soa")
