@@ -233,7 +233,7 @@ def main():
                 "bytes_per_agent_substep": ALG_BYTES[family],
             },
         }
-        if not args.no_cpu_baseline and args.model != "orca":
+        if not args.no_cpu_baseline and args.model != "orca" and world_size == 1:  # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -108,7 +108,7 @@ class CrowdWorlds:
             wf = np.ascontiguousarray(np.broadcast_to(np.asarray(respawn_worlds), (self.W,)).astype(np.int32) & 1)
             self.d_world_flags = DeviceBuffer.from_numpy(wf, dtype=np.int32)
         self.unicycle = False
-        self._keep = []
+        self._scratch = {}  # persistent device scratch (no hipMalloc in the stepping loop)
 
     # ------------------------------------------------------------------ descriptor
     def _flags(self, respawn=None) -> int:
@@ -164,19 +164,29 @@ class CrowdWorlds:
         a_ptr = None
         if action is not None:
             if isinstance(action, np.ndarray) or isinstance(action, (list, tuple)):
-                act = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=np.float32), (self.W, 2)))
-                buf = DeviceBuffer.from_numpy(act)
-                self._keep = [buf]
-                a_ptr = buf.ptr
+                a_ptr = self._upload("action", np.broadcast_to(np.asarray(action, dtype=np.float32), (self.W, 2))).ptr
             else:
                 a_ptr = _ptr(action)
         check(_lib.load().cs_step(C.byref(d), C.c_float(dt), C.c_int(n_substeps), C.c_void_p(a_ptr),
                                   C.c_void_p(self.stream)))
 
+    def _buffer(self, name, shape, dtype=np.float32) -> DeviceBuffer:
+        buf = self._scratch.get(name)
+        if buf is None or buf.shape != tuple(shape) or buf.dtype != np.dtype(dtype):
+            buf = DeviceBuffer(tuple(shape), dtype)
+            self._scratch[name] = buf
+        return buf
+
+    def _upload(self, name, arr, dtype=np.float32) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        buf = self._buffer(name, arr.shape, dtype)
+        buf.upload(arr, self.stream)
+        return buf
+
     def peek(self, dt: float) -> np.ndarray:
         """[W, n, 8] rows x, y, yaw, Vx, Vy, Omega, Gx, Gy of the next state; nothing is committed."""
         d = self.descriptor(respawn=False)
-        out = DeviceBuffer((self.W, self.n, 8))
+        out = self._buffer("peek", (self.W, self.n, 8))
         check(_lib.load().cs_peek(C.byref(d), C.c_float(dt), C.c_void_p(out.ptr), C.c_void_p(self.stream)))
         return out.download(self.stream)
 
@@ -185,9 +195,9 @@ class CrowdWorlds:
         if self.d_robot is None:
             raise ValueError("collision_reward needs the robot rows")
         d = self.descriptor()
-        act = DeviceBuffer.from_numpy(np.broadcast_to(np.asarray(action, dtype=np.float32), (self.W, 2)))
-        gt = DeviceBuffer.from_numpy(np.broadcast_to(np.asarray(global_time, dtype=np.float32), (self.W,)))
-        out = DeviceBuffer((self.W, 7))
+        act = self._upload("reward_action", np.broadcast_to(np.asarray(action, dtype=np.float32), (self.W, 2)))
+        gt = self._upload("global_time", np.broadcast_to(np.asarray(global_time, dtype=np.float32), (self.W,)))
+        out = self._buffer("reward_out", (self.W, 7))
         cfg = (C.c_float * 5)(*[float(x) for x in reward_cfg])
         check(_lib.load().cs_collision_reward(C.byref(d), C.c_void_p(act.ptr), C.c_float(T), C.c_void_p(gt.ptr),
                                               cfg, C.c_void_p(out.ptr), C.c_void_p(self.stream)))
