@@ -153,6 +153,18 @@ int cs_peek(const cs_worlds* w, float dt, float* d_next, void* stream);
 int cs_collision_reward(const cs_worlds* w, const float* d_action, float T, const float* d_global_time,
                         const float* reward_cfg /* host, 5 floats */, float* d_out, void* stream);
 
+/*
+ * cs_lookahead  replaces compute_rotated_states_and_reward(action_space, next_humans_state, current_humans_state,
+ *   current_robot_state, dt, theta_and_omega_visible) -> (rotated_states, rewards)
+ *   (crowd_nav/policy/cadrl.py:42-83, with transform_state_to_agent_centric :13-39) for W robots at once.
+ *   d_actions [A][2]; d_next [W][n][4] (px,py,vx,vy) or [W][n][6] (x,y,yaw,Vx,Vy,Omega) when theta_and_omega_visible;
+ *   d_current [W][n][5] (px,py,vx,vy,r) or [W][n][7] (+theta,omega); d_robot [W][robot_stride] rows starting with
+ *   px,py,vx,vy,r,gx,gy,v_pref.  Outputs d_rotated [W][A][n][13|15] (the value-network input), d_rewards [W][A].
+ */
+int cs_lookahead(int W, int n, int A, int theta_and_omega_visible, const float* d_actions, const float* d_next,
+                 const float* d_current, const float* d_robot, int robot_stride, float dt, float* d_rotated,
+                 float* d_rewards, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

@@ -185,6 +185,21 @@ def collision_reward(hp, hv, hr, rp, rr, rgoal, act, T, global_time, time_limit=
                 terminated=bool(out[4]), truncated=bool(out[5]), info=INFO_NAMES[int(out[6])])
 
 
+def lookahead(actions, nxt, cur, robot, dt, headed=False, dtype=np.float64):
+    """compute_rotated_states_and_reward (cadrl.py:42-83): returns (rotated [A,n,13|15], rewards [A])."""
+    sfx, ct = _suffix(dtype)
+    actions = np.ascontiguousarray(actions, dtype=dtype); nxt = np.ascontiguousarray(nxt, dtype=dtype)
+    cur = np.ascontiguousarray(cur, dtype=dtype); robot = np.ascontiguousarray(robot, dtype=dtype)
+    A, n = actions.shape[0], cur.shape[0]
+    rot = np.zeros((A, n, 15 if headed else 13), dtype=dtype)
+    rew = np.zeros(A, dtype=dtype)
+    fn = getattr(lib(), f"orc_lookahead_{sfx}")
+    fn.restype = None
+    fn(C.c_int(A), C.c_int(n), C.c_int(int(headed)), _ptr(actions, ct), _ptr(nxt, ct), _ptr(cur, ct), _ptr(robot, ct),
+       ct(dt), _ptr(rot, ct), _ptr(rew, ct))
+    return rot, rew
+
+
 def orca_new_velocities(pos, vel, pref, radius, maxspeed, neighbor_dist=10.0, max_nb=10, time_horizon=5.0,
                         time_step=0.25, return_lines=False):
     """One RVO2 doStep velocity solve for one world (float32, PARITY UNPINNED)."""

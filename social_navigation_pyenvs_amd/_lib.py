@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "cs_free", "cs_memcpy_h2d", "cs_memcpy_d2h", "cs_memcpy_d2d", "cs_memset", "cs_stream_create",
     "cs_stream_destroy", "cs_stream_sync", "cs_event_create", "cs_event_destroy", "cs_event_record",
     "cs_event_elapsed_ms", "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
-    "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry",
+    "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry", "cs_lookahead",
 ]
 
 

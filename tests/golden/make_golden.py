@@ -17,6 +17,7 @@ reference produced) is written to the ``.npz`` fixtures.  Groups (SURVEY.md §8c
   g5_reward   ``collision_detection_and_reaching_goal`` + ``compute_reward_and_infos``
   g6_generators  scenario generator outputs for fixed seeds
   g7_respawn  parallel-traffic respawn (state just before / after)
+  g8_lookahead  compute_rotated_states_and_reward (CADRL / SARL 81-action look-ahead)
 """
 from __future__ import annotations
 
@@ -541,9 +542,47 @@ def gen_g7_respawn():
     print("g7_respawn:", len(cases), "cases ->", save_cases("g7_respawn", cases))
 
 
+def gen_g8_lookahead():
+    """compute_rotated_states_and_reward (crowd_nav/policy/cadrl.py:42-83) on random robot / human states with the
+    81-action holonomic action space of CADRL.build_action_space (cadrl.py:181-206)."""
+    import itertools
+    from crowd_nav.policy.cadrl import compute_rotated_states_and_reward
+
+    rng = np.random.default_rng(80_000)
+    v_pref = 1.0
+    speeds = [(np.exp((i + 1) / 5) - 1) / (np.e - 1) * v_pref for i in range(5)]
+    rotations = np.linspace(0, 2 * np.pi, 16, endpoint=False)
+    actions = np.array([[0.0, 0.0]] + [[s * np.cos(r), s * np.sin(r)] for r, s in itertools.product(rotations, speeds)])
+    cases = []
+    for k in range(24):
+        n = int(rng.choice([1, 5, 10, 25]))
+        headed = bool(k % 2)
+        robot = np.array([*rng.uniform(-3, 3, 2), *rng.normal(0, 0.5, 2), 0.3, *rng.uniform(-6, 6, 2), v_pref, 0.0])
+        if k % 5 == 0:  # goal within reach of some action
+            robot[5:7] = robot[0:2] + rng.uniform(-0.2, 0.2, 2)
+        cur = np.zeros((n, 7 if headed else 5))
+        cur[:, 0:2] = robot[0:2] + rng.uniform(-2.5, 2.5, (n, 2)) * (0.4 if k % 3 == 0 else 1.0)
+        cur[:, 2:4] = rng.normal(0, 0.6, (n, 2))
+        cur[:, 4] = rng.uniform(0.25, 0.45, n)
+        if headed:
+            cur[:, 5] = rng.uniform(-np.pi, np.pi, n); cur[:, 6] = rng.normal(0, 0.5, n)
+        dt = 0.25
+        nxt = np.zeros((n, 6 if headed else 4))
+        drift = rng.normal(0, 0.05, (n, 2))
+        if headed:
+            nxt[:, 0:2] = cur[:, 0:2] + cur[:, 2:4] * dt + drift; nxt[:, 2] = cur[:, 5] + cur[:, 6] * dt
+            nxt[:, 3:5] = cur[:, 2:4] + drift; nxt[:, 5] = cur[:, 6]
+        else:
+            nxt[:, 0:2] = cur[:, 0:2] + cur[:, 2:4] * dt + drift; nxt[:, 2:4] = cur[:, 2:4] + drift
+        rot, rew = compute_rotated_states_and_reward(actions, nxt, cur, robot, dt, theta_and_omega_visible=headed)
+        cases.append(dict(n=n, headed=headed, dt=dt, actions=actions, robot=robot, current=cur, next=nxt,
+                          rotated=rot, rewards=rew))
+    print("g8_lookahead:", len(cases), "cases ->", save_cases("g8_lookahead", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
-              g7_respawn=gen_g7_respawn)
+              g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

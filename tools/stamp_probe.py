@@ -18,7 +18,8 @@ os.makedirs(os.path.dirname(so), exist_ok=True)
 subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-DCS_STAMPS",
                        "-I", os.path.join(ROOT, "include"), "-o", so,
                        os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "crowdstep.hip"),
-                       os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "orca.hip")])
+                       os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "orca.hip"),
+                       os.path.join(ROOT, "social_navigation_pyenvs_amd", "csrc", "lookahead.hip")])
 _lib.LIB_PATH = so
 _lib._lib = None
 from social_navigation_pyenvs_amd.batched import CrowdWorlds  # noqa: E402
