@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.0125)
     ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
     ap.add_argument("--walls", action="store_true", help="add 3 shared polygon walls")
+    ap.add_argument("--eager", action="store_true", help="launch every step from Python (default: one HIP graph of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -93,6 +94,19 @@ def build_worlds(args, rank):
     return cw, host
 
 
+def effective_cores() -> int:
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants 16 through cpu.max; more OpenMP threads than that only get throttled)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(args, host, type_id):
     """The C oracle (port of the reference's f64 array kernel) on this box's host cores, on a bounded
     sample of the same workload: the first `sample_worlds` worlds, blocks of `substeps` substeps, stepped in
@@ -100,7 +114,7 @@ def cpu_baseline(args, host, type_id):
     from oracle import crowd_oracle as orc
 
     orc.build()
-    cores = orc.num_threads()
+    cores = min(orc.num_threads(), effective_cores())
     respawn = host["respawn_bounds"] is not None
     rp = (host["respawn_bounds"][0], host["respawn_bounds"][1], 0.0) if respawn else (0.0, 0.0, 0.0)
 
@@ -169,17 +183,35 @@ def main():
     for _ in range(args.warmup):
         cw.step(args.dt, n_sub)
     barrier()
-    starts = [_lib.Event() for _ in range(args.steps)]
-    stops = [_lib.Event() for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        starts[k].record(stream)
-        cw.step(args.dt, n_sub)
-        stops[k].record(stream)
-    _lib.stream_sync(stream)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = np.array([starts[k].elapsed_ms(stops[k]) for k in range(args.steps)])
+    if args.eager:
+        # one launch per step from Python, a HIP event pair around every launch
+        starts = [_lib.Event() for _ in range(args.steps)]
+        stops = [_lib.Event() for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            starts[k].record(stream)
+            cw.step(args.dt, n_sub)
+            stops[k].record(stream)
+        _lib.stream_sync(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = np.array([starts[k].elapsed_ms(stops[k]) for k in range(args.steps)])
+    else:
+        # the K steps are captured once into a HIP graph (untimed) and replayed with ONE launch in the timed region:
+        # no per-launch host gap; HIP events on the launch stream bracket the K kernels
+        with _lib.Graph.capture(stream) as graph:
+            for k in range(args.steps):
+                cw.step(args.dt, n_sub)
+        e0, e1 = _lib.Event(), _lib.Event()
+        barrier()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        graph.launch()
+        e1.record(stream)
+        _lib.stream_sync(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = np.array([e0.elapsed_ms(e1) / args.steps])
     from social_navigation_pyenvs_amd.sharding import max_over_ranks
 
     elapsed = max_over_ranks(elapsed, dist, device="cuda")
@@ -229,6 +261,7 @@ def main():
                             if (args.model, args.scenario, args.walls) in MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH else None),
                 "traffic_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)",
                 "kernel": "k_orca_step" if args.model == "orca" else "k_sfm_step", "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kernel_ms)),
+                "launch_mode": "eager, one HIP event pair per launch" if args.eager else "HIP graph of K launches, events around the graph",
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "bytes_per_agent_substep": ALG_BYTES[family],
             },

@@ -110,6 +110,13 @@ int cs_event_destroy(void* event);
 int cs_event_record(void* event, void* stream);
 int cs_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 
+/* HIP graphs: capture the launches issued on `stream` between begin and end (e.g. K cs_step calls of a rollout) and
+ * replay them with one launch -- removes the per-launch host gap of a launch-bound loop. */
+int cs_graph_begin_capture(void* stream);
+int cs_graph_end_capture(void* stream, void** graph_exec);
+int cs_graph_launch(void* graph_exec, void* stream);
+int cs_graph_destroy(void* graph_exec);
+
 /* ---------------------------------------------------------------- the hot path
  *
  * cs_update_humans_parallel  replaces  update_humans_parallel(type, agents_state, goals, obstacles,

@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "cs_last_error", "cs_abi_version", "cs_device_count", "cs_set_device", "cs_device_name", "cs_malloc",
     "cs_free", "cs_memcpy_h2d", "cs_memcpy_d2h", "cs_memcpy_d2d", "cs_memset", "cs_stream_create",
     "cs_stream_destroy", "cs_stream_sync", "cs_event_create", "cs_event_destroy", "cs_event_record",
-    "cs_event_elapsed_ms", "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
+    "cs_event_elapsed_ms", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
+    "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
     "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry", "cs_lookahead",
 ]
 
@@ -168,6 +169,39 @@ class Event:
         try:
             if self.ptr:
                 load().cs_event_destroy(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+class Graph:
+    """with Graph.capture(stream) as g: ...launches...   then g.launch()"""
+
+    def __init__(self, stream):
+        self.stream, self.exec = stream, None
+
+    @classmethod
+    def capture(cls, stream):
+        return cls(stream)
+
+    def __enter__(self):
+        check(load().cs_graph_begin_capture(C.c_void_p(self.stream)))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        p = C.c_void_p()
+        rc = load().cs_graph_end_capture(C.c_void_p(self.stream), C.byref(p))
+        if exc_type is None:
+            check(rc)
+            self.exec = p.value
+        return False
+
+    def launch(self):
+        check(load().cs_graph_launch(C.c_void_p(self.exec), C.c_void_p(self.stream)))
+
+    def __del__(self):
+        try:
+            if self.exec:
+                load().cs_graph_destroy(C.c_void_p(self.exec))
         except Exception:
             pass
 

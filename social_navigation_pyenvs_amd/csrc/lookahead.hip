@@ -98,3 +98,37 @@ extern "C" int cs_lookahead(int W, int n, int A, int theta_and_omega_visible, co
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
+
+// ---- HIP graph helpers (include/crowdstep.h) --------------------------------------------------------------
+extern "C" int cs_graph_begin_capture(void* stream)
+{
+    if (!stream) return fail(CS_ERR_ARG, "graph capture needs a non-default stream (cs_stream_create)");
+    HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return CS_OK;
+}
+
+extern "C" int cs_graph_end_capture(void* stream, void** graph_exec)
+{
+    if (!stream || !graph_exec) return fail(CS_ERR_ARG, "null argument");
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(CS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    *graph_exec = exec;
+    return CS_OK;
+}
+
+extern "C" int cs_graph_launch(void* graph_exec, void* stream)
+{
+    if (!graph_exec) return fail(CS_ERR_ARG, "null graph");
+    HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+    return CS_OK;
+}
+
+extern "C" int cs_graph_destroy(void* graph_exec)
+{
+    if (graph_exec) HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return CS_OK;
+}

@@ -81,3 +81,37 @@ def test_fused_block_equals_repeated_single_substeps_bitwise():
         b.step(0.0125, 1)
     np.testing.assert_array_equal(a.get_states(), b.get_states())
     np.testing.assert_array_equal(a.get_goals(), b.get_goals())
+
+
+@pytest.mark.parametrize("n,model,robot", [(80, "hsfm_farina", False), (150, "sfm_guo", True), (64, "sfm_helbing", True)])
+def test_large_worlds_one_block_per_world(n, model, robot):
+    """rows > 64: one world per block of up to 1024 threads (multi-wave barriers, block-wide contact / respawn votes)."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    W = 5
+    rng = np.random.default_rng(n)
+    pos, yaw, g = sc.circular_crossing(W, n + int(robot), 0.28 * n, 7)
+    S = sc.make_states(pos, yaw, g).astype(np.float32)
+    S[..., 3:5] = rng.normal(0, 0.4, S[..., 3:5].shape)
+    S[..., 5:7] = rng.normal(0, 0.4, S[..., 5:7].shape)
+    S[:, ::7, 0:2] = S[:, 1::7, 0:2][:, : S[:, ::7].shape[1]] + 0.45   # some overlapping pairs -> contact pass
+    goals = g[:, :n].astype(np.float32)
+    P = np.tile(sc.default_params(model), (n, 1)).astype(np.float32)
+    t = SFMS.index(model)
+    cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, robot_row=robot)
+    grid, block, wpb = cw.launch_geometry()
+    assert wpb == 1 and block >= n + int(robot) and block % 64 == 0
+    out = cw.get_states(cw.update_humans_parallel(0.0125, in_place=False))
+    for w in range(W):
+        ref, _, _ = orc.update_humans(t, S[w].astype(np.float64), goals[w].astype(np.float64), None, P.astype(np.float64),
+                                      0.0125, np.zeros(n + int(robot)), True, robot)
+        err = np.max(np.abs(out[w][:n, [0, 1, 3, 4]] - ref[:n][:, [0, 1, 3, 4]]))
+        assert err < 5e-5, (n, model, w, err)
+    # fused block on the big variant == repeated single substeps, bitwise
+    a = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, robot_row=robot)
+    b = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, robot_row=robot)
+    a.step(0.0125, 5)
+    for _ in range(5):
+        b.step(0.0125, 1)
+    np.testing.assert_array_equal(a.get_states(), b.get_states())
