@@ -1,0 +1,1 @@
+"""Test infrastructure only: CPU restatement of the reference algorithm (see crowdstep_oracle.c)."""

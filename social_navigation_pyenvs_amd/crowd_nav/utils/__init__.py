@@ -1,0 +1,1 @@
+"""CrowdNav state / action records exchanged at the Gym boundary."""

@@ -29,6 +29,18 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float seed)
             } else if (OP == 5) { // one dependent chain of fma
                 a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f);
                 a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f);
+            } else if (OP == 7) { // 8 independent ds_bpermute_b32 (rotate by one lane) + add
+                const int src = ((threadIdx.x + 63) & 63) << 2;
+                a0 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a1)));
+                a1 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a2)));
+                a2 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a3)));
+                a3 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a4)));
+                a4 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a5)));
+                a5 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a6)));
+                a6 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a7)));
+                a7 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a0)));
+            } else if (OP == 8) { // the same 8 adds without the permute (baseline for OP 7)
+                a0 += a1; a1 += a2; a2 += a3; a3 += a4; a4 += a5; a5 += a6; a6 += a7; a7 += a0;
             } else if (OP == 6) { // 8 v_mul_f32 (plain, not fma)
                 a0 *= 1.0001f; a1 *= 1.0001f; a2 *= 1.0001f; a3 *= 1.0001f; a4 *= 1.0001f; a5 *= 1.0001f; a6 *= 1.0001f; a7 *= 1.0001f;
             }
@@ -67,6 +79,8 @@ int main()
         run<3>("v_rsq_f32 x8 indep", w, d_out);
         run<4>("v_cmp+v_cndmask x8", w, d_out);
         run<5>("v_fma_f32 dependent chain", w, d_out);
+        run<7>("ds_bpermute_b32 + v_add x8", w, d_out);
+        run<8>("v_add x8 (chain, no permute)", w, d_out);
     }
     return 0;
 }
