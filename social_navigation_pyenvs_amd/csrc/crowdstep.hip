@@ -194,7 +194,8 @@ __device__ __forceinline__ void pair_force_moussaid(const SocP& p, float pix, fl
     const float iinv = rsq_fast(i2);
     const float inorm = i2 * iinv;
     const float ix = ivx * iinv, iy = ivy * iinv;
-    const float th = bound_angle(atan2f(ny, nx) - atan2f(iy, ix) + 3.141592653589793f);
+    // theta_ij = wrap(angle(n) - angle(i) + pi) is the signed angle from i to -n (:124): one atan2 of (cross, dot)
+    const float th = atan2_fast(iy * nx - ix * ny, -(ix * nx + iy * ny));
     const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
     const float hx = -iy, hy = ix;
     const float F = p.gam * inorm;
