@@ -163,6 +163,7 @@ __device__ __forceinline__ float atan2_fast(float y, float x)
 struct SocP {
     float Ai, cB, Ci, cD, Ei, k1, k2, lam, gam, ns, ns1;
     float lA, sA, lC, sC; // A * exp(x/B) = sA * exp2(x * cB + lA),  lA = log2|A|  (A = 0 -> exp2(-inf) = 0)
+    float sAC;            // sA * sC
 };
 
 __device__ __forceinline__ SocP load_socp(const float* P)
@@ -172,6 +173,7 @@ __device__ __forceinline__ SocP load_socp(const float* P)
     s.k1 = P[10]; s.k2 = P[11]; s.lam = P[12]; s.gam = P[13]; s.ns = P[14]; s.ns1 = P[15];
     s.lA = log2f(fabsf(s.Ai)); s.sA = copysignf(1.0f, s.Ai);
     s.lC = log2f(fabsf(s.Ci)); s.sC = copysignf(1.0f, s.Ci);
+    s.sAC = s.sA * s.sC;
     return s;
 }
 
@@ -209,6 +211,34 @@ __device__ __forceinline__ void pair_force_moussaid(const SocP& p, float pix, fl
     fy -= sel * (e0 * (e1 * iy + k * e2 * hy) + kk * iy + kt * hy);
 }
 
+// Same force, returned instead of accumulated (no own-row / padding slot): used by the pair-once loop, which
+// also hands -f to the partner (the reference's all_params_equal path does exactly that, :100-104).
+__device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx, float dy, float vdx, float vdy,
+                                                         float rij, float& fx, float& fy)
+{
+    const float d2 = fmaf(dx, dx, dy * dy);
+    const float inv = rsq_fast(d2);
+    const float dist = d2 * inv;
+    const float nx = dx * inv, ny = dy * inv;
+    const float m0 = fmaxf(0.0f, rij - dist);
+    const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);
+    const float i2 = fmaxf(fmaf(ivx, ivx, ivy * ivy), 1e-30f);
+    const float iinv = rsq_fast(i2);
+    const float inorm = i2 * iinv;
+    const float ix = ivx * iinv, iy = ivy * iinv;
+    const float th = atan2_fast(iy * nx - ix * ny, -(ix * nx + iy * ny));
+    const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
+    const float hx = -iy, hy = ix;
+    const float F = p.gam * inorm;
+    const float dv = -(vdx * hx + vdy * hy);
+    const float e0 = p.Ei * exp2_fast(-dist * rcp_fast(F) * LOG2E);
+    const float a1 = p.ns1 * F * th, a2 = p.ns * F * th;
+    const float e1 = exp2_fast(-(a1 * a1) * LOG2E), e2 = exp2_fast(-(a2 * a2) * LOG2E);
+    const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
+    fx = -(e0 * (e1 * ix + k * e2 * hx) + kk * ix + kt * hx);
+    fy = -(e0 * (e1 * iy + k * e2 * hy) + kk * iy + kt * hy);
+}
+
 // ------------------------------------------------------------------------------------------
 // the fused SFM / HSFM step kernel
 //   SOC    = type % 3  (0 Helbing, 1 Guo, 2 Moussaid)          forces_parallel.py:215
@@ -216,20 +246,26 @@ __device__ __forceinline__ void pair_force_moussaid(const SocP& p, float pix, fl
 //   PEQ    = all_params_equal
 //   MAXT   = 64 (one wavefront, floor(64/rows) worlds) or 1024 (one world per block)
 // ------------------------------------------------------------------------------------------
+constexpr int UA = 4; // reaction accumulator rows of the pair-once loop (independent LDS read-modify-write chains)
+
 template <int SOC, int HEADED, bool PEQ, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    // all_params_equal, whole worlds inside one wavefront: every unordered pair is evaluated ONCE (as the reference
+    // does, forces_parallel.py:100-131: F[i,j] = f, F[j,i] = -f) and the reaction handed over through LDS.
+    constexpr bool N3L = PEQ && MAXT == 64;
     const int T = blockDim.x;
     // Every world's rows are stored TWICE, back to back ([w][2][rows]): lane i then reads its partners
     // i+1 .. i+rows-1 at constant offsets from one base address -- no own-row slot, no modulo, no
     // per-partner compare (v_cmp + v_cndmask costs as much as a transcendental on this SIMD).
     const int TP = 2 * T + PADR;                                   // rows per position buffer (+ finite padding)
     float4* lds_p = reinterpret_cast<float4*>(smem_raw);           // [2][TP] x, y, radius+safety, -
-    float2* lds_v = reinterpret_cast<float2*>(lds_p + 2 * TP);     // [2][T] stored linear velocity
-    float2* lds_vr = lds_v + 2 * T;                                // [2][T] velocity as refreshed in-place
+    float2* lds_v = reinterpret_cast<float2*>(lds_p + 2 * TP);     // [2][TP] stored linear velocity (doubled rows like lds_p)
+    float2* lds_vr = lds_v + 2 * TP;                               // [2][T] velocity as refreshed in-place
     float* lds_g0x = reinterpret_cast<float*>(lds_vr + 2 * T);     // [T] respawn scratch
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);           // [T] respawn scratch
+    float2* lds_acc = reinterpret_cast<float2*>(lds_flag + T);     // [UA][2T] reaction accumulators (N3L only)
 
     const int tid = threadIdx.x;
     const int rows = a.rows, n = a.n;
@@ -268,8 +304,11 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     float m_tau = 0, Aw = 0, cBw = 0, Cw = 0, cDw = 0, k1 = 0, k2 = 0, ko = 0, kd = 0, alpha = 1, klam = 0;
     float dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0;
     SocP sp = {};
-    float g0x = gx, g0y = gy;
+    float g0x = gx, g0y = gy, g1x = 0, g1y = 0;
+    int gk = 0;          // length of the non-NaN prefix of my goal list
+    bool gdirty = false; // a two-goal list rotated in registers, to be written back in the epilogue
     float* gi = nullptr;
+    if (N3L && valid) sp = load_socp(a.params + ((a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20));
     if (human) {
         const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20;
         const float* P = a.params + pw + (long)row * 20;
@@ -280,9 +319,14 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
         inv_alpha = 1.0f / alpha;
         inertia = 0.5f * m * r * r;             // :265
         dt_inertia = a.dt / inertia;            // (torque / I) * dt        (:279)
-        sp = load_socp(PEQ ? (a.params + pw) : P);
+        if constexpr (!N3L) sp = load_socp(PEQ ? (a.params + pw) : P);
         gi = a.goals + ((long)w * n + row) * a.G * 2;
         g0x = gi[0]; g0y = gi[1];
+        // goal lists of <= 2 entries (every Gym scenario) rotate in registers; longer ones go through memory
+        gk = a.G;
+        for (int g = a.G - 1; g >= 0; --g)
+            if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) gk = g;
+        if (gk == 2) { g1x = gi[2]; g1y = gi[3]; }
     }
     const float inv_O = a.O > 0 ? 1.0f / (float)a.O : 0.0f;
     const float* obst = nullptr;
@@ -313,16 +357,23 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     // ---- prologue: publish substep-0 rows ----------------------------------------------
     if (is_robot && robot_moves) robot_step();
     const float my_rs = r + safety;
-    for (int i = tid; i < 2 * TP; i += T) lds_p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // padding stays finite
+    for (int i = tid; i < 2 * TP; i += T) { // padding stays finite
+        lds_p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        lds_v[i] = make_float2(0.0f, 0.0f);
+    }
     __syncthreads();
     auto publish = [&](int buf) {      // my row, both copies
         const float4 me = make_float4(px, py, my_rs, 0.0f);
         lds_p[buf * TP + pbase + row] = me;
         lds_p[buf * TP + pbase + rows + row] = me;
     };
+    auto publish_v = [&](int buf) {    // stored linear velocity; second copy only where the rotated loop reads it
+        lds_v[buf * TP + pbase + row] = make_float2(vx, vy);
+        if constexpr (N3L && SOC == 2) lds_v[buf * TP + pbase + rows + row] = make_float2(vx, vy);
+    };
     if (valid) {
         publish(0);
-        lds_v[tid] = make_float2(vx, vy);
+        publish_v(0);
         float rvx = vx, rvy = vy;
         if (HEADED > 0 && human) {
             sincos_fast(th, sn, cs);
@@ -346,10 +397,14 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
             // -- goal switch, forces_parallel.py:226-234 (on the incoming position)
             const float gdx = g0x - px, gdy = g0y - py;
             if (fmaf(gdx, gdx, gdy * gdy) <= r * r) { // |goals[i][0] - p| <= r ; rare, divergent
-                int k = a.G;
-                for (int g = 0; g < a.G; ++g)
-                    if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) { k = g; break; }
-                if (a.mode & M_COMMIT_GOALS) {
+                const int k = gk;
+                if (k <= 2) {                       // rotation of a list of 0, 1 or 2 goals: registers only
+                    if (k == 2) {
+                        const float t0 = g0x, t1 = g0y;
+                        g0x = g1x; g0y = g1y; g1x = t0; g1y = t1;
+                        gdirty = true;
+                    }
+                } else if (a.mode & M_COMMIT_GOALS) {
                     const float r0 = gi[0], r1 = gi[1];
                     for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
                     if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
@@ -359,7 +414,114 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 }
                 gx = g0x; gy = g0y;
             }
-            STAMP(0);
+        }
+        STAMP(0);
+        // -- social force, pair-once form (:87-133).  Lane i evaluates its partners at ring distance 1 .. (rows-1)/2
+        //    inside its world (rows even: plus the antipodal one, evaluated by both ends).  The partner's share -f
+        //    is added to accumulator slot [k mod UA][i + distance] of UA LDS rows: plain read-modify-write, no
+        //    atomics -- one wavefront executes its LDS operations in order, so each of the UA chains is race-free.
+        //    Index i + distance runs past the world's rows without a modulo: receiver j sums slots j and j + rows.
+        float fsx = 0.0f, fsy = 0.0f;
+        if constexpr (N3L) {
+            {
+                float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 per row = T float4: one per lane
+#pragma unroll
+                for (int u = 0; u < UA; ++u) z[u * T + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            if (valid) {
+                const int Hf = (rows - 1) >> 1;
+                const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
+                const float2* rv = lds_v + cur * TP + pbase + row + 1;
+                float2* acc = lds_acc + pbase + row + 1;                 // acc[u * 2T + k]: that partner's slot in row u
+                float ex = 0.0f, ey = 0.0f, rdmax = -1.0f;
+                auto pair_once = [&](const float4 q, const float2 vq, float& fx, float& fy) {
+                    const float dx = px - q.x, dy = py - q.y;
+                    if constexpr (SOC == 2) {
+                        pair_force_moussaid_once(sp, dx, dy, vx - vq.x, vy - vq.y, my_rs + q.z, fx, fy);
+                    } else {
+                        // [A e^{rd/B}] n + [C e^{rd/D}] t, in units of sign(A); the k1 / k2 contact parts are exact
+                        // zeros unless rd > 0 and are added by the contact pass below
+                        const float d2 = fmaf(dx, dx, dy * dy);
+                        const float inv = rsq_fast(d2);
+                        const float rd = fmaf(-d2, inv, my_rs + q.z);             // rij - dist
+                        const float ga = exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv; // |A| e^{rd/B} / dist
+                        fx = ga * dx; fy = ga * dy;
+                        if constexpr (SOC == 1) {
+                            const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * (inv * sp.sAC); // +-|C| e^{rd/D} / dist
+                            fx = fmaf(-gc, dy, fx); fy = fmaf(gc, dx, fy);                       // along t = (-ny, nx)
+                        }
+                        rdmax = fmaxf(rdmax, rd);
+                    }
+                };
+                int k0 = 0;
+                for (; k0 + UA <= Hf; k0 += UA) {
+                    float4 q[UA];
+                    float2 vq[UA], ac[UA];
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        q[u] = rp[k0 + u];
+                        if constexpr (SOC == 2) vq[u] = rv[k0 + u]; else vq[u] = make_float2(0.0f, 0.0f);
+                        ac[u] = acc[u * 2 * T + k0 + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        float fx, fy;
+                        pair_once(q[u], vq[u], fx, fy);
+                        ex += fx; ey += fy;
+                        ac[u].x += fx; ac[u].y += fy;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) acc[u * 2 * T + k0 + u] = ac[u];
+                }
+                for (int k = k0; k < Hf; ++k) {
+                    float fx, fy;
+                    float2 vq = make_float2(0.0f, 0.0f);
+                    if constexpr (SOC == 2) vq = rv[k];
+                    pair_once(rp[k], vq, fx, fy);
+                    ex += fx; ey += fy;
+                    float2 ac = acc[k];
+                    ac.x += fx; ac.y += fy;
+                    acc[k] = ac;
+                }
+                if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself
+                    float fx, fy;
+                    float2 vq = make_float2(0.0f, 0.0f);
+                    if constexpr (SOC == 2) vq = rv[Hf];
+                    pair_once(rp[Hf], vq, fx, fy);
+                    ex += fx; ey += fy;
+                }
+                float rx = 0.0f, ry = 0.0f;
+                const float2* rr = lds_acc + pbase + row;
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    const float2 lo = rr[u * 2 * T], hi = rr[u * 2 * T + rows];
+                    rx += lo.x + hi.x; ry += lo.y + hi.y;
+                }
+                fsx = ex - rx; fsy = ey - ry;
+                if constexpr (SOC != 2) {
+                    fsx *= sp.sA; fsy *= sp.sA;
+                    if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
+                        const float4* pp = lds_p + cur * TP + pbase;
+                        const float2* pvel = lds_v + cur * TP + pbase;
+                        for (int j = 0; j < rows; ++j) {
+                            const float4 q = pp[j];
+                            const float2 vj = pvel[j];
+                            const float dx = px - q.x, dy = py - q.y;
+                            const float d2 = (j == row) ? 1.0e30f : fmaf(dx, dx, dy * dy);
+                            const float inv = rsq_fast(d2);
+                            const float m0 = fmaxf(0.0f, fmaf(-d2, inv, my_rs + q.z));
+                            const float nx = dx * inv, ny = dy * inv;
+                            const float dv = (vj.y - vy) * nx - (vj.x - vx) * ny;     // (v_j - v_i) . t
+                            const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;
+                            fsx += fn * nx - ft * ny;
+                            fsy += fn * ny + ft * nx;
+                        }
+                    }
+                }
+            }
+        }
+        STAMP(2);
+        if (human) {
             // -- rotation matrix and refreshed linear velocity, :254-256
             const float c = cs, s = sn;
             float cvx = vx, cvy = vy;
@@ -415,15 +577,14 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 fox *= inv_O; foy *= inv_O;
             }
             STAMP(1);
-            // -- social force: O(N) partners broadcast from LDS, :87-133 / :43-84
-            float fsx = 0.0f, fsy = 0.0f;
-            {
+            // -- social force, every lane evaluates all its partners: O(N) rows broadcast from LDS, :43-84
+            if constexpr (!N3L) {
                 // all_params_equal: every row's stored velocity (the reference evaluates all pairs
                 // before any in-place refresh); else: my refreshed velocity, partner j<i refreshed,
                 // j>i stored (prange == range order; identical from the 2nd fused substep on)
                 const float vix = PEQ ? vx : cvx, viy = PEQ ? vy : cvy;
                 const float4* pp = lds_p + cur * TP + pbase;
-                const float2* pvel = lds_v + cur * T + base;
+                const float2* pvel = lds_v + cur * TP + pbase;
                 const float2* vr = lds_vr + cur * T + base;
                 auto partner_vel = [&](int j) {
                     float2 v2 = pvel[j];
@@ -512,7 +673,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                     }
                 }
             }
-            STAMP(2);
+            STAMP(6);
             // -- total force, body frame, torque  :262-271, :165-182
             const float fix = fdx + fox + fsx, fiy = fdy + foy + fsy;
             float gfx = fix, gfy = fiy, torque = 0.0f;
@@ -553,14 +714,14 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 si[10 * a.in_fs] = gx; si[11 * a.in_fs] = gy;
             }
             publish(nxt);
-            lds_v[nxt * T + tid] = make_float2(vx, vy);
+            publish_v(nxt);
             if constexpr (!PEQ && HEADED > 0) lds_vr[nxt * T + tid] = make_float2(vx, vy);
             STAMP(3);
         } else if (is_robot) {
             // the robot's move of the NEXT substep happens before that substep's update_humans
             if (robot_moves && sub + 1 < a.nsub) robot_step();
             publish(nxt);
-            lds_v[nxt * T + tid] = make_float2(vx, vy);
+            publish_v(nxt);
             if constexpr (!PEQ && HEADED > 0) lds_vr[nxt * T + tid] = make_float2(vx, vy);
         }
         __syncthreads();
@@ -569,10 +730,37 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
         if (a.flags & CS_RESPAWN) {
             const float rdx = px - g0x, rdy = py - g0y;
             const int flag = (human && respawn_here && fmaf(rdx, rdx, rdy * rdy) < 9.0f) ? 1 : 0; // |p - g| < 3
-            bool any_flag;
-            if constexpr (MAXT == 64) any_flag = __builtin_amdgcn_ballot_w64(flag != 0) != 0; // one wave per block
-            else any_flag = __syncthreads_or(flag) != 0;
-            if (any_flag) {
+            if constexpr (MAXT == 64) {
+                // one wavefront holds whole worlds: no barrier, no serial lane.  The reference respawns the flagged
+                // humans of a world in index order, each behind everybody else (:411-417): x_0 = max(max_x + 2 max_r,
+                // bound), and the c-th flagged one (c lower-indexed flagged rows in its world) lands at
+                // x_c = max(x_{c-1} + 2 max_r, bound) because x_{c-1} is then the rightmost human.
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag != 0);
+                if (fm != 0 && flag) {
+                    const unsigned long long wm = (rows >= 64 ? ~0ull : ((1ull << rows) - 1ull)) << base;
+                    const int c = __builtin_popcountll(fm & wm & ((1ull << tid) - 1ull));
+                    const float4* pvn = lds_p + nxt * TP + pbase;
+                    float mx = pvn[0].x, mr = pvn[0].z;
+                    for (int j = 1; j < n; ++j) {
+                        mx = fmaxf(mx, pvn[j].x);
+                        mr = fmaxf(mr, pvn[j].z);
+                    }
+                    if (robot_row) { // consider_robot: the robot where it stands in THIS substep
+                        const float4 qr = lds_p[cur * TP + pbase + n];
+                        mx = fmaxf(mx, qr.x);
+                        mr = fmaxf(mr, qr.z);
+                    }
+                    float x = fmaxf(mx + mr * 2.0f, a.bx);
+                    for (int t = 0; t < c; ++t) x = fmaxf(x + mr * 2.0f, a.bx);
+                    px = x;
+                    py = (py >= 0.0f) ? fminf(py, a.by) : fmaxf(py, -a.by);
+                    publish(nxt);
+                    g0y = py;               // human.set_goals([[goals[0][0], position[1]]])   :418
+                    bvy = g0x; om = g0y;    // states[i,6:8] = goal  (reference writes cols 6:8) :421
+                    for (int g = 0; g < a.G; ++g) { gi[2 * g] = g0x; gi[2 * g + 1] = g0y; } //   :422
+                    gk = a.G; g1x = g0x; g1y = g0y;
+                }
+            } else if (__syncthreads_or(flag) != 0) {
                 lds_flag[tid] = flag;
                 lds_g0x[tid] = g0x;
                 __syncthreads();
@@ -604,6 +792,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                     g0y = py;               // human.set_goals([[goals[0][0], position[1]]])   :418
                     bvy = g0x; om = g0y;    // states[i,6:8] = goal  (reference writes cols 6:8) :421
                     for (int g = 0; g < a.G; ++g) { gi[2 * g] = g0x; gi[2 * g + 1] = g0y; } //   :422
+                    gk = a.G; g1x = g0x; g1y = g0y;
                 }
             }
         }
@@ -626,6 +815,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
         }
         return;
     }
+    if (human && gdirty && (a.mode & M_COMMIT_GOALS)) { gi[0] = g0x; gi[1] = g0y; gi[2] = g1x; gi[3] = g1y; }
     if (valid) {
         float* o = a.Sout + sidx * a.out_as;
         const long fs = a.out_fs;
@@ -791,8 +981,11 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
 #endif
     const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
     kfn fn = (g.block == 64) ? pick_kernel<64>(w->type, peq) : pick_kernel<1024>(w->type, peq);
-    const size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float)) +
-                         2 * PADR * sizeof(float4);
+    // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
+    // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
+    const size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
+                         2 * PADR * (sizeof(float4) + sizeof(float2)) +
+                         ((peq && g.block == 64) ? (size_t)UA * 2 * g.block * sizeof(float2) : 0);
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(fn, dim3(g.grid), dim3(g.block), shmem, stream, a);
