@@ -453,16 +453,18 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                         rdmax = fmaxf(rdmax, rd);
                     }
                 };
-                int k0 = 0;
-                for (; k0 + UA <= Hf; k0 += UA) {
-                    float4 q[UA];
-                    float2 vq[UA], ac[UA];
+                // groups of UA partners; the partner rows of the NEXT group are fetched while the current group is
+                // evaluated (two register sets, a compiler memory barrier pins the prefetch), and the accumulator
+                // slots are read before the evaluation and written after it
+                constexpr int AR = 2 * 64;  // accumulator row pitch (block = one wavefront)
+                auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
-                        q[u] = rp[k0 + u];
-                        if constexpr (SOC == 2) vq[u] = rv[k0 + u]; else vq[u] = make_float2(0.0f, 0.0f);
-                        ac[u] = acc[u * 2 * T + k0 + u];
+                        q[u] = rp[kk + u];
+                        if constexpr (SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
                     }
+                };
+                auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], float2 (&ac)[UA], int kk) {
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
                         float fx, fy;
@@ -471,7 +473,31 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                         ac[u].x += fx; ac[u].y += fy;
                     }
 #pragma unroll
-                    for (int u = 0; u < UA; ++u) acc[u * 2 * T + k0 + u] = ac[u];
+                    for (int u = 0; u < UA; ++u) acc[u * AR + kk + u] = ac[u];
+                };
+                int k0 = 0;
+                if (Hf >= UA) {
+                    float4 qa[UA], qb[UA];
+                    float2 va[UA], vb[UA], ac[UA];
+                    fetch(qa, va, 0);
+                    for (;;) {
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + k0 + u];
+                        const bool more_b = k0 + 2 * UA <= Hf;
+                        if (more_b) fetch(qb, vb, k0 + UA);
+                        asm volatile("" ::: "memory");
+                        group(qa, va, ac, k0);
+                        k0 += UA;
+                        if (!more_b) break;
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + k0 + u];
+                        const bool more_a = k0 + 2 * UA <= Hf;
+                        if (more_a) fetch(qa, va, k0 + UA);
+                        asm volatile("" ::: "memory");
+                        group(qb, vb, ac, k0);
+                        k0 += UA;
+                        if (!more_a) break;
+                    }
                 }
                 for (int k = k0; k < Hf; ++k) {
                     float fx, fy;
@@ -494,7 +520,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 const float2* rr = lds_acc + pbase + row;
 #pragma unroll
                 for (int u = 0; u < UA; ++u) {
-                    const float2 lo = rr[u * 2 * T], hi = rr[u * 2 * T + rows];
+                    const float2 lo = rr[u * AR], hi = rr[u * AR + rows];
                     rx += lo.x + hi.x; ry += lo.y + hi.y;
                 }
                 fsx = ex - rx; fsy = ey - ry;
