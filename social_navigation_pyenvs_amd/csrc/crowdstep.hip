@@ -48,6 +48,7 @@ struct KArgs {
     int W, n, rows, G, O, Smax;
     int type, flags, mode;
     int nsub, wpb;
+    int ws;                // LDS rows between the doubled row blocks of consecutive worlds of a block (>= 2 * rows)
     float dt;
     float* Sin;            // mutated only with M_MUTATE_INPUT
     float* Sout;
@@ -247,6 +248,7 @@ __device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx
 //   MAXT   = 64 (one wavefront, floor(64/rows) worlds) or 1024 (one world per block)
 // ------------------------------------------------------------------------------------------
 constexpr int UA = 4; // reaction accumulator rows of the pair-once loop (independent LDS read-modify-write chains)
+constexpr int ACC_PITCH = 256; // float2 slots per accumulator row (128 used by a one-wavefront block)
 
 template <int SOC, int HEADED, bool PEQ, int MAXT>
 __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     const bool human = valid && row < n;
     const bool is_robot = valid && robot_row && row == n;
     const int base = lw * rows;        // first row of my world in the per-row arrays (lds_v, lds_vr, ...)
-    const int pbase = 2 * base;        // first row of my world in the doubled position buffers
+    const int pbase = lw * a.ws;       // first row of my world in the doubled position buffers
     const float dt = a.dt;
     const int obs_type = (a.type == 1 || a.type == 4 || a.type == 7) ? 1 : 0;
 
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     __syncthreads();
 
 #ifdef CS_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
@@ -424,10 +426,11 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
         float fsx = 0.0f, fsy = 0.0f;
         if constexpr (N3L) {
             {
-                float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 per row = T float4: one per lane
+                float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 used per row = T float4: one per lane
 #pragma unroll
-                for (int u = 0; u < UA; ++u) z[u * T + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
+            STAMP(8);
             if (valid) {
                 const int Hf = (rows - 1) >> 1;
                 const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
@@ -456,7 +459,9 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                 // groups of UA partners; the partner rows of the NEXT group are fetched while the current group is
                 // evaluated (two register sets, a compiler memory barrier pins the prefetch), and the accumulator
                 // slots are read before the evaluation and written after it
-                constexpr int AR = 2 * 64;  // accumulator row pitch (block = one wavefront)
+                // accumulator row pitch: 2 KiB, out of reach of the ds_read2_b64 / ds_write2_b64 offset fields on purpose:
+                // the paired forms take 8 / 13 LDS cycles, two single b64 accesses 4 / 12 (MI355X_MICROARCH.md, LDS table)
+                constexpr int AR = ACC_PITCH;
                 auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
@@ -465,12 +470,54 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                     }
                 };
                 auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], float2 (&ac)[UA], int kk) {
+                    if constexpr (SOC == 2) {
 #pragma unroll
-                    for (int u = 0; u < UA; ++u) {
-                        float fx, fy;
-                        pair_once(q[u], vq[u], fx, fy);
-                        ex += fx; ey += fy;
-                        ac[u].x += fx; ac[u].y += fy;
+                        for (int u = 0; u < UA; ++u) {
+                            float fx, fy;
+                            pair_once(q[u], vq[u], fx, fy);
+                            ex += fx; ey += fy;
+                            ac[u].x += fx; ac[u].y += fy;
+                        }
+                    } else {
+                        // Helbing / Guo: the UA partners advance stage by stage (scheduling barriers between the
+                        // stages), so the UA v_rsq_f32 and the UA v_exp_f32 issue back to back and each result is
+                        // consumed ~UA instructions later instead of right behind its transcendental
+                        float dx[UA], dy[UA], d2[UA], inv[UA], rd[UA], ea[UA], ec[UA];
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            dx[u] = px - q[u].x; dy[u] = py - q[u].y;
+                            d2[u] = fmaf(dx[u], dx[u], dy[u] * dy[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) inv[u] = rsq_fast(d2[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            rd[u] = fmaf(-d2[u], inv[u], my_rs + q[u].z);
+                            ea[u] = fmaf(rd[u], sp.cB, sp.lA);
+                            if constexpr (SOC == 1) ec[u] = fmaf(rd[u], sp.cD, sp.lC);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            ea[u] = exp2_fast(ea[u]);
+                            if constexpr (SOC == 1) ec[u] = exp2_fast(ec[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            const float ga = ea[u] * inv[u];
+                            float fx = ga * dx[u], fy = ga * dy[u];
+                            if constexpr (SOC == 1) {
+                                const float gc = ec[u] * (inv[u] * sp.sAC);
+                                fx = fmaf(-gc, dy[u], fx); fy = fmaf(gc, dx[u], fy);
+                            }
+                            ex += fx; ey += fy;
+                            ac[u].x += fx; ac[u].y += fy;
+                        }
+#pragma unroll
+                        for (int u = 0; u < UA; u += 2) rdmax = fmaxf(fmaxf(rdmax, rd[u]), rd[u + 1]);
                     }
 #pragma unroll
                     for (int u = 0; u < UA; ++u) acc[u * AR + kk + u] = ac[u];
@@ -516,6 +563,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                     pair_once(rp[Hf], vq, fx, fy);
                     ex += fx; ey += fy;
                 }
+                STAMP(9);
                 float rx = 0.0f, ry = 0.0f;
                 const float2* rr = lds_acc + pbase + row;
 #pragma unroll
@@ -524,6 +572,7 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                     rx += lo.x + hi.x; ry += lo.y + hi.y;
                 }
                 fsx = ex - rx; fsy = ey - ry;
+                STAMP(10);
                 if constexpr (SOC != 2) {
                     fsx *= sp.sA; fsy *= sp.sA;
                     if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
@@ -827,8 +876,8 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     }
 #ifdef CS_STAMPS
     if (a.stamps != nullptr && (threadIdx.x & 63) == 0) {
-        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 8;
-        for (int k = 0; k < 8; ++k) o[k] = st_acc[k];
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 12;
+        for (int k = 0; k < 12; ++k) o[k] = st_acc[k];
     }
 #endif
 
@@ -953,7 +1002,7 @@ kfn pick_kernel(int type, bool peq)
 using csimpl::g_stamp_buf;
 #endif
 
-struct Geometry { int grid, block, wpb; };
+struct Geometry { int grid, block, wpb, ws; };
 
 int geometry(const cs_worlds* w, Geometry& g)
 {
@@ -961,6 +1010,13 @@ int geometry(const cs_worlds* w, Geometry& g)
     if (rows <= 0 || rows > 1024) return fail(CS_ERR_ARG, "rows per world must be in 1..1024");
     if (rows <= 64) { g.block = 64; g.wpb = 64 / rows; }
     else { g.block = ((rows + 63) / 64) * 64; g.wpb = 1; }
+    // world pitch in the doubled LDS buffers: 2 * rows, padded so that row index == lane (mod 32) in every world of the
+    // wavefront (bank-conflict-free b64 / b96 / b128 accesses across the world boundary) when that fits the 2T rows
+    g.ws = 2 * rows;
+    if (g.block == 64) {
+        const int padded = 2 * rows + (32 - rows % 32) % 32;
+        if (g.wpb * padded <= 2 * g.block) g.ws = padded;
+    }
     g.grid = (w->W + g.wpb - 1) / g.wpb;
     return CS_OK;
 }
@@ -994,7 +1050,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     KArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = w->W; a.n = w->n; a.rows = rows; a.G = w->G; a.O = w->O; a.Smax = w->Smax;
-    a.type = w->type; a.flags = w->flags; a.mode = mode; a.nsub = nsub; a.wpb = g.wpb; a.dt = dt;
+    a.type = w->type; a.flags = w->flags; a.mode = mode; a.nsub = nsub; a.wpb = g.wpb; a.ws = g.ws; a.dt = dt;
     a.Sin = w->d_state; a.Sout = d_out ? d_out : w->d_state;
     strides(w, rows, a.in_as, a.in_fs);
     a.out_as = a.in_as; a.out_fs = a.in_fs;
@@ -1011,7 +1067,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
     const size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
                          2 * PADR * (sizeof(float4) + sizeof(float2)) +
-                         ((peq && g.block == 64) ? (size_t)UA * 2 * g.block * sizeof(float2) : 0);
+                         ((peq && g.block == 64) ? (size_t)UA * ACC_PITCH * sizeof(float2) : 0);
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(fn, dim3(g.grid), dim3(g.block), shmem, stream, a);

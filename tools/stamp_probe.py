@@ -49,14 +49,15 @@ S, goals, P, rb = sc.hybrid_worlds(W, n, model)
 cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
                  respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), layout="soa")
 g, b, wpb = cw.launch_geometry()
-buf = _lib.DeviceBuffer((g * (b // 64), 8), np.uint64)
+buf = _lib.DeviceBuffer((g * (b // 64), 12), np.uint64)
 lib = _lib.load()
 lib.cs_debug_set_stamp_buffer(C.c_void_p(buf.ptr))
 for _ in range(5):
     cw.step(0.0125, 20)
 cw.sync()
 st = buf.download().astype(np.float64)
-names = ["goal switch", "rot+desired+walls", "pair loop", "torque+euler+lds write", "barrier", "respawn check", "-", "loop top"]
+names = ["goal switch", "rot+desired+walls", "pair-once: contact pass/ballot", "torque+euler+lds write", "barrier", "respawn check", "all-partners pair loop (not pair-once)", "loop top",
+         "pair-once: zero accumulators", "pair-once: partner groups", "pair-once: reaction sum", "-"]
 tot = st.sum(1).mean()
 print(f"N={n} {model}: mean wave cycles in loop = {tot:.0f} (per substep {tot / 20:.0f})")
 for k, nm in enumerate(names):
