@@ -172,6 +172,44 @@ int cs_lookahead(int W, int n, int A, int theta_and_omega_visible, const float* 
                  const float* d_current, const float* d_robot, int robot_stride, float dt, float* d_rotated,
                  float* d_rewards, void* stream);
 
+/*
+ * cs_generate_worlds  replaces, for W worlds at once and on the device, what SocialNavGym.reset does per world on the
+ *   host (social_nav_gym.py:135-197):  np.random.seed(seed) ; [hybrid: np.random.choice + re-seed] ;
+ *   generate_circular_crossing_setting / generate_parallel_traffic_scenario /
+ *   generate_circular_crossing_with_static_obstacles (social_nav_sim.py:200-431) ; the HumanAgent rows reset_sim
+ *   builds (:97-198) ; robot.set(...) (social_nav_gym.py:211-213).
+ *   One lane per world restates numpy's legacy MT19937 stream (init_genrand seeding, 53-bit random_sample,
+ *   uniform, choice-of-two) and the generators' rejection loops in f64, draw for draw; rows are rounded to f32 when
+ *   stored.  d_seeds [W] = offset[phase] + case (social_nav_gym.py:135-137).  Writes w->d_state (humans, and the
+ *   robot row with CS_ROBOT_ROW), w->d_goals ([W][n][G][2], NaN-padded), w->d_robot (if not NULL), w->d_world_flags
+ *   (if not NULL: 1 for parallel-traffic worlds = respawn rule on).
+ *   d_mask     optional [W]: only worlds with a non-zero entry are regenerated (auto-reset of finished episodes).
+ *   d_status   optional [W]: 0 ok, 1 = a human could not be placed within max_tries (the reference loops forever),
+ *              2 = parallel traffic too dense (ValueError in the reference, :318-319); such worlds are left untouched.
+ *   d_scenario optional [W]: the scenario each world got (the hybrid choice).
+ *   d_scratch  cs_generate_scratch_bytes(W) bytes (624 MT19937 words per world).
+ */
+enum {
+    CS_SCN_CIRCULAR_CROSSING = 0,                  /* 'circle_crossing'                          */
+    CS_SCN_PARALLEL_TRAFFIC = 1,                   /* 'parallel_traffic'                         */
+    CS_SCN_CIRCULAR_CROSSING_STATIC_OBSTACLES = 2, /* 'circular_crossing_with_static_obstacles'  */
+    CS_SCN_HYBRID = 3                              /* 'hybrid_scenario': choice of the first two */
+};
+typedef struct cs_generator {
+    int32_t scenario;             /* CS_SCN_*                                                               */
+    int32_t n;                    /* n_actors                                                               */
+    int32_t insert_robot;         /* robot start / goal take part in the rejection tests (:284-287)         */
+    int32_t randomize_attributes; /* uniform(0.5,1.5) speed and uniform(0.3,0.5) radius per human (:217-220) */
+    int32_t randomize_positions;  /* circular crossing only: 0 = evenly spaced (:231-251)                    */
+    int32_t max_tries;            /* bound of every rejection loop                                           */
+    double  circle_radius, traffic_length, traffic_height, robot_radius;
+    double  human_mass;           /* 75 (reset_sim, :167)                                                    */
+    double  robot_mass, robot_desired_speed; /* RobotAgent defaults (agent.py)                               */
+} cs_generator;
+size_t cs_generate_scratch_bytes(int W);
+int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32_t* d_seeds, const int32_t* d_mask,
+                       int32_t* d_status, int32_t* d_scenario, void* d_scratch, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "cs_event_elapsed_ms", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
     "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
     "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry", "cs_lookahead",
+    "cs_generate_scratch_bytes", "cs_generate_worlds",
 ]
 
 
@@ -68,6 +69,8 @@ def load():
     for name in ABI_SYMBOLS:
         if name != "cs_last_error" and hasattr(lib, name):
             getattr(lib, name).restype = C.c_int
+    if hasattr(lib, "cs_generate_scratch_bytes"):
+        lib.cs_generate_scratch_bytes.restype = C.c_size_t
     _lib = lib
     return lib
 

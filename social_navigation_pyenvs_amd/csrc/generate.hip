@@ -1,0 +1,332 @@
+// generate.hip -- device-side scenario generators: reset() of W worlds without W serial host
+// rejection-sampling loops.
+//
+// Restates, one GPU lane per world, what SocialNavGym.reset does per world on the host:
+//   np.random.seed(offset[phase] + case)                         /root/reference/social_gym/social_nav_gym.py:135-137
+//   hybrid_scenario: np.random.choice([...]) then re-seed         social_nav_gym.py:156-157, 185-186
+//   generate_circular_crossing_setting                            /root/reference/social_gym/social_nav_sim.py:200-299
+//   generate_parallel_traffic_scenario                            social_nav_sim.py:301-362
+//   generate_circular_crossing_with_static_obstacles              social_nav_sim.py:364-431
+//   HumanAgent rows built by reset_sim                            social_nav_sim.py:97-198 (mass 75, zero velocities)
+// The reference draws from numpy's legacy global stream: MT19937 seeded by init_genrand (integer seed),
+// random_sample() = (a >> 5, b >> 6) 53-bit doubles, uniform(lo, hi) = lo + (hi - lo) * random_sample(),
+// choice of two = next_uint32 & 1.  All of it is restated here in integer / f64 arithmetic, so the draw ORDER and the
+// accept / reject decisions are the reference's; rows are rounded to f32 only when they are stored.
+//
+// MT19937 state: 624 words per world, kept in a caller-provided scratch [624][W] (word-major: the seeding and twist
+// loops of the 64 lanes of a wavefront touch consecutive addresses).
+//
+// gfx950 only; not a hot path (one launch per reset), written for clarity.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "common.h"
+#include "crowdstep.h"
+
+#pragma clang fp contract(off) // the reference's numpy expressions are not fused
+
+namespace {
+
+using csimpl::fail;
+
+constexpr int GEN_MAXN = 128; // humans per world the per-lane placement arrays hold
+
+struct GArgs {
+    cs_generator g;
+    int W, rows, G, robot_row;
+    float* S;
+    long as, fs;
+    float* goals;
+    float* robot;
+    int* world_flags;
+    const uint32_t* seeds;
+    const int32_t* mask;
+    int32_t* status;
+    int32_t* scenario_out;
+    uint32_t* mt; // [624][W]
+};
+
+struct MT {
+    uint32_t* s;
+    long stride;
+    int pos;
+    __device__ uint32_t& at(int k) { return s[(long)k * stride]; }
+};
+
+// numpy/random/src/mt19937/mt19937.c: mt19937_seed (init_genrand)
+__device__ void mt_seed(MT& m, uint32_t seed)
+{
+    uint32_t prev = seed;
+    m.at(0) = prev;
+    for (int i = 1; i < 624; ++i) {
+        prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i;
+        m.at(i) = prev;
+    }
+    m.pos = 624;
+}
+
+__device__ void mt_twist(MT& m)
+{
+    constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+    int kk = 0;
+    for (; kk < 624 - 397; ++kk) {
+        const uint32_t y = (m.at(kk) & UPPER) | (m.at(kk + 1) & LOWER);
+        m.at(kk) = m.at(kk + 397) ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+    }
+    for (; kk < 623; ++kk) {
+        const uint32_t y = (m.at(kk) & UPPER) | (m.at(kk + 1) & LOWER);
+        m.at(kk) = m.at(kk - 227) ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+    }
+    const uint32_t y = (m.at(623) & UPPER) | (m.at(0) & LOWER);
+    m.at(623) = m.at(396) ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+    m.pos = 0;
+}
+
+__device__ uint32_t mt_next(MT& m)
+{
+    if (m.pos >= 624) mt_twist(m);
+    uint32_t y = m.at(m.pos++);
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// legacy random_sample(): 53-bit double in [0, 1)
+__device__ double rnd(MT& m)
+{
+    const uint32_t a = mt_next(m) >> 5, b = mt_next(m) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+__device__ double uniform(MT& m, double lo, double hi) { return lo + (hi - lo) * rnd(m); }
+
+// social_gym/src/utils.py:7-13 (Python's sign-of-divisor modulo == fmod for the operand signs of each branch)
+__device__ double bound_angle_d(double a)
+{
+    const double two_pi = 2.0 * 3.141592653589793, pi = 3.141592653589793;
+    if (a >= two_pi) a = fmod(a, two_pi);
+    if (a <= -two_pi) a = fmod(a, two_pi);
+    if (a > pi) a -= two_pi;
+    if (a < -pi) a += two_pi;
+    return a;
+}
+
+__device__ double norm2d(double x, double y) { return sqrt(x * x + y * y); } // np.linalg.norm of a 2-vector
+
+__global__ __launch_bounds__(64) void k_generate(const GArgs a)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    if (a.mask != nullptr && a.mask[w] == 0) return;
+    const cs_generator& g = a.g;
+    const int n = g.n;
+    const double pi = 3.141592653589793;
+    MT m{a.mt + w, (long)a.W, 624};
+    const uint32_t seed = a.seeds[w];
+    mt_seed(m, seed);
+    int scenario = g.scenario;
+    if (scenario == CS_SCN_HYBRID) { // np.random.choice(['circle_crossing', 'parallel_traffic']); np.random.seed(seed)
+        scenario = (mt_next(m) & 1u) ? CS_SCN_PARALLEL_TRAFFIC : CS_SCN_CIRCULAR_CROSSING;
+        mt_seed(m, seed);
+    }
+    double px[GEN_MAXN], py[GEN_MAXN], yaw[GEN_MAXN], rad[GEN_MAXN], spd[GEN_MAXN];
+    int status = 0;
+    const double R = g.circle_radius, L = g.traffic_length, H = g.traffic_height, rr = g.robot_radius;
+    double rpx = 0, rpy = 0, ryaw = 0, rgx = 0, rgy = 0;
+    const bool insert_robot = g.insert_robot != 0;
+
+    if (scenario == CS_SCN_CIRCULAR_CROSSING || scenario == CS_SCN_PARALLEL_TRAFFIC) {
+        for (int i = 0; i < n; ++i) { // one speed draw then one radius draw per human (:217-220)
+            if (g.randomize_attributes) { spd[i] = uniform(m, 0.5, 1.5); rad[i] = uniform(m, 0.3, 0.5); }
+            else { spd[i] = 1.0; rad[i] = 0.3; }
+        }
+    }
+    if (scenario == CS_SCN_CIRCULAR_CROSSING) {
+        rpx = 0.0; rpy = 0.0 - R; ryaw = pi / 2.0; rgx = 0.0; rgy = 0.0 + R;
+        if (!g.randomize_positions) { // evenly spaced (:231-251)
+            const int slots = n + (insert_robot ? 1 : 0);
+            const double step = (2.0 * pi) / slots;
+            for (int i = 0; i < n; ++i) {
+                const int k = insert_robot ? i + 1 : i;
+                const double off = insert_robot ? -(pi / 2.0) : 0.0;
+                px[i] = 0.0 + R * cos(off + step * k); py[i] = 0.0 + R * sin(off + step * k);
+                yaw[i] = insert_robot ? bound_angle_d((pi / 2.0) + step * k) : bound_angle_d(-pi + step * k);
+            }
+        } else {
+            for (int i = 0; i < n && status == 0; ++i) {
+                bool placed = false;
+                for (int t = 0; t < g.max_tries; ++t) {
+                    const double angle = rnd(m) * pi * 2.0;
+                    const double nx = (rnd(m) - 0.5) * spd[i];
+                    const double ny = (rnd(m) - 0.5) * spd[i];
+                    const double x = 0.0 + R * cos(angle) + nx, y = 0.0 + R * sin(angle) + ny;
+                    bool collide = false;
+                    for (int j = 0; j < i; ++j) {
+                        const double md = rad[i] + rad[j] + 0.2;
+                        // goal of a placed human: (-x + 2 cx, -y + 2 cx)  (:280 uses the centre's x twice; cx = cy = 0)
+                        if (norm2d(x - px[j], y - py[j]) < md || norm2d(x - (-px[j] + 0.0), y - (-py[j] + 0.0)) < md) {
+                            collide = true;
+                            break;
+                        }
+                    }
+                    if (insert_robot && (norm2d(x - rpx, y - rpy) < rad[i] + rr + 0.2 || norm2d(x - rgx, y - rgy) < rad[i] + rr + 0.2))
+                        collide = true;
+                    if (!collide) {
+                        px[i] = x; py[i] = y; yaw[i] = bound_angle_d(pi + angle);
+                        placed = true;
+                        break;
+                    }
+                }
+                if (!placed) status = 1;
+            }
+        }
+    } else if (scenario == CS_SCN_PARALLEL_TRAFFIC) {
+        rpx = -(L / 2.0) + 1.0; rpy = 0.0; ryaw = 0.0; rgx = (L / 2.0) - 1.0; rgy = 0.0;
+        double area = 0.0;
+        for (int i = 0; i < n; ++i) area += pi * (rad[i] * rad[i]);
+        if (area > L * H * 0.4) status = 2; // ValueError in the reference (:318-319)
+        for (int i = 0; i < n && status == 0; ++i) {
+            bool placed = false;
+            for (int t = 0; t < g.max_tries; ++t) {
+                const double lo = -(L / 2.0) + rad[i], hi = L / 2.0 - rad[i];
+                const double x = (hi - lo) * rnd(m) + lo;
+                const double y = (rnd(m) - 0.5) * H;
+                bool collide = false;
+                for (int j = 0; j < i; ++j)
+                    if (norm2d(x - px[j], y - py[j]) - rad[i] - rad[j] - 0.1 < 0.0) { collide = true; break; }
+                if (insert_robot && norm2d(x - rpx, y - rpy) - rad[i] - rr - 0.1 < 0.0) collide = true;
+                if (!collide) {
+                    px[i] = x; py[i] = y; yaw[i] = bound_angle_d(-pi);
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) status = 1;
+        }
+    } else { // circular crossing with static obstacles
+        rpx = 0.0; rpy = 0.0 - R; ryaw = pi / 2.0; rgx = 0.0; rgy = 0.0 + R;
+        const double inner = R - 3.0;
+        for (int i = 0; i < n; ++i) { // the three "obstacles" are immobile humans with a drawn radius (:381-387)
+            if (i < 3) { spd[i] = 0.0; rad[i] = 1.0 + (rnd(m) - 1.0) * 0.4; }
+            else { spd[i] = 1.0; rad[i] = 0.3; }
+        }
+        const double sector = pi / (double)(n / 2);
+        for (int i = 0; i < n && status == 0; ++i) {
+            bool placed = false;
+            for (int t = 0; t < g.max_tries; ++t) {
+                double angle, nx, ny, ring;
+                if (i < 3) {
+                    angle = sector * (-0.5 + 2.0 * i + (rnd(m) - 0.5) * 0.5);
+                    nx = (rnd(m) - 0.5) * 0.1; ny = (rnd(m) - 0.5) * 0.1;
+                    ring = inner;
+                } else {
+                    angle = sector * (0.5 + 2.0 * i + (rnd(m) - 0.5) * 0.5);
+                    nx = (rnd(m) - 0.5) * 0.7; ny = (rnd(m) - 0.5) * 0.7;
+                    ring = R;
+                }
+                const double x = 0.0 + ring * cos(angle) + nx, y = 0.0 + ring * sin(angle) + ny;
+                bool collide = false;
+                for (int j = 0; j < i; ++j) {
+                    const double md = rad[i] + rad[j] + 0.2;
+                    const double gxj = (j < 3) ? px[j] : (-px[j] + 0.0), gyj = (j < 3) ? py[j] : (-py[j] + 0.0);
+                    if (norm2d(x - px[j], y - py[j]) < md || norm2d(x - gxj, y - gyj) < md) { collide = true; break; }
+                }
+                if (norm2d(x - rpx, y - rpy) < rad[i] + rr + 0.2 || norm2d(x - rgx, y - rgy) < rad[i] + rr + 0.2) collide = true;
+                if (!collide) {
+                    px[i] = x; py[i] = y; yaw[i] = bound_angle_d(pi + angle);
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) status = 1;
+        }
+    }
+    if (a.status != nullptr) a.status[w] = status;
+    if (a.scenario_out != nullptr) a.scenario_out[w] = scenario;
+    if (status != 0) return; // the rows of a world that could not be generated are left untouched
+
+    // ---- rows: [px,py,theta,vx,vy,bvx,bvy,omega,r,m,gx,gy,vd]  (agent.py:256-258), goals [n][G][2] NaN-padded
+    const float nanf_ = __builtin_nanf("");
+    for (int i = 0; i < n; ++i) {
+        double g0x, g0y, g1x, g1y;
+        int ng;
+        if (scenario == CS_SCN_PARALLEL_TRAFFIC) { g0x = -(L / 2.0) - 3.0; g0y = py[i]; g1x = g1y = 0; ng = 1; }
+        else if (scenario == CS_SCN_CIRCULAR_CROSSING_STATIC_OBSTACLES && i < 3) { g0x = px[i]; g0y = py[i]; g1x = px[i]; g1y = py[i]; ng = 2; }
+        else { g0x = 0.0 * 2.0 - px[i]; g0y = 0.0 * 2.0 - py[i]; g1x = px[i]; g1y = py[i]; ng = 2; }
+        float* s = a.S + ((long)w * a.rows + i) * a.as;
+        const long fs = a.fs;
+        s[0] = (float)px[i]; s[fs] = (float)py[i]; s[2 * fs] = (float)yaw[i];
+        for (int c = 3; c < 8; ++c) s[c * fs] = 0.0f;
+        s[8 * fs] = (float)rad[i]; s[9 * fs] = (float)g.human_mass; s[10 * fs] = (float)g0x; s[11 * fs] = (float)g0y;
+        s[12 * fs] = (float)spd[i];
+        float* gl = a.goals + ((long)w * n + i) * a.G * 2;
+        for (int k = 0; k < a.G; ++k) {
+            float gx = nanf_, gy = nanf_;
+            if (k == 0) { gx = (float)g0x; gy = (float)g0y; }
+            else if (k == 1 && ng == 2) { gx = (float)g1x; gy = (float)g1y; }
+            gl[2 * k] = gx; gl[2 * k + 1] = gy;
+        }
+    }
+    // robot safe-state row (social_nav_gym.py:211-213: robot.set(px, py, gx, gy, 0, 0, yaw, w=0))
+    auto robot_row = [&](float* o, long fs) {
+        o[0] = (float)rpx; o[fs] = (float)rpy; o[2 * fs] = (float)ryaw;
+        for (int c = 3; c < 8; ++c) o[c * fs] = 0.0f;
+        o[8 * fs] = (float)rr; o[9 * fs] = (float)g.robot_mass; o[10 * fs] = (float)rgx; o[11 * fs] = (float)rgy;
+        o[12 * fs] = (float)g.robot_desired_speed;
+    };
+    if (a.robot != nullptr) robot_row(a.robot + (long)w * 13, 1);
+    if (a.robot_row) robot_row(a.S + ((long)w * a.rows + n) * a.as, a.fs);
+    if (a.world_flags != nullptr) a.world_flags[w] = (scenario == CS_SCN_PARALLEL_TRAFFIC) ? 1 : 0; // respawn rule on (:359-360)
+}
+
+} // namespace
+
+extern "C" {
+
+size_t cs_generate_scratch_bytes(int W) { return W > 0 ? (size_t)624 * (size_t)W * sizeof(uint32_t) : 0; }
+
+int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32_t* d_seeds, const int32_t* d_mask,
+                       int32_t* d_status, int32_t* d_scenario, void* d_scratch, void* stream)
+{
+    if (!gen || !w || !d_seeds || !d_scratch) return fail(CS_ERR_ARG, "null argument");
+    if (!w->d_state || !w->d_goals) return fail(CS_ERR_ARG, "null device buffer in cs_worlds");
+    if (w->W <= 0 || w->n <= 0 || w->G <= 0) return fail(CS_ERR_ARG, "W, n, G must be positive");
+    if (gen->n != w->n) return fail(CS_ERR_ARG, "cs_generator.n differs from cs_worlds.n");
+    if (gen->n > GEN_MAXN) return fail(CS_ERR_ARG, "the device generators place at most 128 humans per world");
+    if (gen->scenario < CS_SCN_CIRCULAR_CROSSING || gen->scenario > CS_SCN_HYBRID) return fail(CS_ERR_ARG, "unknown scenario");
+    if (gen->scenario != CS_SCN_PARALLEL_TRAFFIC && w->G < 2) return fail(CS_ERR_ARG, "circular scenarios need G >= 2 goal slots");
+    if (gen->scenario == CS_SCN_CIRCULAR_CROSSING_STATIC_OBSTACLES) {
+        if (!(gen->circle_radius > 5.0)) return fail(CS_ERR_ARG, "Radius must be greater than 5 for this scenario"); // :375
+        if (gen->n < 2) return fail(CS_ERR_ARG, "static-obstacle scenario needs at least 2 humans (sector = pi / (n // 2))");
+    }
+    if (gen->max_tries <= 0) return fail(CS_ERR_ARG, "max_tries must be positive (the reference's loops are unbounded)");
+    GArgs a;
+    a.g = *gen;
+    a.W = w->W;
+    a.robot_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0;
+    a.rows = w->n + a.robot_row;
+    a.G = w->G;
+    a.S = w->d_state;
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; }
+    else if (w->layout == CS_LAYOUT_SOA) { a.as = 1; a.fs = (long)w->W * a.rows; }
+    else return fail(CS_ERR_ARG, "bad layout");
+    a.goals = w->d_goals;
+    a.robot = w->d_robot;
+    a.world_flags = const_cast<int*>(w->d_world_flags);
+    a.seeds = d_seeds;
+    a.mask = d_mask;
+    a.status = d_status;
+    a.scenario_out = d_scenario;
+    a.mt = (uint32_t*)d_scratch;
+    const int block = 64, grid = (w->W + block - 1) / block;
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+} // extern "C"

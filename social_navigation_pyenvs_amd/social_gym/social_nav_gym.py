@@ -263,7 +263,12 @@ class BatchedSocialNavGym:
         self.global_time = None
         self.cw = None
 
-    def reset(self, phase="test", first_case=0, safety_space=0.0):
+    def reset(self, phase="test", first_case=0, safety_space=0.0, device=False):
+        """Generate W worlds from the seeds ``offset[phase] + (first_case + w) % case_size``.  ``device=False`` runs the
+        host generators world by world (W serial rejection-sampling loops); ``device=True`` runs them in one launch of
+        ``cs_generate_worlds`` (one GPU lane per world, same legacy random stream, same rows)."""
+        if device:
+            return self._reset_on_device(phase, first_case, safety_space)
         from .src.agent import RobotAgent
         from types import SimpleNamespace
 
@@ -304,6 +309,53 @@ class BatchedSocialNavGym:
         self.cw = CrowdWorlds(S, goals, P, margin, None, type=model, all_params_equal=True, robot_row=self.robot_visible,
                               robot=np.stack(rows_r), respawn_bounds=self._bounds if any_respawn else None,
                               respawn_worlds=np.array(respawn, np.int32) if any_respawn else None)
+        self.global_time = np.zeros(self.W, np.float32)
+        return self.observe()
+
+    def _reset_on_device(self, phase, first_case, safety_space):
+        from .. import generators as gen
+        from .. import scenarios as sc
+        from .src.agent import RobotAgent
+
+        proto = self._proto
+        assert phase in ["train", "val", "test"]
+        scenario = proto.train_val_sim if phase in ("train", "val") else proto.test_sim
+        if scenario not in gen.SCENARIOS:
+            raise NotImplementedError(f"no device generator for scenario {scenario!r}")
+        model = proto.human_policy
+        n = proto.human_num
+        robot = RobotAgent(proto)
+        robot.set_radius_and_update_graphics(proto.robot_radius)
+        traffic = scenario in ("parallel_traffic", "hybrid_scenario")
+        G = 1 if scenario == "parallel_traffic" else 2
+        rows = n + int(self.robot_visible)
+        margin = np.zeros((self.W, rows))
+        if model == "orca":
+            margin += 0.01 + safety_space
+        elif safety_space > 0:
+            margin[:, :n] = 0.01 + safety_space
+        P = None if model == "orca" else np.tile(sc.default_params(model), (n, 1))
+        self._bounds = (proto.traffic_length / 2, proto.traffic_height / 2)
+        self.cw = CrowdWorlds(np.zeros((self.W, rows, 13), np.float32), np.full((self.W, n, G, 2), np.nan, np.float32), P, margin,
+                              None, type=model, all_params_equal=True, robot_row=self.robot_visible,
+                              robot=np.zeros((self.W, 13), np.float32), respawn_bounds=self._bounds if traffic else None,
+                              respawn_worlds=np.zeros(self.W, np.int32) if traffic else None)
+        seeds = gen.phase_seeds(phase, first_case, self.W, proto.case_capacity)
+        status, scn = gen.generate_worlds(
+            self.cw, scenario, seeds, insert_robot=True, randomize_attributes=proto.randomize_attributes,
+            randomize_positions=True, circle_radius=proto.circle_radius, traffic_length=proto.traffic_length,
+            traffic_height=proto.traffic_height, robot_radius=proto.robot_radius, human_mass=75, robot_mass=robot.mass,
+            robot_desired_speed=robot.desired_speed)
+        if traffic and not np.any(scn == gen.SCENARIOS["parallel_traffic"]):
+            self.cw.respawn_bounds = None  # a hybrid batch that drew no traffic world: same descriptor as the host path
+        if model == "orca":  # RVO2 preferred velocity lives in columns 5:7 (set_state_orca, motion_model_manager.py:105-123)
+            S = self.cw.get_states()
+            d = S[:, :n, 10:12] - S[:, :n, 0:2]
+            dn = np.linalg.norm(d, axis=-1, keepdims=True)
+            S[:, :n, 5:7] = np.where(dn > S[:, :n, 12:13], d / np.maximum(dn, 1e-30), d)
+            self.cw.set_states(S)
+        self.n = n
+        self.radius = self.cw.get_states()[:, :n, 8].astype(np.float32)
         self.global_time = np.zeros(self.W, np.float32)
         return self.observe()
 

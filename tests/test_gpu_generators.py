@@ -1,0 +1,203 @@
+"""the device-side scenario generators (cs_generate_worlds) against the golden vectors G6
+captured from the reference itself, and against the host generators (exact restatement, bit-exact on G6)."""
+import collections
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from golden_io import load_cases  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = dict(rtol=3e-7, atol=1e-6)  # f64 rows rounded to f32; device libm cos/sin may differ in the last f64 bit
+
+
+def _blank(W, n, G, robot_row=False, layout="aos"):
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rows = n + int(robot_row)
+    return CrowdWorlds(np.zeros((W, rows, 13)), np.full((W, n, G, 2), np.nan), np.zeros((n, 20)), None, None,
+                       type="sfm_helbing", all_params_equal=True, robot_row=robot_row, robot=np.zeros((W, 13)),
+                       respawn_worlds=np.zeros(W, np.int32), layout=layout)
+
+
+def test_device_generators_match_golden_g6():
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+
+    groups = collections.defaultdict(list)
+    hybrid = None
+    for c in load_cases("g6_generators"):
+        if c["generator"] == "hybrid_choice":
+            hybrid = c
+            continue
+        groups[(c["generator"], int(c["n"]), bool(c["insert_robot"]), bool(c["randomize_attributes"]))].append(c)
+    checked = 0
+    for (name, n, insert_robot, rand_attr), cases in groups.items():
+        scenario = {"circular_crossing": "circle_crossing", "circular_crossing_fixed": "circle_crossing"}.get(name, name)
+        G = 1 if name == "parallel_traffic" else 2
+        cw = _blank(len(cases), n, G)
+        seeds = [max(int(c["seed"]), 0) for c in cases]
+        status, scn = generate_worlds(cw, scenario, seeds, insert_robot=insert_robot, randomize_attributes=rand_attr,
+                                      randomize_positions=(name != "circular_crossing_fixed"))
+        assert not status.any()
+        S, goals, robot, flags = cw.get_states(), cw.get_goals(), cw.get_robot(), cw.d_world_flags.download()
+        for k, c in enumerate(cases):
+            np.testing.assert_allclose(S[k, :, 0:2], c["pos"].astype(np.float32), **F32_TOL)
+            np.testing.assert_allclose(S[k, :, 2], c["yaw"].astype(np.float32), **F32_TOL)
+            assert np.all(S[k, :, 3:8] == 0)
+            np.testing.assert_array_equal(S[k, :, 8], c["radius"].astype(np.float32))       # draws only: bit-exact
+            np.testing.assert_array_equal(S[k, :, 12], c["des_speed"].astype(np.float32))
+            assert np.all(S[k, :, 9] == 75)
+            g = np.asarray(c["goals"], np.float64)[:, :G]
+            np.testing.assert_allclose(goals[k], g.astype(np.float32), **F32_TOL)
+            np.testing.assert_allclose(S[k, :, 10:12], g[:, 0].astype(np.float32), **F32_TOL)
+            if c["insert_robot"]:
+                np.testing.assert_allclose(robot[k, 0:2], np.asarray(c["robot_pos"], np.float32), **F32_TOL)
+                np.testing.assert_allclose(robot[k, 10:12], np.asarray(c["robot_goals"], np.float32)[0], **F32_TOL)
+            assert flags[k] == (1 if name == "parallel_traffic" else 0)
+            checked += 1
+    assert checked > 100
+    # the hybrid choice: np.random.choice of two = next_uint32 & 1 on the freshly seeded stream
+    seeds = np.asarray(hybrid["seeds"], np.uint32)
+    cw = _blank(len(seeds), 5, 2)
+    _, scn = generate_worlds(cw, "hybrid_scenario", seeds)
+    want = np.array([1 if str(ch) == "parallel_traffic" else 0 for ch in hybrid["choice"]], np.int32)
+    np.testing.assert_array_equal(scn, want)
+
+
+def _config(test_sim="hybrid_scenario", human_num=10, policy="hsfm_farina", randomize="false"):
+    import configparser
+
+    cfg = configparser.RawConfigParser()
+    cfg.read_dict({
+        "env": {"time_limit": 50, "time_step": 0.0125, "robot_time_step": 0.25, "val_size": 100, "test_size": 100,
+                "randomize_attributes": randomize},
+        "reward": {"success_reward": 1, "collision_penalty": -0.25, "discomfort_dist": 0.2, "discomfort_penalty_factor": 0.5},
+        "sim": {"train_val_sim": test_sim, "test_sim": test_sim, "square_width": 10, "circle_radius": 7, "human_num": human_num,
+                "traffic_length": 14, "traffic_height": 3},
+        "humans": {"visible": "true", "policy": policy, "radius": 0.3, "v_pref": 1, "sensor": "coordinates"},
+        "robot": {"visible": "false", "policy": "none", "radius": 0.3, "v_pref": 1, "sensor": "coordinates"},
+    })
+    return cfg
+
+
+@pytest.mark.parametrize("sim,visible,layout_phase", [("hybrid_scenario", False, "test"), ("circle_crossing", True, "val"),
+                                                      ("parallel_traffic", False, "train"),
+                                                      ("circular_crossing_with_static_obstacles", True, "test")])
+def test_batched_gym_device_reset_equals_host_reset(sim, visible, layout_phase):
+    """BatchedSocialNavGym.reset(device=True) fills the same rows as W serial host resets of the reference logic."""
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W = 96
+    host = BatchedSocialNavGym(_config(sim), W, robot_visible=visible)
+    host.reset(phase=layout_phase, first_case=7)
+    dev = BatchedSocialNavGym(_config(sim), W, robot_visible=visible)
+    dev.reset(phase=layout_phase, first_case=7, device=True)
+    Sh, Sd = host.cw.get_states(), dev.cw.get_states()
+    assert Sh.shape == Sd.shape
+    np.testing.assert_allclose(Sd, Sh, **F32_TOL)
+    np.testing.assert_allclose(dev.cw.get_goals(), host.cw.get_goals(), **F32_TOL)  # NaN padding compares equal
+    np.testing.assert_allclose(dev.cw.get_robot(), host.cw.get_robot(), **F32_TOL)
+    if host.cw.d_world_flags is not None:
+        np.testing.assert_array_equal(dev.cw.d_world_flags.download(), host.cw.d_world_flags.download())
+    assert dev.cw.respawn_bounds == host.cw.respawn_bounds
+    # and both step identically from there
+    a = np.tile(np.array([[0.3, 0.1]], np.float32), (W, 1))
+    oh = host.step(a)
+    od = dev.step(a)
+    np.testing.assert_allclose(od[0], oh[0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(od[2], oh[2])
+
+
+def test_masked_regeneration_and_soa_layout():
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+
+    W, n = 130, 12
+    cw = _blank(W, n, 2, robot_row=True, layout="soa")
+    generate_worlds(cw, "circle_crossing", 1000 + np.arange(W))
+    S0, g0 = cw.get_states(), cw.get_goals()
+    assert np.all(np.isfinite(S0)) and np.all(S0[:, n, 8] == np.float32(0.3))  # robot row filled
+    ref = _blank(W, n, 2, robot_row=True, layout="aos")
+    generate_worlds(ref, "circle_crossing", 1000 + np.arange(W))
+    np.testing.assert_array_equal(S0, ref.get_states())  # same rows through either layout
+    mask = (np.arange(W) % 3 == 0)
+    status, scn = generate_worlds(cw, "circle_crossing", 5000 + np.arange(W), mask=mask)
+    S1 = cw.get_states()
+    np.testing.assert_array_equal(S1[~mask], S0[~mask])
+    assert np.all(np.any(S1[mask][:, :n, 0:2] != S0[mask][:, :n, 0:2], axis=(1, 2)))
+    np.testing.assert_array_equal(cw.get_goals()[~mask], g0[~mask])
+    assert np.all(scn[~mask] == -1) and np.all(scn[mask] == 0)
+
+
+def test_generator_failures_are_reported_not_hung():
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+
+    cw = _blank(8, 60, 2)  # 60 humans cannot stand on a circle of radius 2
+    with pytest.raises(RuntimeError):
+        generate_worlds(cw, "circle_crossing", np.arange(8), circle_radius=2, max_tries=200)
+    status, _ = generate_worlds(cw, "circle_crossing", np.arange(8), circle_radius=2, max_tries=200, raise_on_failure=False)
+    assert np.all(status == 1)
+    cw = _blank(4, 100, 1)  # 100 x pi 0.3^2 = 28.3 m^2 > 0.4 x 14 x 3
+    with pytest.raises(ValueError):
+        generate_worlds(cw, "parallel_traffic", np.arange(4))
+
+
+def test_full_size_device_reset_properties():
+    """Full-size resets in one launch each: one GPU's shard of BASELINE.json configs[4] (8192 worlds x 50 humans, circular
+    crossing on R = 20: the generator also keeps every human off the earlier humans' goals, 100 blocked spots) and 8192 worlds of the reference's static-obstacle scenario (10 humans: with more, its slots
+    i and i + n/2 coincide and the reference's own loop stops terminating).  Placement invariants of the generators
+    hold in every world, sampled worlds equal the host generator, and a seed gives the same world in any batch."""
+    import time
+
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+    from social_navigation_pyenvs_amd.social_gym.social_nav_sim import SocialNavSim
+
+    host = types.SimpleNamespace(_attributes=SocialNavSim._attributes)
+    W = 8192
+    seeds = 1000 + np.arange(W)
+    for scenario, n, R in (("circle_crossing", 50, 20), ("circular_crossing_with_static_obstacles", 10, 7)):
+        cw = _blank(W, n, 2)
+        t0 = time.perf_counter()
+        status, scn = generate_worlds(cw, scenario, seeds, circle_radius=R)
+        el = time.perf_counter() - t0
+        assert not status.any()
+        S, goals = cw.get_states(), cw.get_goals()
+        assert np.all(np.isfinite(S)) and np.all(np.isfinite(goals))
+        p, r = S[:, :, 0:2].astype(np.float64), S[:, :, 8].astype(np.float64)
+        gap = r[:, :, None] + r[:, None, :] + 0.2 - 1e-5
+        d = np.linalg.norm(p[:, :, None] - p[:, None, :], axis=-1) + np.eye(n)[None] * 1e9
+        assert np.all(d >= gap)                                                  # accepted placements keep the gap
+        static = scenario != "circle_crossing"
+        if static:
+            assert np.all((r[:, :3] > 0.6 - 1e-6) & (r[:, :3] <= 1.0)) and np.all(r[:, 3:] == np.float32(0.3))
+            assert np.all(S[:, :3, 12] == 0) and np.all(S[:, 3:, 12] == 1)
+            np.testing.assert_array_equal(goals[:, :3, 0], S[:, :3, 0:2])        # obstacles: goal = own position
+            np.testing.assert_array_equal(goals[:, 3:, 0], -S[:, 3:, 0:2])
+            np.testing.assert_array_equal(goals[:, :, 1], S[:, :, 0:2])
+        else:
+            assert np.all(r == np.float32(0.3)) and np.all(S[..., 12] == 1)
+            np.testing.assert_array_equal(goals[:, :, 0], -S[:, :, 0:2])
+            np.testing.assert_array_equal(goals[:, :, 1], S[:, :, 0:2])
+            dg = np.linalg.norm(p[:, :, None] + p[:, None, :], axis=-1)           # a later human also keeps off earlier goals
+            iu = np.triu_indices(n, 1)
+            assert np.all(dg[:, iu[1], iu[0]] >= gap[:, iu[1], iu[0]])
+        for w in (0, 4097, W - 1):
+            np.random.seed(int(seeds[w]))
+            if static:
+                data = SocialNavSim.generate_circular_crossing_with_static_obstacles(
+                    host, insert_robot=True, human_policy="hsfm_farina", robot_radius=0.3, circle_radius=R, n_actors=n)
+            else:
+                data = SocialNavSim.generate_circular_crossing_setting(
+                    host, insert_robot=True, human_policy="hsfm_farina", robot_radius=0.3, circle_radius=R, n_actors=n,
+                    randomize_human_positions=True, randomize_human_attributes=False)
+            hp = np.array([data["humans"][i]["pos"] for i in range(n)])
+            np.testing.assert_allclose(S[w, :, 0:2], hp.astype(np.float32), **F32_TOL)
+        sub = _blank(5, n, 2)
+        pick = np.array([17, 4097, 3, 8191, 100])
+        generate_worlds(sub, scenario, seeds[pick], circle_radius=R)
+        np.testing.assert_array_equal(sub.get_states(), S[pick])                 # batch composition does not matter
+        print(f"device reset of {W} x {n} ({scenario}): {el * 1e3:.1f} ms including the seed upload and status download")
