@@ -210,6 +210,19 @@ size_t cs_generate_scratch_bytes(int W);
 int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32_t* d_seeds, const int32_t* d_mask,
                        int32_t* d_status, int32_t* d_scenario, void* d_scratch, void* stream);
 
+/*
+ * cs_laser_scan  replaces LaserSensor.get_laser_measurements(humans, walls) without the noise term
+ *   (social_gym/src/sensors.py:51-66; disc hit :24-33, one-sided segment hit :35-49) for W sensors at once.
+ *   Humans (x, y, radius) are read from w->d_state, walls from w->d_obstacles.  Sensor poses (x, y, yaw in columns
+ *   0..2 of rows of `pose_stride` floats) come from d_pose, or from w->d_robot (robot safe-state rows) when d_pose
+ *   is NULL.  Ray k of `samples` points at linspace(yaw - range/2, yaw + range/2, samples)[k] (:53).
+ *   d_out [W][samples] = min(hit distance, max_distance); RobotAgent.get_laser_readings subtracts the robot radius
+ *   afterwards (robot_agent.py:77-82) -- the host mirror does that.
+ *   Errors: max_distance > 10 -> CS_ERR_ARG with the reference's message (sensors.py:13).
+ */
+int cs_laser_scan(const cs_worlds* w, const float* d_pose, int pose_stride, float range, int samples,
+                  float max_distance, float* d_out, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

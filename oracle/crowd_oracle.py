@@ -253,3 +253,50 @@ def num_threads() -> int:
     f = lib().orc_num_threads
     f.restype = C.c_int
     return int(f())
+
+
+def laser_scan(pos, yaw, rng, samples, max_distance, human_pos, human_radius, obstacles=None, dtype=np.float64):
+    """numpy restatement of LaserSensor.get_laser_measurements without noise
+    (/root/reference/social_gym/src/sensors.py:51-66; disc hit :24-33, one-sided segment hit :35-49).
+    obstacles: [O][Smax][2][2] NaN-padded, endpoints ordered as Obstacle.segments stores them (obstacle.py:31-32).
+    Returns (angles [samples], measurements [samples])."""
+    dt = np.dtype(dtype).type
+    pos = np.asarray(pos, dtype)
+    angles = np.linspace(dt(yaw) - dt(rng) / dt(2), dt(yaw) + dt(rng) / dt(2), int(samples), dtype=dtype)   # :53
+    md = dt(max_distance)
+    out = np.full(int(samples), md, dtype)
+    dirs = np.stack([np.cos(angles), np.sin(angles)], axis=-1).astype(dtype)                                   # :57
+    hp = np.asarray(human_pos, dtype).reshape(-1, 2)
+    hr = np.asarray(human_radius, dtype).reshape(-1)
+    for k in range(int(samples)):
+        d = dirs[k]
+        m = md
+        for i in range(len(hp)):                                                                             # :58-60
+            s = pos - hp[i]
+            b = s[0] * d[0] + s[1] * d[1]
+            c = s[0] * s[0] + s[1] * s[1] - hr[i] * hr[i]
+            h = b * b - c
+            if h < 0:
+                continue
+            t = -b - np.sqrt(h)
+            if t < 0:
+                continue
+            m = min(m, min(t, md))
+        if obstacles is not None:
+            segs = np.asarray(obstacles, dtype).reshape(-1, 2, 2)
+            for sg in segs:                                                                                  # :61-64
+                if np.isnan(sg[0, 0]):
+                    continue
+                x1, y1, x2, y2 = sg[0, 0], sg[0, 1], sg[1, 0], sg[1, 1]
+                x3, y3 = pos[0], pos[1]
+                x4, y4 = pos[0] + d[0], pos[1] + d[1]
+                den = (x1 - x2) * (y3 - y4) - (y1 - y2) * (x3 - x4)
+                if den <= 0:
+                    continue
+                t = ((x1 - x3) * (y3 - y4) - (y1 - y3) * (x3 - x4)) / den
+                u = -((x1 - x2) * (y1 - y3) - (y1 - y2) * (x1 - x3)) / den
+                if 0 < t < 1 and u > 0:
+                    ix, iy = x1 + t * (x2 - x1), y1 + t * (y2 - y1)
+                    m = min(m, min(np.sqrt((x3 - ix) ** 2 + (y3 - iy) ** 2), md))
+        out[k] = m
+    return angles, out

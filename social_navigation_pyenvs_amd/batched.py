@@ -203,6 +203,20 @@ class CrowdWorlds:
                                               cfg, C.c_void_p(out.ptr), C.c_void_p(self.stream)))
         return out.download(self.stream)
 
+    def laser_scan(self, range_: float, samples: int, max_distance: float, pose=None) -> np.ndarray:
+        """[W, samples] laser distances of every world's sensor (LaserSensor.get_laser_measurements without noise,
+        sensors.py:51-66).  ``pose`` [W, 3] (x, y, yaw) or None = the robot rows."""
+        if max_distance > 10:
+            raise ValueError("Maxium distance for laser is 10 meters")
+        d = self.descriptor()
+        p_ptr = None
+        if pose is not None:
+            p_ptr = self._upload("laser_pose", np.broadcast_to(np.asarray(pose, dtype=np.float32), (self.W, 3))).ptr
+        out = self._buffer("laser_out", (self.W, int(samples)))
+        check(_lib.load().cs_laser_scan(C.byref(d), C.c_void_p(p_ptr), C.c_int(3), C.c_float(range_), C.c_int(int(samples)),
+                                        C.c_float(max_distance), C.c_void_p(out.ptr), C.c_void_p(self.stream)))
+        return out.download(self.stream)
+
     # ------------------------------------------------------------------ state access
     def sync(self):
         _lib.stream_sync(self.stream)

@@ -162,6 +162,21 @@ class RobotAgent(Agent):
     def set_radius_and_update_graphics(self, radius):
         self.radius = radius
 
+    # -- laser range finder (robot_agent.py:67-82; ray casting on the GPU, csrc/laser.hip) ----------
+    def add_laser_sensor(self, range: float, samples: int, max_distance: float, uncertainty=None, render=False):
+        from .sensors import LaserSensor
+
+        self.laser = LaserSensor(self.position, self.yaw, range, samples, max_distance, uncertainty=uncertainty)
+        self.laser_data = {}
+        self.laser_render = render
+
+    def get_laser_readings(self, humans: list, walls):
+        self.laser.update_pose(self.position, self.yaw)
+        readings = self.laser.get_laser_measurements(humans, walls)
+        # the laser sits at the robot centre: readings are reported from the robot's surface (:80-81)
+        self.laser_data = {k: v - self.radius for k, v in readings.items()}
+        return self.laser_data
+
     # -- CrowdNav interface (robot_agent.py:93-160) -------------------------------------------------
     def set_policy(self, policy):
         self.policy = policy

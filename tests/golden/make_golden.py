@@ -18,6 +18,7 @@ reference produced) is written to the ``.npz`` fixtures.  Groups (SURVEY.md §8c
   g6_generators  scenario generator outputs for fixed seeds
   g7_respawn  parallel-traffic respawn (state just before / after)
   g8_lookahead  compute_rotated_states_and_reward (CADRL / SARL 81-action look-ahead)
+  g9_laser    LaserSensor.get_laser_measurements (social_gym/src/sensors.py:51-66)
 """
 from __future__ import annotations
 
@@ -580,9 +581,49 @@ def gen_g8_lookahead():
     print("g8_lookahead:", len(cases), "cases ->", save_cases("g8_lookahead", cases))
 
 
+def gen_g9_laser():
+    """LaserSensor.get_laser_measurements on random robot poses, human discs and polygon walls (sensors.py:24-66)."""
+    from social_gym.src.sensors import LaserSensor
+
+    rng = np.random.default_rng(90_000)
+    game = types.SimpleNamespace(real_size=15, display_to_real_ratio=1000 / 15)
+    cases = []
+    for k in range(40):
+        n = int(rng.choice([0, 1, 5, 10, 25]))
+        with_walls = k % 2 == 1
+        samples = int(rng.choice([1, 2, 31, 61, 181])) if k > 3 else [1, 2, 61, 360][k]
+        rng_angle = float(rng.choice([math.pi / 2, math.pi, 2 * math.pi]))
+        max_distance = float(rng.choice([4.0, 8.0, 10.0]))
+        pos = rng.uniform(-2.5, 2.5, 2)
+        yaw = float(rng.uniform(-math.pi, math.pi))
+        hp = pos + rng.uniform(-6, 6, (n, 2))
+        hr = rng.uniform(0.2, 1.0, n)
+        if n and k % 5 == 0:
+            hp[0] = pos + 0.1  # the sensor stands inside a disc: t < 0 -> max_distance (sensors.py:32)
+        humans = [types.SimpleNamespace(position=hp[i].copy(), radius=float(hr[i])) for i in range(n)]
+        verts = my_walls(rng) if with_walls else []
+        from social_gym.src.obstacle import Obstacle
+        walls = [Obstacle(game, v) for v in verts] if with_walls else []
+        # uncertainty=None leaves the attribute unset in the reference (sensors.py:15) and get_laser_measurements then
+        # raises AttributeError (:65); the noise-free path is reached by setting the attribute from outside
+        sigma = 0.05 if k % 4 == 3 else None
+        laser = LaserSensor(pos.copy(), yaw, rng_angle, samples, max_distance, uncertainty=sigma)
+        if sigma is None:
+            laser.uncertainty = None
+        noise_seed = 900 + k
+        np.random.seed(noise_seed)
+        out = laser.get_laser_measurements(humans, walls)
+        cases.append(dict(n=n, samples=samples, range=rng_angle, max_distance=max_distance, pos=pos, yaw=yaw,
+                          uncertainty=sigma, noise_seed=noise_seed,
+                          human_pos=hp.reshape(n, 2), human_radius=hr,
+                          obstacles=walls_to_array(verts) if with_walls else np.zeros((0, 1, 2, 2)),
+                          angles=np.array(list(out.keys()), dtype=float), measurements=np.array(list(out.values()), dtype=float)))
+    print("g9_laser:", len(cases), "cases ->", save_cases("g9_laser", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
-              g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead)
+              g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
