@@ -48,6 +48,7 @@ struct KArgs {
     int W, n, rows, G, O, Smax;
     int type, flags, mode;
     int nsub, wpb;
+    int seg_tab;           // wall segments staged in LDS per block (0: read them from global memory in every substep)
     int ws;                // LDS rows between the doubled row blocks of consecutive worlds of a block (>= 2 * rows)
     float dt;
     float* Sin;            // mutated only with M_MUTATE_INPUT
@@ -248,10 +249,13 @@ __device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx
 //   MAXT   = 64 (one wavefront, floor(64/rows) worlds) or 1024 (one world per block)
 // ------------------------------------------------------------------------------------------
 constexpr int UA = 4; // reaction accumulator rows of the pair-once loop (independent LDS read-modify-write chains)
-constexpr int ACC_PITCH = 256; // float2 slots per accumulator row (128 used by a one-wavefront block)
+constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one wavefront: 2 x 64 doubled rows)
 
-template <int SOC, int HEADED, bool PEQ, int MAXT>
-__global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
+//   OCC    = waves per SIMD the register allocation must allow: 4 (<= 128 VGPRs, a few spills) when the grid holds more
+//            than two wavefronts per SIMD, 1 (unconstrained, ~150 VGPRs, no spills) otherwise -- at 4096 x 25 there
+//            are exactly two waves per SIMD and the spill-free build is 6 % faster; at 16384 x 25 the 4-wave build is 7 % faster
+template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC>
+__global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // all_params_equal, whole worlds inside one wavefront: every unordered pair is evaluated ONCE (as the reference
@@ -268,6 +272,8 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     float* lds_g0x = reinterpret_cast<float*>(lds_vr + 2 * T);     // [T] respawn scratch
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);           // [T] respawn scratch
     float2* lds_acc = reinterpret_cast<float2*>(lds_flag + T);     // [UA][2T] reaction accumulators (N3L only)
+    float4* lds_seg = reinterpret_cast<float4*>(lds_acc + (N3L ? UA * ACC_PITCH : 0)); // [seg_tab] x1, y1, ex, ey
+    float* lds_sinv = reinterpret_cast<float*>(lds_seg + a.seg_tab);                   // [seg_tab] 1 / |e|^2, -1 = NaN slot
 
     const int tid = threadIdx.x;
     const int rows = a.rows, n = a.n;
@@ -333,6 +339,26 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
     const float inv_O = a.O > 0 ? 1.0f / (float)a.O : 0.0f;
     const float* obst = nullptr;
     if (a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
+    // wall segments are constant over the launch: stage (x1, y1, e, 1/|e|^2) in LDS once instead of re-loading and
+    // re-deriving them in every substep (3 polygons x 5 segments cost as much as the whole 50-agent pair loop otherwise)
+    const int nseg = a.O * a.Smax;
+    const int sbase = (a.flags & CS_OBSTACLES_SHARED) ? 0 : lw * nseg;
+    for (int i = tid; i < a.seg_tab; i += T) {
+        const int lwi = i / nseg;
+        const long wi = (long)blockIdx.x * a.wpb + lwi;
+        float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float inv = -1.0f;
+        if ((a.flags & CS_OBSTACLES_SHARED) || wi < a.W) {
+            const float* src = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? (long)i * 4 : (wi * nseg + (i - lwi * nseg)) * 4);
+            const float4 seg = *reinterpret_cast<const float4*>(src);
+            if (!isnan(seg.x)) {
+                e = make_float4(seg.x, seg.y, seg.z - seg.x, seg.w - seg.y);
+                inv = rcp_fast(fmaf(e.z, e.z, e.w * e.w));
+            }
+        }
+        lds_seg[i] = e;
+        lds_sinv[i] = inv;
+    }
 
     const bool respawn_here = valid && (a.world_flags == nullptr || (a.world_flags[w] & 1));
 
@@ -623,15 +649,23 @@ __global__ __launch_bounds__(MAXT) void k_sfm_step(const KArgs a)
                     float best = 0.0f, bdx = 0.0f, bdy = 0.0f;
                     bool have = false;
                     for (int sg = 0; sg < a.Smax; ++sg) {
-                        const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)o * a.Smax + sg) * 4);
-                        float d, ddx = 0.0f, ddy = 0.0f;
-                        if (isnan(seg.x)) {
-                            d = 3.0e38f; // the reference stores iinfo(int64).max as the distance (:247)
+                        float x1, y1, ex, ey, einv;
+                        if (a.seg_tab > 0) {
+                            const float4 e = lds_seg[sbase + o * a.Smax + sg];
+                            x1 = e.x; y1 = e.y; ex = e.z; ey = e.w;
+                            einv = lds_sinv[sbase + o * a.Smax + sg];
                         } else {
-                            const float ex = seg.z - seg.x, ey = seg.w - seg.y;
-                            const float t = ((px - seg.x) * ex + (py - seg.y) * ey) * rcp_fast(fmaf(ex, ex, ey * ey));
+                            const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)o * a.Smax + sg) * 4);
+                            x1 = seg.x; y1 = seg.y; ex = seg.z - seg.x; ey = seg.w - seg.y;
+                            einv = isnan(seg.x) ? -1.0f : rcp_fast(fmaf(ex, ex, ey * ey));
+                        }
+                        float d, ddx = 0.0f, ddy = 0.0f;
+                        if (einv < 0.0f) {
+                            d = 3.0e38f; // NaN slot: the reference stores iinfo(int64).max as the distance (:247)
+                        } else {
+                            const float t = ((px - x1) * ex + (py - y1) * ey) * einv;
                             const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
-                            ddx = px - fmaf(ts, ex, seg.x); ddy = py - fmaf(ts, ey, seg.y);
+                            ddx = px - fmaf(ts, ex, x1); ddy = py - fmaf(ts, ey, y1);
                             d = fmaf(ddx, ddx, ddy * ddy);
                         }
                         if (!have || d < best) { best = d; bdx = ddx; bdy = ddy; have = true; }
@@ -984,11 +1018,11 @@ __global__ void k_transpose_state(const float* src, float* dst, long total_rows,
 // ------------------------------------------------------------------------------------------
 using kfn = void (*)(const KArgs);
 
-template <int MAXT>
+template <int MAXT, int OCC>
 kfn pick_kernel(int type, bool peq)
 {
 #define CS_CASE(SOC, HD)                                                                          \
-    return peq ? (kfn)k_sfm_step<SOC, HD, true, MAXT> : (kfn)k_sfm_step<SOC, HD, false, MAXT>;
+    return peq ? (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC> : (kfn)k_sfm_step<SOC, HD, false, MAXT, OCC>;
     switch (type) {
         case 0: CS_CASE(0, 0) case 1: CS_CASE(1, 0) case 2: CS_CASE(2, 0)
         case 3: CS_CASE(0, 1) case 4: CS_CASE(1, 1) case 5: CS_CASE(2, 1)
@@ -1062,12 +1096,19 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.stamps = g_stamp_buf;
 #endif
     const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
-    kfn fn = (g.block == 64) ? pick_kernel<64>(w->type, peq) : pick_kernel<1024>(w->type, peq);
+    // 256 CUs x 4 SIMDs: more than two one-wave blocks per SIMD -> the 4-waves-per-SIMD register budget pays
+    const bool crowded = g.block == 64 && g.grid > 2 * 1024;
+    kfn fn = (g.block == 64) ? (crowded ? pick_kernel<64, 4>(w->type, peq) : pick_kernel<64, 1>(w->type, peq))
+                             : pick_kernel<1024, 1>(w->type, peq);
     // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
     // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
-    const size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
-                         2 * PADR * (sizeof(float4) + sizeof(float2)) +
-                         ((peq && g.block == 64) ? (size_t)UA * ACC_PITCH * sizeof(float2) : 0);
+    size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
+                   2 * PADR * (sizeof(float4) + sizeof(float2)) +
+                   ((peq && g.block == 64) ? (size_t)UA * ACC_PITCH * sizeof(float2) : 0);
+    // wall segment table (x1, y1, e, 1/|e|^2), shared or one per world of the block, when it is small enough
+    const long seg_tab = (long)w->O * w->Smax * ((w->flags & CS_OBSTACLES_SHARED) ? 1 : g.wpb);
+    a.seg_tab = (seg_tab > 0 && seg_tab * 20 <= 16 * 1024) ? (int)seg_tab : 0;
+    shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float));
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(fn, dim3(g.grid), dim3(g.block), shmem, stream, a);
