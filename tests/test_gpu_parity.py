@@ -233,3 +233,49 @@ def test_bad_type_raises_value_error():
     c = load_cases("g1_episode")[0]
     with pytest.raises(ValueError):
         CrowdWorlds(f32(c["state_in"]), f32(c["goals_in"]), f32(c["params"]), type=10)
+
+
+@pytest.mark.parametrize("rows_case", [(1, False), (2, False), (1, True), (3, False), (4, True), (7, False), (21, True),
+                                       (31, True), (32, False), (33, False), (63, True), (64, False)])
+def test_pair_once_loop_world_sizes(rows_case):
+    """Edge sizes of the pair-once loop (ring distance (rows-1)/2, antipodal partner for even rows, several worlds per
+    wavefront with the padded LDS pitch, worlds that fill the wavefront): dense random worlds, all 9 types,
+    all_params_equal, 3 fused substeps against the f64 oracle from the same f32 inputs."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    n, robot_row = rows_case
+    rows = n + int(robot_row)
+    W = 2 * (64 // rows) + 1 if rows <= 32 else 3
+    rng = np.random.default_rng(1000 * n + int(robot_row))
+    half = max(1.5, 0.45 * np.sqrt(rows))                       # dense: several pairs within a metre
+    for t, model in enumerate(SFMS):
+        S = np.zeros((W, rows, 13))
+        for w in range(W):
+            pts = []
+            while len(pts) < rows:
+                p = rng.uniform(-half, half, 2)
+                if all(np.linalg.norm(p - q) > 0.65 for q in pts):
+                    pts.append(p)
+            S[w, :, 0:2] = np.array(pts)
+        S[:, :, 2] = rng.uniform(-np.pi, np.pi, (W, rows))
+        S[:, :, 5:7] = rng.normal(0, 0.4, (W, rows, 2))
+        c, s = np.cos(S[:, :, 2]), np.sin(S[:, :, 2])
+        S[:, :, 3] = c * S[:, :, 5] - s * S[:, :, 6]; S[:, :, 4] = s * S[:, :, 5] + c * S[:, :, 6]
+        if t < 3:
+            S[:, :, 3:5] = rng.normal(0, 0.4, (W, rows, 2)); S[:, :, 5:8] = 0
+        else:
+            S[:, :, 7] = rng.normal(0, 0.3, (W, rows))
+        S[:, :, 8] = rng.uniform(0.25, 0.35, (W, rows)); S[:, :, 9] = 75; S[:, :, 12] = 1.0
+        goals = rng.uniform(-6, 6, (W, n, 2, 2))
+        S[:, :n, 10:12] = goals[:, :, 0]
+        P = np.tile(sc.default_params(model), (n, 1))
+        safety = np.zeros((W, rows))
+        S32, g32, P32 = f32(S), f32(goals), f32(P)
+        cw = CrowdWorlds(S32, g32, P32, f32(safety), None, type=model, all_params_equal=True, robot_row=robot_row)
+        cw.step(0.0125, 3)
+        got = cw.get_states()
+        ref, _, _ = orc.step_block(t, S32.astype(np.float64), g32.astype(np.float64), None, P32.astype(np.float64),
+                                   0.0125, 3, safety, True, robot_visible=robot_row)
+        err = np.max(np.abs(got[:, :n][..., PV] - ref[:, :n][..., PV]), axis=(1, 2))
+        assert np.all(err < (3e-4 if t % 3 == 2 else 5e-5)), f"{model} rows={rows}: worst world {int(np.argmax(err))}: {err.max()}"

@@ -22,7 +22,7 @@ _lib.LIB_PATH = so
 _lib._lib = None
 from social_navigation_pyenvs_amd.batched import CrowdWorlds  # noqa: E402
 
-W, n = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 25
+W, n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 25
 model = sys.argv[2] if len(sys.argv) > 2 else "hsfm_farina"
 if model == "orca":
     pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)

@@ -41,6 +41,41 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float seed)
                 a7 += __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(a0)));
             } else if (OP == 8) { // the same 8 adds without the permute (baseline for OP 7)
                 a0 += a1; a1 += a2; a2 += a3; a3 += a4; a4 += a5; a5 += a6; a6 += a7; a7 += a0;
+            } else if (OP == 9) { // 8 x { fma ; rare divergent branch that no lane takes (v_cmp, s_and_saveexec, s_cbranch_execz) }
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); if (a0 < -1e30f) { a0 = out[threadIdx.x]; }
+                a1 = __builtin_fmaf(a1, 1.0001f, 1e-6f); if (a1 < -1e30f) { a1 = out[threadIdx.x + 1]; }
+                a2 = __builtin_fmaf(a2, 1.0001f, 1e-6f); if (a2 < -1e30f) { a2 = out[threadIdx.x + 2]; }
+                a3 = __builtin_fmaf(a3, 1.0001f, 1e-6f); if (a3 < -1e30f) { a3 = out[threadIdx.x + 3]; }
+                a4 = __builtin_fmaf(a4, 1.0001f, 1e-6f); if (a4 < -1e30f) { a4 = out[threadIdx.x + 4]; }
+                a5 = __builtin_fmaf(a5, 1.0001f, 1e-6f); if (a5 < -1e30f) { a5 = out[threadIdx.x + 5]; }
+                a6 = __builtin_fmaf(a6, 1.0001f, 1e-6f); if (a6 < -1e30f) { a6 = out[threadIdx.x + 6]; }
+                a7 = __builtin_fmaf(a7, 1.0001f, 1e-6f); if (a7 < -1e30f) { a7 = out[threadIdx.x + 7]; }
+            } else if (OP == 10) { // 8 x { fma ; wave-uniform branch on a ballot that is never set (v_cmp, s_cmp, s_cbranch_scc) }
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a0 < -1e30f) != 0) { a0 = out[threadIdx.x]; }
+                a1 = __builtin_fmaf(a1, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a1 < -1e30f) != 0) { a1 = out[threadIdx.x + 1]; }
+                a2 = __builtin_fmaf(a2, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a2 < -1e30f) != 0) { a2 = out[threadIdx.x + 2]; }
+                a3 = __builtin_fmaf(a3, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a3 < -1e30f) != 0) { a3 = out[threadIdx.x + 3]; }
+                a4 = __builtin_fmaf(a4, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a4 < -1e30f) != 0) { a4 = out[threadIdx.x + 4]; }
+                a5 = __builtin_fmaf(a5, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a5 < -1e30f) != 0) { a5 = out[threadIdx.x + 5]; }
+                a6 = __builtin_fmaf(a6, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a6 < -1e30f) != 0) { a6 = out[threadIdx.x + 6]; }
+                a7 = __builtin_fmaf(a7, 1.0001f, 1e-6f); if (__builtin_amdgcn_ballot_w64(a7 < -1e30f) != 0) { a7 = out[threadIdx.x + 7]; }
+            } else if (OP == 11) { // 8 x { LDS round trip: ds_write_b32 own slot, ds_read_b32 neighbour slot, use }
+                __shared__ float sh[64];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+                sh[threadIdx.x] = a0; a0 += sh[(threadIdx.x + 1) & 63];
+            } else if (OP == 12) { // dependent chain: rsq -> fma -> fma -> exp -> mul -> fma  (one pair evaluation), x8 serial
+                for (int r = 0; r < 8; ++r) {
+                    float i = __builtin_amdgcn_rsqf(a0 * a0 + 1.0f);
+                    float rd = __builtin_fmaf(-a0, i, 0.6f);
+                    float e = __builtin_amdgcn_exp2f(__builtin_fmaf(rd, 18.0f, 10.9f)) * i;
+                    a0 = __builtin_fmaf(e, 1e-6f, a0);
+                }
             } else if (OP == 6) { // 8 v_mul_f32 (plain, not fma)
                 a0 *= 1.0001f; a1 *= 1.0001f; a2 *= 1.0001f; a3 *= 1.0001f; a4 *= 1.0001f; a5 *= 1.0001f; a6 *= 1.0001f; a7 *= 1.0001f;
             }
@@ -71,7 +106,7 @@ void run(const char* name, int waves_per_simd, float* d_out)
 int main()
 {
     float* d_out; hipMalloc(&d_out, 256 * 4 * 8 * 64 * sizeof(float));
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2, 4}) {
         run<0>("v_fma_f32 x8 indep", w, d_out);
         run<1>("v_pk_fma_f32 x4 indep", w, d_out);
         run<6>("v_mul_f32 x8 indep", w, d_out);
@@ -81,6 +116,10 @@ int main()
         run<5>("v_fma_f32 dependent chain", w, d_out);
         run<7>("ds_bpermute_b32 + v_add x8", w, d_out);
         run<8>("v_add x8 (chain, no permute)", w, d_out);
+        run<9>("fma + untaken divergent branch x8", w, d_out);
+        run<10>("fma + untaken uniform branch x8", w, d_out);
+        run<11>("LDS write->read->use chain x8", w, d_out);
+        run<12>("pair chain rsq..exp..fma x8 (7 ops)", w, d_out);
     }
     return 0;
 }
