@@ -129,14 +129,15 @@ __device__ __forceinline__ float bound_angle(float a)
     return a;
 }
 
-// bound_angle for the heading update: identical to the branches above for |a| < 2 pi (k = rint(a / 2 pi)
-// is 1 above pi, -1 below -pi, 0 between; ties at exactly +-pi stay, as in the reference); the fmod
-// branch for |a| >= 2 pi is wave-uniformly skipped.
+// bound_angle for the heading update, branch-free: a - 2 pi rint(a / 2 pi) with a two-term (Cody-Waite) 2 pi, which
+// is what the reference's branches give for any |a| (fmod by 2 pi, then one fold into [-pi, pi]); ties at exactly
+// +-pi stay, as in the reference.  A data-dependent branch costs ~55 cycles of wave latency on this SIMD
+// (tools/valu_microbench.hip), the four instructions below ~12.
 __device__ __forceinline__ float wrap_angle(float a)
 {
-    const float two_pi = 6.283185307179586f;
-    if (fabsf(a) >= two_pi) a = fmodf(a, two_pi);
-    return fmaf(-two_pi, rintf(a * 0.15915494309189535f), a);
+    const float k = rintf(a * 0.15915494309189535f);
+    a = fmaf(k, -6.2831854820251465f, a);      // float(2 pi)
+    return fmaf(k, 1.7484556000744883e-07f, a); // float(2 pi) - 2 pi
 }
 
 // atan2 with |error| < 2e-7 rad (degree-7 minimax in a^2 on [0,1], a = min/max); atan2(0, 0) = 0
@@ -254,7 +255,12 @@ constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one 
 //   OCC    = waves per SIMD the register allocation must allow: 4 (<= 128 VGPRs, a few spills) when the grid holds more
 //            than two wavefronts per SIMD, 1 (unconstrained, ~150 VGPRs, no spills) otherwise -- at 4096 x 25 there
 //            are exactly two waves per SIMD and the spill-free build is 6 % faster; at 16384 x 25 the 4-wave build is 7 % faster
-template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC>
+//   ROWS_CT = rows per world known at compile time (0: read from the arguments): the partner-group loop unrolls and
+//            its ~9 scalar branches per substep (~24 cycles of wave latency each) disappear
+//   LEAN   = pair-once build for the plain crowd batch: no walls, no robot row, goal lists of <= 2 entries, state
+//            committed in place -- the wall / robot / goal-list-in-memory code and their branches are compiled out and
+//            the goal switch is predicated
+template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, bool LEAN>
 __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -276,12 +282,15 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     float* lds_sinv = reinterpret_cast<float*>(lds_seg + a.seg_tab);                   // [seg_tab] 1 / |e|^2, -1 = NaN slot
 
     const int tid = threadIdx.x;
-    const int rows = a.rows, n = a.n;
+    static_assert(!LEAN || (PEQ && MAXT == 64), "the lean build is a pair-once build");
+    const int rows = ROWS_CT > 0 ? ROWS_CT : a.rows;
+    const int n = LEAN ? rows : a.n;
+    const int kmode = LEAN ? (int)M_COMMIT_GOALS : a.mode;
     const int lw = tid / rows;
     const int row = tid - lw * rows;
     const int w = blockIdx.x * a.wpb + lw;
     const bool valid = (lw < a.wpb) && (w < a.W);
-    const bool robot_row = (a.flags & CS_ROBOT_ROW) != 0;
+    const bool robot_row = LEAN ? false : (a.flags & CS_ROBOT_ROW) != 0;
     const bool human = valid && row < n;
     const bool is_robot = valid && robot_row && row == n;
     const int base = lw * rows;        // first row of my world in the per-row arrays (lds_v, lds_vr, ...)
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     const long sidx = (long)w * rows + row;
     if (valid) {
         const float* s = a.Sin + sidx * a.in_as;
-        if (is_robot && (a.mode & M_ROBOT_FROM_ARRAY)) {
+        if (is_robot && (kmode & M_ROBOT_FROM_ARRAY)) {
             const float* rb = a.robot + (long)w * 13;
             px = rb[0]; py = rb[1]; th = rb[2]; vx = rb[3]; vy = rb[4]; bvx = rb[5]; bvy = rb[6]; om = rb[7];
             r = rb[8]; m = rb[9]; gx = rb[10]; gy = rb[11]; vd = rb[12];
@@ -338,13 +347,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     }
     const float inv_O = a.O > 0 ? 1.0f / (float)a.O : 0.0f;
     const float* obst = nullptr;
-    if (a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
+    if (!LEAN && a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
     // wall segments are constant over the launch: stage (x1, y1, e, 1/|e|^2) in LDS once instead of re-loading and
     // re-deriving them in every substep (3 polygons x 5 segments cost as much as the whole 50-agent pair loop otherwise)
-    const int nseg = a.O * a.Smax;
+    const int nseg = LEAN ? 0 : a.O * a.Smax;
     const int sbase = (a.flags & CS_OBSTACLES_SHARED) ? 0 : lw * nseg;
-    for (int i = tid; i < a.seg_tab; i += T) {
-        const int lwi = i / nseg;
+    for (int i = tid; i < (LEAN ? 0 : a.seg_tab); i += T) {
+        const int lwi = i / (nseg > 0 ? nseg : 1);
         const long wi = (long)blockIdx.x * a.wpb + lwi;
         float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float inv = -1.0f;
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     const bool respawn_here = valid && (a.world_flags == nullptr || (a.world_flags[w] & 1));
 
     // robot action (held for the whole block, social_nav_gym.py:240-243)
-    const bool robot_moves = a.action != nullptr;
+    const bool robot_moves = a.action != nullptr; // (lean build: only the invisible robot of the epilogue)
     float ax = 0, ay = 0;
     if (valid && robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
     auto robot_step = [&]() { // robot_agent.py:114-136
@@ -421,7 +430,17 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
         STAMP(7);
-        if (human) {
+        if constexpr (LEAN) {
+            // -- goal switch, forces_parallel.py:226-234, predicated: lists of <= 2 goals rotate in registers
+            const float gdx = g0x - px, gdy = g0y - py;
+            const bool hit = human && fmaf(gdx, gdx, gdy * gdy) <= r * r;
+            const bool sw = hit && gk == 2;
+            const float t0 = g0x, t1 = g0y;
+            g0x = sw ? g1x : g0x; g0y = sw ? g1y : g0y;
+            g1x = sw ? t0 : g1x; g1y = sw ? t1 : g1y;
+            gdirty = gdirty || sw;
+            gx = hit ? g0x : gx; gy = hit ? g0y : gy;
+        } else if (human) {
             // -- goal switch, forces_parallel.py:226-234 (on the incoming position)
             const float gdx = g0x - px, gdy = g0y - py;
             if (fmaf(gdx, gdx, gdy * gdy) <= r * r) { // |goals[i][0] - p| <= r ; rare, divergent
@@ -432,7 +451,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         g0x = g1x; g0y = g1y; g1x = t0; g1y = t1;
                         gdirty = true;
                     }
-                } else if (a.mode & M_COMMIT_GOALS) {
+                } else if (kmode & M_COMMIT_GOALS) {
                     const float r0 = gi[0], r1 = gi[1];
                     for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
                     if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
@@ -817,7 +836,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
                 if (nb2 * ninv > vd) { const float sc = vd * ninv; vx *= sc; vy *= sc; }
             }
-            if ((a.mode & M_MUTATE_INPUT) && sub == 0) {
+            if ((kmode & M_MUTATE_INPUT) && sub == 0) {
                 float* si = a.Sin + sidx * a.in_as;
                 if (HEADED > 0) { si[3 * a.in_fs] = in_vx; si[4 * a.in_fs] = in_vy; }
                 si[10 * a.in_fs] = gx; si[11 * a.in_fs] = gy;
@@ -916,7 +935,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 #endif
 
     // ---- epilogue ---------------------------------------------------------------------------
-    if (a.mode & M_PEEK) {
+    if (kmode & M_PEEK) {
         if (human) {
             float* o = a.peek_out + ((long)w * n + row) * 8;
             o[0] = px; o[1] = py; o[2] = th; o[3] = vx; o[4] = vy; o[5] = om;
@@ -924,7 +943,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         }
         return;
     }
-    if (human && gdirty && (a.mode & M_COMMIT_GOALS)) { gi[0] = g0x; gi[1] = g0y; gi[2] = g1x; gi[3] = g1y; }
+    if (human && gdirty && (kmode & M_COMMIT_GOALS)) { gi[0] = g0x; gi[1] = g0y; gi[2] = g1x; gi[3] = g1y; }
     if (valid) {
         float* o = a.Sout + sidx * a.out_as;
         const long fs = a.out_fs;
@@ -1018,11 +1037,13 @@ __global__ void k_transpose_state(const float* src, float* dst, long total_rows,
 // ------------------------------------------------------------------------------------------
 using kfn = void (*)(const KArgs);
 
-template <int MAXT, int OCC>
+template <int MAXT, int OCC, int ROWS_CT, bool LEAN>
 kfn pick_kernel(int type, bool peq)
 {
-#define CS_CASE(SOC, HD)                                                                          \
-    return peq ? (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC> : (kfn)k_sfm_step<SOC, HD, false, MAXT, OCC>;
+#define CS_CASE(SOC, HD)                                                                                      \
+    if constexpr (LEAN) return (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, true>;                      \
+    else return peq ? (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, false>                               \
+                    : (kfn)k_sfm_step<SOC, HD, false, MAXT, OCC, ROWS_CT, false>;
     switch (type) {
         case 0: CS_CASE(0, 0) case 1: CS_CASE(1, 0) case 2: CS_CASE(2, 0)
         case 3: CS_CASE(0, 1) case 4: CS_CASE(1, 1) case 5: CS_CASE(2, 1)
@@ -1098,8 +1119,14 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
     // 256 CUs x 4 SIMDs: more than two one-wave blocks per SIMD -> the 4-waves-per-SIMD register budget pays
     const bool crowded = g.block == 64 && g.grid > 2 * 1024;
-    kfn fn = (g.block == 64) ? (crowded ? pick_kernel<64, 4>(w->type, peq) : pick_kernel<64, 1>(w->type, peq))
-                             : pick_kernel<1024, 1>(w->type, peq);
+    // the plain crowd batch (what Gym scenarios and the bench step): pair-once, no walls, no robot row, <= 2 goal slots,
+    // committed in place -> the lean build; 25 rows per world also has its partner groups unrolled at compile time
+    const bool lean = peq && g.block == 64 && w->O == 0 && !(w->flags & CS_ROBOT_ROW) && w->G <= 2 && mode == M_COMMIT_GOALS;
+    kfn fn;
+    if (g.block != 64) fn = pick_kernel<1024, 1, 0, false>(w->type, peq);
+    else if (lean && rows == 25) fn = crowded ? pick_kernel<64, 4, 25, true>(w->type, true) : pick_kernel<64, 1, 25, true>(w->type, true);
+    else if (lean) fn = crowded ? pick_kernel<64, 4, 0, true>(w->type, true) : pick_kernel<64, 1, 0, true>(w->type, true);
+    else fn = crowded ? pick_kernel<64, 4, 0, false>(w->type, peq) : pick_kernel<64, 1, 0, false>(w->type, peq);
     // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
     // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
     size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +

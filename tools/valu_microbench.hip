@@ -5,7 +5,7 @@
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 template <int OP>
-__global__ __launch_bounds__(64) void k(float* out, int iters, float seed)
+__global__ __launch_bounds__(64) void k(float* out, int iters, float seed, int flags)
 {
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, c = {1.0001f, 0.9999f}, d = {1e-6f, -1e-6f};
@@ -76,6 +76,24 @@ __global__ __launch_bounds__(64) void k(float* out, int iters, float seed)
                     float e = __builtin_amdgcn_exp2f(__builtin_fmaf(rd, 18.0f, 10.9f)) * i;
                     a0 = __builtin_fmaf(e, 1e-6f, a0);
                 }
+            } else if (OP == 13) { // 8 x { fma ; SALU-only branch on a kernel argument bit, body skipped (taken s_cbranch) }
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); if (flags & 1) { a0 = out[threadIdx.x]; }
+                a1 = __builtin_fmaf(a1, 1.0001f, 1e-6f); if (flags & 2) { a1 = out[threadIdx.x + 1]; }
+                a2 = __builtin_fmaf(a2, 1.0001f, 1e-6f); if (flags & 4) { a2 = out[threadIdx.x + 2]; }
+                a3 = __builtin_fmaf(a3, 1.0001f, 1e-6f); if (flags & 8) { a3 = out[threadIdx.x + 3]; }
+                a4 = __builtin_fmaf(a4, 1.0001f, 1e-6f); if (flags & 16) { a4 = out[threadIdx.x + 4]; }
+                a5 = __builtin_fmaf(a5, 1.0001f, 1e-6f); if (flags & 32) { a5 = out[threadIdx.x + 5]; }
+                a6 = __builtin_fmaf(a6, 1.0001f, 1e-6f); if (flags & 64) { a6 = out[threadIdx.x + 6]; }
+                a7 = __builtin_fmaf(a7, 1.0001f, 1e-6f); if (flags & 128) { a7 = out[threadIdx.x + 7]; }
+            } else if (OP == 14) { // 8 x { fma ; loop-invariant exec-mask region (lanes < 50), body = one fma }
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a1 = __builtin_fmaf(a1, 1.0001f, 1e-6f); }
+                a2 = __builtin_fmaf(a2, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a3 = __builtin_fmaf(a3, 1.0001f, 1e-6f); }
+                a4 = __builtin_fmaf(a4, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a5 = __builtin_fmaf(a5, 1.0001f, 1e-6f); }
+                a6 = __builtin_fmaf(a6, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a7 = __builtin_fmaf(a7, 1.0001f, 1e-6f); }
+                a0 = __builtin_fmaf(a0, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a1 = __builtin_fmaf(a1, 1.0001f, 1e-6f); }
+                a2 = __builtin_fmaf(a2, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a3 = __builtin_fmaf(a3, 1.0001f, 1e-6f); }
+                a4 = __builtin_fmaf(a4, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a5 = __builtin_fmaf(a5, 1.0001f, 1e-6f); }
+                a6 = __builtin_fmaf(a6, 1.0001f, 1e-6f); if (threadIdx.x < 50) { a7 = __builtin_fmaf(a7, 1.0001f, 1e-6f); }
             } else if (OP == 6) { // 8 v_mul_f32 (plain, not fma)
                 a0 *= 1.0001f; a1 *= 1.0001f; a2 *= 1.0001f; a3 *= 1.0001f; a4 *= 1.0001f; a5 *= 1.0001f; a6 *= 1.0001f; a7 *= 1.0001f;
             }
@@ -91,9 +109,9 @@ void run(const char* name, int waves_per_simd, float* d_out)
     const int blocks = 256 * 4 * waves_per_simd; // one wave per block
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d_out, iters, 1.0f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d_out, iters, 1.0f, 0);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d_out, iters, 1.0f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(64), 0, 0, d_out, iters, 1.0f, 0);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -120,6 +138,8 @@ int main()
         run<10>("fma + untaken uniform branch x8", w, d_out);
         run<11>("LDS write->read->use chain x8", w, d_out);
         run<12>("pair chain rsq..exp..fma x8 (7 ops)", w, d_out);
+        run<13>("fma + SALU-only skipped branch x8", w, d_out);
+        run<14>("fma + invariant exec-mask region x8", w, d_out);
     }
     return 0;
 }
