@@ -18,6 +18,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "crowdstep.h"
@@ -249,6 +250,18 @@ __device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx
 //   PEQ    = all_params_equal
 //   MAXT   = 64 (one wavefront, floor(64/rows) worlds) or 1024 (one world per block)
 // ------------------------------------------------------------------------------------------
+template <class F, int... I>
+__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// The pair-once loop hands values from lane to lane through LDS inside ONE wavefront.  The hardware executes a wave's LDS
+// operations in order, so no s_barrier / s_waitcnt is needed -- but the compiler does not know that another lane's store
+// feeds this lane's load, and with compile-time offsets it can prove "no alias" for the lane's own addresses and hoist the
+// load above the store.  This compiler-only fence pins the program order of the LDS accesses around it.
+#define LDS_ORDER_FENCE() asm volatile("" ::: "memory")
+
 constexpr int UA = 4; // reaction accumulator rows of the pair-once loop (independent LDS read-modify-write chains)
 constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one wavefront: 2 x 64 doubled rows)
 
@@ -468,20 +481,116 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         //    is added to accumulator slot [k mod UA][i + distance] of UA LDS rows: plain read-modify-write, no
         //    atomics -- one wavefront executes its LDS operations in order, so each of the UA chains is race-free.
         //    Index i + distance runs past the world's rows without a modulo: receiver j sums slots j and j + rows.
+        //    Order of a substep: the first group's partner rows are requested from LDS, then everything that does not
+        //    depend on this substep's social force is computed while they are in flight (rotation, desired and wall
+        //    forces, the Farina torque, the new heading and its sine / cosine), then the partner groups, and only the
+        //    short force-dependent tail (body-frame projection, Euler step, publish) follows the reaction sum.
         float fsx = 0.0f, fsy = 0.0f;
+        const int Hf = (rows - 1) >> 1;
+        const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
+        const float2* rv = lds_v + cur * TP + pbase + row + 1;
+        float4 qa[UA];
+        float2 va[UA];
+        auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                q[u] = rp[kk + u];
+                if constexpr (N3L && SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
+            }
+        };
         if constexpr (N3L) {
             {
                 float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 used per row = T float4: one per lane
 #pragma unroll
                 for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                LDS_ORDER_FENCE();
             }
+            // lean build: request the first group's rows now, part A below runs while they are in flight (with walls the
+            // rows would be held in registers across the segment loops: fetched at the head of the group loop instead)
+            if constexpr (LEAN) { if (valid && Hf >= UA) fetch(qa, va, 0); }
             STAMP(8);
+        }
+        // -- part A of the per-agent update: everything that does not need this substep's social force
+        const float c = cs, s = sn;          // rotation matrix of the incoming heading, :254-256
+        float cvx = vx, cvy = vy;            // refreshed linear velocity
+        float fdx = 0.0f, fdy = 0.0f, fox = 0.0f, foy = 0.0f;
+        float th_n = th, sn_n = sn, cs_n = cs, torque_a = 0.0f;
+        if (human) {
+            if constexpr (HEADED > 0) {
+                cvx = c * bvx + (-s) * bvy;
+                cvy = s * bvx + c * bvy;
+            }
+            // -- desired force, :23-40
+            {
+                const float dx = gx - px, dy = gy - py;
+                const float d2 = fmaf(dx, dx, dy * dy);
+                const float inv = rsq_fast(fmaxf(d2, 1e-30f));
+                const float wx = m_tau * (dx * inv * vd - cvx), wy = m_tau * (dy * inv * vd - cvy);
+                const bool far_ = d2 * inv > r;   // selects, not a branch: a data-dependent branch costs ~55 cycles of latency
+                fdx = far_ ? wx : 0.0f;
+                fdy = far_ ? wy : 0.0f;
+            }
+            // -- obstacle force: closest point per polygon :236-252, then :136-162
+            if (obst != nullptr) {
+                for (int o = 0; o < a.O; ++o) {
+                    // first argmin over the polygon's segments, on squared distances (same order)
+                    float best = 0.0f, bdx = 0.0f, bdy = 0.0f;
+                    bool have = false;
+                    for (int sg = 0; sg < a.Smax; ++sg) {
+                        float x1, y1, ex, ey, einv;
+                        if (a.seg_tab > 0) {
+                            const float4 e = lds_seg[sbase + o * a.Smax + sg];
+                            x1 = e.x; y1 = e.y; ex = e.z; ey = e.w;
+                            einv = lds_sinv[sbase + o * a.Smax + sg];
+                        } else {
+                            const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)o * a.Smax + sg) * 4);
+                            x1 = seg.x; y1 = seg.y; ex = seg.z - seg.x; ey = seg.w - seg.y;
+                            einv = isnan(seg.x) ? -1.0f : rcp_fast(fmaf(ex, ex, ey * ey));
+                        }
+                        float d, ddx = 0.0f, ddy = 0.0f;
+                        if (einv < 0.0f) {
+                            d = 3.0e38f; // NaN slot: the reference stores iinfo(int64).max as the distance (:247)
+                        } else {
+                            const float t = ((px - x1) * ex + (py - y1) * ey) * einv;
+                            const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                            ddx = px - fmaf(ts, ex, x1); ddy = py - fmaf(ts, ey, y1);
+                            d = fmaf(ddx, ddx, ddy * ddy);
+                        }
+                        if (!have || d < best) { best = d; bdx = ddx; bdy = ddy; have = true; }
+                    }
+                    const float inv = rsq_fast(fmaxf(best, 1e-30f));
+                    const float dist = best * inv;
+                    const float nx = bdx * inv, ny = bdy * inv;
+                    const float dv = -(cvy * nx - cvx * ny);                 // -(v . t), t = (-ny, nx)
+                    const float rd = r - dist + safety;
+                    const float m0 = fmaxf(0.0f, rd);
+                    const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
+                    float ft;                                                 // coefficient of t
+                    if (obs_type == 0) ft = -(k2 * m0) * dv;
+                    else ft = (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
+                    fox += fn * nx - ft * ny;
+                    foy += fn * ny + ft * nx;
+                }
+                fox *= inv_O; foy *= inv_O;
+            }
+            if constexpr (HEADED > 0) {
+                th_n = wrap_angle(fmaf(om, dt, th));   // :278; the new heading needs omega of the incoming row only
+                sincos_fast(th_n, sn_n, cs_n);
+            }
+            if constexpr (HEADED == 1) {               // Farina: the torque follows the desired force alone, :165-182
+                const float kf = klam * norm2(fdx, fdy);
+                const float k_theta = inertia * kf;
+                const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf * inv_alpha);
+                const float delta = atan2_fast(s * fdx - c * fdy, c * fdx + s * fdy);
+                torque_a = -k_theta * delta - k_omega * om;
+            }
+        }
+        STAMP(1);
+        if constexpr (N3L) {
             if (valid) {
-                const int Hf = (rows - 1) >> 1;
-                const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
-                const float2* rv = lds_v + cur * TP + pbase + row + 1;
                 float2* acc = lds_acc + pbase + row + 1;                 // acc[u * 2T + k]: that partner's slot in row u
                 float ex = 0.0f, ey = 0.0f, rdmax = -1.0f;
+                if constexpr (!LEAN) { if (Hf >= UA) fetch(qa, va, 0); }
                 auto pair_once = [&](const float4 q, const float2 vq, float& fx, float& fy) {
                     const float dx = px - q.x, dy = py - q.y;
                     if constexpr (SOC == 2) {
@@ -507,13 +616,6 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 // accumulator row pitch: 2 KiB, out of reach of the ds_read2_b64 / ds_write2_b64 offset fields on purpose:
                 // the paired forms take 8 / 13 LDS cycles, two single b64 accesses 4 / 12 (MI355X_MICROARCH.md, LDS table)
                 constexpr int AR = ACC_PITCH;
-                auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
-#pragma unroll
-                    for (int u = 0; u < UA; ++u) {
-                        q[u] = rp[kk + u];
-                        if constexpr (SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
-                    }
-                };
                 auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], float2 (&ac)[UA], int kk) {
                     if constexpr (SOC == 2) {
 #pragma unroll
@@ -566,12 +668,28 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     }
 #pragma unroll
                     for (int u = 0; u < UA; ++u) acc[u * AR + kk + u] = ac[u];
+                    LDS_ORDER_FENCE(); // the next group's slots were written by other lanes in this group
                 };
                 int k0 = 0;
-                if (Hf >= UA) {
-                    float4 qa[UA], qb[UA];
-                    float2 va[UA], vb[UA], ac[UA];
-                    fetch(qa, va, 0);
+                if constexpr (ROWS_CT > 0) {
+                    // rows known at compile time: the groups are laid out one after the other, no loop, no scalar branches
+                    constexpr int NG = ((ROWS_CT - 1) / 2) / UA;
+                    float4 qb[UA];
+                    float2 vb[UA], ac[UA];
+                    for_each_index([&](auto gtag) {
+                        constexpr int g = decltype(gtag)::value;
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + g * UA + u];
+                        if constexpr (g + 1 < NG) {
+                            if constexpr (g & 1) fetch(qa, va, (g + 1) * UA); else fetch(qb, vb, (g + 1) * UA);
+                        }
+                        asm volatile("" ::: "memory");
+                        if constexpr (g & 1) group(qb, vb, ac, g * UA); else group(qa, va, ac, g * UA);
+                    }, std::make_integer_sequence<int, NG>{});
+                    k0 = NG * UA;
+                } else if (Hf >= UA) {
+                    float4 qb[UA];
+                    float2 vb[UA], ac[UA];
                     for (;;) {
 #pragma unroll
                         for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + k0 + u];
@@ -600,6 +718,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     float2 ac = acc[k];
                     ac.x += fx; ac.y += fy;
                     acc[k] = ac;
+                    LDS_ORDER_FENCE();
                 }
                 if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself
                     float fx, fy;
@@ -609,6 +728,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     ex += fx; ey += fy;
                 }
                 STAMP(9);
+                LDS_ORDER_FENCE(); // the reaction slots of this lane were written by its partners
                 float rx = 0.0f, ry = 0.0f;
                 const float2* rr = lds_acc + pbase + row;
 #pragma unroll
@@ -623,7 +743,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
                         const float4* pp = lds_p + cur * TP + pbase;
                         const float2* pvel = lds_v + cur * TP + pbase;
-                        for (int j = 0; j < rows; ++j) {
+#pragma nounroll
+                        for (int j = 0; j < rows; ++j) { // rare path: keep it small in the instruction cache
                             const float4 q = pp[j];
                             const float2 vj = pvel[j];
                             const float dx = px - q.x, dy = py - q.y;
@@ -642,69 +763,6 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         }
         STAMP(2);
         if (human) {
-            // -- rotation matrix and refreshed linear velocity, :254-256
-            const float c = cs, s = sn;
-            float cvx = vx, cvy = vy;
-            if constexpr (HEADED > 0) {
-                cvx = c * bvx + (-s) * bvy;
-                cvy = s * bvx + c * bvy;
-            }
-            // -- desired force, :23-40
-            float fdx = 0.0f, fdy = 0.0f;
-            {
-                const float dx = gx - px, dy = gy - py;
-                const float d2 = fmaf(dx, dx, dy * dy);
-                const float inv = rsq_fast(fmaxf(d2, 1e-30f));
-                if (d2 * inv > r) {
-                    fdx = m_tau * (dx * inv * vd - cvx);
-                    fdy = m_tau * (dy * inv * vd - cvy);
-                }
-            }
-            // -- obstacle force: closest point per polygon :236-252, then :136-162
-            float fox = 0.0f, foy = 0.0f;
-            if (obst != nullptr) {
-                for (int o = 0; o < a.O; ++o) {
-                    // first argmin over the polygon's segments, on squared distances (same order)
-                    float best = 0.0f, bdx = 0.0f, bdy = 0.0f;
-                    bool have = false;
-                    for (int sg = 0; sg < a.Smax; ++sg) {
-                        float x1, y1, ex, ey, einv;
-                        if (a.seg_tab > 0) {
-                            const float4 e = lds_seg[sbase + o * a.Smax + sg];
-                            x1 = e.x; y1 = e.y; ex = e.z; ey = e.w;
-                            einv = lds_sinv[sbase + o * a.Smax + sg];
-                        } else {
-                            const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)o * a.Smax + sg) * 4);
-                            x1 = seg.x; y1 = seg.y; ex = seg.z - seg.x; ey = seg.w - seg.y;
-                            einv = isnan(seg.x) ? -1.0f : rcp_fast(fmaf(ex, ex, ey * ey));
-                        }
-                        float d, ddx = 0.0f, ddy = 0.0f;
-                        if (einv < 0.0f) {
-                            d = 3.0e38f; // NaN slot: the reference stores iinfo(int64).max as the distance (:247)
-                        } else {
-                            const float t = ((px - x1) * ex + (py - y1) * ey) * einv;
-                            const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
-                            ddx = px - fmaf(ts, ex, x1); ddy = py - fmaf(ts, ey, y1);
-                            d = fmaf(ddx, ddx, ddy * ddy);
-                        }
-                        if (!have || d < best) { best = d; bdx = ddx; bdy = ddy; have = true; }
-                    }
-                    const float inv = rsq_fast(fmaxf(best, 1e-30f));
-                    const float dist = best * inv;
-                    const float nx = bdx * inv, ny = bdy * inv;
-                    const float dv = -(cvy * nx - cvx * ny);                 // -(v . t), t = (-ny, nx)
-                    const float rd = r - dist + safety;
-                    const float m0 = fmaxf(0.0f, rd);
-                    const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
-                    float ft;                                                 // coefficient of t
-                    if (obs_type == 0) ft = -(k2 * m0) * dv;
-                    else ft = (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
-                    fox += fn * nx - ft * ny;
-                    foy += fn * ny + ft * nx;
-                }
-                fox *= inv_O; foy *= inv_O;
-            }
-            STAMP(1);
             // -- social force, every lane evaluates all its partners: O(N) rows broadcast from LDS, :43-84
             if constexpr (!N3L) {
                 // all_params_equal: every row's stored velocity (the reference evaluates all pairs
@@ -802,18 +860,19 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 }
             }
             STAMP(6);
-            // -- total force, body frame, torque  :262-271, :165-182
+            // -- part B: total force, body frame, torque  :262-271, :165-182
             const float fix = fdx + fox + fsx, fiy = fdy + foy + fsy;
-            float gfx = fix, gfy = fiy, torque = 0.0f;
+            float gfx = fix, gfy = fiy, torque = torque_a;
             if constexpr (HEADED > 0) {
-                const float drx = (HEADED == 1) ? fdx : fix, dry = (HEADED == 1) ? fdy : fiy;
-                const float kf = klam * norm2(drx, dry);
-                const float k_theta = inertia * kf;
-                const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf * inv_alpha);
-                // bound_angle(theta - atan2(Fy, Fx)) is the signed angle from F to the heading:
-                // atan2(|F| sin(theta - phi), |F| cos(theta - phi)) -- one atan2, no wrap needed
-                const float delta = atan2_fast(s * drx - c * dry, c * drx + s * dry);
-                torque = -k_theta * delta - k_omega * om;
+                if constexpr (HEADED == 2) {  // torque on the total force
+                    const float kf = klam * norm2(fix, fiy);
+                    const float k_theta = inertia * kf;
+                    const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf * inv_alpha);
+                    // bound_angle(theta - atan2(Fy, Fx)) is the signed angle from F to the heading:
+                    // atan2(|F| sin(theta - phi), |F| cos(theta - phi)) -- one atan2, no wrap needed
+                    const float delta = atan2_fast(s * fix - c * fiy, c * fix + s * fiy);
+                    torque = -k_theta * delta - k_omega * om;
+                }
                 gfx = fix * c + fiy * s;
                 gfy = ko * ((fox + fsx) * (-s) + (foy + fsy) * c) - kd * bvy;
             }
@@ -821,13 +880,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             const float in_vx = cvx, in_vy = cvy; // what the reference leaves in agents_state[i,3:5]
             px += vx * dt; py += vy * dt;
             if constexpr (HEADED > 0) {
-                th = wrap_angle(fmaf(om, dt, th));
+                th = th_n;
                 bvx = fmaf(gfx, dt_m, bvx); bvy = fmaf(gfy, dt_m, bvy);
                 const float nb2 = fmaf(bvx, bvx, bvy * bvy);
                 const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
                 if (nb2 * ninv > vd) { const float sc = vd * ninv; bvx *= sc; bvy *= sc; }
                 om = fmaf(torque, dt_inertia, om);
-                sincos_fast(th, sn, cs);
+                sn = sn_n; cs = cs_n;
                 vx = cs * bvx + (-sn) * bvy;
                 vy = sn * bvx + cs * bvy;
             } else {
@@ -869,6 +928,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     const int c = __builtin_popcountll(fm & wm & ((1ull << tid) - 1ull));
                     const float4* pvn = lds_p + nxt * TP + pbase;
                     float mx = pvn[0].x, mr = pvn[0].z;
+#pragma nounroll
                     for (int j = 1; j < n; ++j) {
                         mx = fmaxf(mx, pvn[j].x);
                         mr = fmaxf(mr, pvn[j].z);
@@ -925,6 +985,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             }
         }
         STAMP(5);
+        LDS_ORDER_FENCE(); // rows republished by the respawn rule are read by other lanes in the next substep
         cur = nxt;
     }
 #ifdef CS_STAMPS
