@@ -45,3 +45,29 @@ def test_product_fails_loudly_without_gpu():
 
     with pytest.raises(_lib.CrowdstepError):
         CrowdWorlds(np.zeros((1, 2, 13)), np.zeros((1, 2, 1, 2)), np.zeros((2, 20)), type=0)
+
+
+def test_header_is_plain_c_and_generator_struct_matches():
+    """include/crowdstep.h is the contract a non-C++ host binds: it must compile as C, and the ctypes mirrors of its
+    structs must have the compiler's layout."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+
+    from social_navigation_pyenvs_amd._lib import cs_worlds
+    from social_navigation_pyenvs_amd.generators import cs_generator
+
+    src = ('#include "crowdstep.h"\n#include <stdio.h>\n#include <stddef.h>\n'
+           'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(cs_worlds), sizeof(cs_generator), '
+           'offsetof(cs_generator, circle_radius), offsetof(cs_generator, robot_desired_speed), offsetof(cs_worlds, d_world_flags));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes[0] == C.sizeof(cs_worlds)
+    assert sizes[1] == C.sizeof(cs_generator)
+    assert sizes[2] == cs_generator.circle_radius.offset
+    assert sizes[3] == cs_generator.robot_desired_speed.offset
+    assert sizes[4] == cs_worlds.d_world_flags.offset
