@@ -922,8 +922,10 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 // humans of a world in index order, each behind everybody else (:411-417): x_0 = max(max_x + 2 max_r,
                 // bound), and the c-th flagged one (c lower-indexed flagged rows in its world) lands at
                 // x_c = max(x_{c-1} + 2 max_r, bound) because x_{c-1} is then the rightmost human.
-                const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag != 0);
-                if (fm != 0 && flag) {
+                // ONE data-dependent branch in the common (nobody flagged) case: the vote is taken inside the branch, where
+                // only the flagged lanes are active -- exactly the lanes it has to count
+                if (flag) {
+                    const unsigned long long fm = __builtin_amdgcn_ballot_w64(true);
                     const unsigned long long wm = (rows >= 64 ? ~0ull : ((1ull << rows) - 1ull)) << base;
                     const int c = __builtin_popcountll(fm & wm & ((1ull << tid) - 1ull));
                     const float4* pvn = lds_p + nxt * TP + pbase;
