@@ -45,7 +45,9 @@ enum {
     CS_SFM_HELBING = 0, CS_SFM_GUO = 1, CS_SFM_MOUSSAID = 2,
     CS_HSFM_FARINA = 3, CS_HSFM_GUO = 4, CS_HSFM_MOUSSAID = 5,
     CS_HSFM_NEW = 6, CS_HSFM_NEW_GUO = 7, CS_HSFM_NEW_MOUSSAID = 8,
-    CS_ORCA = 9 /* HUMAN_MODELS[9] (social_nav_gym.py:11-12); only cs_step / cs_peek accept it */
+    CS_ORCA = 9, /* HUMAN_MODELS[9] (social_nav_gym.py:11-12); only cs_step / cs_peek accept it */
+    CS_SOCIAL_MOMENTUM = 10 /* MotionModelManager("social_momentum") (motion_model_manager.py:247-251, 395-404;
+                               social_gym/src/social_momentum.py); only cs_step / cs_peek accept it */
 };
 
 /* memory layout of a state array: element (world w, row a, field f) lives at
@@ -87,6 +89,8 @@ typedef struct cs_worlds {
     /* ORCA only (type == CS_ORCA): ORCA_DEFAULTS of motion_model_manager.py:14 */
     float   orca_neighbor_dist, orca_time_horizon, orca_time_horizon_obst;
     int32_t orca_max_neighbors;
+    /* social momentum only (type == CS_SOCIAL_MOMENTUM): n_actions of motion_model_manager.py:249 (0 = 20) */
+    int32_t sm_n_actions;
 } cs_worlds;
 
 /* ---------------------------------------------------------------- runtime / memory helpers */

@@ -300,3 +300,106 @@ def laser_scan(pos, yaw, rng, samples, max_distance, human_pos, human_radius, ob
                     m = min(m, min(np.sqrt((x3 - ix) ** 2 + (y3 - iy) ** 2), md))
         out[k] = m
     return angles, out
+
+
+def social_momentum_step(pos, vel, radius, safety, vd, goals, dt, robot=None, n_actions=20, lam=0.11, dtype=np.float64,
+                         amb_eps=None):
+    """numpy restatement of one update_humans(t, dt) of the social-momentum crowd model
+    (/root/reference/social_gym/src/motion_model_manager.py:395-404 with :66-70 update_goals and :247-251 action set;
+    /root/reference/social_gym/src/social_momentum.py:10-27 filter, :29-44 reactive agents, :46-75 optimize_momentum).
+    robot = [px, py, vx, vy, radius, safety] when the robot is considered, else None.
+    Returns (pos', vel', goals', rewards [n, A] with -inf for filtered actions, chosen [n] action index or -1).
+
+    The model tests the SIGN of `current_momentum * expected_momentum` (:69).  That product is exactly zero in exact
+    arithmetic whenever two agents move with the same velocity, or a candidate action equals the partner's velocity --
+    both common with 20 discrete headings and equal speeds -- and the reference then follows float64 rounding noise.
+    With `amb_eps` the function also returns, as a 6th value, (lo, hi) [n, A]: the smallest / largest reward each action
+    can get when every pair with |product| < amb_eps may fall either way (a zeroed momentum term or the full sum)."""
+    pos = np.array(pos, dtype); vel = np.array(vel, dtype); goals = np.array(goals, dtype)
+    radius = np.asarray(radius, dtype); safety = np.asarray(safety, dtype); vd = np.asarray(vd, dtype)
+    n = len(pos)
+    dt = np.dtype(dtype).type(dt)
+    ang = np.array([((2 * np.pi) / n_actions) * i for i in range(n_actions)])                        # :249-250
+    unit = np.stack([np.cos(ang), np.sin(ang)], axis=-1).astype(dtype)
+    ep, ev = pos, vel
+    er, es = radius, safety
+    if robot is not None and len(robot):                                                                  # entities (:13-14)
+        rb = np.asarray(robot, dtype)
+        ep = np.vstack([pos, rb[None, 0:2]]); ev = np.vstack([vel, rb[None, 2:4]])
+        er = np.append(radius, rb[4]); es = np.append(safety, rb[5])
+    rewards = np.full((n, n_actions), -np.inf, dtype)
+    r_lo = np.full((n, n_actions), -np.inf, dtype)
+    r_hi = np.full((n, n_actions), -np.inf, dtype)
+    chosen = np.full(n, -1)
+    new_vel = np.zeros_like(vel)
+    for i in range(n):
+        gi = goals[i]
+        k = int(np.argmax(np.isnan(gi[:, 0]))) if np.isnan(gi[:, 0]).any() else len(gi)
+        if k and np.linalg.norm(gi[0] - pos[i]) < radius[i]:                                             # update_goals :66-70
+            goals[i, :k] = np.roll(gi[:k], -1, axis=0)
+        others = np.array([j for j in range(len(ep)) if j != i], dtype=int)
+        acts = unit * vd[i]
+        nxt_i = pos[i] + acts * dt                                                                       # [A, 2]
+        nxt_o = ep[others] + ev[others] * dt
+        dist = np.linalg.norm(nxt_o[None] - nxt_i[:, None], axis=-1)                                     # [A, J]
+        thr = radius[i] + er[others] + safety[i] + es[others]
+        free = ~np.any(dist < thr[None], axis=1) if len(others) else np.ones(n_actions, bool)           # :16-26
+        diff = ep[others] - pos[i]
+        dn = np.linalg.norm(diff, axis=-1)
+        speed = np.linalg.norm(vel[i])
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if speed == 0:
+                angle = np.zeros(len(others), dtype)
+            else:
+                angle = np.arccos(np.clip(diff @ vel[i] / (speed * dn), -1, 1))
+            react = others[angle <= np.pi]                                                               # :36-43 (NaN -> not reactive)
+            w = 1 / np.linalg.norm(ep[react] - pos[i], axis=-1)
+            w = w / np.sum(w)                                                                            # :49-52
+        best, best_a = -100000, -1
+        for a in range(n_actions):
+            if not free[a]:
+                continue
+            nd = np.linalg.norm(goals[i, 0] - (pos[i] + acts[a] * dt))
+            rew = 1 / nd
+            mom = 0
+            mom_full, amb, hard_break = 0, False, False
+            for t, j in enumerate(react):
+                c = (pos[i] + ep[j]) / 2
+                pr, ph = pos[i] - c, ep[j] - c
+                other = ph[0] * ev[j][1] - ph[1] * ev[j][0]
+                cur = pr[0] * vel[i][1] - pr[1] * vel[i][0] + other
+                exp = pr[0] * acts[a][1] - pr[1] * acts[a][0] + other
+                if amb_eps is not None and not hard_break:
+                    if abs(cur * exp) < amb_eps:
+                        amb = True                      # either way: contributes ~0 if kept
+                    elif cur * exp > 0:
+                        mom_full += w[t] * exp
+                    else:
+                        hard_break = True
+            for t, j in enumerate(react):
+                c = (pos[i] + ep[j]) / 2
+                pr, ph = pos[i] - c, ep[j] - c
+                other = ph[0] * ev[j][1] - ph[1] * ev[j][0]
+                cur = pr[0] * vel[i][1] - pr[1] * vel[i][0] + other
+                exp = pr[0] * acts[a][1] - pr[1] * acts[a][0] + other
+                if cur * exp > 0:
+                    mom += w[t] * exp
+                else:
+                    mom = 0
+                    break
+            base_rew = rew
+            rew = rew + lam * mom
+            rewards[i, a] = rew
+            if amb_eps is not None:
+                full = base_rew if hard_break else base_rew + lam * mom_full
+                cands = [full, base_rew] if amb else [full]
+                r_lo[i, a], r_hi[i, a] = min(cands), max(cands)
+            if rew > best:
+                best, best_a = rew, a
+        chosen[i] = best_a
+        if best_a >= 0:
+            new_vel[i] = acts[best_a]
+    new_pos = pos + vel * dt                                                                             # :401-403
+    if amb_eps is not None:
+        return new_pos, new_vel, goals, rewards, chosen, (r_lo, r_hi)
+    return new_pos, new_vel, goals, rewards, chosen

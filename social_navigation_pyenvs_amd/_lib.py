@@ -23,6 +23,7 @@ CS_OBSTACLES_SHARED = 1 << 3
 CS_RESPAWN = 1 << 4
 CS_ROBOT_UNICYCLE = 1 << 5
 CS_ORCA = 9
+CS_SOCIAL_MOMENTUM = 10
 
 # every symbol include/crowdstep.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -48,7 +49,7 @@ class cs_worlds(C.Structure):
         ("d_obstacles", C.c_void_p), ("d_robot", C.c_void_p), ("d_world_flags", C.c_void_p),
         ("respawn_bound_x", C.c_float), ("respawn_bound_y", C.c_float),
         ("orca_neighbor_dist", C.c_float), ("orca_time_horizon", C.c_float), ("orca_time_horizon_obst", C.c_float),
-        ("orca_max_neighbors", C.c_int32),
+        ("orca_max_neighbors", C.c_int32), ("sm_n_actions", C.c_int32),
     ]
 
 

@@ -18,6 +18,8 @@ from ._lib import DeviceBuffer, check, cs_worlds
 SFMS = ["sfm_helbing", "sfm_guo", "sfm_moussaid", "hsfm_farina", "hsfm_guo", "hsfm_moussaid",
         "hsfm_new", "hsfm_new_guo", "hsfm_new_moussaid"]  # motion_model_manager.py:15-17
 HUMAN_MODELS = SFMS + ["orca"]  # social_nav_gym.py:11-12
+# model titles MotionModelManager accepts beyond the Gym's list (motion_model_manager.py:247-251); index = C-ABI type id
+CROWD_MODELS = HUMAN_MODELS + ["social_momentum"]
 # motion_model_manager.py:14  neighbor_dist, max_neighbors, time_horizon, time_horizon_obstacles
 ORCA_DEFAULTS = dict(neighbor_dist=10.0, max_neighbors=10, time_horizon=5.0, time_horizon_obst=5.0)
 
@@ -49,11 +51,13 @@ class CrowdWorlds:
         if device is not None:
             _lib.set_device(device)
         if isinstance(type, str):
-            type = HUMAN_MODELS.index(type)
-        if type < 0 or type > 9:
+            type = CROWD_MODELS.index(type)
+        if type < 0 or type > 10:
             raise ValueError(f"Type {type} does not exist for this implementation")
         self.type = int(type)
         self.orca = self.type == _lib.CS_ORCA
+        self.social_momentum = self.type == _lib.CS_SOCIAL_MOMENTUM
+        self.sm_n_actions = 20  # motion_model_manager.py:249
         self.orca_params = dict(ORCA_DEFAULTS)
         self.stream = stream
         states = np.asarray(states, dtype=np.float32)
@@ -69,7 +73,7 @@ class CrowdWorlds:
             raise ValueError(f"goals shape {goals.shape} does not match W={self.W}, n={self.n}")
         self.G = goals.shape[2]
         if params is None:
-            if not self.orca:
+            if not (self.orca or self.social_momentum):
                 raise ValueError("params are required for the SFM / HSFM models")
             params = np.zeros((self.n, 20), dtype=np.float32)
         params = np.asarray(params, dtype=np.float32)
@@ -146,6 +150,7 @@ class CrowdWorlds:
         d.orca_max_neighbors = int(self.orca_params["max_neighbors"])
         d.orca_time_horizon = float(self.orca_params["time_horizon"])
         d.orca_time_horizon_obst = float(self.orca_params["time_horizon_obst"])
+        d.sm_n_actions = int(self.sm_n_actions)
         return d
 
     # ------------------------------------------------------------------ hot path

@@ -22,6 +22,8 @@ extern unsigned long long* g_stamp_buf; // diagnostic build only (tools/stamp_pr
 
 // ORCA branch (orca.hip)
 int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);
+// social-momentum branch (social_momentum.hip)
+int social_momentum_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);
 
 } // namespace csimpl
 

@@ -1274,6 +1274,7 @@ int cs_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action,
     if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
     if (d_action && !w->d_robot) return fail(CS_ERR_ARG, "robot action given but cs_worlds.d_robot is null");
     if (w->type == CS_ORCA) return csimpl::orca_launch(w, dt, n_substeps, d_action, nullptr, (hipStream_t)stream);
+    if (w->type == CS_SOCIAL_MOMENTUM) return csimpl::social_momentum_launch(w, dt, n_substeps, d_action, nullptr, (hipStream_t)stream);
     int mode = M_COMMIT_GOALS;
     if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
     return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream);
@@ -1283,6 +1284,7 @@ int cs_peek(const cs_worlds* w, float dt, float* d_next, void* stream)
 {
     if (!w || !d_next) return fail(CS_ERR_ARG, "null argument");
     if (w->type == CS_ORCA) return csimpl::orca_launch(w, dt, 1, nullptr, d_next, (hipStream_t)stream);
+    if (w->type == CS_SOCIAL_MOMENTUM) return csimpl::social_momentum_launch(w, dt, 1, nullptr, d_next, (hipStream_t)stream);
     int mode = M_PEEK;
     if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
     cs_worlds ww = *w;

@@ -76,8 +76,8 @@ class MotionModelManager:
     # ------------------------------------------------------------------ model set-up (:222-283)
     def set_human_motion_model(self, motion_model_title: str):
         self.motion_model_title = motion_model_title
-        if motion_model_title not in HUMAN_MODELS:
-            if motion_model_title in ("sfm_roboticsupo", "social_momentum"):
+        if motion_model_title not in HUMAN_MODELS and motion_model_title != "social_momentum":
+            if motion_model_title == "sfm_roboticsupo":
                 raise NotImplementedError(f"'{motion_model_title}' is not reachable from SocialNavGym and not on the accelerated path")
             raise Exception(f"The human motion model '{motion_model_title}' does not exist")
         n = len(self.humans)
@@ -88,7 +88,20 @@ class MotionModelManager:
         for i, h in enumerate(self.humans):
             for j, goal in enumerate(h.goals):
                 self.goals[i, j] = np.array(goal, PRECISION)
-        if motion_model_title == "orca":
+        if motion_model_title == "social_momentum":  # (:247-251) the step itself runs in csrc/social_momentum.hip
+            self.sm, self.orca, self.headed, self.include_mass = True, False, False, False
+            self.sfm_type = _lib.CS_SOCIAL_MOMENTUM
+            self.params = None
+            self.obstacles = None  # the model ignores walls (:395-404)
+            self.n_actions = 20
+            self.actions_angles = [((2 * np.pi) / self.n_actions) * i for i in range(self.n_actions)]
+            for h in self.humans:
+                h.action_set = [np.array([np.cos(a), np.sin(a)], dtype=PRECISION) * h.desired_speed for a in self.actions_angles]
+            self.states = np.array([h.get_safe_state() for h in self.humans], PRECISION)
+            if self.consider_robot:
+                self.states = np.append(self.states, [self.robot.get_safe_state()], axis=0)
+            self.all_equal_humans = True
+        elif motion_model_title == "orca":
             self.orca, self.headed, self.include_mass = True, False, False
             self.sfm_type = _lib.CS_ORCA
             self.params = None
@@ -188,6 +201,11 @@ class MotionModelManager:
             if self.orca:  # the simulator's robot agent keeps what set_state_orca last gave it
                 rb = self.states[-1]
             self.states[-1] = rb
+        if self.sm:  # the filter reads every entity's own safety_space attribute (social_momentum.py:22)
+            for i, h in enumerate(self.humans):
+                self.safety_space[i] = h.safety_space
+            if self.consider_robot:
+                self.safety_space[-1] = self.robot.safety_space
         margin = self.safety_space + (self._orca_margin if self.orca else 0.0)
         robot_rows = self.robot.get_safe_state() if (self.robot is not None and len(self.robot.goals) > 0) else None
         if respawn is None:

@@ -19,6 +19,8 @@ reference produced) is written to the ``.npz`` fixtures.  Groups (SURVEY.md §8c
   g7_respawn  parallel-traffic respawn (state just before / after)
   g8_lookahead  compute_rotated_states_and_reward (CADRL / SARL 81-action look-ahead)
   g9_laser    LaserSensor.get_laser_measurements (social_gym/src/sensors.py:51-66)
+  g10_social_momentum  MotionModelManager("social_momentum").update_humans single steps (motion_model_manager.py:395-404,
+              social_gym/src/social_momentum.py)
 """
 from __future__ import annotations
 
@@ -621,9 +623,60 @@ def gen_g9_laser():
     print("g9_laser:", len(cases), "cases ->", save_cases("g9_laser", cases))
 
 
+def gen_g10_social_momentum():
+    """Single update_humans(t, dt) calls of the social-momentum crowd model on dense crossings: with / without a visible
+    robot, uniform / per-human radius and speed, a safety space, two substep sizes."""
+    cases = []
+    seed = 0
+    for n, radius in ((2, 1.2), (5, 2.0), (10, 2.6), (25, 3.8)):
+        for robot_visible in (False, True):
+            for attrs in (False, True):
+                seed += 1
+                rng = np.random.default_rng(100_000 + seed)
+                robot = None
+                if robot_visible:
+                    robot = {"pos": [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))], "yaw": 0.0, "radius": 0.3,
+                             "goals": [[4.0, 4.0]]}
+                cfg = crossing_config(rng, "social_momentum", n, radius, robot=robot, robot_visible=robot_visible, attrs=attrs)
+                sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=False)
+                mm = sim.motion_model_manager
+                if seed % 3 == 0:  # set_safety_space raises for this model (:159); the filter reads the attribute (:22)
+                    for h in mm.humans:
+                        h.safety_space = 0.05
+                if robot_visible:
+                    sim.robot.linear_velocity = np.array([0.4, -0.3])
+                dt = DT if seed % 2 else 0.25
+                for k in range(int(round((0.6 * radius) / dt))):      # walk into the dense middle
+                    mm.update_humans(0, dt)
+                for rep in range(6):
+                    for k in range(int(round(0.5 / dt)) if rep else 0):
+                        mm.update_humans(0, dt)
+                    gmax = max(len(h.goals) for h in mm.humans)
+                    def snap():
+                        g = np.full((n, gmax, 2), np.nan)
+                        for i, h in enumerate(mm.humans):
+                            g[i, :len(h.goals)] = np.array(h.goals, dtype=float)
+                        return dict(pos=np.array([h.position for h in mm.humans], dtype=float),
+                                    vel=np.array([h.linear_velocity for h in mm.humans], dtype=float), goals=g)
+                    before = snap()
+                    rb = None
+                    if robot_visible:
+                        rb = np.array([*sim.robot.position, *sim.robot.linear_velocity, sim.robot.radius, sim.robot.safety_space], dtype=float)
+                    mm.update_humans(0, dt)
+                    after = snap()
+                    cases.append(dict(n=n, dt=dt, robot_visible=robot_visible,
+                                      radius=np.array([h.radius for h in mm.humans], dtype=float),
+                                      safety=np.array([h.safety_space for h in mm.humans], dtype=float),
+                                      vd=np.array([h.desired_speed for h in mm.humans], dtype=float),
+                                      robot=rb if rb is not None else np.zeros(0),
+                                      **{f"in_{k}": v for k, v in before.items()}, **{f"out_{k}": v for k, v in after.items()}))
+    print("g10_social_momentum:", len(cases), "cases ->", save_cases("g10_social_momentum", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
-              g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser)
+              g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
+              g10_social_momentum=gen_g10_social_momentum)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -29,8 +29,8 @@ def test_struct_layout_matches_header():
 
     from social_navigation_pyenvs_amd._lib import cs_worlds
 
-    # 8 int32 + 7 pointers + 5 floats + 1 int32, natural alignment
-    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 4
+    # 8 int32 + 7 pointers + 5 floats + 2 int32, natural alignment (8-byte: 4 bytes of tail padding)
+    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 2 * 4 + 4
     assert cs_worlds.d_state.offset == 32
 
 
