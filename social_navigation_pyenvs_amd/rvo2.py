@@ -1,0 +1,170 @@
+"""``rvo2`` -- drop-in for the Python-RVO2 module the reference imports, backed by the ORCA HIP kernel.
+
+The reference reaches RVO2 through the ``rvo2.PyRVOSimulator`` object API (second seam):
+  /root/reference/social_gym/src/motion_model_manager.py:8       ``import rvo2``
+  :237-246   PyRVOSimulator(...), addAgent(...), addObstacle(...), processObstacles()
+  :105-141   setAgentPosition / setAgentVelocity / setAgentPrefVelocity, :157-158 setAgentRadius
+  :386-394   setTimeStep(dt); doStep(); getAgentPosition / getAgentVelocity
+  /root/reference/crowd_nav/policy_no_train/orca.py:95-129       one simulator per decision, robot = agent 0
+``import social_navigation_pyenvs_amd.rvo2 as rvo2`` keeps those call sites unchanged.  ``doStep`` is ONE launch of
+``cs_step`` (type CS_ORCA, one world) on the agents' current rows: neighbour search, ORCA half-planes, the 2-D linear
+programmes and ``position += velocity * timeStep`` (RVO2 ``Agent::computeNeighbors / computeNewVelocity / update``,
+restated in csrc/orca.hip; parity with the third-party library itself is unpinned).
+
+Supported: any number of agents up to 64, per-agent radius / maxSpeed / position / velocity / preferred velocity;
+``neighborDist``, ``maxNeighbors``, ``timeHorizon`` must be the same for every agent (the reference never varies
+them: ORCA_DEFAULTS, motion_model_manager.py:14).  Static obstacles are not implemented: ``addObstacle`` raises
+(every Gym scenario has ``walls == []``); ``processObstacles()`` with no obstacle is a no-op, as the reference calls it
+unconditionally (:246).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .batched import CrowdWorlds
+
+_FAR = 1.0e9  # goal the kernel's own goal / preferred-velocity glue never reaches: the shim owns prefVelocity
+
+
+class PyRVOSimulator:
+    def __init__(self, timeStep, neighborDist, maxNeighbors, timeHorizon, timeHorizonObst, radius, maxSpeed, velocity=(0, 0)):
+        self._dt = float(timeStep)
+        self._defaults = dict(neighborDist=float(neighborDist), maxNeighbors=int(maxNeighbors), timeHorizon=float(timeHorizon),
+                              timeHorizonObst=float(timeHorizonObst), radius=float(radius), maxSpeed=float(maxSpeed),
+                              velocity=(float(velocity[0]), float(velocity[1])))
+        self._pos, self._vel, self._pref, self._radius, self._maxspeed = [], [], [], [], []
+        self._time = 0.0
+        self._cw = None
+
+    # ------------------------------------------------------------------ building the scene
+    def setAgentDefaults(self, neighborDist, maxNeighbors, timeHorizon, timeHorizonObst, radius, maxSpeed, velocity=(0, 0)):
+        if self._pos and (float(neighborDist), int(maxNeighbors), float(timeHorizon)) != (
+                self._defaults["neighborDist"], self._defaults["maxNeighbors"], self._defaults["timeHorizon"]):
+            raise NotImplementedError("per-agent neighborDist / maxNeighbors / timeHorizon are not supported")
+        self._defaults.update(neighborDist=float(neighborDist), maxNeighbors=int(maxNeighbors), timeHorizon=float(timeHorizon),
+                              timeHorizonObst=float(timeHorizonObst), radius=float(radius), maxSpeed=float(maxSpeed),
+                              velocity=(float(velocity[0]), float(velocity[1])))
+
+    def addAgent(self, pos, neighborDist=None, maxNeighbors=None, timeHorizon=None, timeHorizonObst=None, radius=None,
+                 maxSpeed=None, velocity=None):
+        d = self._defaults
+        for name, val in (("neighborDist", neighborDist), ("maxNeighbors", maxNeighbors), ("timeHorizon", timeHorizon)):
+            if val is not None and float(val) != float(d[name]):
+                raise NotImplementedError(f"per-agent {name} is not supported (the reference uses ORCA_DEFAULTS for every agent)")
+        if len(self._pos) >= 64:
+            raise NotImplementedError("the ORCA step supports up to 64 agents per simulator")
+        self._pos.append([float(pos[0]), float(pos[1])])
+        v = d["velocity"] if velocity is None else velocity
+        self._vel.append([float(v[0]), float(v[1])])
+        self._pref.append([0.0, 0.0])
+        self._radius.append(float(d["radius"] if radius is None else radius))
+        self._maxspeed.append(float(d["maxSpeed"] if maxSpeed is None else maxSpeed))
+        self._cw = None
+        return len(self._pos) - 1
+
+    def addObstacle(self, vertices):
+        raise NotImplementedError("ORCA static obstacles (RVO2 obstacle lines) are not implemented on the MI355X path "
+                                  "(SURVEY.md §8 row f3); no Gym scenario has walls")
+
+    def processObstacles(self):
+        return None
+
+    # ------------------------------------------------------------------ stepping
+    def setTimeStep(self, timeStep):
+        self._dt = float(timeStep)
+
+    def getTimeStep(self):
+        return self._dt
+
+    def getGlobalTime(self):
+        return self._time
+
+    def doStep(self):
+        n = len(self._pos)
+        if n == 0:
+            self._time += self._dt
+            return
+        S = np.zeros((1, n, 13), np.float32)
+        S[0, :, 0:2] = self._pos
+        S[0, :, 3:5] = self._vel
+        S[0, :, 5:7] = self._pref
+        S[0, :, 8] = self._radius
+        S[0, :, 9] = 1.0
+        S[0, :, 10:12] = _FAR
+        S[0, :, 12] = self._maxspeed
+        if self._cw is None or self._cw.n != n:
+            self._cw = CrowdWorlds(S, np.full((1, n, 1, 2), _FAR, np.float32), None, None, None, type="orca")
+            self._cw.orca_params = dict(neighbor_dist=self._defaults["neighborDist"], max_neighbors=self._defaults["maxNeighbors"],
+                                        time_horizon=self._defaults["timeHorizon"], time_horizon_obst=self._defaults["timeHorizonObst"])
+        else:
+            self._cw.set_states(S)
+        self._cw.step(self._dt, 1, None)
+        out = self._cw.get_states()[0]
+        self._pos = out[:, 0:2].astype(np.float64).tolist()
+        self._vel = out[:, 3:5].astype(np.float64).tolist()
+        self._time += self._dt
+
+    # ------------------------------------------------------------------ accessors (rvo2.pyx names)
+    def getNumAgents(self):
+        return len(self._pos)
+
+    def getAgentPosition(self, i):
+        return (self._pos[i][0], self._pos[i][1])
+
+    def getAgentVelocity(self, i):
+        return (self._vel[i][0], self._vel[i][1])
+
+    def getAgentPrefVelocity(self, i):
+        return (self._pref[i][0], self._pref[i][1])
+
+    def getAgentRadius(self, i):
+        return self._radius[i]
+
+    def getAgentMaxSpeed(self, i):
+        return self._maxspeed[i]
+
+    def getAgentNeighborDist(self, i):
+        return self._defaults["neighborDist"]
+
+    def getAgentMaxNeighbors(self, i):
+        return self._defaults["maxNeighbors"]
+
+    def getAgentTimeHorizon(self, i):
+        return self._defaults["timeHorizon"]
+
+    def getAgentTimeHorizonObst(self, i):
+        return self._defaults["timeHorizonObst"]
+
+    def getNumObstacleVertices(self):
+        return 0
+
+    def setAgentPosition(self, i, pos):
+        self._pos[i] = [float(pos[0]), float(pos[1])]
+
+    def setAgentVelocity(self, i, vel):
+        self._vel[i] = [float(vel[0]), float(vel[1])]
+
+    def setAgentPrefVelocity(self, i, vel):
+        self._pref[i] = [float(vel[0]), float(vel[1])]
+
+    def setAgentRadius(self, i, radius):
+        self._radius[i] = float(radius)
+
+    def setAgentMaxSpeed(self, i, maxSpeed):
+        self._maxspeed[i] = float(maxSpeed)
+
+    def _uniform_only(self, name, value):
+        if float(value) != float(self._defaults[name]):
+            raise NotImplementedError(f"per-agent {name} is not supported")
+
+    def setAgentNeighborDist(self, i, v):
+        self._uniform_only("neighborDist", v)
+
+    def setAgentMaxNeighbors(self, i, v):
+        self._uniform_only("maxNeighbors", v)
+
+    def setAgentTimeHorizon(self, i, v):
+        self._uniform_only("timeHorizon", v)
+
+    def setAgentTimeHorizonObst(self, i, v):
+        self._defaults["timeHorizonObst"] = float(v)

@@ -92,3 +92,43 @@ def test_orca_rejects_update_humans_parallel():
     cw = CrowdWorlds(S, goals, None, None, None, type="orca")
     with pytest.raises(ValueError):  # the reference raises ValueError for type > 8 (forces_parallel.py:211)
         cw.update_humans_parallel(0.0125)
+
+
+def test_rvo2_module_drop_in():
+    """``social_navigation_pyenvs_amd.rvo2`` used the way the reference uses Python-RVO2 (motion_model_manager.py:237-246,
+    386-394; policy_no_train/orca.py:95-129): the positions / velocities after doStep equal the C restatement's."""
+    from social_navigation_pyenvs_amd import rvo2
+
+    rng = np.random.default_rng(7)
+    n = 12
+    ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+    pos = 2.5 * np.stack([np.cos(ang), np.sin(ang)], -1) + rng.uniform(-0.2, 0.2, (n, 2))
+    vel = rng.normal(0, 0.3, (n, 2))
+    radius = rng.uniform(0.25, 0.4, n)
+    vmax = rng.uniform(0.8, 1.2, n)
+    sim = rvo2.PyRVOSimulator(1 / 60, 10, 10, 5, 5, 0.3, 1)
+    ids = [sim.addAgent((pos[i, 0], pos[i, 1]), 10, 10, 5, 5, radius[i] + 0.01, vmax[i], (vel[i, 0], vel[i, 1])) for i in range(n)]
+    assert ids == list(range(n)) and sim.getNumAgents() == n
+    sim.processObstacles()
+    with pytest.raises(NotImplementedError):
+        sim.addObstacle([(0, 0), (1, 0), (1, 1)])
+    p32, v32 = pos.astype(np.float32), vel.astype(np.float32)
+    for step in range(5):
+        pref = -p32 / np.linalg.norm(p32, axis=1, keepdims=True)
+        for i in range(n):
+            sim.setAgentPrefVelocity(i, (float(pref[i, 0]), float(pref[i, 1])))
+        sim.setTimeStep(0.25)
+        sim.doStep()
+        nv = orc.orca_new_velocities(p32, v32, pref, (radius + 0.01).astype(np.float32), vmax.astype(np.float32), 10.0, 10, 5.0, 0.25)
+        p32 = p32 + nv * np.float32(0.25)
+        v32 = nv
+        got_p = np.array([sim.getAgentPosition(i) for i in range(n)])
+        got_v = np.array([sim.getAgentVelocity(i) for i in range(n)])
+        np.testing.assert_allclose(got_v, v32, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(got_p, p32, rtol=0, atol=2e-5)
+        p32, v32 = got_p.astype(np.float32), got_v.astype(np.float32)   # re-synchronise (per-step parity)
+    assert abs(sim.getGlobalTime() - 5 * 0.25) < 1e-12
+    sim.setAgentPosition(0, (9.0, 9.0)); sim.setAgentVelocity(0, (0.0, 0.0)); sim.setAgentRadius(0, 0.5)
+    assert sim.getAgentPosition(0) == (9.0, 9.0) and sim.getAgentRadius(0) == 0.5
+    with pytest.raises(NotImplementedError):
+        sim.addAgent((0, 0), 5.0)   # a per-agent neighborDist
