@@ -141,6 +141,21 @@ class DeviceBuffer:
                                    C.c_void_p(stream)))
         return out
 
+    @property
+    def __cuda_array_interface__(self):
+        """Zero-copy hand-over to torch / cupy (``torch.as_tensor(buf, device="cuda")``): the learner reads observations
+        and writes actions in HBM, nothing crosses PCIe."""
+        return {"shape": tuple(self.shape), "typestr": self.dtype.str, "data": (int(self.ptr), False), "version": 2,
+                "strides": None}
+
+    def torch(self):
+        """A torch tensor aliasing this buffer (same HBM; the buffer must outlive the tensor)."""
+        import torch
+
+        t = torch.as_tensor(self, device="cuda")
+        t._crowdstep_owner = self  # keep the allocation alive as long as the view
+        return t
+
     def free(self):
         if getattr(self, "ptr", None):
             try:

@@ -284,6 +284,250 @@ __global__ __launch_bounds__(64) void k_generate(const GArgs a)
     if (a.world_flags != nullptr) a.world_flags[w] = (scenario == CS_SCN_PARALLEL_TRAFFIC) ? 1 : 0; // respawn rule on (:359-360)
 }
 
+// ------------------------------------------------------------------------------------------
+// One WAVEFRONT per world (n <= 64): the latency form, used for the masked auto-reset inside a device-resident loop.
+// Every lane runs the same random stream redundantly (MT19937 state in LDS, words read as wave-wide broadcasts, so all
+// lanes hold the same candidate), the twist is done cooperatively, lane j keeps placed human j in registers and the
+// rejection test against all placed humans is ONE instruction sequence + a wave vote instead of a serial loop.
+// Same draws, same f64 expressions, same accept / reject decisions as k_generate above.
+// ------------------------------------------------------------------------------------------
+struct WMT {
+    uint32_t* s; // [624] in LDS
+    int pos;     // wave-uniform
+};
+
+__device__ void wmt_seed(WMT& m, uint32_t seed, int lane)
+{
+    if (lane == 0) { // the init_genrand recurrence is serial
+        uint32_t prev = seed;
+        m.s[0] = prev;
+        for (int i = 1; i < 624; ++i) {
+            prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i;
+            m.s[i] = prev;
+        }
+    }
+    m.pos = 624;
+    __syncthreads();
+}
+
+__device__ void wmt_twist(WMT& m, int lane)
+{
+    constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
+    // chunks of 64 in increasing order keep the serial algorithm's old / new value pattern: element kk reads old[kk],
+    // old[kk + 1] (not yet rewritten: it belongs to this or a later chunk, and a chunk loads before it stores) and either
+    // old[kk + 397] (kk < 227) or new[kk - 227] (rewritten at least three chunks earlier)
+    for (int k0 = 0; k0 < 623; k0 += 64) {
+        const int kk = k0 + lane;
+        uint32_t v = 0;
+        if (kk < 623) {
+            const uint32_t y = (m.s[kk] & UPPER) | (m.s[kk + 1] & LOWER);
+            v = m.s[kk < 227 ? kk + 397 : kk - 227] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+        }
+        __syncthreads();
+        if (kk < 623) m.s[kk] = v;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const uint32_t y = (m.s[623] & UPPER) | (m.s[0] & LOWER);
+        m.s[623] = m.s[396] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+    }
+    m.pos = 0;
+    __syncthreads();
+}
+
+__device__ uint32_t wmt_next(WMT& m, int lane)
+{
+    if (m.pos >= 624) wmt_twist(m, lane);
+    uint32_t y = m.s[m.pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+__device__ double wrnd(WMT& m, int lane)
+{
+    const uint32_t a = wmt_next(m, lane) >> 5, b = wmt_next(m, lane) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+__global__ __launch_bounds__(64) void k_generate_wave(const GArgs a)
+{
+    __shared__ uint32_t s_mt[624];
+    __shared__ double s_rad[64], s_spd[64];
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (a.mask != nullptr && a.mask[w] == 0) return; // block-uniform
+    const cs_generator& g = a.g;
+    const int n = g.n;
+    const double pi = 3.141592653589793;
+    WMT m;
+    m.s = s_mt;
+    m.pos = 624;
+    const uint32_t seed = a.seeds[w];
+    wmt_seed(m, seed, lane);
+    int scenario = g.scenario;
+    if (scenario == CS_SCN_HYBRID) {
+        scenario = (wmt_next(m, lane) & 1u) ? CS_SCN_PARALLEL_TRAFFIC : CS_SCN_CIRCULAR_CROSSING;
+        __syncthreads();
+        wmt_seed(m, seed, lane);
+    }
+    const double R = g.circle_radius, L = g.traffic_length, H = g.traffic_height, rr = g.robot_radius;
+    const bool insert_robot = g.insert_robot != 0;
+    double rpx = 0, rpy = 0, ryaw = 0, rgx = 0, rgy = 0;
+    double mx = 0, my = 0, myaw = 0; // placed human `lane`
+    int status = 0;
+
+    // attributes: every lane sees every draw; slot i keeps its own in LDS for the uniform reads below
+    if (scenario == CS_SCN_CIRCULAR_CROSSING || scenario == CS_SCN_PARALLEL_TRAFFIC) {
+        for (int i = 0; i < n; ++i) {
+            double sp = 1.0, ra = 0.3;
+            if (g.randomize_attributes) { sp = 0.5 + (1.5 - 0.5) * wrnd(m, lane); ra = 0.3 + (0.5 - 0.3) * wrnd(m, lane); }
+            if (lane == i) { s_spd[i] = sp; s_rad[i] = ra; }
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            double sp = 1.0, ra = 0.3;
+            if (i < 3) { sp = 0.0; ra = 1.0 + (wrnd(m, lane) - 1.0) * 0.4; }
+            if (lane == i) { s_spd[i] = sp; s_rad[i] = ra; }
+        }
+    }
+    __syncthreads();
+    const double myrad = lane < n ? s_rad[lane] : 0.0;
+
+    if (scenario == CS_SCN_CIRCULAR_CROSSING) {
+        rpx = 0.0; rpy = 0.0 - R; ryaw = pi / 2.0; rgx = 0.0; rgy = 0.0 + R;
+        if (!g.randomize_positions) {
+            const int slots = n + (insert_robot ? 1 : 0);
+            const double step = (2.0 * pi) / slots;
+            const int k = insert_robot ? lane + 1 : lane;
+            const double off = insert_robot ? -(pi / 2.0) : 0.0;
+            mx = 0.0 + R * cos(off + step * k); my = 0.0 + R * sin(off + step * k);
+            myaw = insert_robot ? bound_angle_d((pi / 2.0) + step * k) : bound_angle_d(-pi + step * k);
+        } else {
+            for (int i = 0; i < n && status == 0; ++i) {
+                const double ri = s_rad[i], si = s_spd[i];
+                bool placed = false;
+                for (int t = 0; t < g.max_tries; ++t) {
+                    const double angle = wrnd(m, lane) * pi * 2.0;
+                    const double nx = (wrnd(m, lane) - 0.5) * si;
+                    const double ny = (wrnd(m, lane) - 0.5) * si;
+                    double sa, ca;
+                    sincos(angle, &sa, &ca); // one range reduction for both (same values as cos() and sin(): G6 parity)
+                    const double x = 0.0 + R * ca + nx, y = 0.0 + R * sa + ny;
+                    const double md = ri + myrad + 0.2;
+                    const bool hit = lane < i && (norm2d(x - mx, y - my) < md || norm2d(x - (-mx + 0.0), y - (-my + 0.0)) < md);
+                    bool collide = __builtin_amdgcn_ballot_w64(hit) != 0;
+                    if (insert_robot && (norm2d(x - rpx, y - rpy) < ri + rr + 0.2 || norm2d(x - rgx, y - rgy) < ri + rr + 0.2))
+                        collide = true;
+                    if (!collide) {
+                        if (lane == i) { mx = x; my = y; myaw = bound_angle_d(pi + angle); }
+                        placed = true;
+                        break;
+                    }
+                }
+                if (!placed) status = 1;
+            }
+        }
+    } else if (scenario == CS_SCN_PARALLEL_TRAFFIC) {
+        rpx = -(L / 2.0) + 1.0; rpy = 0.0; ryaw = 0.0; rgx = (L / 2.0) - 1.0; rgy = 0.0;
+        double area = 0.0;
+        for (int i = 0; i < n; ++i) area += pi * (s_rad[i] * s_rad[i]);
+        if (area > L * H * 0.4) status = 2;
+        for (int i = 0; i < n && status == 0; ++i) {
+            const double ri = s_rad[i];
+            bool placed = false;
+            for (int t = 0; t < g.max_tries; ++t) {
+                const double lo = -(L / 2.0) + ri, hi = L / 2.0 - ri;
+                const double x = (hi - lo) * wrnd(m, lane) + lo;
+                const double y = (wrnd(m, lane) - 0.5) * H;
+                const bool hit = lane < i && (norm2d(x - mx, y - my) - ri - myrad - 0.1 < 0.0);
+                bool collide = __builtin_amdgcn_ballot_w64(hit) != 0;
+                if (insert_robot && norm2d(x - rpx, y - rpy) - ri - rr - 0.1 < 0.0) collide = true;
+                if (!collide) {
+                    if (lane == i) { mx = x; my = y; myaw = bound_angle_d(-pi); }
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) status = 1;
+        }
+    } else {
+        rpx = 0.0; rpy = 0.0 - R; ryaw = pi / 2.0; rgx = 0.0; rgy = 0.0 + R;
+        const double inner = R - 3.0;
+        const double sector = pi / (double)(n / 2);
+        for (int i = 0; i < n && status == 0; ++i) {
+            const double ri = s_rad[i];
+            bool placed = false;
+            for (int t = 0; t < g.max_tries; ++t) {
+                double angle, nx, ny, ring;
+                if (i < 3) {
+                    angle = sector * (-0.5 + 2.0 * i + (wrnd(m, lane) - 0.5) * 0.5);
+                    nx = (wrnd(m, lane) - 0.5) * 0.1; ny = (wrnd(m, lane) - 0.5) * 0.1;
+                    ring = inner;
+                } else {
+                    angle = sector * (0.5 + 2.0 * i + (wrnd(m, lane) - 0.5) * 0.5);
+                    nx = (wrnd(m, lane) - 0.5) * 0.7; ny = (wrnd(m, lane) - 0.5) * 0.7;
+                    ring = R;
+                }
+                double sa, ca;
+                sincos(angle, &sa, &ca);
+                const double x = 0.0 + ring * ca + nx, y = 0.0 + ring * sa + ny;
+                const double md = ri + myrad + 0.2;
+                const double gxj = (lane < 3) ? mx : (-mx + 0.0), gyj = (lane < 3) ? my : (-my + 0.0);
+                const bool hit = lane < i && (norm2d(x - mx, y - my) < md || norm2d(x - gxj, y - gyj) < md);
+                bool collide = __builtin_amdgcn_ballot_w64(hit) != 0;
+                if (norm2d(x - rpx, y - rpy) < ri + rr + 0.2 || norm2d(x - rgx, y - rgy) < ri + rr + 0.2) collide = true;
+                if (!collide) {
+                    if (lane == i) { mx = x; my = y; myaw = bound_angle_d(pi + angle); }
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) status = 1;
+        }
+    }
+    if (lane == 0) {
+        if (a.status != nullptr) a.status[w] = status;
+        if (a.scenario_out != nullptr) a.scenario_out[w] = scenario;
+    }
+    if (status != 0) return;
+
+    const float nanf_ = __builtin_nanf("");
+    if (lane < n) {
+        const int i = lane;
+        double g0x, g0y, g1x, g1y;
+        int ng;
+        if (scenario == CS_SCN_PARALLEL_TRAFFIC) { g0x = -(L / 2.0) - 3.0; g0y = my; g1x = g1y = 0; ng = 1; }
+        else if (scenario == CS_SCN_CIRCULAR_CROSSING_STATIC_OBSTACLES && i < 3) { g0x = mx; g0y = my; g1x = mx; g1y = my; ng = 2; }
+        else { g0x = 0.0 * 2.0 - mx; g0y = 0.0 * 2.0 - my; g1x = mx; g1y = my; ng = 2; }
+        float* s = a.S + ((long)w * a.rows + i) * a.as;
+        const long fs = a.fs;
+        s[0] = (float)mx; s[fs] = (float)my; s[2 * fs] = (float)myaw;
+        for (int c = 3; c < 8; ++c) s[c * fs] = 0.0f;
+        s[8 * fs] = (float)myrad; s[9 * fs] = (float)g.human_mass; s[10 * fs] = (float)g0x; s[11 * fs] = (float)g0y;
+        s[12 * fs] = (float)s_spd[i];
+        float* gl = a.goals + ((long)w * n + i) * a.G * 2;
+        for (int k = 0; k < a.G; ++k) {
+            float gx = nanf_, gy = nanf_;
+            if (k == 0) { gx = (float)g0x; gy = (float)g0y; }
+            else if (k == 1 && ng == 2) { gx = (float)g1x; gy = (float)g1y; }
+            gl[2 * k] = gx; gl[2 * k + 1] = gy;
+        }
+    }
+    if (lane == 0) {
+        auto robot_row = [&](float* o, long fs) {
+            o[0] = (float)rpx; o[fs] = (float)rpy; o[2 * fs] = (float)ryaw;
+            for (int c = 3; c < 8; ++c) o[c * fs] = 0.0f;
+            o[8 * fs] = (float)rr; o[9 * fs] = (float)g.robot_mass; o[10 * fs] = (float)rgx; o[11 * fs] = (float)rgy;
+            o[12 * fs] = (float)g.robot_desired_speed;
+        };
+        if (a.robot != nullptr) robot_row(a.robot + (long)w * 13, 1);
+        if (a.robot_row) robot_row(a.S + ((long)w * a.rows + n) * a.as, a.fs);
+        if (a.world_flags != nullptr) a.world_flags[w] = (scenario == CS_SCN_PARALLEL_TRAFFIC) ? 1 : 0;
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -323,8 +567,12 @@ int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32
     a.status = d_status;
     a.scenario_out = d_scenario;
     a.mt = (uint32_t*)d_scratch;
-    const int block = 64, grid = (w->W + block - 1) / block;
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
+    if (gen->n <= 64) { // one wavefront per world: ~10x shorter latency per world, and faster for full batches too
+        hipLaunchKernelGGL(k_generate_wave, dim3(w->W), dim3(64), 0, (hipStream_t)stream, a);
+    } else {            // one lane per world, MT19937 state in the scratch buffer
+        const int block = 64, grid = (w->W + block - 1) / block;
+        hipLaunchKernelGGL(k_generate, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

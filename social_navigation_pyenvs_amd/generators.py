@@ -40,6 +40,35 @@ def phase_seeds(phase: str, first_case: int, W: int, case_capacity=None) -> np.n
     return (offset + int(first_case) + np.arange(W, dtype=np.int64)).astype(np.uint32)
 
 
+def make_generator(cw, scenario, *, insert_robot=True, randomize_attributes=False, randomize_positions=True, circle_radius=7,
+                   traffic_length=14, traffic_height=3, robot_radius=0.3, human_mass=75, robot_mass=80, robot_desired_speed=1,
+                   max_tries=MAX_PLACEMENT_TRIES) -> cs_generator:
+    if isinstance(scenario, str):
+        scenario = SCENARIOS[scenario]
+    g = cs_generator()
+    g.scenario, g.n = int(scenario), int(cw.n)
+    g.insert_robot, g.randomize_attributes, g.randomize_positions = int(insert_robot), int(randomize_attributes), int(randomize_positions)
+    g.max_tries = int(max_tries)
+    g.circle_radius, g.traffic_length, g.traffic_height = float(circle_radius), float(traffic_length), float(traffic_height)
+    g.robot_radius, g.human_mass = float(robot_radius), float(human_mass)
+    g.robot_mass, g.robot_desired_speed = float(robot_mass), float(robot_desired_speed)
+    return g
+
+
+def generate_worlds_device(cw, gen: cs_generator, d_seeds, d_mask=None, d_status=None, d_scenario=None) -> None:
+    """Asynchronous form for a device-resident loop: seeds / mask / status are device pointers (DeviceBuffer, torch CUDA
+    tensor or int); nothing is copied to or from the host and the call does not synchronise."""
+    from .batched import _ptr
+
+    lib = _lib.load()
+    nbytes = int(lib.cs_generate_scratch_bytes(C.c_int(cw.W)))
+    d_scratch = cw._buffer("gen_mt19937", (nbytes // 4,), np.uint32)
+    d = cw.descriptor()
+    check(lib.cs_generate_worlds(C.byref(gen), C.byref(d), C.c_void_p(_ptr(d_seeds)), C.c_void_p(_ptr(d_mask)),
+                                 C.c_void_p(_ptr(d_status)), C.c_void_p(_ptr(d_scenario)), C.c_void_p(d_scratch.ptr),
+                                 C.c_void_p(cw.stream)))
+
+
 def generate_worlds(cw, scenario, seeds, *, mask=None, insert_robot=True, randomize_attributes=False,
                     randomize_positions=True, circle_radius=7, traffic_length=14, traffic_height=3, robot_radius=0.3,
                     human_mass=75, robot_mass=80, robot_desired_speed=1, max_tries=MAX_PLACEMENT_TRIES,

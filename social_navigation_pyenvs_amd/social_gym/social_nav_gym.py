@@ -341,11 +341,12 @@ class BatchedSocialNavGym:
                               robot=np.zeros((self.W, 13), np.float32), respawn_bounds=self._bounds if traffic else None,
                               respawn_worlds=np.zeros(self.W, np.int32) if traffic else None)
         seeds = gen.phase_seeds(phase, first_case, self.W, proto.case_capacity)
-        status, scn = gen.generate_worlds(
-            self.cw, scenario, seeds, insert_robot=True, randomize_attributes=proto.randomize_attributes,
-            randomize_positions=True, circle_radius=proto.circle_radius, traffic_length=proto.traffic_length,
-            traffic_height=proto.traffic_height, robot_radius=proto.robot_radius, human_mass=75, robot_mass=robot.mass,
-            robot_desired_speed=robot.desired_speed)
+        self._gen_kw = dict(insert_robot=True, randomize_attributes=proto.randomize_attributes, randomize_positions=True,
+                            circle_radius=proto.circle_radius, traffic_length=proto.traffic_length,
+                            traffic_height=proto.traffic_height, robot_radius=proto.robot_radius, human_mass=75,
+                            robot_mass=robot.mass, robot_desired_speed=robot.desired_speed)
+        self._gen_scenario, self._seeds_host = scenario, seeds
+        status, scn = gen.generate_worlds(self.cw, scenario, seeds, **self._gen_kw)
         if traffic and not np.any(scn == gen.SCENARIOS["parallel_traffic"]):
             self.cw.respawn_bounds = None  # a hybrid batch that drew no traffic world: same descriptor as the host path
         if model == "orca":  # RVO2 preferred velocity lives in columns 5:7 (set_state_orca, motion_model_manager.py:105-123)
@@ -358,6 +359,84 @@ class BatchedSocialNavGym:
         self.radius = self.cw.get_states()[:, :n, 8].astype(np.float32)
         self.global_time = np.zeros(self.W, np.float32)
         return self.observe()
+
+    # ------------------------------------------------------------------ device-resident loop (torch tensors in HBM)
+    def _device_loop_state(self):
+        """Per-world step counters, seeds and the float32 clock table, resident on the GPU."""
+        import torch
+
+        from .. import generators as gen
+
+        if getattr(self, "_dl", None) is not None and self._dl["cw"] is self.cw:
+            return self._dl
+        if getattr(self, "_gen_scenario", None) is None:
+            raise RuntimeError("step_device needs a world batch generated on the device: reset(..., device=True)")
+        try:
+            torch.zeros(1, device="cuda")
+        except RuntimeError as e:  # torch ships its own HIP / HSA runtime; the first one loaded owns the device
+            raise _lib.CrowdstepError("torch cannot see the GPU in this process: `import torch` BEFORE the first crowdstep "
+                                      f"object is created so both share one HIP runtime ({e})") from e
+        W = self.W
+        # global_time is accumulated in float32, time_step_factor additions of time_step per step (social_nav_gym.py:244):
+        # the same sequence as a table indexed by the per-world step counter
+        max_steps = int(self.time_limit / (self.time_step * self.time_step_factor)) + 8
+        clock = np.zeros(max_steps, np.float32)
+        t = np.float32(0)
+        for k in range(1, max_steps):
+            for _ in range(self.time_step_factor):
+                t = t + np.float32(self.time_step)
+            clock[k] = t
+        dl = dict(cw=self.cw, clock=torch.as_tensor(clock, device="cuda"),
+                  counter=torch.zeros(W, dtype=torch.int64, device="cuda"),
+                  gtime=torch.zeros(W, dtype=torch.float32, device="cuda"),
+                  seeds=torch.as_tensor(self._seeds_host.astype(np.int64), device="cuda").to(torch.int32),
+                  mask=torch.zeros(W, dtype=torch.int32, device="cuda"),
+                  out=self.cw._buffer("reward_out", (W, 7)).torch(),
+                  state=self.cw.d_state.torch().view(W, self.cw.rows, 13),
+                  gen=gen.make_generator(self.cw, self._gen_scenario, **self._gen_kw),
+                  cols=torch.as_tensor([0, 1, 3, 4, 8] + ([2, 7] if self.headed_obs else []), device="cuda"))
+        self._dl = dl
+        return dl
+
+    def observe_device(self):
+        """Observations [W, N, 5|7] as a torch CUDA tensor gathered from the resident state (no host copy)."""
+        dl = self._device_loop_state()
+        return dl["state"][:, :self.n].index_select(2, dl["cols"])
+
+    def step_device(self, actions, auto_reset=True):
+        """``step`` without leaving the GPU: ``actions`` is a float32 torch CUDA tensor [W, 2] (holonomic vx, vy).
+        Returns torch CUDA tensors (obs [W, N, 5|7], reward [W], terminated [W], truncated [W], info_code [W]).
+        With ``auto_reset`` the worlds whose episode ended are regenerated on the device (``cs_generate_worlds`` with a
+        mask) from the next unused seeds before the observation is taken, as vectorised Gym environments do."""
+        import ctypes as C
+
+        import torch
+
+        from .. import generators as gen
+
+        dl = self._device_loop_state()
+        cw = self.cw
+        a = actions.to(device="cuda", dtype=torch.float32).contiguous()
+        d = cw.descriptor()
+        cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
+        lib = _lib.load()
+        _lib.check(lib.cs_collision_reward(C.byref(d), C.c_void_p(a.data_ptr()), C.c_float(self.robot_time_step),
+                                           C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()),
+                                           C.c_void_p(cw.stream)))
+        _lib.check(lib.cs_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(a.data_ptr()),
+                               C.c_void_p(cw.stream)))
+        out = dl["out"]
+        reward, terminated, truncated = out[:, 3].clone(), out[:, 4] > 0, out[:, 5] > 0
+        info = out[:, 6].to(torch.int32)
+        dl["counter"] += 1
+        if auto_reset:
+            done = terminated | truncated
+            dl["mask"].copy_(done)
+            dl["seeds"] += dl["mask"] * self.W               # every world walks its own arithmetic sequence of seeds
+            gen.generate_worlds_device(cw, dl["gen"], dl["seeds"], dl["mask"])
+            dl["counter"].masked_fill_(done, 0)
+        torch.index_select(dl["clock"], 0, dl["counter"].clamp_(max=dl["clock"].numel() - 1), out=dl["gtime"])
+        return self.observe_device(), reward, terminated, truncated, info
 
     def observe(self):
         S = self.cw.get_states()[:, :self.n]

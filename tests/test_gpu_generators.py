@@ -201,3 +201,73 @@ def test_full_size_device_reset_properties():
         generate_worlds(sub, scenario, seeds[pick], circle_radius=R)
         np.testing.assert_array_equal(sub.get_states(), S[pick])                 # batch composition does not matter
         print(f"device reset of {W} x {n} ({scenario}): {el * 1e3:.1f} ms including the seed upload and status download")
+
+
+def test_device_resident_step_equals_host_step_and_auto_resets():
+    """BatchedSocialNavGym.step_device (torch tensors in HBM, no host copies, masked device reset of finished worlds)
+    against the host-array step of the same batch, and the regenerated worlds against the host generator."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W = 64
+    cfg = _config("circle_crossing", human_num=6)
+    host = BatchedSocialNavGym(cfg, W)
+    host.reset(phase="test", first_case=3, device=True)
+    dev = BatchedSocialNavGym(cfg, W)
+    dev.reset(phase="test", first_case=3, device=True)
+    rng = np.random.default_rng(0)
+    for k in range(6):   # no episode ends this early: the two paths must agree exactly
+        a = rng.uniform(-0.5, 0.5, (W, 2)).astype(np.float32)
+        oh, rh, th, uh, ih = host.step(a)
+        od, rd, td, ud, idv = dev.step_device(torch.as_tensor(a, device="cuda"))
+        assert od.is_cuda and od.shape == (W, 6, 5)
+        np.testing.assert_array_equal(od.cpu().numpy(), oh)
+        np.testing.assert_array_equal(rd.cpu().numpy(), rh)
+        np.testing.assert_array_equal(td.cpu().numpy(), th)
+        np.testing.assert_array_equal(idv.cpu().numpy(), ih)
+    np.testing.assert_array_equal(dev._dl["gtime"].cpu().numpy(), host.global_time)
+    # drive every robot straight to its goal (0, R): ReachGoal ends the episode and the world is regenerated
+    seeds0 = dev._dl["seeds"].cpu().numpy().copy()
+    ended = np.zeros(W, bool)
+    for k in range(80):
+        rb = dev.cw.d_robot.torch()
+        to_goal = rb[:, 10:12] - rb[:, 0:2]
+        a = to_goal / to_goal.norm(dim=1, keepdim=True).clamp(min=1e-6)
+        od, rd, td, ud, idv = dev.step_device(a)
+        ended |= (td | ud).cpu().numpy()
+        if ended.all():
+            break
+    assert ended.all()
+    seeds1 = dev._dl["seeds"].cpu().numpy()
+    assert np.all((seeds1 - seeds0) % W == 0) and np.all(seeds1 > seeds0)
+    fresh = (dev._dl["counter"] == 0).cpu().numpy()          # worlds regenerated in the very last step
+    assert fresh.any()
+    check = BatchedSocialNavGym(cfg, W)
+    check.reset(phase="test", first_case=3, device=True)
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+    generate_worlds(check.cw, "circle_crossing", seeds1.astype(np.uint32), insert_robot=True)
+    np.testing.assert_array_equal(dev.cw.get_states()[fresh], check.cw.get_states()[fresh])
+    np.testing.assert_array_equal(dev.cw.get_robot()[fresh], check.cw.get_robot()[fresh])
+    assert np.all(dev._dl["gtime"].cpu().numpy()[fresh] == 0)
+
+
+def test_more_than_64_humans_use_the_lane_per_world_kernel():
+    """n <= 64 runs one wavefront per world, larger worlds one lane per world: both restate the same stream."""
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+    from social_navigation_pyenvs_amd.social_gym.social_nav_sim import SocialNavSim
+
+    host = types.SimpleNamespace(_attributes=SocialNavSim._attributes)
+    for n, R in ((70, 30), (64, 28)):
+        cw = _blank(4, n, 2)
+        seeds = np.array([11, 12, 13, 14])
+        generate_worlds(cw, "circle_crossing", seeds, circle_radius=R, randomize_attributes=True)
+        S = cw.get_states()
+        for w in range(4):
+            np.random.seed(int(seeds[w]))
+            data = SocialNavSim.generate_circular_crossing_setting(
+                host, insert_robot=True, human_policy="hsfm_farina", robot_radius=0.3, circle_radius=R, n_actors=n,
+                randomize_human_positions=True, randomize_human_attributes=True)
+            hp = np.array([data["humans"][i]["pos"] for i in range(n)])
+            hr = np.array([data["humans"][i]["radius"] for i in range(n)])
+            np.testing.assert_allclose(S[w, :, 0:2], hp.astype(np.float32), **F32_TOL)
+            np.testing.assert_array_equal(S[w, :, 8], hr.astype(np.float32))
