@@ -1082,6 +1082,60 @@ __global__ void k_collision_reward(int W, int n, int rows, const float* S, long 
     o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
 }
 
+// The same, one lane per (world, human) for n <= 64: the humans' swept distances are evaluated in parallel (the rows are
+// read once, coalesced), then one lane per world walks them in index order with the reference's early `break`.
+__global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int rows, int wpb, const float* S, long as, long fs,
+                                                              const float* robot, const float* action, float T,
+                                                              const float* gtime, float time_limit, float success_reward,
+                                                              float collision_penalty, float discomfort_dist,
+                                                              float discomfort_factor, float* out)
+{
+    __shared__ float s_closest[64];
+    const int tid = threadIdx.x;
+    const int lw = tid / n, i = tid - lw * n;
+    const int w = blockIdx.x * wpb + lw;
+    const bool valid = lw < wpb && w < W;
+    float rpx = 0, rpy = 0, rr = 0, rgx = 0, rgy = 0, ax = 0, ay = 0;
+    float closest = INFINITY;
+    if (valid) {
+        const float* rb = robot + (long)w * 13;
+        rpx = rb[0]; rpy = rb[1]; rr = rb[8]; rgx = rb[10]; rgy = rb[11];
+        ax = action[(long)w * 2]; ay = action[(long)w * 2 + 1];
+        const float* s = S + ((long)w * rows + i) * as;
+        const float x1 = s[0] - rpx, y1 = s[fs] - rpy;
+        const float x2 = x1 + (s[3 * fs] - ax) * T, y2 = y1 + (s[4 * fs] - ay) * T;
+        const float dx = x2 - x1, dy = y2 - y1;
+        float d;
+        if (dx == 0.0f && dy == 0.0f) d = norm2(0.0f - x1, 0.0f - y1);
+        else {
+            float u = ((0.0f - x1) * dx + (0.0f - y1) * dy) / (dx * dx + dy * dy);
+            if (u > 1.0f) u = 1.0f; else if (u < 0.0f) u = 0.0f;
+            d = norm2(x1 + u * dx, y1 + u * dy);
+        }
+        closest = d - s[8 * fs] - rr;
+    }
+    s_closest[tid] = closest;
+    __syncthreads();
+    if (!valid || i != 0) return;
+    float dmin = INFINITY;
+    int collision = 0;
+    for (int j = 0; j < n; ++j) {
+        const float c = s_closest[lw * n + j];
+        if (c < 0.0f) { collision = 1; break; }
+        else if (c < dmin) dmin = c;
+    }
+    const float ex = rpx + ax * T, ey = rpy + ay * T;
+    const int reaching = norm2(ex - rgx, ey - rgy) < rr;
+    float reward = 0.0f; int term = 0, trunc = 0, info = 0;
+    if (gtime[w] >= time_limit - 1.0f) { trunc = 1; info = 4; }
+    else if (collision) { reward = collision_penalty; term = 1; info = 3; }
+    else if (reaching) { reward = success_reward; term = 1; info = 2; }
+    else if (dmin < discomfort_dist) { reward = (dmin - discomfort_dist) * discomfort_factor * T; info = 1; }
+    float* o = out + (long)w * 7;
+    o[0] = (float)collision; o[1] = dmin; o[2] = (float)reaching; o[3] = reward;
+    o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
+}
+
 __global__ void k_transpose_state(const float* src, float* dst, long total_rows, int to_soa)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // one lane per (row, field)
@@ -1295,16 +1349,25 @@ int cs_peek(const cs_worlds* w, float dt, float* d_next, void* stream)
 int cs_collision_reward(const cs_worlds* w, const float* d_action, float T, const float* d_global_time,
                         const float* reward_cfg, float* d_out, void* stream)
 {
-    int rc = check_worlds(w);
-    if (rc) return rc;
+    // the swept test only reads positions, velocities and radii: every crowd model (0..8, ORCA, social momentum) qualifies
+    if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
+    if (w->W <= 0 || w->n <= 0 || !w->d_state) return fail(CS_ERR_ARG, "bad cs_worlds");
+    if (w->layout != CS_LAYOUT_AOS && w->layout != CS_LAYOUT_SOA) return fail(CS_ERR_ARG, "bad layout");
     if (!d_action || !d_global_time || !reward_cfg || !d_out || !w->d_robot) return fail(CS_ERR_ARG, "null argument");
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     long as, fs;
     strides(w, rows, as, fs);
-    const int block = 64, grid = (w->W + block - 1) / block;
-    hipLaunchKernelGGL(k_collision_reward, dim3(grid), dim3(block), 0, (hipStream_t)stream, w->W, w->n, rows,
-                       (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, d_global_time,
-                       reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out);
+    if (w->n <= 64) {
+        const int wpb = 64 / w->n, grid = (w->W + wpb - 1) / wpb;
+        hipLaunchKernelGGL(k_collision_reward_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w->W, w->n, rows, wpb,
+                           (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, d_global_time,
+                           reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out);
+    } else {
+        const int block = 64, grid = (w->W + block - 1) / block;
+        hipLaunchKernelGGL(k_collision_reward, dim3(grid), dim3(block), 0, (hipStream_t)stream, w->W, w->n, rows,
+                           (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, d_global_time,
+                           reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out);
+    }
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

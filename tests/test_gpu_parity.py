@@ -232,7 +232,7 @@ def test_bad_type_raises_value_error():
 
     c = load_cases("g1_episode")[0]
     with pytest.raises(ValueError):
-        CrowdWorlds(f32(c["state_in"]), f32(c["goals_in"]), f32(c["params"]), type=10)
+        CrowdWorlds(f32(c["state_in"]), f32(c["goals_in"]), f32(c["params"]), type=11)  # 0..8 SFM/HSFM, 9 ORCA, 10 social momentum
 
 
 @pytest.mark.parametrize("rows_case", [(1, False), (2, False), (1, True), (3, False), (4, True), (7, False), (21, True),
