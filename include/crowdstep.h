@@ -113,6 +113,7 @@ int cs_event_create(void** event);
 int cs_event_destroy(void* event);
 int cs_event_record(void* event, void* stream);
 int cs_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int cs_stream_wait_event(void* stream, void* event);         /* later work of `stream` waits for `event` (no host sync) */
 
 /* HIP graphs: capture the launches issued on `stream` between begin and end (e.g. K cs_step calls of a rollout) and
  * replay them with one launch -- removes the per-launch host gap of a launch-bound loop. */

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "cs_last_error", "cs_abi_version", "cs_device_count", "cs_set_device", "cs_device_name", "cs_malloc",
     "cs_free", "cs_memcpy_h2d", "cs_memcpy_d2h", "cs_memcpy_d2d", "cs_memset", "cs_stream_create",
     "cs_stream_destroy", "cs_stream_sync", "cs_event_create", "cs_event_destroy", "cs_event_record",
-    "cs_event_elapsed_ms", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
+    "cs_event_elapsed_ms", "cs_stream_wait_event", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
     "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
     "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry", "cs_lookahead",
     "cs_generate_scratch_bytes", "cs_generate_worlds", "cs_laser_scan",
@@ -178,6 +178,10 @@ class Event:
 
     def record(self, stream=None):
         check(load().cs_event_record(C.c_void_p(self.ptr), C.c_void_p(stream)))
+
+    def wait(self, stream=None):
+        """Make later work of `stream` wait for this event (device-side, the host does not block)."""
+        check(load().cs_stream_wait_event(C.c_void_p(stream), C.c_void_p(self.ptr)))
 
     def elapsed_ms(self, stop: "Event") -> float:
         ms = C.c_float(0)

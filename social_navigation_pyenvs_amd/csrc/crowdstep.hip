@@ -1303,6 +1303,7 @@ int cs_stream_sync(void* s) { HIP_TRY(hipStreamSynchronize((hipStream_t)s)); ret
 int cs_event_create(void** e) { if (!e) return fail(CS_ERR_ARG, "null out pointer"); hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); *e = ev; return CS_OK; }
 int cs_event_destroy(void* e) { HIP_TRY(hipEventDestroy((hipEvent_t)e)); return CS_OK; }
 int cs_event_record(void* e, void* s) { HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return CS_OK; }
+int cs_stream_wait_event(void* s, void* e) { HIP_TRY(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); return CS_OK; }
 int cs_event_elapsed_ms(void* a, void* b, float* ms)
 {
     if (!ms) return fail(CS_ERR_ARG, "null ms");
