@@ -412,17 +412,27 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         lds_v[i] = make_float2(0.0f, 0.0f);
     }
     __syncthreads();
-    auto publish = [&](int buf) {      // my row, both copies
-        const float4 me = make_float4(px, py, my_rs, 0.0f);
-        lds_p[buf * TP + pbase + row] = me;
-        lds_p[buf * TP + pbase + rows + row] = me;
+    // radius + safety space never changes during a launch: it is stored once in both buffers, a substep only rewrites
+    // (x, y) -- two 8-byte LDS stores instead of two 16-byte ones
+    auto publish = [&](int buf) {      // my position, both copies
+        const float2 me = make_float2(px, py);
+        *reinterpret_cast<float2*>(&lds_p[buf * TP + pbase + row]) = me;
+        *reinterpret_cast<float2*>(&lds_p[buf * TP + pbase + rows + row]) = me;
     };
+    // Helbing / Guo pair-once builds read partner velocities only in the (rare) contact pass, which publishes them itself
+    constexpr bool VEL_ON_DEMAND = N3L && SOC != 2;
     auto publish_v = [&](int buf) {    // stored linear velocity; second copy only where the rotated loop reads it
-        lds_v[buf * TP + pbase + row] = make_float2(vx, vy);
-        if constexpr (N3L && SOC == 2) lds_v[buf * TP + pbase + rows + row] = make_float2(vx, vy);
+        if constexpr (!VEL_ON_DEMAND) {
+            lds_v[buf * TP + pbase + row] = make_float2(vx, vy);
+            if constexpr (N3L && SOC == 2) lds_v[buf * TP + pbase + rows + row] = make_float2(vx, vy);
+        }
     };
     if (valid) {
-        publish(0);
+        const float4 me = make_float4(px, py, my_rs, 0.0f);
+        for (int buf = 0; buf < 2; ++buf) {
+            lds_p[buf * TP + pbase + row] = me;
+            lds_p[buf * TP + pbase + rows + row] = me;
+        }
         publish_v(0);
         float rvx = vx, rvy = vy;
         if (HEADED > 0 && human) {
@@ -742,7 +752,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     fsx *= sp.sA; fsy *= sp.sA;
                     if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
                         const float4* pp = lds_p + cur * TP + pbase;
-                        const float2* pvel = lds_v + cur * TP + pbase;
+                        float2* pvel = lds_v + cur * TP + pbase;
+                        pvel[row] = make_float2(vx, vy); // every lane of the wavefront is here: publish the velocities now
+                        LDS_ORDER_FENCE();
 #pragma nounroll
                         for (int j = 0; j < rows; ++j) { // rare path: keep it small in the instruction cache
                             const float4 q = pp[j];
@@ -911,7 +923,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             publish_v(nxt);
             if constexpr (!PEQ && HEADED > 0) lds_vr[nxt * T + tid] = make_float2(vx, vy);
         }
-        __syncthreads();
+        // block of one wavefront: its LDS operations execute in order, program order is all the next substep needs
+        // (no s_waitcnt lgkmcnt(0) + s_barrier on the published rows)
+        if constexpr (MAXT == 64) LDS_ORDER_FENCE(); else __syncthreads();
         STAMP(4);
         // -- parallel-traffic respawn, motion_model_manager.py:407-422 (sequential inside a world)
         if (a.flags & CS_RESPAWN) {
