@@ -200,6 +200,60 @@ def lookahead(actions, nxt, cur, robot, dt, headed=False, dtype=np.float64):
     return rot, rew
 
 
+def process_obstacle(vertices) -> np.ndarray:
+    """RVOSimulator::addObstacle for one polygon (vertex order as given, counter-clockwise): [n, 8] float32 records
+    px, py, unitDir.x, unitDir.y, isConvex, next, prev, 0 with polygon-local next / prev indices."""
+    v = np.asarray(vertices, dtype=np.float32).reshape(-1, 2)
+    n = len(v)
+    out = np.zeros((n, 8), np.float32)
+    for i in range(n):
+        nxt, prv = (i + 1) % n, (i - 1) % n
+        d = v[nxt] - v[i]
+        u = d / np.float32(np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1])))
+        if n == 2:
+            convex = True
+        else:  # leftOf(prev, this, next) >= 0, leftOf(a, b, c) = det(a - c, b - a)
+            a, b, c = v[prv], v[i], v[nxt]
+            convex = np.float32((a[0] - c[0]) * (b[1] - a[1])) - np.float32((a[1] - c[1]) * (b[0] - a[0])) >= 0
+        out[i] = [v[i, 0], v[i, 1], u[0], u[1], 1.0 if convex else 0.0, nxt, prv, 0.0]
+    return out
+
+
+def process_obstacles(polygons) -> np.ndarray:
+    """All polygons of a scene in one vertex table (next / prev become global indices)."""
+    recs, base = [], 0
+    for poly in polygons:
+        r = process_obstacle(poly)
+        r[:, 5] += base
+        r[:, 6] += base
+        base += len(r)
+        recs.append(r)
+    return np.concatenate(recs) if recs else np.zeros((0, 8), np.float32)
+
+
+def orca_new_velocities_obst(pos, vel, pref, radius, maxspeed, verts, neighbor_dist=10.0, max_nb=10, time_horizon=5.0,
+                             time_horizon_obst=5.0, time_step=0.25):
+    """One RVO2 doStep velocity solve with static obstacles (float32, PARITY UNPINNED).
+    Returns (new_vel [na, 2], lines [na, max_nb + 32, 4], nlines [na], nobst [na]); obstacle lines come first."""
+    f = np.float32
+    pos = np.ascontiguousarray(pos, dtype=f); vel = np.ascontiguousarray(vel, dtype=f)
+    pref = np.ascontiguousarray(pref, dtype=f); radius = np.ascontiguousarray(radius, dtype=f)
+    maxspeed = np.ascontiguousarray(maxspeed, dtype=f)
+    verts = np.ascontiguousarray(verts, dtype=f).reshape(-1, 8)
+    na = pos.shape[0]
+    out = np.zeros((na, 2), dtype=f)
+    lines = np.zeros((na, max_nb + 32, 4), dtype=f)
+    nl = np.zeros(na, dtype=np.int32)
+    no = np.zeros(na, dtype=np.int32)
+    fn = lib().orc_orca_new_velocities_obst
+    fn.restype = None
+    fn(C.c_int(na), _ptr(pos, C.c_float), _ptr(vel, C.c_float), _ptr(pref, C.c_float), _ptr(radius, C.c_float),
+       _ptr(maxspeed, C.c_float), C.c_float(neighbor_dist), C.c_int(max_nb), C.c_float(time_horizon),
+       C.c_float(time_horizon_obst), C.c_float(time_step), _ptr(verts, C.c_float), C.c_int(len(verts)), _ptr(out, C.c_float),
+       lines.ctypes.data_as(C.c_void_p), nl.ctypes.data_as(C.POINTER(C.c_int)), no.ctypes.data_as(C.POINTER(C.c_int)))
+    return out, lines, nl, no
+
+
 def orca_new_velocities(pos, vel, pref, radius, maxspeed, neighbor_dist=10.0, max_nb=10, time_horizon=5.0,
                         time_step=0.25, return_lines=False):
     """One RVO2 doStep velocity solve for one world (float32, PARITY UNPINNED)."""
@@ -221,7 +275,8 @@ def orca_new_velocities(pos, vel, pref, radius, maxspeed, neighbor_dist=10.0, ma
 
 
 def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot=None, action=None,
-                    neighbor_dist=10.0, max_nb=10, time_horizon=5.0, respawn=False, bounds=(0.0, 0.0), threads=0):
+                    neighbor_dist=10.0, max_nb=10, time_horizon=5.0, respawn=False, bounds=(0.0, 0.0), threads=0,
+                    verts=None, time_horizon_obst=5.0):
     """Batched ([W, rows, 13]) or single-world block of ORCA substeps on the shared row layout
     (cols 5:7 = preferred velocity).  Returns (S, goals, robot)."""
     f = np.float32
@@ -238,12 +293,14 @@ def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot
         robot = np.ascontiguousarray(robot, dtype=f).copy().reshape(W, 13)
     if action is not None:
         action = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=f), (W, 2)))
-    fn = lib().orc_orca_step_block_batched
+    vt = None if verts is None else np.ascontiguousarray(verts, dtype=f).reshape(-1, 8)
+    fn = lib().orc_orca_step_block_batched_obst
     fn.restype = None
     fn(C.c_int(W), _ptr(S, C.c_float), _ptr(goals, C.c_float), C.c_int(G), C.c_int(rows), C.c_int(int(robot_visible)),
        _ptr(margin, C.c_float), _ptr(robot, C.c_float), _ptr(action, C.c_float), C.c_float(dt), C.c_int(n_substeps),
        C.c_float(neighbor_dist), C.c_int(max_nb), C.c_float(time_horizon), C.c_int(int(respawn)),
-       C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_int(threads))
+       C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_int(threads), C.c_float(time_horizon_obst), _ptr(vt, C.c_float),
+       C.c_int(0 if vt is None else len(vt)))
     if single:
         return S[0], goals[0], (robot[0] if robot is not None else None)
     return S, goals, robot

@@ -21,8 +21,12 @@
  *
  * Differences from RVO2 that cannot change a result: neighbours are found by brute force in index
  * order instead of a kd-tree (same set; only the order of exactly tied distances could differ, for
- * N <= 10 = MAX_LEAF_SIZE even that is identical); static obstacles (ORCA obstacle lines) are not
- * modelled (every Gym scenario has walls == [], social_nav_sim.py:296,355,428).
+ * N <= 10 = MAX_LEAF_SIZE even that is identical).
+ * Static obstacles (motion_model_manager.py:244-246 addObstacle / processObstacles): the obstacle
+ * ORCA lines of Agent::computeNewVelocity and linearProgram3 with numObstLines are restated below; the obstacle
+ * neighbours are found by brute force over the polygon edges (RVO2's obstacle kd-tree may SPLIT an edge into collinear
+ * pieces -- the pieces give the same half-planes except where a piece boundary decides which end vertex defines the
+ * velocity obstacle; that splitting is not modelled).  No Gym scenario has walls (social_nav_sim.py:296,355,428).
  */
 #include <math.h>
 #include <stddef.h>
@@ -34,6 +38,8 @@
 
 #define RVO_EPSILON 0.00001f
 #define ORCA_MAX_NEIGHBORS 32
+#define ORCA_MAX_OBST 32
+#define ORCA_MAX_LINES (ORCA_MAX_NEIGHBORS + ORCA_MAX_OBST)
 
 typedef struct { float px, py, dx, dy; } orca_line;
 
@@ -87,15 +93,16 @@ static int lp2(const orca_line* L, int nl, float radius, float ox, float oy, int
     return nl;
 }
 
-/* RVO2 linearProgram3 (numObstLines = 0) */
-static void lp3(const orca_line* L, int nl, int begin, float radius, float* rx, float* ry)
+/* RVO2 linearProgram3: the first numObst lines (static obstacles) are hard constraints, copied unprojected */
+static void lp3(const orca_line* L, int nl, int numObst, int begin, float radius, float* rx, float* ry)
 {
     float distance = 0.0f;
-    orca_line proj[ORCA_MAX_NEIGHBORS];
+    orca_line proj[ORCA_MAX_LINES];
     for (int i = begin; i < nl; ++i) {
         if (det2(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry) > distance) {
             int np = 0;
-            for (int j = 0; j < i; ++j) {
+            for (int j = 0; j < numObst; ++j) proj[np++] = L[j];
+            for (int j = numObst; j < i; ++j) {
                 orca_line ln;
                 const float d = det2(L[i].dx, L[i].dy, L[j].dx, L[j].dy);
                 if (fabsf(d) <= RVO_EPSILON) {
@@ -117,18 +124,191 @@ static void lp3(const orca_line* L, int nl, int begin, float radius, float* rx, 
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Static obstacles.  One record per polygon vertex, as RVOSimulator::addObstacle builds them:
+ *   point, unitDir = normalize(next.point - point), isConvex = leftOf(prev, this, next) >= 0 (2 vertices: convex),
+ *   next / prev vertex indices.  The edge of vertex v runs from v to next(v); agents stay on its right side
+ *   (polygons are given counter-clockwise, obstacle.py:11-12).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct { float px, py, ux, uy, convex, next, prev, pad; } orca_vertex;
+
+static inline float absSq2(float x, float y) { return x * x + y * y; }
+
+static float dist_sq_point_segment(float ax, float ay, float bx, float by, float cx, float cy)
+{
+    const float r = ((cx - ax) * (bx - ax) + (cy - ay) * (by - ay)) / absSq2(bx - ax, by - ay);
+    if (r < 0.0f) return absSq2(cx - ax, cy - ay);
+    if (r > 1.0f) return absSq2(cx - bx, cy - by);
+    return absSq2(cx - (ax + r * (bx - ax)), cy - (ay + r * (by - ay)));
+}
+
+/* Agent::computeNeighbors (obstacle part) + insertObstacleNeighbor, brute force over the edges in index order:
+ * edges the agent is on the right of and closer than rangeSq, sorted by distance (strict <, ties keep order). */
+static int obstacle_neighbors(const orca_vertex* V, int nv, float px, float py, float rangeSq, int* oi)
+{
+    float od[ORCA_MAX_OBST];
+    int cnt = 0;
+    for (int v = 0; v < nv; ++v) {
+        const orca_vertex* o1 = V + v;
+        const orca_vertex* o2 = V + (int)o1->next;
+        const float agentLeftOfLine = det2(o1->px - px, o1->py - py, o2->px - o1->px, o2->py - o1->py);
+        const float distSqLine = agentLeftOfLine * agentLeftOfLine / absSq2(o2->px - o1->px, o2->py - o1->py);
+        if (distSqLine < rangeSq && agentLeftOfLine < 0.0f) {
+            const float distSq = dist_sq_point_segment(o1->px, o1->py, o2->px, o2->py, px, py);
+            if (distSq < rangeSq && cnt < ORCA_MAX_OBST) {
+                int i = cnt++;
+                while (i != 0 && distSq < od[i - 1]) { od[i] = od[i - 1]; oi[i] = oi[i - 1]; --i; }
+                od[i] = distSq; oi[i] = v;
+            }
+        }
+    }
+    return cnt;
+}
+
+/* Agent::computeNewVelocity, "Create obstacle ORCA lines" */
+static int obstacle_lines(const orca_vertex* V, const int* oi, int no, float px, float py, float vx, float vy,
+                          float radius, float invT, orca_line* L)
+{
+    int nl = 0;
+    for (int k = 0; k < no; ++k) {
+        const orca_vertex* o1 = V + oi[k];
+        const orca_vertex* o2 = V + (int)o1->next;
+        const float r1x = o1->px - px, r1y = o1->py - py, r2x = o2->px - px, r2y = o2->py - py;
+        /* already covered by a previous obstacle line? */
+        int covered = 0;
+        for (int j = 0; j < nl; ++j) {
+            if (det2(invT * r1x - L[j].px, invT * r1y - L[j].py, L[j].dx, L[j].dy) - invT * radius >= -RVO_EPSILON &&
+                det2(invT * r2x - L[j].px, invT * r2y - L[j].py, L[j].dx, L[j].dy) - invT * radius >= -RVO_EPSILON) {
+                covered = 1;
+                break;
+            }
+        }
+        if (covered) continue;
+        const float distSq1 = absSq2(r1x, r1y), distSq2 = absSq2(r2x, r2y), radiusSq = radius * radius;
+        const float ovx = o2->px - o1->px, ovy = o2->py - o1->py;
+        const float s = (-r1x * ovx + -r1y * ovy) / absSq2(ovx, ovy);
+        const float distSqLine = absSq2(-r1x - s * ovx, -r1y - s * ovy);
+        orca_line ln;
+        if (s < 0.0f && distSq1 <= radiusSq) {            /* collision with left vertex; ignore if non-convex */
+            if (o1->convex != 0.0f) {
+                const float n = sqrtf(absSq2(-r1y, r1x));
+                ln.px = 0.0f; ln.py = 0.0f; ln.dx = -r1y / n; ln.dy = r1x / n;
+                L[nl++] = ln;
+            }
+            continue;
+        } else if (s > 1.0f && distSq2 <= radiusSq) {     /* collision with right vertex */
+            if (o2->convex != 0.0f && det2(r2x, r2y, o2->ux, o2->uy) >= 0.0f) {
+                const float n = sqrtf(absSq2(-r2y, r2x));
+                ln.px = 0.0f; ln.py = 0.0f; ln.dx = -r2y / n; ln.dy = r2x / n;
+                L[nl++] = ln;
+            }
+            continue;
+        } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) { /* collision with the segment */
+            ln.px = 0.0f; ln.py = 0.0f; ln.dx = -o1->ux; ln.dy = -o1->uy;
+            L[nl++] = ln;
+            continue;
+        }
+        /* no collision: legs */
+        float llx, lly, rlx, rly;
+        const orca_vertex* a1 = o1;
+        const orca_vertex* a2 = o2;
+        if (s < 0.0f && distSqLine <= radiusSq) {         /* obliquely viewed: left vertex defines the velocity obstacle */
+            if (o1->convex == 0.0f) continue;
+            a2 = o1;
+            const float leg1 = sqrtf(distSq1 - radiusSq);
+            llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
+            rlx = (r1x * leg1 + r1y * radius) / distSq1; rly = (-r1x * radius + r1y * leg1) / distSq1;
+        } else if (s > 1.0f && distSqLine <= radiusSq) {  /* right vertex defines it */
+            if (o2->convex == 0.0f) continue;
+            a1 = o2;
+            const float leg2 = sqrtf(distSq2 - radiusSq);
+            llx = (r2x * leg2 - r2y * radius) / distSq2; lly = (r2x * radius + r2y * leg2) / distSq2;
+            rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+        } else {                                          /* usual situation */
+            if (o1->convex != 0.0f) {
+                const float leg1 = sqrtf(distSq1 - radiusSq);
+                llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
+            } else { llx = -o1->ux; lly = -o1->uy; }     /* left leg extends the cut-off line */
+            if (o2->convex != 0.0f) {
+                const float leg2 = sqrtf(distSq2 - radiusSq);
+                rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+            } else { rlx = o1->ux; rly = o1->uy; }
+        }
+        /* legs never point into a neighbouring edge of a convex vertex: take that edge's cut-off line instead */
+        const orca_vertex* leftNb = V + (int)a1->prev;
+        int leftForeign = 0, rightForeign = 0;
+        if (a1->convex != 0.0f && det2(llx, lly, -leftNb->ux, -leftNb->uy) >= 0.0f) { llx = -leftNb->ux; lly = -leftNb->uy; leftForeign = 1; }
+        if (a2->convex != 0.0f && det2(rlx, rly, a2->ux, a2->uy) <= 0.0f) { rlx = a2->ux; rly = a2->uy; rightForeign = 1; }
+        /* cut-off centres */
+        const float lcx = invT * (a1->px - px), lcy = invT * (a1->py - py);
+        const float rcx = invT * (a2->px - px), rcy = invT * (a2->py - py);
+        const float cvx = rcx - lcx, cvy = rcy - lcy;
+        const int same = (a1 == a2);
+        /* project the current velocity on the velocity obstacle */
+        const float t = same ? 0.5f : ((vx - lcx) * cvx + (vy - lcy) * cvy) / absSq2(cvx, cvy);
+        const float tL = (vx - lcx) * llx + (vy - lcy) * lly;
+        const float tR = (vx - rcx) * rlx + (vy - rcy) * rly;
+        if ((t < 0.0f && tL < 0.0f) || (same && tL < 0.0f && tR < 0.0f)) { /* left cut-off circle */
+            const float wx = vx - lcx, wy = vy - lcy, wn = sqrtf(absSq2(wx, wy));
+            const float ux = wx / wn, uy = wy / wn;
+            ln.dx = uy; ln.dy = -ux; ln.px = lcx + radius * invT * ux; ln.py = lcy + radius * invT * uy;
+            L[nl++] = ln;
+            continue;
+        } else if (t > 1.0f && tR < 0.0f) {                                  /* right cut-off circle */
+            const float wx = vx - rcx, wy = vy - rcy, wn = sqrtf(absSq2(wx, wy));
+            const float ux = wx / wn, uy = wy / wn;
+            ln.dx = uy; ln.dy = -ux; ln.px = rcx + radius * invT * ux; ln.py = rcy + radius * invT * uy;
+            L[nl++] = ln;
+            continue;
+        }
+        /* left leg, right leg or cut-off line, whichever is closest to the velocity */
+        const float dCut = (t < 0.0f || t > 1.0f || same) ? INFINITY : absSq2(vx - (lcx + t * cvx), vy - (lcy + t * cvy));
+        const float dLeft = (tL < 0.0f) ? INFINITY : absSq2(vx - (lcx + tL * llx), vy - (lcy + tL * lly));
+        const float dRight = (tR < 0.0f) ? INFINITY : absSq2(vx - (rcx + tR * rlx), vy - (rcy + tR * rly));
+        if (dCut <= dLeft && dCut <= dRight) {            /* cut-off line */
+            ln.dx = -a1->ux; ln.dy = -a1->uy;
+            ln.px = lcx + radius * invT * -ln.dy; ln.py = lcy + radius * invT * ln.dx;
+            L[nl++] = ln;
+        } else if (dLeft <= dRight) {                     /* left leg */
+            if (leftForeign) continue;
+            ln.dx = llx; ln.dy = lly;
+            ln.px = lcx + radius * invT * -ln.dy; ln.py = lcy + radius * invT * ln.dx;
+            L[nl++] = ln;
+        } else {                                          /* right leg */
+            if (rightForeign) continue;
+            ln.dx = -rlx; ln.dy = -rly;
+            ln.px = rcx + radius * invT * -ln.dy; ln.py = rcy + radius * invT * ln.dx;
+            L[nl++] = ln;
+        }
+    }
+    return nl;
+}
+
 /*
  * One RVO2 doStep for one world of `na` agents (Jacobi: every agent reads the old state).
  *   pos, vel, pref [na][2]; radius, maxspeed [na] (radius already includes the +0.01 (+safety)).
  *   out_vel [na][2]; positions are advanced by the caller.
  * lines_out (optional): [na][max_nb] lines for inspection, nlines_out [na].
  */
-void orc_orca_new_velocities(int na, const float* pos, const float* vel, const float* pref, const float* radius,
-                             const float* maxspeed, float neighbor_dist, int max_nb, float time_horizon,
-                             float time_step, float* out_vel, orca_line* lines_out, int* nlines_out)
+/* with static obstacles: verts [nv] orca_vertex records (or nv = 0); lines_out rows hold max_nb + ORCA_MAX_OBST lines,
+ * nobst_out [na] = how many of them are obstacle lines (they come first) */
+void orc_orca_new_velocities_obst(int na, const float* pos, const float* vel, const float* pref, const float* radius,
+                                  const float* maxspeed, float neighbor_dist, int max_nb, float time_horizon,
+                                  float time_horizon_obst, float time_step, const float* verts, int nv, float* out_vel,
+                                  orca_line* lines_out, int* nlines_out, int* nobst_out)
 {
+    const orca_vertex* V = (const orca_vertex*)verts;
     if (max_nb > ORCA_MAX_NEIGHBORS) max_nb = ORCA_MAX_NEIGHBORS;
     for (int a = 0; a < na; ++a) {
+        orca_line L[ORCA_MAX_LINES];
+        int numObst = 0;
+        if (nv > 0) { /* rangeSq = sqr(timeHorizonObst * maxSpeed + radius) */
+            int oi[ORCA_MAX_OBST];
+            const float rng = time_horizon_obst * maxspeed[a] + radius[a];
+            const int no = obstacle_neighbors(V, nv, pos[2 * a], pos[2 * a + 1], rng * rng, oi);
+            numObst = obstacle_lines(V, oi, no, pos[2 * a], pos[2 * a + 1], vel[2 * a], vel[2 * a + 1], radius[a],
+                                     1.0f / time_horizon_obst, L);
+        }
         /* Agent::computeNeighbors + insertAgentNeighbor, brute force in index order */
         float nd[ORCA_MAX_NEIGHBORS]; int ni[ORCA_MAX_NEIGHBORS]; int cnt = 0;
         float rangeSq = neighbor_dist * neighbor_dist;
@@ -146,8 +326,7 @@ void orc_orca_new_velocities(int na, const float* pos, const float* vel, const f
                 }
             }
         }
-        /* Agent::computeNewVelocity, agent lines */
-        orca_line L[ORCA_MAX_NEIGHBORS];
+        /* Agent::computeNewVelocity, agent lines (appended behind the obstacle lines) */
         const float invT = 1.0f / time_horizon;
         const float vx = vel[2 * a], vy = vel[2 * a + 1];
         for (int k = 0; k < cnt; ++k) {
@@ -187,17 +366,28 @@ void orc_orca_new_velocities(int na, const float* pos, const float* vel, const f
                 const float s = R * invDt - wLen;
                 ux = s * uwx; uy = s * uwy;
             }
-            L[k].px = vx + 0.5f * ux; L[k].py = vy + 0.5f * uy; L[k].dx = dx; L[k].dy = dy;
+            L[numObst + k].px = vx + 0.5f * ux; L[numObst + k].py = vy + 0.5f * uy; L[numObst + k].dx = dx; L[numObst + k].dy = dy;
         }
+        const int total = numObst + cnt;
         float rx, ry;
-        const int failed = lp2(L, cnt, maxspeed[a], pref[2 * a], pref[2 * a + 1], 0, &rx, &ry);
-        if (failed < cnt) lp3(L, cnt, failed, maxspeed[a], &rx, &ry);
+        const int failed = lp2(L, total, maxspeed[a], pref[2 * a], pref[2 * a + 1], 0, &rx, &ry);
+        if (failed < total) lp3(L, total, numObst, failed, maxspeed[a], &rx, &ry);
         out_vel[2 * a] = rx; out_vel[2 * a + 1] = ry;
         if (lines_out) {
-            memcpy(lines_out + (size_t)a * max_nb, L, sizeof(orca_line) * cnt);
-            nlines_out[a] = cnt;
+            const int stride = nv > 0 ? max_nb + ORCA_MAX_OBST : max_nb;
+            memcpy(lines_out + (size_t)a * stride, L, sizeof(orca_line) * total);
+            nlines_out[a] = total;
+            if (nobst_out) nobst_out[a] = numObst;
         }
     }
+}
+
+void orc_orca_new_velocities(int na, const float* pos, const float* vel, const float* pref, const float* radius,
+                             const float* maxspeed, float neighbor_dist, int max_nb, float time_horizon,
+                             float time_step, float* out_vel, orca_line* lines_out, int* nlines_out)
+{
+    orc_orca_new_velocities_obst(na, pos, vel, pref, radius, maxspeed, neighbor_dist, max_nb, time_horizon, 5.0f, time_step,
+                                 NULL, 0, out_vel, lines_out, nlines_out, NULL);
 }
 
 /*
@@ -209,15 +399,15 @@ void orc_orca_new_velocities(int na, const float* pos, const float* vel, const f
  * overwritten AFTER doStep (motion_model_manager.py:389), so humans see the robot one substep late.
  * margin[rows]: what is added to the radius (0.01 or 0.01 + safety_space).
  */
-void orc_orca_step_block(float* S, float* goals, int G, int rows, int robot_visible, const float* margin,
-                         float* robot, const float* action, float dt, int n_substeps, float neighbor_dist,
-                         int max_nb, float time_horizon, int respawn, float bound_x, float bound_y)
+void orc_orca_step_block_obst(float* S, float* goals, int G, int rows, int robot_visible, const float* margin,
+                              float* robot, const float* action, float dt, int n_substeps, float neighbor_dist,
+                              int max_nb, float time_horizon, int respawn, float bound_x, float bound_y,
+                              float time_horizon_obst, const float* verts, int nv)
 {
     const int n = rows - (robot_visible ? 1 : 0);
     float* pos = (float*)malloc(sizeof(float) * rows * 9);
-    float *vel = pos + 2 * rows, *pref = vel + 2 * rows, *rad = pref + 2 * rows, *vmax = rad + rows, *nv = vmax + rows;
+    float *vel = pos + 2 * rows, *pref = vel + 2 * rows, *rad = pref + 2 * rows, *vmax = rad + rows;
     float* nvv = (float*)malloc(sizeof(float) * rows * 2);
-    (void)nv;
     for (int s = 0; s < n_substeps; ++s) {
         if (robot && action) { robot[0] += action[0] * dt; robot[1] += action[1] * dt; robot[3] = action[0]; robot[4] = action[1]; }
         for (int i = 0; i < rows; ++i) {
@@ -225,7 +415,8 @@ void orc_orca_step_block(float* S, float* goals, int G, int rows, int robot_visi
             pos[2 * i] = r[0]; pos[2 * i + 1] = r[1]; vel[2 * i] = r[3]; vel[2 * i + 1] = r[4];
             pref[2 * i] = r[5]; pref[2 * i + 1] = r[6]; rad[i] = r[8] + margin[i]; vmax[i] = r[12];
         }
-        orc_orca_new_velocities(rows, pos, vel, pref, rad, vmax, neighbor_dist, max_nb, time_horizon, dt, nvv, NULL, NULL);
+        orc_orca_new_velocities_obst(rows, pos, vel, pref, rad, vmax, neighbor_dist, max_nb, time_horizon, time_horizon_obst, dt,
+                                     verts, nv, nvv, NULL, NULL, NULL);
         for (int i = 0; i < n; ++i) {
             float* r = S + 13 * i;
             float* gi = goals + (size_t)i * G * 2;
@@ -280,10 +471,18 @@ void orc_orca_step_block(float* S, float* goals, int G, int rows, int robot_visi
     free(nvv);
 }
 
-void orc_orca_step_block_batched(int W, float* S, float* goals, int G, int rows, int robot_visible,
-                                 const float* margin, float* robot, const float* action, float dt, int n_substeps,
-                                 float neighbor_dist, int max_nb, float time_horizon, int respawn, float bound_x,
-                                 float bound_y, int threads)
+void orc_orca_step_block(float* S, float* goals, int G, int rows, int robot_visible, const float* margin,
+                         float* robot, const float* action, float dt, int n_substeps, float neighbor_dist,
+                         int max_nb, float time_horizon, int respawn, float bound_x, float bound_y)
+{
+    orc_orca_step_block_obst(S, goals, G, rows, robot_visible, margin, robot, action, dt, n_substeps, neighbor_dist, max_nb,
+                             time_horizon, respawn, bound_x, bound_y, 5.0f, NULL, 0);
+}
+
+void orc_orca_step_block_batched_obst(int W, float* S, float* goals, int G, int rows, int robot_visible,
+                                      const float* margin, float* robot, const float* action, float dt, int n_substeps,
+                                      float neighbor_dist, int max_nb, float time_horizon, int respawn, float bound_x,
+                                      float bound_y, int threads, float time_horizon_obst, const float* verts, int nv)
 {
     const int n = rows - (robot_visible ? 1 : 0);
 #ifdef _OPENMP
@@ -291,8 +490,17 @@ void orc_orca_step_block_batched(int W, float* S, float* goals, int G, int rows,
 #pragma omp parallel for schedule(static)
 #endif
     for (int w = 0; w < W; ++w)
-        orc_orca_step_block(S + (size_t)w * rows * 13, goals + (size_t)w * n * G * 2, G, rows, robot_visible,
-                            margin + (size_t)w * rows, robot ? robot + (size_t)w * 13 : NULL,
-                            action ? action + (size_t)w * 2 : NULL, dt, n_substeps, neighbor_dist, max_nb,
-                            time_horizon, respawn, bound_x, bound_y);
+        orc_orca_step_block_obst(S + (size_t)w * rows * 13, goals + (size_t)w * n * G * 2, G, rows, robot_visible,
+                                 margin + (size_t)w * rows, robot ? robot + (size_t)w * 13 : NULL,
+                                 action ? action + (size_t)w * 2 : NULL, dt, n_substeps, neighbor_dist, max_nb,
+                                 time_horizon, respawn, bound_x, bound_y, time_horizon_obst, verts, nv);
+}
+
+void orc_orca_step_block_batched(int W, float* S, float* goals, int G, int rows, int robot_visible,
+                                 const float* margin, float* robot, const float* action, float dt, int n_substeps,
+                                 float neighbor_dist, int max_nb, float time_horizon, int respawn, float bound_x,
+                                 float bound_y, int threads)
+{
+    orc_orca_step_block_batched_obst(W, S, goals, G, rows, robot_visible, margin, robot, action, dt, n_substeps, neighbor_dist,
+                                     max_nb, time_horizon, respawn, bound_x, bound_y, threads, 5.0f, NULL, 0);
 }

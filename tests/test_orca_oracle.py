@@ -138,3 +138,123 @@ def test_step_block_goal_rotation_pref_velocity_and_robot_lag():
     S3, g3, _ = orc.orca_step_block(S2, g2, [0.01], 0.25, 2)           # reaches |g - p| < r -> rotate
     assert np.allclose(g3[0, 0], [-3.0, 0.0]) and np.allclose(g3[0, 1], [0.5, 0.0])
     assert abs(np.linalg.norm(S3[0, 5:7]) - 1.0) < 1e-6                # far goal: unit preferred velocity
+
+
+# ------------------------------------------------------------------ static obstacles
+def test_obstacle_preprocessing_known_answers():
+    sq = orc.process_obstacle([[0, 0], [2, 0], [2, 2], [0, 2]])                 # counter-clockwise square
+    assert sq[:, 4].tolist() == [1, 1, 1, 1]
+    np.testing.assert_allclose(sq[:, 2:4], [[1, 0], [0, 1], [-1, 0], [0, -1]], atol=1e-7)
+    assert sq[:, 5].tolist() == [1, 2, 3, 0] and sq[:, 6].tolist() == [3, 0, 1, 2]
+    ell = orc.process_obstacle([[0, 0], [2, 0], [2, 1], [1, 1], [1, 2], [0, 2]])  # L shape: one reflex vertex (1, 1)
+    assert ell[:, 4].tolist() == [1, 1, 1, 0, 1, 1]
+    two = orc.process_obstacles([[[0, 0], [1, 0], [0, 1]], [[5, 5], [6, 5], [6, 6], [5, 6]]])
+    assert two[:, 5].tolist() == [1, 2, 0, 4, 5, 6, 3] and two[3:, 6].tolist() == [6, 3, 4, 5]
+    line = orc.process_obstacle([[3, 0], [-3, 0]])                                # two vertices: always convex
+    assert line[:, 4].tolist() == [1, 1]
+
+
+def test_agent_walking_into_a_wall_is_slowed_to_the_cutoff_speed():
+    """Wall along the x axis, agent above it heading straight down: the cut-off line of the wall's velocity obstacle
+    gives v_y >= -(d - r) / timeHorizonObst, so the new velocity is exactly that (its preferred speed is larger)."""
+    wall = orc.process_obstacle([[6, 0], [-6, 0]])     # the edge (6,0) -> (-6,0) has the agent on its right
+    d, r, tau = 2.0, 0.31, 5.0
+    v, lines, nl, no = orc.orca_new_velocities_obst([[0.3, d]], [[0, -1]], [[0, -1]], [r], [1.0], wall, time_horizon_obst=tau)
+    assert no[0] == 1 and nl[0] == 1
+    np.testing.assert_allclose(lines[0, 0], [0.3 * 0 + (6 - 0.3) / tau, (r - d) / tau, 1.0, 0.0], atol=1e-6)
+    np.testing.assert_allclose(v[0], [0.0, -(d - r) / tau], atol=1e-6)
+    # far from the wall (beyond timeHorizonObst * maxSpeed + radius) it is not even a neighbour
+    v, _, nl, no = orc.orca_new_velocities_obst([[0.0, 6.0]], [[0, -1]], [[0, -1]], [r], [1.0], wall, time_horizon_obst=tau)
+    assert no[0] == 0 and np.allclose(v[0], [0, -1])
+    # on the other side of the directed edge the wall does not exist for the agent (RVO2: polygons are one-sided)
+    v, _, nl, no = orc.orca_new_velocities_obst([[0.0, -2.0]], [[0, 1]], [[0, 1]], [r], [1.0], wall[:1], time_horizon_obst=tau)
+    assert np.allclose(v[0], [0, 1])
+    # touching the wall: the line through the origin along -unitDir, only sliding (or leaving) is allowed
+    v, lines, nl, no = orc.orca_new_velocities_obst([[0.0, 0.25]], [[0.5, -0.5]], [[0.5, -0.5]], [r], [1.0], wall)
+    np.testing.assert_allclose(lines[0, 0], [0, 0, 1, 0], atol=1e-7)
+    np.testing.assert_allclose(v[0], [0.5, 0.0], atol=1e-6)
+
+
+def _polys(rng):
+    out = []
+    for k in range(int(rng.integers(1, 4))):
+        c = rng.uniform(-3, 3, 2)
+        nv = int(rng.integers(3, 6))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, nv))
+        if np.min(np.diff(np.append(ang, ang[0] + 2 * np.pi))) < 0.5:
+            ang = np.linspace(0, 2 * np.pi, nv, endpoint=False) + rng.uniform(0, 1)
+        rad = rng.uniform(0.4, 1.0, nv)
+        out.append([[float(c[0] + rad[i] * np.cos(ang[i])), float(c[1] + rad[i] * np.sin(ang[i]))] for i in range(nv)])  # CCW
+    return out
+
+
+def _inside_or_near(p, poly, margin):
+    poly = np.array(poly)
+    n = len(poly)
+    inside = all((poly[(i + 1) % n][0] - poly[i][0]) * (p[1] - poly[i][1]) - (poly[(i + 1) % n][1] - poly[i][1]) * (p[0] - poly[i][0]) >= 0
+                 for i in range(n))
+    if inside:
+        return True
+    for i in range(n):
+        a, b = poly[i], poly[(i + 1) % n]
+        t = np.clip(np.dot(p - a, b - a) / np.dot(b - a, b - a), 0, 1)
+        if np.linalg.norm(p - (a + t * (b - a))) < margin:
+            return True
+    return False
+
+
+def test_obstacle_lines_are_hard_constraints_and_the_lp_matches_brute_force():
+    """Random agents among random convex-ish polygons: every obstacle line is satisfied by the returned velocity (they are
+    hard constraints of linearProgram3 too), and where the whole programme is feasible the velocity is the unique closest
+    point to the preferred velocity (brute-force f64 vertex enumeration over obstacle + agent lines)."""
+    rng = np.random.default_rng(11)
+    with_obst = feasible = checked = 0
+    for trial in range(250):
+        polys = _polys(rng)
+        verts = orc.process_obstacles(polys)
+        na = int(rng.integers(1, 9))
+        pos = []
+        while len(pos) < na:
+            p = rng.uniform(-4, 4, 2)
+            if all(np.linalg.norm(p - q) > 0.7 for q in pos) and not any(_inside_or_near(p, poly, 0.36) for poly in polys):
+                pos.append(p)
+        pos = np.array(pos)
+        vel = rng.normal(0, 0.5, (na, 2))
+        pref = rng.normal(0, 0.8, (na, 2))
+        v, lines, nl, no = orc.orca_new_velocities_obst(pos, vel, pref, np.full(na, 0.31), np.ones(na), verts, time_step=0.0125)
+        assert np.all(np.linalg.norm(v, axis=1) <= 1.0 + 1e-5)
+        for a in range(na):
+            L = lines[a, :nl[a]].astype(float)
+            with_obst += no[a] > 0
+            ref = _brute_force(L, 1.0, pref[a])
+            checked += 1
+            if ref is not None:
+                feasible += 1
+                assert np.linalg.norm(v[a] - ref) < 3e-4, (trial, a, v[a], ref)
+            obst_feasible = _brute_force(L[:no[a]], 1.0, pref[a]) is not None
+            if obst_feasible:   # the obstacle half-planes alone admit a velocity: none of them may be violated
+                for px, py, dx, dy in L[:no[a]]:
+                    assert dx * (py - v[a, 1]) - dy * (px - v[a, 0]) <= 2e-4, (trial, a)
+    assert with_obst > 200 and feasible > 0.8 * checked
+
+
+def test_agent_does_not_cross_a_wall_over_many_steps():
+    """An agent whose goal lies straight behind a box walks up to it and stops / slides along it (ORCA is local: it does
+    not plan around): it never comes closer to the polygon than its radius (minus float slack), in 120 steps."""
+    verts = orc.process_obstacles([[[-1, -0.5], [1, -0.5], [1, 0.5], [-1, 0.5]]])
+    for x0 in (0.2, 0.9, 1.25):
+        S = np.zeros((1, 1, 13), np.float32)
+        S[0, 0, 0:2] = [x0, 3.0]; S[0, 0, 8] = 0.3; S[0, 0, 12] = 1.0
+        goals = np.array([[[[x0 + 0.1, -3.0]]]], np.float32)
+        S[0, 0, 10:12] = goals[0, 0, 0]; S[0, 0, 5:7] = [0.0, -1.0]
+        closest = 1e9
+        for k in range(120):
+            S, goals, _ = orc.orca_step_block(S, goals, [[0.01]], 0.1, 1, verts=verts)
+            p = S[0, 0, 0:2].astype(float)
+            d = math.hypot(max(abs(p[0]) - 1.0, 0.0), max(abs(p[1]) - 0.5, 0.0))    # distance to the box
+            assert d > 0.31 - 5e-3, (x0, k, p, d)
+            closest = min(closest, d)
+        if x0 < 0.5:   # head-on: v_n = -(d - r) / tau per step -> the gap decays geometrically, d_k - r = (d_0 - r)(1 - dt/tau)^k
+            np.testing.assert_allclose(closest, 0.31 + (2.5 - 0.31) * (1 - 0.1 / 5.0) ** 120, rtol=5e-3)
+        if x0 > 1.2:   # the path beside the box is free: it gets past
+            assert S[0, 0, 1] < -1.0
