@@ -91,6 +91,11 @@ typedef struct cs_worlds {
     int32_t orca_max_neighbors;
     /* social momentum only (type == CS_SOCIAL_MOMENTUM): n_actions of motion_model_manager.py:249 (0 = 20) */
     int32_t sm_n_actions;
+    /* ORCA only: static obstacles as RVO2 keeps them after addObstacle / processObstacles (motion_model_manager.py:244-246):
+     * [orca_n_vertices][8] records  point.x, point.y, unitDir.x, unitDir.y, isConvex, next, prev, 0  (polygon vertices in
+     * the order given, counter-clockwise; next / prev = vertex indices), shared by all worlds.  NULL / 0 = no obstacles. */
+    const float* d_orca_vertices;
+    int32_t orca_n_vertices;
 } cs_worlds;
 
 /* ---------------------------------------------------------------- runtime / memory helpers */

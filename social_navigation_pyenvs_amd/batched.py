@@ -46,7 +46,7 @@ class CrowdWorlds:
 
     def __init__(self, states, goals, params, safety=None, obstacles=None, *, type, all_params_equal=False,
                  robot_row=False, robot=None, respawn_bounds=None, respawn_worlds=None, layout="aos", device=None,
-                 stream=None):
+                 stream=None, orca_vertices=None):
         _lib.require_gpu()
         if device is not None:
             _lib.set_device(device)
@@ -113,6 +113,13 @@ class CrowdWorlds:
             self.d_world_flags = DeviceBuffer.from_numpy(wf, dtype=np.int32)
         self.unicycle = False
         self._scratch = {}  # persistent device scratch (no hipMalloc in the stepping loop)
+        # ORCA static obstacles: RVO2 vertex records [Nv][8] (rvo2.process_obstacles), shared by all worlds
+        self.d_orca_vertices, self.orca_n_vertices = None, 0
+        if orca_vertices is not None and len(orca_vertices):
+            if not self.orca:
+                raise ValueError("orca_vertices only apply to ORCA worlds (SFM / HSFM worlds take `obstacles` segments)")
+            ov = np.ascontiguousarray(orca_vertices, dtype=np.float32).reshape(-1, 8)
+            self.d_orca_vertices, self.orca_n_vertices = DeviceBuffer.from_numpy(ov), len(ov)
 
     # ------------------------------------------------------------------ descriptor
     def _flags(self, respawn=None) -> int:
@@ -151,6 +158,8 @@ class CrowdWorlds:
         d.orca_time_horizon = float(self.orca_params["time_horizon"])
         d.orca_time_horizon_obst = float(self.orca_params["time_horizon_obst"])
         d.sm_n_actions = int(self.sm_n_actions)
+        d.d_orca_vertices = _ptr(self.d_orca_vertices)
+        d.orca_n_vertices = int(self.orca_n_vertices)
         return d
 
     # ------------------------------------------------------------------ hot path

@@ -6,6 +6,9 @@
 // build image): it is restated here from the published algorithm -- Agent::computeNeighbors (brute force
 // in index order instead of the kd-tree; same neighbour set), computeNewVelocity (ORCA half-planes),
 // linearProgram1/2/3, update -- in float32 like RVO2.  PARITY UNPINNED (see oracle/orca_oracle.c).
+// Static obstacles: addObstacle's vertex records come in cs_worlds.d_orca_vertices; the obstacle
+// neighbours (brute force over the edges), the obstacle ORCA lines and linearProgram3 with hard obstacle lines run on the
+// generic LDS-column path below.
 //
 // Mapping: lane = agent row, floor(64/rows) worlds per wavefront, the rows' (x, y, vx, vy, radius) in LDS,
 // every lane's neighbour list / ORCA lines / LP3 projection lines in per-lane LDS columns (the 2-D
@@ -40,6 +43,7 @@ using csimpl::fail;
 
 constexpr float RVO_EPSILON = 0.00001f;
 constexpr int KMAX = 16; // max_neighbors supported (ORCA_DEFAULTS uses 10)
+constexpr int KOBST = 16; // obstacle edges kept per agent (the nearest ones), static-obstacle worlds only
 
 struct OArgs {
     int W, n, rows, G, flags, nsub, wpb, K;
@@ -52,6 +56,11 @@ struct OArgs {
     float* peek_out;
     const int* world_flags;
     unsigned long long* stamps;
+    // static obstacles: [nv][8] vertex records px, py, unitDir.x, unitDir.y, isConvex, next, prev, 0
+    // (RVOSimulator::addObstacle), shared by all worlds; KO = obstacle lines kept per agent
+    const float* verts;
+    int nv, KO;
+    float time_horizon_obst;
 };
 
 __device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
@@ -117,15 +126,16 @@ __device__ int lp2(const Lines& L, int nl, float radius, float ox, float oy, boo
     return nl;
 }
 
-// RVO2 linearProgram3 (no obstacle lines)
-__device__ void lp3(const Lines& L, const Lines& P, int nl, int begin, float radius, float& rx, float& ry)
+// RVO2 linearProgram3: the first numObst lines (static obstacles) are hard constraints, copied unprojected
+__device__ void lp3(const Lines& L, const Lines& P, int nl, int numObst, int begin, float radius, float& rx, float& ry)
 {
     float distance = 0.0f;
     for (int i = begin; i < nl; ++i) {
         const float4 li = L.get(i);
         if (det2(li.z, li.w, li.x - rx, li.y - ry) > distance) {
             int np = 0;
-            for (int j = 0; j < i; ++j) {
+            for (int j = 0; j < numObst; ++j) P.set(np++, L.get(j));
+            for (int j = numObst; j < i; ++j) {
                 const float4 lj = L.get(j);
                 float4 ln;
                 const float d = det2(li.z, li.w, lj.z, lj.w);
@@ -146,6 +156,150 @@ __device__ void lp3(const Lines& L, const Lines& P, int nl, int begin, float rad
             distance = det2(li.z, li.w, li.x - rx, li.y - ry);
         }
     }
+}
+
+
+// ---- static obstacles: RVO2 Agent::computeNeighbors (obstacle part), insertObstacleNeighbor and the "Create obstacle
+// ORCA lines" block of Agent::computeNewVelocity, op for op as oracle/orca_oracle.c restates them ------------------------
+struct Vtx { float px, py, ux, uy, convex; int next, prev; };
+__device__ __forceinline__ Vtx load_vtx(const float* V, int i)
+{
+    const float4 a = *reinterpret_cast<const float4*>(V + (long)i * 8);
+    const float4 b = *reinterpret_cast<const float4*>(V + (long)i * 8 + 4);
+    return Vtx{a.x, a.y, a.z, a.w, b.x, (int)b.y, (int)b.z};
+}
+__device__ __forceinline__ float absSq2(float x, float y) { return x * x + y * y; }
+__device__ __forceinline__ float dist_sq_point_segment(float ax, float ay, float bx, float by, float cx, float cy)
+{
+    const float r = ((cx - ax) * (bx - ax) + (cy - ay) * (by - ay)) / absSq2(bx - ax, by - ay);
+    if (r < 0.0f) return absSq2(cx - ax, cy - ay);
+    if (r > 1.0f) return absSq2(cx - bx, cy - by);
+    return absSq2(cx - (ax + r * (bx - ax)), cy - (ay + r * (by - ay)));
+}
+
+// nearest obstacle edges the agent is on the right of, sorted by distance, in the per-lane LDS columns od / oi
+__device__ int obstacle_neighbors(const float* V, int nv, int KO, float px, float py, float rangeSq, float* od, int* oi, int T, int tid)
+{
+    int cnt = 0;
+    for (int v = 0; v < nv; ++v) {
+        const Vtx o1 = load_vtx(V, v);
+        const Vtx o2 = load_vtx(V, o1.next);
+        const float agentLeftOfLine = det2(o1.px - px, o1.py - py, o2.px - o1.px, o2.py - o1.py);
+        const float distSqLine = agentLeftOfLine * agentLeftOfLine / absSq2(o2.px - o1.px, o2.py - o1.py);
+        if (distSqLine < rangeSq && agentLeftOfLine < 0.0f) {
+            const float distSq = dist_sq_point_segment(o1.px, o1.py, o2.px, o2.py, px, py);
+            if (distSq < rangeSq) {
+                int i;
+                if (cnt < KO) i = cnt++;
+                else if (distSq < od[(KO - 1) * T + tid]) i = KO - 1; // full: the farthest edge drops out
+                else continue;
+                while (i != 0 && distSq < od[(i - 1) * T + tid]) {
+                    od[i * T + tid] = od[(i - 1) * T + tid];
+                    oi[i * T + tid] = oi[(i - 1) * T + tid];
+                    --i;
+                }
+                od[i * T + tid] = distSq;
+                oi[i * T + tid] = v;
+            }
+        }
+    }
+    return cnt;
+}
+
+__device__ int obstacle_lines(const float* V, const int* oi, int no, int T, int tid, float px, float py, float vx, float vy,
+                              float radius, float invT, const Lines& L)
+{
+    int nl = 0;
+    for (int k = 0; k < no; ++k) {
+        const Vtx o1 = load_vtx(V, oi[k * T + tid]);
+        const Vtx o2 = load_vtx(V, o1.next);
+        const float r1x = o1.px - px, r1y = o1.py - py, r2x = o2.px - px, r2y = o2.py - py;
+        bool covered = false;
+        for (int j = 0; j < nl; ++j) {
+            const float4 lj = L.get(j);
+            if (det2(invT * r1x - lj.x, invT * r1y - lj.y, lj.z, lj.w) - invT * radius >= -RVO_EPSILON &&
+                det2(invT * r2x - lj.x, invT * r2y - lj.y, lj.z, lj.w) - invT * radius >= -RVO_EPSILON) {
+                covered = true;
+                break;
+            }
+        }
+        if (covered) continue;
+        const float distSq1 = absSq2(r1x, r1y), distSq2 = absSq2(r2x, r2y), radiusSq = radius * radius;
+        const float ovx = o2.px - o1.px, ovy = o2.py - o1.py;
+        const float s = (-r1x * ovx + -r1y * ovy) / absSq2(ovx, ovy);
+        const float distSqLine = absSq2(-r1x - s * ovx, -r1y - s * ovy);
+        if (s < 0.0f && distSq1 <= radiusSq) {            // collision with left vertex; ignore if non-convex
+            if (o1.convex != 0.0f) {
+                const float n = sqrtf(absSq2(-r1y, r1x));
+                L.set(nl++, make_float4(0.0f, 0.0f, -r1y / n, r1x / n));
+            }
+            continue;
+        } else if (s > 1.0f && distSq2 <= radiusSq) {     // collision with right vertex
+            if (o2.convex != 0.0f && det2(r2x, r2y, o2.ux, o2.uy) >= 0.0f) {
+                const float n = sqrtf(absSq2(-r2y, r2x));
+                L.set(nl++, make_float4(0.0f, 0.0f, -r2y / n, r2x / n));
+            }
+            continue;
+        } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) { // collision with the segment
+            L.set(nl++, make_float4(0.0f, 0.0f, -o1.ux, -o1.uy));
+            continue;
+        }
+        float llx, lly, rlx, rly;
+        Vtx a1 = o1, a2 = o2;
+        bool same = false;
+        if (s < 0.0f && distSqLine <= radiusSq) {         // obliquely viewed: the left vertex defines the velocity obstacle
+            if (o1.convex == 0.0f) continue;
+            a2 = o1; same = true;
+            const float leg1 = sqrtf(distSq1 - radiusSq);
+            llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
+            rlx = (r1x * leg1 + r1y * radius) / distSq1; rly = (-r1x * radius + r1y * leg1) / distSq1;
+        } else if (s > 1.0f && distSqLine <= radiusSq) {  // the right vertex defines it
+            if (o2.convex == 0.0f) continue;
+            a1 = o2; same = true;
+            const float leg2 = sqrtf(distSq2 - radiusSq);
+            llx = (r2x * leg2 - r2y * radius) / distSq2; lly = (r2x * radius + r2y * leg2) / distSq2;
+            rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+        } else {                                          // usual situation
+            if (o1.convex != 0.0f) {
+                const float leg1 = sqrtf(distSq1 - radiusSq);
+                llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
+            } else { llx = -o1.ux; lly = -o1.uy; }
+            if (o2.convex != 0.0f) {
+                const float leg2 = sqrtf(distSq2 - radiusSq);
+                rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+            } else { rlx = o1.ux; rly = o1.uy; }
+        }
+        const Vtx leftNb = load_vtx(V, a1.prev);
+        bool leftForeign = false, rightForeign = false;
+        if (a1.convex != 0.0f && det2(llx, lly, -leftNb.ux, -leftNb.uy) >= 0.0f) { llx = -leftNb.ux; lly = -leftNb.uy; leftForeign = true; }
+        if (a2.convex != 0.0f && det2(rlx, rly, a2.ux, a2.uy) <= 0.0f) { rlx = a2.ux; rly = a2.uy; rightForeign = true; }
+        const float lcx = invT * (a1.px - px), lcy = invT * (a1.py - py);
+        const float rcx = invT * (a2.px - px), rcy = invT * (a2.py - py);
+        const float cvx = rcx - lcx, cvy = rcy - lcy;
+        const float t = same ? 0.5f : ((vx - lcx) * cvx + (vy - lcy) * cvy) / absSq2(cvx, cvy);
+        const float tL = (vx - lcx) * llx + (vy - lcy) * lly;
+        const float tR = (vx - rcx) * rlx + (vy - rcy) * rly;
+        if ((t < 0.0f && tL < 0.0f) || (same && tL < 0.0f && tR < 0.0f)) { // left cut-off circle
+            const float wx = vx - lcx, wy = vy - lcy, wn = sqrtf(absSq2(wx, wy));
+            const float ux = wx / wn, uy = wy / wn;
+            L.set(nl++, make_float4(lcx + radius * invT * ux, lcy + radius * invT * uy, uy, -ux));
+            continue;
+        } else if (t > 1.0f && tR < 0.0f) {                                  // right cut-off circle
+            const float wx = vx - rcx, wy = vy - rcy, wn = sqrtf(absSq2(wx, wy));
+            const float ux = wx / wn, uy = wy / wn;
+            L.set(nl++, make_float4(rcx + radius * invT * ux, rcy + radius * invT * uy, uy, -ux));
+            continue;
+        }
+        const float dCut = (t < 0.0f || t > 1.0f || same) ? INFINITY : absSq2(vx - (lcx + t * cvx), vy - (lcy + t * cvy));
+        const float dLeft = (tL < 0.0f) ? INFINITY : absSq2(vx - (lcx + tL * llx), vy - (lcy + tL * lly));
+        const float dRight = (tR < 0.0f) ? INFINITY : absSq2(vx - (rcx + tR * rlx), vy - (rcy + tR * rly));
+        float dx, dy, bx, by;
+        if (dCut <= dLeft && dCut <= dRight) { dx = -a1.ux; dy = -a1.uy; bx = lcx; by = lcy; }            // cut-off line
+        else if (dLeft <= dRight) { if (leftForeign) continue; dx = llx; dy = lly; bx = lcx; by = lcy; }   // left leg
+        else { if (rightForeign) continue; dx = -rlx; dy = -rly; bx = rcx; by = rcy; }                     // right leg
+        L.set(nl++, make_float4(bx + radius * invT * -dy, by + radius * invT * dx, dx, dy));
+    }
+    return nl;
 }
 
 // One ORCA half-plane (RVO2 Agent::computeNewVelocity, agent part): q = (x, y, vx, vy) of the neighbour,
@@ -280,7 +434,7 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
     if (__builtin_amdgcn_ballot_w64(failed < cnt) != 0) { // some lane's programme is infeasible: linearProgram3
 #pragma unroll
         for (int k = 0; k < KF; ++k) L.set(k, Lr[k]);
-        if (failed < cnt) lp3(L, P, cnt, failed, vmax, rx, ry);
+        if (failed < cnt) lp3(L, P, cnt, 0, failed, vmax, rx, ry);
     }
     OSTAMP(4);
     nvx = rx; nvy = ry;
@@ -292,15 +446,18 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int T = blockDim.x;
     const int K = a.K;
+    const int KL = a.K + a.KO;                                       // lines per agent: obstacle lines first, then agents
     float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [2][T] x, y, vx, vy
-    float4* lds_L = lds_pv + 2 * T;                                  // [K][T] ORCA lines
-    float4* lds_P = lds_L + K * T;                                   // [K][T] LP3 projection lines
-    float* lds_r = reinterpret_cast<float*>(lds_P + K * T);          // [T] radius + margin
+    float4* lds_L = lds_pv + 2 * T;                                  // [KL][T] ORCA lines
+    float4* lds_P = lds_L + KL * T;                                  // [KL][T] LP3 projection lines
+    float* lds_r = reinterpret_cast<float*>(lds_P + KL * T);         // [T] radius + margin
     float* lds_nd = lds_r + T;                                       // [K][T] neighbour distSq
     int* lds_ni = reinterpret_cast<int*>(lds_nd + K * T);            // [K][T] neighbour row
     float* lds_rp = reinterpret_cast<float*>(lds_ni + K * T);        // [T] plain radius (respawn rule)
     float* lds_g0x = lds_rp + T;                                     // [T] respawn scratch
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);             // [T] respawn scratch
+    float* lds_od = reinterpret_cast<float*>(lds_flag + T);          // [KO][T] obstacle edge distSq
+    int* lds_oi = reinterpret_cast<int*>(lds_od + a.KO * T);         // [KO][T] obstacle edge (first vertex)
 
     const int tid = threadIdx.x;
     const int rows = a.rows, n = a.n;
@@ -386,14 +543,21 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
                         }
                     }
                 }
-                // ---- Agent::computeNewVelocity: one ORCA half-plane per neighbour
+                // ---- Agent::computeNewVelocity: obstacle half-planes first (static-obstacle worlds), then one per neighbour
+                int nobst = 0;
+                if (a.nv > 0) {
+                    const float rng = a.time_horizon_obst * vmax + (r + margin);   // rangeSq = sqr(timeHorizonObst * maxSpeed + radius)
+                    const int no = obstacle_neighbors(a.verts, a.nv, a.KO, px, py, rng * rng, lds_od, lds_oi, T, tid);
+                    nobst = obstacle_lines(a.verts, lds_oi, no, T, tid, px, py, vx, vy, r + margin, 1.0f / a.time_horizon_obst, L);
+                }
                 const float invT = 1.0f / a.time_horizon;
                 for (int k = 0; k < cnt; ++k) {
                     const int b = lds_ni[k * T + tid];
-                    L.set(k, orca_line(px, py, vx, vy, pv[b], (r + margin) + rr[b], invT, dt));
+                    L.set(nobst + k, orca_line(px, py, vx, vy, pv[b], (r + margin) + rr[b], invT, dt));
                 }
-                const int failed = lp2(L, cnt, vmax, pvx, pvy, false, nvx, nvy);
-                if (failed < cnt) lp3(L, P, cnt, failed, vmax, nvx, nvy);
+                const int total = nobst + cnt;
+                const int failed = lp2(L, total, vmax, pvx, pvy, false, nvx, nvy);
+                if (failed < total) lp3(L, P, total, nobst, failed, vmax, nvx, nvy);
             }
             // ---- Agent::update, then the reference's read-back + update_goals_orca (:390-394, :125-133)
             vx = nvx; vy = nvy;
@@ -484,7 +648,10 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
     if (w->W <= 0 || w->n <= 0 || w->G <= 0) return fail(CS_ERR_ARG, "W, n, G must be positive");
     if (!w->d_state || !w->d_goals || !w->d_safety) return fail(CS_ERR_ARG, "null device buffer in cs_worlds");
-    if (w->O != 0) return fail(CS_ERR_ARG, "ORCA static obstacles are not implemented (no Gym scenario has walls)");
+    if (w->O != 0) return fail(CS_ERR_ARG, "ORCA worlds take their static obstacles as RVO2 vertex records "
+                                              "(cs_worlds.d_orca_vertices), not as the SFM segment array");
+    if (w->orca_n_vertices < 0 || (w->orca_n_vertices > 0 && !w->d_orca_vertices)) return fail(CS_ERR_ARG, "bad ORCA obstacle vertices");
+    if (w->orca_n_vertices > 0 && !(w->orca_time_horizon_obst > 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
     if (w->flags & CS_ROBOT_UNICYCLE) return fail(CS_ERR_ARG, "ORCA step supports holonomic robot actions only");
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     if (rows > 64) return fail(CS_ERR_ARG, "ORCA step supports up to 64 rows per world");
@@ -500,6 +667,8 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * rows; }
     a.goals = w->d_goals; a.margin = w->d_safety; a.robot = w->d_robot; a.action = d_action;
     a.peek_out = d_peek; a.world_flags = w->d_world_flags;
+    a.verts = w->d_orca_vertices; a.nv = w->orca_n_vertices; a.time_horizon_obst = w->orca_time_horizon_obst;
+    a.KO = a.nv > 0 ? (a.nv < KOBST ? a.nv : KOBST) : 0;
 #ifdef CS_STAMPS
     a.stamps = g_stamp_buf;
 #endif
@@ -507,8 +676,11 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     const int T = 64;
     const int grid = (w->W + a.wpb - 1) / a.wpb;
     const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
-                         (size_t)a.K * T * (2 * sizeof(float4) + 2 * sizeof(float));
-    if (a.K == 10) hipLaunchKernelGGL(k_orca_step<true>, dim3(grid), dim3(T), shmem, stream, a);
+                         (size_t)(a.K + a.KO) * T * 2 * sizeof(float4) + (size_t)(a.K + a.KO) * T * 2 * sizeof(float);
+    const bool fast10 = a.K == 10 && a.nv == 0; // the register-resident solve has no obstacle lines
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_orca_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    if (fast10) hipLaunchKernelGGL(k_orca_step<true>, dim3(grid), dim3(T), shmem, stream, a);
     else hipLaunchKernelGGL(k_orca_step<false>, dim3(grid), dim3(T), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;

@@ -13,9 +13,11 @@ restated in csrc/orca.hip; parity with the third-party library itself is unpinne
 
 Supported: any number of agents up to 64, per-agent radius / maxSpeed / position / velocity / preferred velocity;
 ``neighborDist``, ``maxNeighbors``, ``timeHorizon`` must be the same for every agent (the reference never varies
-them: ORCA_DEFAULTS, motion_model_manager.py:14).  Static obstacles are not implemented: ``addObstacle`` raises
-(every Gym scenario has ``walls == []``); ``processObstacles()`` with no obstacle is a no-op, as the reference calls it
-unconditionally (:246).
+them: ORCA_DEFAULTS, motion_model_manager.py:14).  Static obstacles: ``addObstacle(vertices)`` (counter-clockwise
+polygons, or two vertices for a one-sided wall) + ``processObstacles()`` build RVO2's vertex records (point, unit direction
+to the next vertex, convexity, links); the kernel restates the obstacle ORCA lines and the hard-constraint form of
+linearProgram3.  The obstacle kd-tree's edge splitting is not modelled and each agent keeps its 16
+nearest edges.
 """
 from __future__ import annotations
 
@@ -24,6 +26,39 @@ import numpy as np
 from .batched import CrowdWorlds
 
 _FAR = 1.0e9  # goal the kernel's own goal / preferred-velocity glue never reaches: the shim owns prefVelocity
+
+
+def process_obstacle(vertices) -> np.ndarray:
+    """RVOSimulator::addObstacle for one polygon: [n, 8] float32 records  point.x, point.y, unitDir.x, unitDir.y, isConvex,
+    next, prev, 0  (polygon-local indices).  unitDir points to the next vertex; a vertex is convex when
+    leftOf(prev, this, next) >= 0; with two vertices both are convex."""
+    v = np.asarray(vertices, dtype=np.float32).reshape(-1, 2)
+    n = len(v)
+    if n < 2:
+        raise ValueError("an obstacle needs at least two vertices")
+    out = np.zeros((n, 8), np.float32)
+    for i in range(n):
+        nxt, prv = (i + 1) % n, (i - 1) % n
+        d = v[nxt] - v[i]
+        u = d / np.float32(np.sqrt(np.float32(d[0] * d[0] + d[1] * d[1])))
+        convex = True
+        if n > 2:
+            a, b, c = v[prv], v[i], v[nxt]
+            convex = np.float32((a[0] - c[0]) * (b[1] - a[1])) - np.float32((a[1] - c[1]) * (b[0] - a[0])) >= 0
+        out[i] = [v[i, 0], v[i, 1], u[0], u[1], 1.0 if convex else 0.0, nxt, prv, 0.0]
+    return out
+
+
+def process_obstacles(polygons) -> np.ndarray:
+    """All polygons of a scene in one vertex table (next / prev become table indices)."""
+    recs, base = [], 0
+    for poly in polygons:
+        r = process_obstacle(poly)
+        r[:, 5] += base
+        r[:, 6] += base
+        base += len(r)
+        recs.append(r)
+    return np.concatenate(recs) if recs else np.zeros((0, 8), np.float32)
 
 
 class PyRVOSimulator:
@@ -35,6 +70,7 @@ class PyRVOSimulator:
         self._pos, self._vel, self._pref, self._radius, self._maxspeed = [], [], [], [], []
         self._time = 0.0
         self._cw = None
+        self._polygons, self._vertices = [], None
 
     # ------------------------------------------------------------------ building the scene
     def setAgentDefaults(self, neighborDist, maxNeighbors, timeHorizon, timeHorizonObst, radius, maxSpeed, velocity=(0, 0)):
@@ -63,11 +99,16 @@ class PyRVOSimulator:
         return len(self._pos) - 1
 
     def addObstacle(self, vertices):
-        raise NotImplementedError("ORCA static obstacles (RVO2 obstacle lines) are not implemented on the MI355X path "
-                                  "(SURVEY.md §8 row f3); no Gym scenario has walls")
+        """Counter-clockwise polygon (or two vertices: a wall seen from its right side).  Returns the number of the
+        obstacle's first vertex, like RVO2."""
+        first = sum(len(p) for p in self._polygons)
+        self._polygons.append([(float(v[0]), float(v[1])) for v in vertices])
+        return first
 
     def processObstacles(self):
-        return None
+        """Builds the vertex table the kernel reads (RVO2 builds its obstacle kd-tree here)."""
+        self._vertices = process_obstacles(self._polygons) if self._polygons else None
+        self._cw = None
 
     # ------------------------------------------------------------------ stepping
     def setTimeStep(self, timeStep):
@@ -93,7 +134,10 @@ class PyRVOSimulator:
         S[0, :, 10:12] = _FAR
         S[0, :, 12] = self._maxspeed
         if self._cw is None or self._cw.n != n:
-            self._cw = CrowdWorlds(S, np.full((1, n, 1, 2), _FAR, np.float32), None, None, None, type="orca")
+            if self._polygons and self._vertices is None:
+                raise RuntimeError("processObstacles() has to be called after addObstacle() (RVO2 ignores unprocessed obstacles)")
+            self._cw = CrowdWorlds(S, np.full((1, n, 1, 2), _FAR, np.float32), None, None, None, type="orca",
+                                   orca_vertices=self._vertices)
             self._cw.orca_params = dict(neighbor_dist=self._defaults["neighborDist"], max_neighbors=self._defaults["maxNeighbors"],
                                         time_horizon=self._defaults["timeHorizon"], time_horizon_obst=self._defaults["timeHorizonObst"])
         else:
@@ -136,7 +180,11 @@ class PyRVOSimulator:
         return self._defaults["timeHorizonObst"]
 
     def getNumObstacleVertices(self):
-        return 0
+        return sum(len(p) for p in self._polygons)
+
+    def getObstacleVertex(self, i):
+        flat = [v for p in self._polygons for v in p]
+        return flat[i]
 
     def setAgentPosition(self, i, pos):
         self._pos[i] = [float(pos[0]), float(pos[1])]

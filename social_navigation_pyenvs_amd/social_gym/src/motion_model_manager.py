@@ -106,8 +106,9 @@ class MotionModelManager:
             self.sfm_type = _lib.CS_ORCA
             self.params = None
             self.obstacles = None
-            if len(self.walls) > 0:
-                raise NotImplementedError("ORCA static obstacles (RVO2 obstacle lines) are not implemented on this path")
+            # sim.addObstacle(list(wall.vertices)) for every wall, then processObstacles (:244-246)
+            from ...rvo2 import process_obstacles
+            self._orca_vertices = process_obstacles([np.asarray(w.vertices) for w in self.walls]) if len(self.walls) > 0 else None
             self._orca_margin = 0.01  # agent.radius + 0.01 at addAgent (:241)
             for i in range(n):  # update_goals_orca at creation (:242)
                 self.update_goals(self.humans[i])
@@ -213,7 +214,8 @@ class MotionModelManager:
         bounds = self.respawn_bounds if respawn else None
         self._cw = CrowdWorlds(self.states, self.goals, self.params, margin, self.obstacles, type=self.sfm_type,
                                all_params_equal=self.all_equal_humans, robot_row=self.consider_robot,
-                               robot=robot_rows, respawn_bounds=bounds)
+                               robot=robot_rows, respawn_bounds=bounds,
+                               orca_vertices=getattr(self, "_orca_vertices", None) if self.orca else None)
         return self._cw
 
     def _readback(self, cw: CrowdWorlds, robot_moved=False):

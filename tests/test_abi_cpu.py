@@ -29,8 +29,8 @@ def test_struct_layout_matches_header():
 
     from social_navigation_pyenvs_amd._lib import cs_worlds
 
-    # 8 int32 + 7 pointers + 5 floats + 2 int32, natural alignment (8-byte: 4 bytes of tail padding)
-    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 2 * 4 + 4
+    # 8 int32 + 7 pointers + 5 floats + 2 int32 (+4 padding) + 1 pointer + 1 int32 (+4 tail padding)
+    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 2 * 4 + 4 + 8 + 4 + 4
     assert cs_worlds.d_state.offset == 32
 
 
@@ -58,8 +58,8 @@ def test_header_is_plain_c_and_generator_struct_matches():
     from social_navigation_pyenvs_amd.generators import cs_generator
 
     src = ('#include "crowdstep.h"\n#include <stdio.h>\n#include <stddef.h>\n'
-           'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(cs_worlds), sizeof(cs_generator), '
-           'offsetof(cs_generator, circle_radius), offsetof(cs_generator, robot_desired_speed), offsetof(cs_worlds, d_world_flags));return 0;}\n')
+           'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(cs_worlds), sizeof(cs_generator), '
+           'offsetof(cs_generator, circle_radius), offsetof(cs_generator, robot_desired_speed), offsetof(cs_worlds, d_world_flags), offsetof(cs_worlds, d_orca_vertices));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
@@ -71,3 +71,4 @@ def test_header_is_plain_c_and_generator_struct_matches():
     assert sizes[2] == cs_generator.circle_radius.offset
     assert sizes[3] == cs_generator.robot_desired_speed.offset
     assert sizes[4] == cs_worlds.d_world_flags.offset
+    assert sizes[5] == cs_worlds.d_orca_vertices.offset
