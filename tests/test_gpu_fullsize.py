@@ -115,3 +115,44 @@ def test_large_worlds_one_block_per_world(n, model, robot):
     for _ in range(5):
         b.step(0.0125, 1)
     np.testing.assert_array_equal(a.get_states(), b.get_states())
+
+
+@pytest.mark.parametrize("model", ["hsfm_farina", "sfm_guo", "hsfm_new_moussaid"])
+def test_long_rollout_soak(model):
+    """250 Gym steps (5000 substeps, 62 s of simulated time) of 1024 hybrid worlds: the crowd crosses, touches (contact
+    pass), switches goals and respawns many times.  Everything stays finite and inside the speed clamp, a sub-batch run on
+    its own ends bit-identical (whatever the wavefront packing), and the evolved state still steps like the f64 oracle."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    W, n = 1024, 25
+    S, goals, P, rb = sc.hybrid_worlds(W, n, model)
+    rw = (np.arange(W) % 2 == 1).astype(np.int32)
+    S, goals, P = S.astype(np.float32), goals.astype(np.float32), P.astype(np.float32)
+    sel = np.r_[3:40, 900:921]                      # 58 worlds: odd count, both kinds
+    full = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw, layout="soa")
+    part = CrowdWorlds(S[sel], goals[sel], P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
+                       respawn_worlds=rw[sel], layout="aos")
+    g_before = goals.copy()
+    for _ in range(250):
+        full.step(0.0125, 20)
+        part.step(0.0125, 20)
+    A, B = full.get_states(), part.get_states()
+    assert np.all(np.isfinite(A[..., :8]))
+    np.testing.assert_array_equal(A[sel], B)
+    np.testing.assert_array_equal(full.get_goals()[sel], part.get_goals())
+    sp = np.linalg.norm(A[..., 3:5], axis=-1)
+    assert np.all(sp <= S[..., 12] * (1 + 1e-5) + 1e-6)
+    assert np.any(full.get_goals()[::2, :, 0] != g_before[::2, :, 0])       # circle worlds: goals were switched
+    assert np.any(A[1::2, :, 0] > 7.0 - 1e-3)                                # traffic worlds: somebody respawned at the bound
+    # one more substep from the evolved state against the f64 oracle (sampled worlds, no respawn in this call)
+    cw = CrowdWorlds(A, full.get_goals(), P, None, None, type=model, all_params_equal=True, layout="aos")
+    out = cw.get_states(cw.update_humans_parallel(0.0125, in_place=False))
+    gA = full.get_goals()
+    rng = np.random.default_rng(5)
+    tol = 3e-4 if model.endswith("moussaid") else 2e-5
+    for w in rng.choice(W, 16, replace=False):
+        ref, _, _ = orc.update_humans(SFMS.index(model), A[w].astype(np.float64), gA[w].astype(np.float64), None,
+                                      P.astype(np.float64), 0.0125, np.zeros(n), True, False)
+        err = np.max(np.abs(out[w][:, [0, 1, 3, 4]] - ref[:, [0, 1, 3, 4]]))
+        assert err < tol, (model, int(w), err)
