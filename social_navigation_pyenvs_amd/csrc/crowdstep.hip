@@ -444,6 +444,12 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     }
     __syncthreads();
 
+    if constexpr (N3L) {
+        float4* z = reinterpret_cast<float4*>(lds_acc);
+#pragma unroll
+        for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        LDS_ORDER_FENCE();
+    }
 #ifdef CS_STAMPS
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last;
@@ -509,12 +515,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             }
         };
         if constexpr (N3L) {
-            {
-                float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 used per row = T float4: one per lane
-#pragma unroll
-                for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                LDS_ORDER_FENCE();
-            }
+            // (the reaction accumulators were zeroed behind the previous substep's reaction sum, off the critical path)
             // lean build: request the first group's rows now, part A below runs while they are in flight (with walls the
             // rows would be held in registers across the segment loops: fetched at the head of the group loop instead)
             if constexpr (LEAN) { if (valid && Hf >= UA) fetch(qa, va, 0); }
@@ -772,6 +773,15 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     }
                 }
             }
+        }
+        if constexpr (N3L) {
+            // zero the reaction accumulators for the next substep now: the LDS executes these stores while the VALU does
+            // the Euler tail, instead of in front of the next substep's first partner fetch
+            LDS_ORDER_FENCE();
+            float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 used per row = T float4: one per lane
+#pragma unroll
+            for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            LDS_ORDER_FENCE();
         }
         STAMP(2);
         if (human) {
