@@ -459,6 +459,22 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
         STAMP(7);
+        const int Hf = (rows - 1) >> 1;
+        const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
+        const float2* rv = lds_v + cur * TP + pbase + row + 1;
+        float4 qa[UA];
+        float2 va[UA];
+        auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                q[u] = rp[kk + u];
+                if constexpr (N3L && SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
+            }
+        };
+        // lean build: request the first group's partner rows first thing; the goal test and part A below run while they
+        // are in flight (with walls the rows would be held in registers across the segment loops: fetched at the head of
+        // the group loop instead)
+        if constexpr (LEAN) { if (valid && Hf >= UA) fetch(qa, va, 0); }
         if constexpr (LEAN) {
             // -- goal switch, forces_parallel.py:226-234, predicated: lists of <= 2 goals rotate in registers
             const float gdx = g0x - px, gdy = g0y - py;
@@ -502,25 +518,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         //    forces, the Farina torque, the new heading and its sine / cosine), then the partner groups, and only the
         //    short force-dependent tail (body-frame projection, Euler step, publish) follows the reaction sum.
         float fsx = 0.0f, fsy = 0.0f;
-        const int Hf = (rows - 1) >> 1;
-        const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
-        const float2* rv = lds_v + cur * TP + pbase + row + 1;
-        float4 qa[UA];
-        float2 va[UA];
-        auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
-#pragma unroll
-            for (int u = 0; u < UA; ++u) {
-                q[u] = rp[kk + u];
-                if constexpr (N3L && SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
-            }
-        };
-        if constexpr (N3L) {
-            // (the reaction accumulators were zeroed behind the previous substep's reaction sum, off the critical path)
-            // lean build: request the first group's rows now, part A below runs while they are in flight (with walls the
-            // rows would be held in registers across the segment loops: fetched at the head of the group loop instead)
-            if constexpr (LEAN) { if (valid && Hf >= UA) fetch(qa, va, 0); }
-            STAMP(8);
-        }
+        // (the reaction accumulators were zeroed behind the previous substep's reaction sum, off the critical path)
+        STAMP(8);
         // -- part A of the per-agent update: everything that does not need this substep's social force
         const float c = cs, s = sn;          // rotation matrix of the incoming heading, :254-256
         float cvx = vx, cvy = vy;            // refreshed linear velocity
