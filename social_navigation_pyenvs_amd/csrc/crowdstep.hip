@@ -4,10 +4,12 @@
 //   update_humans_parallel            /root/reference/social_gym/src/forces_parallel.py:185-284
 //   MotionModelManager.update_humans  /root/reference/social_gym/src/motion_model_manager.py:354-422
 //   SocialNavGym.step substep loop    /root/reference/social_gym/social_nav_gym.py:240-245
-// re-designed for MI355X: lane = agent row, floor(64/rows) independent worlds per wavefront,
-// the interacting columns (px,py,vx,vy,r+safety) staged in LDS and broadcast-read in the O(N^2)
-// pair loop, all substeps of one Gym step fused in one launch with the state in registers, so HBM
-// sees each state row once per launch.  No MFMA (there is no dense contraction on this path).
+// re-designed for MI355X: lane = agent row, floor(64/rows) independent worlds per wavefront, the
+// interacting columns (px, py, r + safety; velocities where a model needs them) staged in LDS, every
+// unordered pair evaluated once with the reaction handed over through in-order LDS read-modify-writes
+// (or all partners per lane for per-agent parameters / worlds of more than 64 rows), all substeps of
+// one Gym step fused in one launch with the state in registers, so HBM sees each state row once per
+// launch.  No MFMA (there is no dense contraction on this path).  Design notes: DESIGN.md §4.1.
 //
 // gfx950 only: no portability macros, no CPU fallback.
 
