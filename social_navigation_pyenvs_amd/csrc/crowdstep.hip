@@ -477,6 +477,15 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         // are in flight (with walls the rows would be held in registers across the segment loops: fetched at the head of
         // the group loop instead)
         if constexpr (LEAN) { if (valid && Hf >= UA) fetch(qa, va, 0); }
+        // even row counts: the antipodal partner (evaluated by both ends, no hand-over) is requested up front as well
+        float4 qz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float2 vz = make_float2(0.0f, 0.0f);
+        if constexpr (LEAN) {
+            if (valid && (rows & 1) == 0) {
+                qz = rp[Hf];
+                if constexpr (SOC == 2) vz = rv[Hf];
+            }
+        }
         if constexpr (LEAN) {
             // -- goal switch, forces_parallel.py:226-234, predicated: lists of <= 2 goals rotate in registers
             const float gdx = g0x - px, gdy = g0y - py;
@@ -732,11 +741,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     acc[k] = ac;
                     LDS_ORDER_FENCE();
                 }
-                if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself
+                if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself (lean build: row fetched at the top)
                     float fx, fy;
-                    float2 vq = make_float2(0.0f, 0.0f);
-                    if constexpr (SOC == 2) vq = rv[Hf];
-                    pair_once(rp[Hf], vq, fx, fy);
+                    if constexpr (!LEAN) {
+                        qz = rp[Hf];
+                        if constexpr (SOC == 2) vz = rv[Hf];
+                    }
+                    pair_once(qz, vz, fx, fy);
                     ex += fx; ey += fy;
                 }
                 STAMP(9);

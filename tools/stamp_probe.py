@@ -43,9 +43,14 @@ if model == "orca":
     for k, nm in enumerate(names):
         print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
     sys.exit(0)
-S, goals, P, rb = sc.hybrid_worlds(W, n, model)
-cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
-                 respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), layout="soa")
+if len(sys.argv) > 4 and sys.argv[4] == "circle":   # cfg2-style: circular crossing only, no respawn rule
+    pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
+    S, goals, P = sc.make_states(pos, yaw, g), g, np.tile(sc.default_params(model), (n, 1))
+    cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, layout="soa")
+else:
+    S, goals, P, rb = sc.hybrid_worlds(W, n, model)
+    cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
+                     respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), layout="soa")
 g, b, wpb = cw.launch_geometry()
 buf = _lib.DeviceBuffer((g * (b // 64), 12), np.uint64)
 lib = _lib.load()
