@@ -1277,7 +1277,10 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     const bool lean = peq && g.block == 64 && w->O == 0 && !(w->flags & CS_ROBOT_ROW) && w->G <= 2 && mode == M_COMMIT_GOALS;
     kfn fn;
     if (g.block != 64) fn = pick_kernel<1024, 1, 0, false>(w->type, peq);
+    // compile-time row counts of the BASELINE.json configurations with 25 and 10 humans (50 rows unrolled spill 30-47 VGPRs
+    // at the 4-wave budget and stay on the run-time loop); 10 rows fit 128 VGPRs without spills in every model
     else if (lean && rows == 25) fn = crowded ? pick_kernel<64, 4, 25, true>(w->type, true) : pick_kernel<64, 1, 25, true>(w->type, true);
+    else if (lean && rows == 10) fn = pick_kernel<64, 4, 10, true>(w->type, true);
     else if (lean) fn = crowded ? pick_kernel<64, 4, 0, true>(w->type, true) : pick_kernel<64, 1, 0, true>(w->type, true);
     else fn = crowded ? pick_kernel<64, 4, 0, false>(w->type, peq) : pick_kernel<64, 1, 0, false>(w->type, peq);
     // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
