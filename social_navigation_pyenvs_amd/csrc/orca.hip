@@ -447,17 +447,22 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
     const int T = blockDim.x;
     const int K = a.K;
     const int KL = a.K + a.KO;                                       // lines per agent: obstacle lines first, then agents
+    // per-lane columns are TL = wpb * rows lanes wide (the lanes that hold an agent: 50 of 64 for 25-agent worlds), and the
+    // register-resident build needs no neighbour columns: 19 KB per block instead of 28 KB, 8 blocks per CU instead of 5,
+    // so the 2048 wavefronts of 4096 x 25 are resident in one round
+    const int TL = a.wpb * a.rows;
+    const int KN = FAST10 ? 0 : K;
     float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [2][T] x, y, vx, vy
-    float4* lds_L = lds_pv + 2 * T;                                  // [KL][T] ORCA lines
-    float4* lds_P = lds_L + KL * T;                                  // [KL][T] LP3 projection lines
-    float* lds_r = reinterpret_cast<float*>(lds_P + KL * T);         // [T] radius + margin
-    float* lds_nd = lds_r + T;                                       // [K][T] neighbour distSq
-    int* lds_ni = reinterpret_cast<int*>(lds_nd + K * T);            // [K][T] neighbour row
-    float* lds_rp = reinterpret_cast<float*>(lds_ni + K * T);        // [T] plain radius (respawn rule)
+    float4* lds_L = lds_pv + 2 * T;                                  // [KL][TL] ORCA lines
+    float4* lds_P = lds_L + KL * TL;                                 // [KL][TL] LP3 projection lines
+    float* lds_r = reinterpret_cast<float*>(lds_P + KL * TL);        // [T] radius + margin
+    float* lds_nd = lds_r + T;                                       // [KN][TL] neighbour distSq
+    int* lds_ni = reinterpret_cast<int*>(lds_nd + KN * TL);          // [KN][TL] neighbour row
+    float* lds_rp = reinterpret_cast<float*>(lds_ni + KN * TL);      // [T] plain radius (respawn rule)
     float* lds_g0x = lds_rp + T;                                     // [T] respawn scratch
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);             // [T] respawn scratch
-    float* lds_od = reinterpret_cast<float*>(lds_flag + T);          // [KO][T] obstacle edge distSq
-    int* lds_oi = reinterpret_cast<int*>(lds_od + a.KO * T);         // [KO][T] obstacle edge (first vertex)
+    float* lds_od = reinterpret_cast<float*>(lds_flag + T);          // [KO][TL] obstacle edge distSq
+    int* lds_oi = reinterpret_cast<int*>(lds_od + a.KO * TL);        // [KO][TL] obstacle edge (first vertex)
 
     const int tid = threadIdx.x;
     const int rows = a.rows, n = a.n;
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
     if (valid) { lds_pv[tid] = make_float4(px, py, vx, vy); lds_r[tid] = r + margin; lds_rp[tid] = r; }
     __syncthreads();
 
-    const Lines L{lds_L, T, tid}, P{lds_P, T, tid};
+    const Lines L{lds_L, TL, tid}, P{lds_P, TL, tid};
     unsigned long long ost_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long* g_ost = nullptr;
     unsigned long long g_ost_last = 0;
@@ -532,14 +537,14 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
                         if (dsq < rangeSq) {
                             if (cnt < K) ++cnt;
                             int i = cnt - 1;
-                            while (i != 0 && dsq < lds_nd[(i - 1) * T + tid]) {
-                                lds_nd[i * T + tid] = lds_nd[(i - 1) * T + tid];
-                                lds_ni[i * T + tid] = lds_ni[(i - 1) * T + tid];
+                            while (i != 0 && dsq < lds_nd[(i - 1) * TL + tid]) {
+                                lds_nd[i * TL + tid] = lds_nd[(i - 1) * TL + tid];
+                                lds_ni[i * TL + tid] = lds_ni[(i - 1) * TL + tid];
                                 --i;
                             }
-                            lds_nd[i * T + tid] = dsq;
-                            lds_ni[i * T + tid] = b;
-                            if (cnt == K) rangeSq = lds_nd[(cnt - 1) * T + tid];
+                            lds_nd[i * TL + tid] = dsq;
+                            lds_ni[i * TL + tid] = b;
+                            if (cnt == K) rangeSq = lds_nd[(cnt - 1) * TL + tid];
                         }
                     }
                 }
@@ -547,12 +552,12 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
                 int nobst = 0;
                 if (a.nv > 0) {
                     const float rng = a.time_horizon_obst * vmax + (r + margin);   // rangeSq = sqr(timeHorizonObst * maxSpeed + radius)
-                    const int no = obstacle_neighbors(a.verts, a.nv, a.KO, px, py, rng * rng, lds_od, lds_oi, T, tid);
-                    nobst = obstacle_lines(a.verts, lds_oi, no, T, tid, px, py, vx, vy, r + margin, 1.0f / a.time_horizon_obst, L);
+                    const int no = obstacle_neighbors(a.verts, a.nv, a.KO, px, py, rng * rng, lds_od, lds_oi, TL, tid);
+                    nobst = obstacle_lines(a.verts, lds_oi, no, TL, tid, px, py, vx, vy, r + margin, 1.0f / a.time_horizon_obst, L);
                 }
                 const float invT = 1.0f / a.time_horizon;
                 for (int k = 0; k < cnt; ++k) {
-                    const int b = lds_ni[k * T + tid];
+                    const int b = lds_ni[k * TL + tid];
                     L.set(nobst + k, orca_line(px, py, vx, vy, pv[b], (r + margin) + rr[b], invT, dt));
                 }
                 const int total = nobst + cnt;
@@ -675,9 +680,10 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (d_peek) a.flags &= ~CS_RESPAWN;
     const int T = 64;
     const int grid = (w->W + a.wpb - 1) / a.wpb;
-    const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
-                         (size_t)(a.K + a.KO) * T * 2 * sizeof(float4) + (size_t)(a.K + a.KO) * T * 2 * sizeof(float);
     const bool fast10 = a.K == 10 && a.nv == 0; // the register-resident solve has no obstacle lines
+    const int TL = a.wpb * rows;                // lanes that hold an agent: the width of the per-lane LDS columns
+    const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) + (size_t)(a.K + a.KO) * TL * 2 * sizeof(float4) +
+                         (size_t)((fast10 ? 0 : a.K) + a.KO) * TL * 2 * sizeof(float);
     if (shmem > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_orca_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if (fast10) hipLaunchKernelGGL(k_orca_step<true>, dim3(grid), dim3(T), shmem, stream, a);
