@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--walls", action="store_true", help="add 3 shared polygon walls")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python (default: one HIP graph of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a one-GPU box")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -162,7 +163,7 @@ def main():
     torch.cuda.set_device(local_rank)
     _lib.set_device(local_rank)
     dist = None
-    if world_size > 1:
+    if world_size > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
