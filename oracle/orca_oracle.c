@@ -8,7 +8,8 @@
  * it; README.md:80 links it) and it is not installed here, so no golden vector can be produced and
  * this file cannot be checked against the real library: it restates the published algorithm
  * (van den Berg, Guy, Lin, Manocha, "Reciprocal n-body collision avoidance", ISRR 2009; RVO2 v2.0.2
- * Agent::computeNeighbors / computeNewVelocity / linearProgram1-3 / update) in float32 as RVO2 does,
+ * Agent::computeNeighbors / computeNewVelocity / linearProgram1-3 / update) in float32 as RVO2 does
+ * (a vector divided by a scalar is multiplied by the scalar's reciprocal, as RVO2's Vector2::operator/ does),
  * and is anchored on the reference's own call sites:
  *   motion_model_manager.py:14        ORCA_DEFAULTS neighborDist=10, maxNeighbors=10, timeHorizon=5, timeHorizonObst=5
  *   motion_model_manager.py:237-246   simulator / agent creation (radius + 0.01, maxSpeed = desired_speed)
@@ -82,7 +83,8 @@ static int lp2(const orca_line* L, int nl, float radius, float ox, float oy, int
     if (dirOpt) { *rx = ox * radius; *ry = oy * radius; }
     else if (ox * ox + oy * oy > radius * radius) {
         const float nrm = sqrtf(ox * ox + oy * oy);
-        *rx = ox / nrm * radius; *ry = oy / nrm * radius;
+        const float inv = 1.0f / nrm;             /* RVO2's Vector2 / float multiplies by the reciprocal (Vector2.h) */
+        *rx = ox * inv * radius; *ry = oy * inv * radius;
     } else { *rx = ox; *ry = oy; }
     for (int i = 0; i < nl; ++i) {
         if (det2(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry) > 0.0f) {
@@ -114,7 +116,8 @@ static void lp3(const orca_line* L, int nl, int numObst, int begin, float radius
                 }
                 const float ex = L[j].dx - L[i].dx, ey = L[j].dy - L[i].dy;
                 const float en = sqrtf(ex * ex + ey * ey);
-                ln.dx = ex / en; ln.dy = ey / en;
+                const float inv = 1.0f / en;
+                ln.dx = ex * inv; ln.dy = ey * inv;
                 proj[np++] = ln;
             }
             const float tx = *rx, ty = *ry;
@@ -191,15 +194,15 @@ static int obstacle_lines(const orca_vertex* V, const int* oi, int no, float px,
         orca_line ln;
         if (s < 0.0f && distSq1 <= radiusSq) {            /* collision with left vertex; ignore if non-convex */
             if (o1->convex != 0.0f) {
-                const float n = sqrtf(absSq2(-r1y, r1x));
-                ln.px = 0.0f; ln.py = 0.0f; ln.dx = -r1y / n; ln.dy = r1x / n;
+                const float inv = 1.0f / sqrtf(absSq2(-r1y, r1x));
+                ln.px = 0.0f; ln.py = 0.0f; ln.dx = -r1y * inv; ln.dy = r1x * inv;
                 L[nl++] = ln;
             }
             continue;
         } else if (s > 1.0f && distSq2 <= radiusSq) {     /* collision with right vertex */
             if (o2->convex != 0.0f && det2(r2x, r2y, o2->ux, o2->uy) >= 0.0f) {
-                const float n = sqrtf(absSq2(-r2y, r2x));
-                ln.px = 0.0f; ln.py = 0.0f; ln.dx = -r2y / n; ln.dy = r2x / n;
+                const float inv = 1.0f / sqrtf(absSq2(-r2y, r2x));
+                ln.px = 0.0f; ln.py = 0.0f; ln.dx = -r2y * inv; ln.dy = r2x * inv;
                 L[nl++] = ln;
             }
             continue;
@@ -216,22 +219,26 @@ static int obstacle_lines(const orca_vertex* V, const int* oi, int no, float px,
             if (o1->convex == 0.0f) continue;
             a2 = o1;
             const float leg1 = sqrtf(distSq1 - radiusSq);
-            llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
-            rlx = (r1x * leg1 + r1y * radius) / distSq1; rly = (-r1x * radius + r1y * leg1) / distSq1;
+            const float inv1 = 1.0f / distSq1;
+            llx = (r1x * leg1 - r1y * radius) * inv1; lly = (r1x * radius + r1y * leg1) * inv1;
+            rlx = (r1x * leg1 + r1y * radius) * inv1; rly = (-r1x * radius + r1y * leg1) * inv1;
         } else if (s > 1.0f && distSqLine <= radiusSq) {  /* right vertex defines it */
             if (o2->convex == 0.0f) continue;
             a1 = o2;
             const float leg2 = sqrtf(distSq2 - radiusSq);
-            llx = (r2x * leg2 - r2y * radius) / distSq2; lly = (r2x * radius + r2y * leg2) / distSq2;
-            rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+            const float inv2 = 1.0f / distSq2;
+            llx = (r2x * leg2 - r2y * radius) * inv2; lly = (r2x * radius + r2y * leg2) * inv2;
+            rlx = (r2x * leg2 + r2y * radius) * inv2; rly = (-r2x * radius + r2y * leg2) * inv2;
         } else {                                          /* usual situation */
             if (o1->convex != 0.0f) {
                 const float leg1 = sqrtf(distSq1 - radiusSq);
-                llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
+                const float inv1 = 1.0f / distSq1;
+                llx = (r1x * leg1 - r1y * radius) * inv1; lly = (r1x * radius + r1y * leg1) * inv1;
             } else { llx = -o1->ux; lly = -o1->uy; }     /* left leg extends the cut-off line */
             if (o2->convex != 0.0f) {
                 const float leg2 = sqrtf(distSq2 - radiusSq);
-                rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+                const float inv2 = 1.0f / distSq2;
+                rlx = (r2x * leg2 + r2y * radius) * inv2; rly = (-r2x * radius + r2y * leg2) * inv2;
             } else { rlx = o1->ux; rly = o1->uy; }
         }
         /* legs never point into a neighbouring edge of a convex vertex: take that edge's cut-off line instead */
@@ -250,13 +257,15 @@ static int obstacle_lines(const orca_vertex* V, const int* oi, int no, float px,
         const float tR = (vx - rcx) * rlx + (vy - rcy) * rly;
         if ((t < 0.0f && tL < 0.0f) || (same && tL < 0.0f && tR < 0.0f)) { /* left cut-off circle */
             const float wx = vx - lcx, wy = vy - lcy, wn = sqrtf(absSq2(wx, wy));
-            const float ux = wx / wn, uy = wy / wn;
+            const float inv = 1.0f / wn;
+            const float ux = wx * inv, uy = wy * inv;
             ln.dx = uy; ln.dy = -ux; ln.px = lcx + radius * invT * ux; ln.py = lcy + radius * invT * uy;
             L[nl++] = ln;
             continue;
         } else if (t > 1.0f && tR < 0.0f) {                                  /* right cut-off circle */
             const float wx = vx - rcx, wy = vy - rcy, wn = sqrtf(absSq2(wx, wy));
-            const float ux = wx / wn, uy = wy / wn;
+            const float inv = 1.0f / wn;
+            const float ux = wx * inv, uy = wy * inv;
             ln.dx = uy; ln.dy = -ux; ln.px = rcx + radius * invT * ux; ln.py = rcy + radius * invT * uy;
             L[nl++] = ln;
             continue;
@@ -343,16 +352,19 @@ void orc_orca_new_velocities_obst(int na, const float* pos, const float* vel, co
                 const float dot1 = wx * rpx + wy * rpy;
                 if (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq) {
                     const float wLen = sqrtf(wLenSq);
-                    const float uwx = wx / wLen, uwy = wy / wLen;
+                    const float inv = 1.0f / wLen;
+                    const float uwx = wx * inv, uwy = wy * inv;
                     dx = uwy; dy = -uwx;
                     const float s = R * invT - wLen;
                     ux = s * uwx; uy = s * uwy;
                 } else {
                     const float leg = sqrtf(distSq - RSq);
                     if (det2(rpx, rpy, wx, wy) > 0.0f) {
-                        dx = (rpx * leg - rpy * R) / distSq; dy = (rpx * R + rpy * leg) / distSq;
+                        const float inv = 1.0f / distSq;
+                        dx = (rpx * leg - rpy * R) * inv; dy = (rpx * R + rpy * leg) * inv;
                     } else {
-                        dx = -(rpx * leg + rpy * R) / distSq; dy = -(-rpx * R + rpy * leg) / distSq;
+                        const float inv = 1.0f / distSq;
+                        dx = -(rpx * leg + rpy * R) * inv; dy = -(-rpx * R + rpy * leg) * inv;
                     }
                     const float dot2 = rvx * dx + rvy * dy;
                     ux = dot2 * dx - rvx; uy = dot2 * dy - rvy;
@@ -361,7 +373,8 @@ void orc_orca_new_velocities_obst(int na, const float* pos, const float* vel, co
                 const float invDt = 1.0f / time_step;
                 const float wx = rvx - invDt * rpx, wy = rvy - invDt * rpy;
                 const float wLen = sqrtf(wx * wx + wy * wy);
-                const float uwx = wx / wLen, uwy = wy / wLen;
+                const float inv = 1.0f / wLen;
+                const float uwx = wx * inv, uwy = wy * inv;
                 dx = uwy; dy = -uwx;
                 const float s = R * invDt - wLen;
                 ux = s * uwx; uy = s * uwy;

@@ -114,7 +114,8 @@ __device__ int lp2(const Lines& L, int nl, float radius, float ox, float oy, boo
     if (dirOpt) { rx = ox * radius; ry = oy * radius; }
     else if (ox * ox + oy * oy > radius * radius) {
         const float nrm = sqrtf(ox * ox + oy * oy);
-        rx = ox / nrm * radius; ry = oy / nrm * radius;
+        const float inv = 1.0f / nrm;             // RVO2's Vector2 / float multiplies by the reciprocal (Vector2.h)
+        rx = ox * inv * radius; ry = oy * inv * radius;
     } else { rx = ox; ry = oy; }
     for (int i = 0; i < nl; ++i) {
         const float4 li = L.get(i);
@@ -148,7 +149,8 @@ __device__ void lp3(const Lines& L, const Lines& P, int nl, int numObst, int beg
                 }
                 const float ex = lj.z - li.z, ey = lj.w - li.w;
                 const float en = sqrtf(ex * ex + ey * ey);
-                ln.z = ex / en; ln.w = ey / en;
+                const float inv = 1.0f / en;
+                ln.z = ex * inv; ln.w = ey * inv;
                 P.set(np++, ln);
             }
             const float tx = rx, ty = ry;
@@ -230,14 +232,14 @@ __device__ int obstacle_lines(const float* V, const int* oi, int no, int T, int 
         const float distSqLine = absSq2(-r1x - s * ovx, -r1y - s * ovy);
         if (s < 0.0f && distSq1 <= radiusSq) {            // collision with left vertex; ignore if non-convex
             if (o1.convex != 0.0f) {
-                const float n = sqrtf(absSq2(-r1y, r1x));
-                L.set(nl++, make_float4(0.0f, 0.0f, -r1y / n, r1x / n));
+                const float inv = 1.0f / sqrtf(absSq2(-r1y, r1x));
+                L.set(nl++, make_float4(0.0f, 0.0f, -r1y * inv, r1x * inv));
             }
             continue;
         } else if (s > 1.0f && distSq2 <= radiusSq) {     // collision with right vertex
             if (o2.convex != 0.0f && det2(r2x, r2y, o2.ux, o2.uy) >= 0.0f) {
-                const float n = sqrtf(absSq2(-r2y, r2x));
-                L.set(nl++, make_float4(0.0f, 0.0f, -r2y / n, r2x / n));
+                const float inv = 1.0f / sqrtf(absSq2(-r2y, r2x));
+                L.set(nl++, make_float4(0.0f, 0.0f, -r2y * inv, r2x * inv));
             }
             continue;
         } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) { // collision with the segment
@@ -251,22 +253,26 @@ __device__ int obstacle_lines(const float* V, const int* oi, int no, int T, int 
             if (o1.convex == 0.0f) continue;
             a2 = o1; same = true;
             const float leg1 = sqrtf(distSq1 - radiusSq);
-            llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
-            rlx = (r1x * leg1 + r1y * radius) / distSq1; rly = (-r1x * radius + r1y * leg1) / distSq1;
+            const float inv1 = 1.0f / distSq1;
+            llx = (r1x * leg1 - r1y * radius) * inv1; lly = (r1x * radius + r1y * leg1) * inv1;
+            rlx = (r1x * leg1 + r1y * radius) * inv1; rly = (-r1x * radius + r1y * leg1) * inv1;
         } else if (s > 1.0f && distSqLine <= radiusSq) {  // the right vertex defines it
             if (o2.convex == 0.0f) continue;
             a1 = o2; same = true;
             const float leg2 = sqrtf(distSq2 - radiusSq);
-            llx = (r2x * leg2 - r2y * radius) / distSq2; lly = (r2x * radius + r2y * leg2) / distSq2;
-            rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+            const float inv2 = 1.0f / distSq2;
+            llx = (r2x * leg2 - r2y * radius) * inv2; lly = (r2x * radius + r2y * leg2) * inv2;
+            rlx = (r2x * leg2 + r2y * radius) * inv2; rly = (-r2x * radius + r2y * leg2) * inv2;
         } else {                                          // usual situation
             if (o1.convex != 0.0f) {
                 const float leg1 = sqrtf(distSq1 - radiusSq);
-                llx = (r1x * leg1 - r1y * radius) / distSq1; lly = (r1x * radius + r1y * leg1) / distSq1;
+                const float inv1 = 1.0f / distSq1;
+                llx = (r1x * leg1 - r1y * radius) * inv1; lly = (r1x * radius + r1y * leg1) * inv1;
             } else { llx = -o1.ux; lly = -o1.uy; }
             if (o2.convex != 0.0f) {
                 const float leg2 = sqrtf(distSq2 - radiusSq);
-                rlx = (r2x * leg2 + r2y * radius) / distSq2; rly = (-r2x * radius + r2y * leg2) / distSq2;
+                const float inv2 = 1.0f / distSq2;
+                rlx = (r2x * leg2 + r2y * radius) * inv2; rly = (-r2x * radius + r2y * leg2) * inv2;
             } else { rlx = o1.ux; rly = o1.uy; }
         }
         const Vtx leftNb = load_vtx(V, a1.prev);
@@ -281,12 +287,14 @@ __device__ int obstacle_lines(const float* V, const int* oi, int no, int T, int 
         const float tR = (vx - rcx) * rlx + (vy - rcy) * rly;
         if ((t < 0.0f && tL < 0.0f) || (same && tL < 0.0f && tR < 0.0f)) { // left cut-off circle
             const float wx = vx - lcx, wy = vy - lcy, wn = sqrtf(absSq2(wx, wy));
-            const float ux = wx / wn, uy = wy / wn;
+            const float inv = 1.0f / wn;
+            const float ux = wx * inv, uy = wy * inv;
             L.set(nl++, make_float4(lcx + radius * invT * ux, lcy + radius * invT * uy, uy, -ux));
             continue;
         } else if (t > 1.0f && tR < 0.0f) {                                  // right cut-off circle
             const float wx = vx - rcx, wy = vy - rcy, wn = sqrtf(absSq2(wx, wy));
-            const float ux = wx / wn, uy = wy / wn;
+            const float inv = 1.0f / wn;
+            const float ux = wx * inv, uy = wy * inv;
             L.set(nl++, make_float4(rcx + radius * invT * ux, rcy + radius * invT * uy, uy, -ux));
             continue;
         }
@@ -317,16 +325,19 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
         const float dot1 = wx * rpx + wy * rpy;
         if (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq) {
             const float wLen = sqrtf(wLenSq);
-            const float uwx = wx / wLen, uwy = wy / wLen;
+            const float inv = 1.0f / wLen;
+            const float uwx = wx * inv, uwy = wy * inv;
             dx = uwy; dy = -uwx;
             const float s = R * invT - wLen;
             ux = s * uwx; uy = s * uwy;
         } else {
             const float leg = sqrtf(distSq - RSq);
             if (det2(rpx, rpy, wx, wy) > 0.0f) {
-                dx = (rpx * leg - rpy * R) / distSq; dy = (rpx * R + rpy * leg) / distSq;
+                const float inv = 1.0f / distSq;
+                dx = (rpx * leg - rpy * R) * inv; dy = (rpx * R + rpy * leg) * inv;
             } else {
-                dx = -(rpx * leg + rpy * R) / distSq; dy = -(-rpx * R + rpy * leg) / distSq;
+                const float inv = 1.0f / distSq;
+                dx = -(rpx * leg + rpy * R) * inv; dy = -(-rpx * R + rpy * leg) * inv;
             }
             const float dot2 = rvx * dx + rvy * dy;
             ux = dot2 * dx - rvx; uy = dot2 * dy - rvy;
@@ -335,7 +346,8 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
         const float invDt = 1.0f / dt;
         const float wx = rvx - invDt * rpx, wy = rvy - invDt * rpy;
         const float wLen = sqrtf(wx * wx + wy * wy);
-        const float uwx = wx / wLen, uwy = wy / wLen;
+        const float inv = 1.0f / wLen;
+        const float uwx = wx * inv, uwy = wy * inv;
         dx = uwy; dy = -uwx;
         const float s = R * invDt - wLen;
         ux = s * uwx; uy = s * uwy;
@@ -395,7 +407,8 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
     float rx, ry;
     if (pvx * pvx + pvy * pvy > vmax * vmax) {
         const float nrm = sqrtf(pvx * pvx + pvy * pvy);
-        rx = pvx / nrm * vmax; ry = pvy / nrm * vmax;
+        const float inv = 1.0f / nrm;
+        rx = pvx * inv * vmax; ry = pvy * inv * vmax;
     } else { rx = pvx; ry = pvy; }
     int failed = cnt;
     bool done = false;

@@ -98,7 +98,9 @@ def test_lp_result_matches_brute_force_on_random_scenes():
         pref = rng.normal(0, 0.7, (na, 2))
         v, lines, nl = orc.orca_new_velocities(pos, vel, pref, np.full(na, 0.31), np.ones(na), time_step=0.0125,
                                                return_lines=True)
-        assert np.all(np.linalg.norm(v, axis=1) <= 1.0 + 1e-5)
+        # float32: with two nearly anti-parallel half-planes linearProgram3's projected line is ill-conditioned and the point
+        # it returns on the speed circle is off by ~6e-5 (one such scene in 300, either side of the circle)
+        assert np.all(np.linalg.norm(v, axis=1) <= 1.0 + 2e-4)
         for a in range(na):
             ref = _brute_force(lines[a, :nl[a]].astype(float), 1.0, pref[a])
             checked += 1
@@ -222,7 +224,7 @@ def test_obstacle_lines_are_hard_constraints_and_the_lp_matches_brute_force():
         vel = rng.normal(0, 0.5, (na, 2))
         pref = rng.normal(0, 0.8, (na, 2))
         v, lines, nl, no = orc.orca_new_velocities_obst(pos, vel, pref, np.full(na, 0.31), np.ones(na), verts, time_step=0.0125)
-        assert np.all(np.linalg.norm(v, axis=1) <= 1.0 + 1e-5)
+        assert np.all(np.linalg.norm(v, axis=1) <= 1.0 + 2e-4)
         for a in range(na):
             L = lines[a, :nl[a]].astype(float)
             with_obst += no[a] > 0
