@@ -355,6 +355,93 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
     return make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
 }
 
+// linearProgram3 on ten register-resident lines (no static obstacles): the same operations in the same order as lp3() /
+// lp2() / lp1() above.  The walk over the violated lines i is a wave-uniform runtime loop (line i is picked with selects); the
+// projected lines j < i and linearProgram2 / linearProgram1 over them are statically unrolled and guarded by the uniform j < i.
+// RVO2 drops a projected line whose source line is parallel to line i and points the same way: here it keeps its slot and a
+// cleared bit in `pvalid`, and every loop skips it, which visits the surviving lines in the same order.
+__device__ __forceinline__ float4 pick10(const float4 (&A)[10], int i)
+{
+    float4 r = A[0];
+#pragma unroll
+    for (int k = 1; k < 10; ++k) if (i == k) r = A[k];
+    return r;
+}
+
+__device__ void lp3_fast10(const float4 (&Lr)[10], int cnt, int failed, float vmax, float& rx, float& ry)
+{
+    float distance = 0.0f;
+#pragma nounroll
+    for (int i = 0; i < 10; ++i) {
+        const float4 li = pick10(Lr, i);
+        const bool act = (i >= failed) && (i < cnt) && (det2(li.z, li.w, li.x - rx, li.y - ry) > distance);
+        if (__builtin_amdgcn_ballot_w64(act) == 0) continue;
+        float4 Pr[9];
+        unsigned pvalid = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j < i) {
+                const float4 lj = Lr[j];
+                const float d = det2(li.z, li.w, lj.z, lj.w);
+                const bool par = fabsf(d) <= RVO_EPSILON;
+                const bool same = li.z * lj.z + li.w * lj.w > 0.0f;
+                const float s = det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
+                float4 ln;
+                ln.x = par ? 0.5f * (li.x + lj.x) : li.x + s * li.z;
+                ln.y = par ? 0.5f * (li.y + lj.y) : li.y + s * li.w;
+                const float ex = lj.z - li.z, ey = lj.w - li.w;
+                const float en = sqrtf(ex * ex + ey * ey);
+                const float inv = 1.0f / en;
+                ln.z = ex * inv; ln.w = ey * inv;
+                Pr[j] = ln;
+                pvalid |= (par && same) ? 0u : (1u << j);
+            }
+        }
+        // linearProgram2(projLines, radius, (-dir.y, dir.x), directionOpt = true)
+        const float ox = -li.w, oy = li.z;
+        float qx = ox * vmax, qy = oy * vmax;
+        bool fail2 = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k < i) {
+                const float4 lk = Pr[k];
+                const bool viol = act && !fail2 && ((pvalid >> k) & 1u) && (det2(lk.z, lk.w, lk.x - qx, lk.y - qy) > 0.0f);
+                if (__builtin_amdgcn_ballot_w64(viol) != 0) { // linearProgram1(projLines, k, ...)
+                    const float dot = lk.x * lk.z + lk.y * lk.w;
+                    const float disc = dot * dot + vmax * vmax - (lk.x * lk.x + lk.y * lk.y);
+                    bool ok = !(disc < 0.0f);
+                    const float sq = sqrtf(fmaxf(disc, 0.0f));
+                    float tL = -dot - sq, tR = -dot + sq;
+#pragma unroll
+                    for (int m = 0; m < k; ++m) {
+                        const float4 lm = Pr[m];
+                        const float den = det2(lk.z, lk.w, lm.z, lm.w);
+                        const float num = det2(lm.z, lm.w, lk.x - lm.x, lk.y - lm.y);
+                        if ((pvalid >> m) & 1u) {
+                            if (fabsf(den) <= RVO_EPSILON) {
+                                if (num < 0.0f) ok = false;
+                            } else if (ok) {
+                                const float t = num / den;
+                                if (den >= 0.0f) tR = fminf(tR, t); else tL = fmaxf(tL, t);
+                                if (tL > tR) ok = false;
+                            }
+                        }
+                    }
+                    const float t = (ox * lk.z + oy * lk.w > 0.0f) ? tR : tL;
+                    if (viol) {
+                        if (ok) { qx = lk.x + t * lk.z; qy = lk.y + t * lk.w; }
+                        else fail2 = true;
+                    }
+                }
+            }
+        }
+        if (act) {
+            if (!fail2) { rx = qx; ry = qy; }   // a failed linearProgram2 leaves the result where it was
+            distance = det2(li.z, li.w, li.x - rx, li.y - ry);
+        }
+    }
+}
+
 // Register-resident solve for maxNeighbors = 10 (ORCA_DEFAULTS): same arithmetic and the same order of
 // operations as the generic path, organised for the SIMD:
 //  * neighbours: the 10 smallest (distSq, row) pairs in lexicographic order -- what RVO2's insertion with
@@ -362,11 +449,11 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
 //    that order like positive doubles, so one insertion is ten v_min_f64 / v_max_f64 compare-exchanges;
 //  * ORCA lines in registers; linearProgram2 / linearProgram1 statically unrolled over the (line, earlier
 //    line) triangle, each line's LP1 skipped wave-uniformly when no lane violates that line;
-//  * linearProgram3 (infeasible programme, rare) spills the lines to the per-lane LDS columns and runs the
-//    generic code.
+//  * linearProgram3 (infeasible programme: about a third of the agents of a circular crossing, every substep) stays in
+//    registers too (lp3_fast10).
 __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
                                      float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
-                                     float time_horizon, float dt, const Lines& L, const Lines& P, float& nvx, float& nvy,
+                                     float time_horizon, float dt, float& nvx, float& nvy,
                                      unsigned long long* g_ost, unsigned long long& g_ost_last)
 {
     constexpr int KF = 10;
@@ -445,9 +532,7 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
     }
     OSTAMP(3);
     if (__builtin_amdgcn_ballot_w64(failed < cnt) != 0) { // some lane's programme is infeasible: linearProgram3
-#pragma unroll
-        for (int k = 0; k < KF; ++k) L.set(k, Lr[k]);
-        if (failed < cnt) lp3(L, P, cnt, 0, failed, vmax, rx, ry);
+        lp3_fast10(Lr, cnt, failed, vmax, rx, ry);
     }
     OSTAMP(4);
     nvx = rx; nvy = ry;
@@ -459,10 +544,9 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int T = blockDim.x;
     const int K = a.K;
-    const int KL = a.K + a.KO;                                       // lines per agent: obstacle lines first, then agents
-    // per-lane columns are TL = wpb * rows lanes wide (the lanes that hold an agent: 50 of 64 for 25-agent worlds), and the
-    // register-resident build needs no neighbour columns: 19 KB per block instead of 28 KB, 8 blocks per CU instead of 5,
-    // so the 2048 wavefronts of 4096 x 25 are resident in one round
+    const int KL = FAST10 ? 0 : a.K + a.KO;                          // lines per agent: obstacle lines first, then agents
+    // per-lane columns are TL = wpb * rows lanes wide (the lanes that hold an agent: 50 of 64 for 25-agent worlds); the
+    // register-resident build (FAST10) keeps lines, projected lines and neighbour keys in registers and has no columns at all
     const int TL = a.wpb * a.rows;
     const int KN = FAST10 ? 0 : K;
     float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [2][T] x, y, vx, vy
@@ -536,7 +620,7 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
             float nvx, nvy;
             if constexpr (FAST10) {
                 orca_velocity_fast10(pv, rr, rows, row, px, py, vx, vy, r + margin, vmax, pvx, pvy, a.neighbor_dist,
-                                     a.time_horizon, dt, L, P, nvx, nvy, g_ost, g_ost_last);
+                                     a.time_horizon, dt, nvx, nvy, g_ost, g_ost_last);
             } else {
                 // ---- Agent::computeNeighbors / insertAgentNeighbor (index order; strict <, ties keep order)
                 int cnt = 0;
@@ -695,8 +779,8 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     const int grid = (w->W + a.wpb - 1) / a.wpb;
     const bool fast10 = a.K == 10 && a.nv == 0; // the register-resident solve has no obstacle lines
     const int TL = a.wpb * rows;                // lanes that hold an agent: the width of the per-lane LDS columns
-    const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) + (size_t)(a.K + a.KO) * TL * 2 * sizeof(float4) +
-                         (size_t)((fast10 ? 0 : a.K) + a.KO) * TL * 2 * sizeof(float);
+    const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
+                         (fast10 ? 0 : (size_t)(a.K + a.KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
     if (shmem > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_orca_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     if (fast10) hipLaunchKernelGGL(k_orca_step<true>, dim3(grid), dim3(T), shmem, stream, a);

@@ -70,6 +70,34 @@ def test_orca_kernel_matches_restatement(n, robot, traffic):
     assert np.all(np.linalg.norm(got[:, :n, 3:5], axis=-1) <= S[:, :n, 12] + 5e-2)
 
 
+def test_orca_register_lp3_bit_exact_on_a_circular_crossing():
+    """25-agent circular crossing, the cfg4 workload: about a third of the agents have an infeasible programme in every
+    substep, so this walks the register-resident linearProgram3 (lp3_fast10) for 160 substeps; same IEEE operations in the
+    same order as the C restatement -> identical bits."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n = 24, 25
+    pos, yaw, g = sc.circular_crossing(W, n, 7.0, 4242)
+    S = sc.make_states(pos, yaw, g).astype(np.float32)
+    d = g[:, :, 0] - S[:, :, 0:2]
+    S[:, :, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    margin = np.full((W, n), 0.01, np.float32)
+    cw = CrowdWorlds(S, g, None, margin, None, type="orca")
+    ref, rg = S, g
+    used_lp3 = 0
+    for _ in range(8):
+        cw.step(0.0125, 20)
+        ref, rg, _ = orc.orca_step_block(ref, rg, margin, 0.0125, 20)
+        v, lines, nl = orc.orca_new_velocities(ref[0, :, 0:2], ref[0, :, 3:5], ref[0, :, 5:7], ref[0, :, 8] + 0.01, ref[0, :, 12],
+                                               time_step=0.0125, return_lines=True)
+        for a in range(n):
+            L = lines[a, :nl[a]].astype(np.float64)
+            used_lp3 += int(len(L) and np.max(L[:, 2] * (L[:, 1] - v[a, 1]) - L[:, 3] * (L[:, 0] - v[a, 0])) > 1e-6)
+    np.testing.assert_array_equal(cw.get_states()[..., [0, 1, 3, 4, 5, 6]], ref[..., [0, 1, 3, 4, 5, 6]])
+    assert used_lp3 >= 20, used_lp3   # the scene does exercise linearProgram3
+
+
 def test_orca_peek_does_not_commit():
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
