@@ -10,7 +10,7 @@
 // neighbours (brute force over the edges), the obstacle ORCA lines and linearProgram3 with hard obstacle lines run on the
 // generic LDS-column path below.
 //
-// Mapping: lane = agent row, floor(64/rows) worlds per wavefront, the rows' (x, y, vx, vy, radius) in LDS,
+// Mapping: lane = agent row, floor(64/rows) worlds per wavefront (one world per block of 256 / 512 lanes above 64 rows), the rows' (x, y, vx, vy, radius) in LDS,
 // every lane's neighbour list / ORCA lines / LP3 projection lines in per-lane LDS columns (the 2-D
 // linear programme is divergent by nature; lanes walk their own constraints).  n_substeps are fused in
 // one launch.  IEEE divide / sqrt and no FMA contraction, to follow the CPU restatement op for op.
@@ -538,8 +538,9 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
     nvx = rx; nvy = ry;
 }
 
-template <bool FAST10>
-__global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
+// MAXT = 64: floor(64 / rows) worlds per one-wavefront block; MAXT = 256 / 512: one world of up to MAXT rows per block
+template <bool FAST10, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int T = blockDim.x;
@@ -688,7 +689,10 @@ __global__ __launch_bounds__(64) void k_orca_step(const OArgs a)
         if (a.flags & CS_RESPAWN) { // motion_model_manager.py:407-422, sequential inside a world
             const float rdx = px - g0x, rdy = py - g0y;
             const int flag = (human && respawn_here && sqrtf(rdx * rdx + rdy * rdy) < 3.0f) ? 1 : 0;
-            if (__builtin_amdgcn_ballot_w64(flag != 0) != 0) {
+            bool any_flag;
+            if constexpr (MAXT == 64) any_flag = __builtin_amdgcn_ballot_w64(flag != 0) != 0;
+            else any_flag = __syncthreads_or(flag) != 0;        // a world spans several wavefronts: block-wide vote
+            if (any_flag) {
                 lds_flag[tid] = flag;
                 lds_g0x[tid] = g0x;
                 __syncthreads();
@@ -756,13 +760,13 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (w->orca_n_vertices > 0 && !(w->orca_time_horizon_obst > 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
     if (w->flags & CS_ROBOT_UNICYCLE) return fail(CS_ERR_ARG, "ORCA step supports holonomic robot actions only");
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
-    if (rows > 64) return fail(CS_ERR_ARG, "ORCA step supports up to 64 rows per world");
+    if (rows > 512) return fail(CS_ERR_ARG, "ORCA step supports up to 512 rows per world");
     if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
     if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
     OArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = w->W; a.n = w->n; a.rows = rows; a.G = w->G; a.flags = w->flags; a.nsub = n_substeps;
-    a.wpb = 64 / rows; a.K = w->orca_max_neighbors;
+    a.wpb = rows <= 64 ? 64 / rows : 1; a.K = w->orca_max_neighbors;
     a.dt = dt; a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
     a.bx = w->respawn_bound_x; a.by = w->respawn_bound_y;
     a.S = w->d_state;
@@ -775,16 +779,25 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     a.stamps = g_stamp_buf;
 #endif
     if (d_peek) a.flags &= ~CS_RESPAWN;
-    const int T = 64;
+    const int T = rows <= 64 ? 64 : (rows <= 256 ? 256 : 512);   // worlds of more than 64 rows: one world per block
     const int grid = (w->W + a.wpb - 1) / a.wpb;
     const bool fast10 = a.K == 10 && a.nv == 0; // the register-resident solve has no obstacle lines
     const int TL = a.wpb * rows;                // lanes that hold an agent: the width of the per-lane LDS columns
     const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
                          (fast10 ? 0 : (size_t)(a.K + a.KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
-    if (shmem > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k_orca_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    if (fast10) hipLaunchKernelGGL(k_orca_step<true>, dim3(grid), dim3(T), shmem, stream, a);
-    else hipLaunchKernelGGL(k_orca_step<false>, dim3(grid), dim3(T), shmem, stream, a);
+    if (shmem > 160 * 1024) return fail(CS_ERR_ARG, "ORCA worlds of this many rows need max_neighbors = 10 and no static obstacles "
+                                                    "(the per-agent line columns do not fit the LDS)");
+    auto launch = [&](auto kernel) -> int {
+        if (shmem > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(T), shmem, stream, a);
+        return CS_OK;
+    };
+    int rc;
+    if (T == 64) rc = fast10 ? launch(k_orca_step<true, 64>) : launch(k_orca_step<false, 64>);
+    else if (T == 256) rc = fast10 ? launch(k_orca_step<true, 256>) : launch(k_orca_step<false, 256>);
+    else rc = fast10 ? launch(k_orca_step<true, 512>) : launch(k_orca_step<false, 512>);
+    if (rc != CS_OK) return rc;
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

@@ -98,6 +98,60 @@ def test_orca_register_lp3_bit_exact_on_a_circular_crossing():
     assert used_lp3 >= 20, used_lp3   # the scene does exercise linearProgram3
 
 
+@pytest.mark.parametrize("n,robot", [(65, False), (150, True), (256, False), (300, True), (512, False)])
+def test_orca_worlds_of_more_than_64_rows(n, robot):
+    """Above 64 rows a world takes a block of 256 / 512 lanes (several wavefronts: block-wide barriers and respawn vote)."""
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    n = n - int(robot)
+    rng = np.random.default_rng(n)
+    W, rows = 3, n + int(robot)
+    S = np.zeros((W, rows, 13), np.float32)
+    goals = np.full((W, n, 2, 2), np.nan, np.float32)
+    side = int(np.ceil(np.sqrt(rows)))
+    for w in range(W):   # a jittered lattice walking towards the mirrored position: dense, every agent has 10 neighbours
+        gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+        pos = (np.stack([gx.ravel(), gy.ravel()], -1)[:rows] - side / 2) * 0.9 + rng.uniform(-0.1, 0.1, (rows, 2))
+        S[w, :, 0:2] = pos
+        S[w, :, 3:5] = rng.normal(0, 0.3, (rows, 2))
+        S[w, :, 8] = rng.uniform(0.25, 0.35, rows)
+        S[w, :, 12] = rng.uniform(0.8, 1.2, rows)
+        goals[w, :, 0] = -pos[:n]
+        goals[w, :, 1] = pos[:n]
+        d = goals[w, :, 0] - pos[:n]
+        nrm = np.linalg.norm(d, axis=1, keepdims=True)
+        S[w, :n, 5:7] = np.where(nrm > S[w, :n, 12:13], d / nrm, d)
+        S[w, :n, 10:12] = goals[w, :, 0]
+    margin = np.full((W, rows), 0.01, np.float32)
+    robots = S[:, -1].copy() if robot else None
+    action = rng.normal(0, 0.5, (W, 2)).astype(np.float32) if robot else None
+    cw = CrowdWorlds(S, goals, None, margin, None, type="orca", robot_row=robot, robot=robots, respawn_bounds=(side * 0.3, 1.0))
+    cw.step(0.0125, 12, action)
+    ref, rgoals, rrobot = orc.orca_step_block(S, goals, margin, 0.0125, 12, robot_visible=robot, robot=robots, action=action,
+                                              respawn=True, bounds=(side * 0.3, 1.0))
+    cols = [0, 1, 3, 4, 5, 6, 10, 11]
+    np.testing.assert_array_equal(cw.get_states()[..., cols], ref[..., cols])
+    np.testing.assert_array_equal(cw.get_goals(), rgoals)
+    if robot:
+        np.testing.assert_array_equal(cw.get_robot()[:, [0, 1, 3, 4]], rrobot[:, [0, 1, 3, 4]])
+
+
+def test_orca_large_world_limits():
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    S = np.zeros((1, 513, 13), np.float32)
+    S[0, :, 0] = np.arange(513)
+    S[0, :, 8] = 0.3
+    S[0, :, 12] = 1.0
+    g = np.zeros((1, 513, 1, 2), np.float32)
+    with pytest.raises(ValueError, match="512"):
+        CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca").step(0.0125, 1)
+    # the generic variant keeps (K + obstacle lines) x 40 B per agent in the LDS: 300 agents with a square of walls do not fit
+    verts = orc.process_obstacles([[[-50, -50], [50, -50], [50, 50], [-50, 50]]])
+    with pytest.raises(ValueError, match="LDS"):
+        CrowdWorlds(S[:, :300], g[:, :300], None, np.zeros((1, 300), np.float32), None, type="orca", orca_vertices=verts).step(0.0125, 1)
+
+
 def test_orca_peek_does_not_commit():
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
