@@ -233,6 +233,36 @@ int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32
 int cs_laser_scan(const cs_worlds* w, const float* d_pose, int pose_stride, float range, int samples,
                   float max_distance, float* d_out, void* stream);
 
+/*
+ * cs_robot_model_step  replaces MotionModelManager.update_robot(t, dt) (motion_model_manager.py:615-653) for a robot that
+ *   follows a HUMAN motion model, as set by set_robot_motion_model / SocialNavGym.set_human_motion_model_as_robot_policy
+ *   (motion_model_manager.py:552-589, social_nav_sim.py:862-873): ONE Euler substep of the robot of every world, the robot half
+ *   of the substep loop of SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263; the human half is cs_step with
+ *   n_substeps = 1 and no action, which picks the moved robot up from w->d_robot when it is visible).
+ *   robot_type 0..8: compute_robot_forces (:591-613) with the single-agent force functions of forces.py and the Euler update
+ *     (:72-86); robot_params = the robot's 20 parameters (agent.py:269 slots; host pointer).  d_robot_memory [W][2] keeps
+ *     robot.desired_force between substeps (the reference leaves it untouched within one radius of the goal, forces.py:12-16);
+ *     zero it when the robot is created.  Walls: w->d_obstacles.
+ *   robot_type CS_ORCA: one doStep of the robot's own RVO2 simulator (:580-589, :641-653: humans with preferred velocity 0,
+ *     the robot last) = the robot's ORCA solve against the humans and w->d_orca_vertices, with w->orca_* parameters;
+ *     robot_params and d_robot_memory are ignored.  PARITY UNPINNED like cs_step with CS_ORCA.
+ *   robot_margin: robot.safety_space (SFM: 0 or 0.01 + safety_space; ORCA: 0.01 + safety_space, :147-170, :588).
+ *   d_human_margin [W][rows]: the humans' safety_space as the ROBOT's model sees it (SFM robot: human.safety_space;
+ *     ORCA robot: 0.01 + safety_space); NULL = w->d_safety.
+ *   Reads the humans from w->d_state; updates w->d_robot rows (x, y, yaw, Vx, Vy, BVx, BVy, Omega) and, with CS_ROBOT_ROW,
+ *   the last state row.  Errors: robot_type outside 0..9 -> CS_ERR_TYPE (the reference raises, :589).
+ */
+int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
+                        const float* d_human_margin, float* d_robot_memory, float dt, void* stream);
+
+/*
+ * cs_actual_collision_reward  replaces SocialNavGym.check_actual_collisions_and_goal (social_nav_gym.py:107-118) +
+ *   compute_reward_and_infos (social_nav_sim.py:986-1029) for W worlds: distances of the CURRENT state (no swept test;
+ *   collision when the smallest distance is <= 0).  Same reward_cfg and d_out layout as cs_collision_reward.
+ */
+int cs_actual_collision_reward(const cs_worlds* w, float T, const float* d_global_time, const float* reward_cfg /* host, 5 floats */,
+                               float* d_out, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

@@ -460,3 +460,135 @@ def social_momentum_step(pos, vel, radius, safety, vd, goals, dt, robot=None, n_
     if amb_eps is not None:
         return new_pos, new_vel, goals, rewards, chosen, (r_lo, r_hi)
     return new_pos, new_vel, goals, rewards, chosen
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The robot driven by a human motion model (imitation learning).  Restates motion_model_manager.py:552-653
+# (set_robot_motion_model / compute_robot_forces / update_robot) with the single-agent force functions of forces.py
+# (:9-16 desired, :27-53 obstacle Helbing / Guo, :153-218 social Helbing / Guo / Moussaid, :279-290 torque) and the Euler
+# updates of motion_model_manager.py:72-86.  float64 like the reference.  Pinned on tests/golden/g11_imitation.npz.
+# The single-agent functions are NOT the parallel ones: Guo's obstacle force is a plain sum (no mean), a robot within its
+# radius of the goal keeps the desired force of the previous substep, the social force sums over the humans in index order.
+ROBOT_MODELS = ["sfm_helbing", "sfm_guo", "sfm_moussaid", "hsfm_farina", "hsfm_guo", "hsfm_moussaid", "hsfm_new",
+                "hsfm_new_guo", "hsfm_new_moussaid"]
+# parameter slots (agent.py:269): 0 relaxation_time 1 Ai 2 Aw 3 Bi 4 Bw 5 Ci 6 Cw 7 Di 8 Dw 9 Ei 10 k1 11 k2 12 lambda
+# 13 gamma 14 ns 15 ns1 16 ko 17 kd 18 alpha 19 k_lambda
+
+
+def _bound_angle(a):
+    """utils.py:7-13 (keeps +pi and -pi as they are)."""
+    import math
+    two_pi = 2 * math.pi
+    if a >= two_pi:
+        a = math.fmod(a, two_pi)
+    if a <= -two_pi:
+        a = math.fmod(a, two_pi)     # Python's a % -two_pi of a negative a
+    if a > math.pi:
+        a -= two_pi
+    if a < -math.pi:
+        a += two_pi
+    return a
+
+
+def closest_points(walls, p):
+    """Wall.get_closest_point for every wall (obstacle.py:53-66): the LAST nearest point over the segments (<=)."""
+    out = []
+    for wall in ([] if walls is None else walls):
+        best, bd = np.zeros(2), 10000.0
+        for seg in wall:
+            if np.any(np.isnan(seg)):
+                continue
+            a, b = seg[0], seg[1]
+            t = np.dot(p - a, b - a) / (np.linalg.norm(b - a) ** 2)
+            h = a + min(max(0.0, t), 1.0) * (b - a)
+            d = np.linalg.norm(h - p)
+            if d <= bd:
+                best, bd = h, d
+        out.append(best)
+    return out
+
+
+def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls, dt):
+    """One update_robot(t, dt) of an SFM / HSFM robot.  row = [x, y, yaw, vx, vy, bvx, bvy, omega, radius, mass, gx, gy,
+    desired_speed, safety_space, desired_force_x, desired_force_y] (copied); returns the new row."""
+    r = np.array(row, dtype=np.float64)
+    headed = model.startswith("hsfm")
+    guo, mou = model.endswith("guo"), model.endswith("moussaid")
+    pos, yaw, vel, bvel, om = r[0:2].copy(), r[2], r[3:5].copy(), r[5:7].copy(), r[7]
+    radius, mass, goal, vd, safety = r[8], r[9], r[10:12], r[12], r[13]
+    inertia = 0.5 * mass * radius * radius
+    R = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]])
+    if headed:
+        vel = R @ bvel
+    # desired force: kept from the previous substep when within one radius of the goal (forces.py:12-16)
+    diff = goal - pos
+    dist = np.linalg.norm(diff)
+    fd = r[14:16].copy()
+    if dist > radius:
+        fd = mass * (diff / dist * vd - vel) / P[0]
+    # obstacle force
+    fo = np.zeros(2)
+    obs = closest_points(walls, pos)
+    for o in obs:
+        d = pos - o
+        dn = np.linalg.norm(d)
+        n_iw = d / dn
+        t_iw = np.array([-n_iw[1], n_iw[0]])
+        dv = -np.dot(vel, t_iw)
+        rd = radius + safety - dn
+        if guo:
+            fo += (P[2] * np.exp(rd / P[4]) + P[10] * max(0, rd)) * n_iw + (-P[6] * np.exp(rd / P[8]) - P[11] * max(0, rd)) * dv * t_iw
+        else:
+            fo += (P[2] * np.exp(rd / P[4]) + P[10] * max(0, rd)) * n_iw - P[11] * max(0, rd) * dv * t_iw
+    if obs and not guo:
+        fo /= len(obs)
+    # social force from the humans, index order
+    fs = np.zeros(2)
+    for j in range(len(hum_pos)):
+        rij = radius + safety + hum_radius[j] + hum_safety[j]
+        d = pos - hum_pos[j]
+        dn = np.linalg.norm(d)
+        n_ij = d / dn
+        rd = rij - dn
+        if mou:
+            iv = P[12] * (vel - hum_vel[j]) - n_ij
+            inorm = np.linalg.norm(iv)
+            i_ij = iv / inorm
+            th = _bound_angle(np.arctan2(n_ij[1], n_ij[0]) - np.arctan2(i_ij[1], i_ij[0]) + np.pi)
+            k = np.sign(th)
+            h_ij = np.array([-i_ij[1], i_ij[0]])
+            F = P[13] * inorm
+            dvh = np.dot(hum_vel[j] - vel, h_ij)
+            fs -= (P[9] * np.exp(-dn / F) * (np.exp(-(P[15] * F * th) ** 2) * i_ij + k * np.exp(-(P[14] * F * th) ** 2) * h_ij)
+                   + P[10] * max(0, rd) * i_ij + P[11] * max(0, rd) * dvh * h_ij)
+        else:
+            t_ij = np.array([-n_ij[1], n_ij[0]])
+            dv = np.dot(hum_vel[j] - vel, t_ij)
+            if guo:
+                fs += (P[1] * np.exp(rd / P[3]) + P[10] * max(0, rd)) * n_ij + (P[5] * np.exp(rd / P[7]) + P[11] * max(0, rd) * dv) * t_ij
+            else:
+                fs += (P[1] * np.exp(rd / P[3]) + P[10] * max(0, rd)) * n_ij + P[11] * max(0, rd) * dv * t_ij
+    if not headed:
+        gf = fd + fo + fs
+        pos = pos + vel * dt
+        vel = vel + gf / mass * dt
+        sp = np.linalg.norm(vel)
+        if sp > vd:
+            vel = vel / sp * vd
+    else:
+        tot = fd if model in ("hsfm_farina", "hsfm_guo", "hsfm_moussaid") else fd + fo + fs
+        tn = np.linalg.norm(tot)
+        k_theta = inertia * P[19] * tn
+        k_omega = inertia * (1 + P[18]) * np.sqrt(P[19] * tn / P[18])
+        torque = -k_theta * _bound_angle(yaw - np.arctan2(tot[1], tot[0])) - k_omega * om
+        gf = np.array([np.dot(fd + fo + fs, R[:, 0]), P[16] * np.dot(fo + fs, R[:, 1]) - P[17] * bvel[1]])
+        pos = pos + vel * dt
+        yaw = _bound_angle(yaw + om * dt)
+        bvel = bvel + gf / mass * dt
+        om = om + torque / inertia * dt
+        sp = np.linalg.norm(bvel)
+        if sp > vd:
+            bvel = bvel / sp * vd
+        vel = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]) @ bvel
+    r[0:2], r[2], r[3:5], r[5:7], r[7], r[14:16] = pos, yaw, vel, bvel, om, fd
+    return r

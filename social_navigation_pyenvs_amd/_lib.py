@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "cs_event_elapsed_ms", "cs_stream_wait_event", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
     "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
     "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry", "cs_lookahead",
-    "cs_generate_scratch_bytes", "cs_generate_worlds", "cs_laser_scan",
+    "cs_generate_scratch_bytes", "cs_generate_worlds", "cs_laser_scan", "cs_robot_model_step", "cs_actual_collision_reward",
 ]
 
 

@@ -231,6 +231,60 @@ class CrowdWorlds:
                                         C.c_float(max_distance), C.c_void_p(out.ptr), C.c_void_p(self.stream)))
         return out.download(self.stream)
 
+    # ------------------------------------------------------------------ the robot under a human motion model
+    def set_robot_model(self, model, params=None, margin=0.0, human_margin=None, orca_vertices=None) -> None:
+        """MotionModelManager.set_robot_motion_model (motion_model_manager.py:552-589) for every world: the robot rows are
+        stepped by ``model`` (one of HUMAN_MODELS: nine SFM / HSFM titles or "orca") instead of an action.
+        ``params``: the robot's 20 parameters (SFM / HSFM); ``margin``: robot.safety_space as its model adds it to the radius;
+        ``human_margin`` [W, rows] / scalar: the humans' safety space as the robot's model sees it (None = the crowd's own);
+        ``orca_vertices``: RVO2 vertex records of the walls for an ORCA robot (rvo2.process_obstacles)."""
+        if self.d_robot is None:
+            raise ValueError("set_robot_model needs the robot rows")
+        if isinstance(model, str):
+            if model not in HUMAN_MODELS:
+                raise Exception(f"The robot motion model '{model}' does not exist")  # motion_model_manager.py:589
+            model = HUMAN_MODELS.index(model)
+        self.robot_model = int(model)
+        self.robot_params = np.zeros(20, np.float32) if params is None else np.ascontiguousarray(params, dtype=np.float32).reshape(20)
+        self.robot_margin = float(margin)
+        self.d_human_margin = None
+        if human_margin is not None:
+            hm = np.ascontiguousarray(np.broadcast_to(np.asarray(human_margin, dtype=np.float32), (self.W, self.rows)))
+            self.d_human_margin = DeviceBuffer.from_numpy(hm)
+        self.d_robot_memory = DeviceBuffer.from_numpy(np.zeros((self.W, 2), np.float32))
+        if orca_vertices is not None and len(orca_vertices):
+            ov = np.ascontiguousarray(orca_vertices, dtype=np.float32).reshape(-1, 8)
+            self.d_orca_vertices, self.orca_n_vertices = DeviceBuffer.from_numpy(ov), len(ov)
+
+    def robot_model_step(self, dt: float) -> None:
+        """update_robot(t, dt) of every world (motion_model_manager.py:615-653), in place on the robot rows."""
+        if getattr(self, "robot_model", None) is None:
+            raise ValueError("no robot motion model set")
+        d = self.descriptor()
+        pr = (C.c_float * 20)(*[float(x) for x in self.robot_params])
+        check(_lib.load().cs_robot_model_step(C.byref(d), C.c_int(self.robot_model), pr, C.c_float(self.robot_margin),
+                                              C.c_void_p(_ptr(self.d_human_margin)), C.c_void_p(_ptr(self.d_robot_memory)),
+                                              C.c_float(dt), C.c_void_p(self.stream)))
+
+    def imitation_block(self, dt: float, n_substeps: int) -> None:
+        """The substep loop of SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263):
+        n_substeps x { update_robot(t, dt) ; update_humans(t, dt) }, launches only, no host copy."""
+        for _ in range(int(n_substeps)):
+            self.robot_model_step(dt)
+            self.step(dt, 1, None)
+
+    def actual_collision_reward(self, T: float, global_time, reward_cfg=(50.0, 1.0, -0.25, 0.2, 0.5)) -> np.ndarray:
+        """[W, 7] like collision_reward, from the distances of the current state (social_nav_gym.py:107-118)."""
+        if self.d_robot is None:
+            raise ValueError("actual_collision_reward needs the robot rows")
+        d = self.descriptor()
+        gt = self._upload("global_time", np.broadcast_to(np.asarray(global_time, dtype=np.float32), (self.W,)))
+        out = self._buffer("reward_out", (self.W, 7))
+        cfg = (C.c_float * 5)(*[float(x) for x in reward_cfg])
+        check(_lib.load().cs_actual_collision_reward(C.byref(d), C.c_float(T), C.c_void_p(gt.ptr), cfg, C.c_void_p(out.ptr),
+                                                     C.c_void_p(self.stream)))
+        return out.download(self.stream)
+
     # ------------------------------------------------------------------ state access
     def sync(self):
         _lib.stream_sync(self.stream)

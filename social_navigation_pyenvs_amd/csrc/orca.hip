@@ -590,12 +590,13 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
     if (human) { gi = a.goals + ((long)w * n + row) * a.G * 2; g0x = gi[0]; g0y = gi[1]; }
 
     // the true robot (moves with the action); the simulator's copy is the state row
-    const bool robot_moves = a.action != nullptr && a.robot != nullptr;
+    const bool has_robot = a.robot != nullptr;
+    const bool robot_moves = a.action != nullptr && has_robot;
     float rbx = 0, rby = 0, rbvx = 0, rbvy = 0, ax = 0, ay = 0;
-    if (valid && robot_moves) {
+    if (valid && has_robot) {
         const float* rb = a.robot + (long)w * 13;
         rbx = rb[0]; rby = rb[1]; rbvx = rb[3]; rbvy = rb[4];
-        ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1];
+        if (robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
     }
 
     if (valid) { lds_pv[tid] = make_float4(px, py, vx, vy); lds_r[tid] = r + margin; lds_rp[tid] = r; }
@@ -681,8 +682,9 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
             if (nrm > vmax) { pvx = ddx / nrm; pvy = ddy / nrm; } else { pvx = ddx; pvy = ddy; }
             lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
         } else if (is_robot) {
-            // set_state_orca(robot) AFTER doStep (:389): the simulator's robot agent takes the true state
-            if (robot_moves) { px = rbx; py = rby; vx = rbvx; vy = rbvy; }
+            // set_state_orca(robot) AFTER doStep (:389): the simulator's robot agent takes the true state (moved by the
+            // action of this launch, or by whoever updated w->d_robot before it: cs_robot_model_step)
+            if (has_robot) { px = rbx; py = rby; vx = rbvx; vy = rbvy; }
             lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
         }
         __syncthreads();
@@ -745,6 +747,92 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
     }
 }
 
+
+// ---- the robot's own ORCA model (imitation learning): motion_model_manager.py:580-589 builds a SECOND simulator whose agents
+// are the humans (preferred velocity (0, 0), re-set from the true human states before every doStep, :641-643) and the robot
+// (last agent); only the robot's new velocity and position are read back (:645-651), so one doStep of that simulator is the
+// robot's computeNeighbors + computeNewVelocity + update: one lane per world, the generic LDS-column code above.
+// The robot's preferred velocity is update_goals_orca(robot) of its current position (:134-141).
+struct ORArgs {
+    int W, n, rows, robot_row, write_row, K, KO, nv;
+    float dt, neighbor_dist, time_horizon, time_horizon_obst, robot_margin;
+    float* S; long as, fs;
+    const float* hmargin;   // [W][rows]
+    float* robot;           // [W][13]
+    const float* verts;
+};
+
+__global__ __launch_bounds__(64) void k_orca_robot_step(const ORArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int T = 64, tid = threadIdx.x;
+    const int KL = a.K + a.KO;
+    float4* lds_L = reinterpret_cast<float4*>(smem_raw);             // [KL][T]
+    float4* lds_P = lds_L + KL * T;                                  // [KL][T]
+    float* lds_nd = reinterpret_cast<float*>(lds_P + KL * T);        // [K][T]
+    int* lds_ni = reinterpret_cast<int*>(lds_nd + a.K * T);          // [K][T]
+    float* lds_od = reinterpret_cast<float*>(lds_ni + a.K * T);      // [KO][T]
+    int* lds_oi = reinterpret_cast<int*>(lds_od + a.KO * T);         // [KO][T]
+    const int w = blockIdx.x * T + tid;
+    if (w >= a.W) return;
+    float* rb = a.robot + (long)w * 13;
+    float px = rb[0], py = rb[1], vx = rb[3], vy = rb[4];
+    const float r = rb[8] + a.robot_margin, gx = rb[10], gy = rb[11], vmax = rb[12];
+    float pvx, pvy;
+    {
+        const float ddx = gx - px, ddy = gy - py;
+        const float nrm = sqrtf(ddx * ddx + ddy * ddy);
+        if (nrm > vmax) { pvx = ddx / nrm; pvy = ddy / nrm; } else { pvx = ddx; pvy = ddy; }
+    }
+    const Lines L{lds_L, T, tid}, P{lds_P, T, tid};
+    const float* Sw = a.S + (long)w * a.rows * a.as;
+    int cnt = 0;
+    float rangeSq = a.neighbor_dist * a.neighbor_dist;
+    if (a.K > 0) {
+        for (int b = 0; b < a.n; ++b) {
+            const float* s = Sw + (long)b * a.as;
+            const float ddx = px - s[0], ddy = py - s[a.fs];
+            const float dsq = ddx * ddx + ddy * ddy;
+            if (dsq < rangeSq) {
+                if (cnt < a.K) ++cnt;
+                int i = cnt - 1;
+                while (i != 0 && dsq < lds_nd[(i - 1) * T + tid]) {
+                    lds_nd[i * T + tid] = lds_nd[(i - 1) * T + tid];
+                    lds_ni[i * T + tid] = lds_ni[(i - 1) * T + tid];
+                    --i;
+                }
+                lds_nd[i * T + tid] = dsq;
+                lds_ni[i * T + tid] = b;
+                if (cnt == a.K) rangeSq = lds_nd[(cnt - 1) * T + tid];
+            }
+        }
+    }
+    int nobst = 0;
+    if (a.nv > 0) {
+        const float rng = a.time_horizon_obst * vmax + r;
+        const int no = obstacle_neighbors(a.verts, a.nv, a.KO, px, py, rng * rng, lds_od, lds_oi, T, tid);
+        nobst = obstacle_lines(a.verts, lds_oi, no, T, tid, px, py, vx, vy, r, 1.0f / a.time_horizon_obst, L);
+    }
+    const float invT = 1.0f / a.time_horizon;
+    for (int k = 0; k < cnt; ++k) {
+        const int b = lds_ni[k * T + tid];
+        const float* s = Sw + (long)b * a.as;
+        const float4 q = make_float4(s[0], s[a.fs], s[3 * a.fs], s[4 * a.fs]);
+        L.set(nobst + k, orca_line(px, py, vx, vy, q, r + (s[8 * a.fs] + a.hmargin[(long)w * a.rows + b]), invT, a.dt));
+    }
+    const int total = nobst + cnt;
+    float nvx, nvy;
+    const int failed = lp2(L, total, vmax, pvx, pvy, false, nvx, nvy);
+    if (failed < total) lp3(L, P, total, nobst, failed, vmax, nvx, nvy);
+    vx = nvx; vy = nvy;
+    px += vx * a.dt; py += vy * a.dt;
+    rb[0] = px; rb[1] = py; rb[3] = vx; rb[4] = vy;
+    if (a.write_row) {
+        float* s = a.S + ((long)w * a.rows + a.n) * a.as;
+        s[0] = px; s[a.fs] = py; s[3 * a.fs] = vx; s[4 * a.fs] = vy;
+    }
+}
+
 } // namespace
 
 namespace csimpl {
@@ -798,6 +886,30 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     else if (T == 256) rc = fast10 ? launch(k_orca_step<true, 256>) : launch(k_orca_step<false, 256>);
     else rc = fast10 ? launch(k_orca_step<true, 512>) : launch(k_orca_step<false, 512>);
     if (rc != CS_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream)
+{
+    if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
+    if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
+    if (w->orca_n_vertices < 0 || (w->orca_n_vertices > 0 && !w->d_orca_vertices)) return fail(CS_ERR_ARG, "bad ORCA obstacle vertices");
+    if (w->orca_n_vertices > 0 && !(w->orca_time_horizon_obst > 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
+    ORArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = w->W; a.n = w->n; a.robot_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0; a.rows = w->n + a.robot_row;
+    a.write_row = a.robot_row && w->type != CS_ORCA;   // an ORCA crowd takes the moved robot after its own doStep (:389)
+    a.K = w->orca_max_neighbors; a.nv = w->orca_n_vertices; a.KO = a.nv > 0 ? (a.nv < KOBST ? a.nv : KOBST) : 0;
+    a.dt = dt; a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
+    a.time_horizon_obst = w->orca_time_horizon_obst; a.robot_margin = robot_margin;
+    a.S = w->d_state;
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * a.rows; }
+    a.hmargin = d_human_margin; a.robot = w->d_robot; a.verts = w->d_orca_vertices;
+    const size_t shmem = (size_t)(a.K + a.KO) * 64 * (2 * sizeof(float4) + 2 * sizeof(float));
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_orca_robot_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_orca_robot_step, dim3((w->W + 63) / 64), dim3(64), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

@@ -1,0 +1,286 @@
+// robot_model.hip -- the robot driven by a human motion model (imitation learning), W worlds at once.
+//
+// Restates MotionModelManager.update_robot(t, dt) with a robot model set by set_robot_motion_model
+//   /root/reference/social_gym/src/motion_model_manager.py:552-653   (compute_robot_forces :591-613)
+// for the nine SFM / HSFM titles, with the SINGLE-AGENT force functions the reference uses for the robot
+//   /root/reference/social_gym/src/forces.py:9-16    desired force (kept from the previous substep within one radius of
+//                                                     the goal: the `else` branch does not touch agent.desired_force)
+//   forces.py:27-53     obstacle force, Helbing (mean over the walls) / Guo (plain sum)
+//   forces.py:153-218   social force Helbing / Guo / Moussaid over the humans in index order (consider_robot = False)
+//   forces.py:279-290   torque Farina (desired force) / "new" (total force)
+// and the Euler updates motion_model_manager.py:72-86 (position first, then velocity, speed clamp; headed: yaw, body
+// velocity, angular velocity, linear velocity from the NEW yaw).  These are not the parallel functions of the crowd step.
+// The robot's ORCA model (a second RVO simulator, :580-589, :641-653) lives in orca.hip (orca_robot_launch).
+//
+// One wavefront per world: lane j sums the social force of humans j, j + 64, ...; a butterfly reduction; lane 0 does the
+// walls (closest point of every polygon, obstacle.py:53-66), the torque and the Euler update and writes the robot row
+// (w->d_robot, and the last state row when the robot is visible).  Not a hot path: W x (n + O*Smax) pair terms per substep.
+// cs_actual_collision_reward restates check_actual_collisions_and_goal + compute_reward_and_infos
+//   /root/reference/social_gym/social_nav_gym.py:107-118, social_nav_sim.py:986-1029.
+// gfx950 only.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "common.h"
+#include "crowdstep.h"
+
+namespace {
+
+using csimpl::fail;
+
+struct RArgs {
+    int W, n, rows, O, Smax, type, robot_row, write_row, obstacles_shared;
+    float dt, robot_margin;
+    float P[20];             // agent.py:269 slots: 0 relaxation_time 1 Ai 2 Aw 3 Bi 4 Bw 5 Ci 6 Cw 7 Di 8 Dw 9 Ei 10 k1 11 k2
+                             // 12 lambda 13 gamma 14 ns 15 ns1 16 ko 17 kd 18 alpha 19 k_lambda
+    float* S; long as, fs;
+    const float* hmargin;    // [W][rows]
+    float* robot;            // [W][13]
+    float* memory;           // [W][2] desired force of the previous substep
+    const float* obstacles;
+};
+
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float TWO_PI_F = 6.28318530717958647692f;
+
+// utils.py:7-13
+__device__ __forceinline__ float bound_angle(float a)
+{
+    if (a >= TWO_PI_F) a = fmodf(a, TWO_PI_F);
+    if (a <= -TWO_PI_F) a = fmodf(a, TWO_PI_F);
+    if (a > PI_F) a -= TWO_PI_F;
+    if (a < -PI_F) a += TWO_PI_F;
+    return a;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= a.W) return;
+    float* rb = a.robot + (long)w * 13;
+    const float px = rb[0], py = rb[1], yaw = rb[2], bvx = rb[5], bvy = rb[6], om = rb[7];
+    const float radius = rb[8], mass = rb[9], gx = rb[10], gy = rb[11], vd = rb[12];
+    const bool headed = a.type >= CS_HSFM_FARINA;
+    const int soc = a.type % 3;                 // 0 Helbing, 1 Guo, 2 Moussaid
+    const bool torque_new = a.type >= CS_HSFM_NEW;
+    float sn, cs;
+    sincosf(yaw, &sn, &cs);
+    float vx = rb[3], vy = rb[4];
+    if (headed) { vx = cs * bvx - sn * bvy; vy = sn * bvx + cs * bvy; }   // headed_agent_update_linear_velocity (:143-145)
+    const float* P = a.P;
+    const float rme = radius + a.robot_margin;
+
+    // ---- social force: humans in strides of 64, then a butterfly sum
+    float fsx = 0.0f, fsy = 0.0f;
+    for (int j = lane; j < a.n; j += 64) {
+        const float* s = a.S + ((long)w * a.rows + j) * a.as;
+        const float hx = s[0], hy = s[a.fs], hvx = s[3 * a.fs], hvy = s[4 * a.fs];
+        const float rij = rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + j];
+        const float dx = px - hx, dy = py - hy;
+        const float dn = sqrtf(dx * dx + dy * dy);
+        const float nx = dx / dn, ny = dy / dn;
+        const float rd = rij - dn;
+        const float comp = fmaxf(0.0f, rd);
+        if (soc == 2) {
+            const float ivx = P[12] * (vx - hvx) - nx, ivy = P[12] * (vy - hvy) - ny;
+            const float inorm = sqrtf(ivx * ivx + ivy * ivy);
+            const float ix = ivx / inorm, iy = ivy / inorm;
+            const float th = bound_angle(atan2f(ny, nx) - atan2f(iy, ix) + PI_F);
+            const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
+            const float hxv = -iy, hyv = ix;
+            const float F = P[13] * inorm;
+            const float dvh = (hvx - vx) * hxv + (hvy - vy) * hyv;
+            const float e0 = P[9] * expf(-dn / F);
+            const float t1 = P[15] * F * th, t2 = P[14] * F * th;
+            const float e1 = expf(-(t1 * t1)), e2 = k * expf(-(t2 * t2));
+            fsx -= e0 * (e1 * ix + e2 * hxv) + P[10] * comp * ix + P[11] * comp * dvh * hxv;
+            fsy -= e0 * (e1 * iy + e2 * hyv) + P[10] * comp * iy + P[11] * comp * dvh * hyv;
+        } else {
+            const float tx = -ny, ty = nx;
+            const float dv = (hvx - vx) * tx + (hvy - vy) * ty;
+            const float fn = P[1] * expf(rd / P[3]) + P[10] * comp;
+            float ft = P[11] * comp * dv;
+            if (soc == 1) ft += P[5] * expf(rd / P[7]);
+            fsx += fn * nx + ft * tx;
+            fsy += fn * ny + ft * ty;
+        }
+    }
+    fsx = wave_sum(fsx);
+    fsy = wave_sum(fsy);
+    if (lane != 0) return;
+
+    // ---- desired force (forces.py:9-16); within one radius of the goal the previous one is kept
+    float* mem = a.memory + (long)w * 2;
+    float fdx = mem[0], fdy = mem[1];
+    {
+        const float ddx = gx - px, ddy = gy - py;
+        const float dist = sqrtf(ddx * ddx + ddy * ddy);
+        if (dist > radius) {
+            fdx = mass * (ddx / dist * vd - vx) / P[0];
+            fdy = mass * (ddy / dist * vd - vy) / P[0];
+        }
+    }
+    // ---- obstacle force: one closest point per polygon (the LAST nearest segment point, `<=`)
+    float fox = 0.0f, foy = 0.0f;
+    if (a.O > 0) {
+        const float* ob = a.obstacles + (a.obstacles_shared ? 0 : (long)w * a.O * a.Smax * 4);
+        for (int o = 0; o < a.O; ++o) {
+            float bx = 0.0f, by = 0.0f, bd = 10000.0f;
+            for (int sg = 0; sg < a.Smax; ++sg) {
+                const float* q = ob + ((long)o * a.Smax + sg) * 4;
+                const float ax = q[0], ay = q[1], ex = q[2], ey = q[3];
+                if (isnan(ax) || isnan(ay) || isnan(ex) || isnan(ey)) continue;
+                const float sx = ex - ax, sy = ey - ay;
+                const float len = sqrtf(sx * sx + sy * sy);
+                float t = ((px - ax) * sx + (py - ay) * sy) / (len * len);
+                t = fminf(fmaxf(0.0f, t), 1.0f);
+                const float hx = ax + t * sx, hy = ay + t * sy;
+                const float d = sqrtf((hx - px) * (hx - px) + (hy - py) * (hy - py));
+                if (d <= bd) { bx = hx; by = hy; bd = d; }
+            }
+            const float dx = px - bx, dy = py - by;
+            const float dn = sqrtf(dx * dx + dy * dy);
+            const float nx = dx / dn, ny = dy / dn, tx = -ny, ty = nx;
+            const float dv = -(vx * tx + vy * ty);
+            const float rd = rme - dn;
+            const float comp = fmaxf(0.0f, rd);
+            const float fn = P[2] * expf(rd / P[4]) + P[10] * comp;
+            float ft;
+            if (soc == 1) ft = (-P[6] * expf(rd / P[8]) - P[11] * comp) * dv;
+            else ft = -P[11] * comp * dv;
+            fox += fn * nx + ft * tx;
+            foy += fn * ny + ft * ty;
+        }
+        if (soc != 1) { fox /= (float)a.O; foy /= (float)a.O; }   // Guo's single-agent obstacle force is not averaged
+    }
+
+    float npx, npy, nyaw = yaw, nvx, nvy, nbx = bvx, nby = bvy, nom = om;
+    if (!headed) {
+        const float gfx = fdx + fox + fsx, gfy = fdy + foy + fsy;
+        npx = px + vx * a.dt; npy = py + vy * a.dt;
+        nvx = vx + gfx / mass * a.dt; nvy = vy + gfy / mass * a.dt;
+        const float sp = sqrtf(nvx * nvx + nvy * nvy);
+        if (sp > vd) { nvx = nvx / sp * vd; nvy = nvy / sp * vd; }
+    } else {
+        const float inertia = 0.5f * mass * radius * radius;
+        const float tx = torque_new ? fdx + fox + fsx : fdx, ty = torque_new ? fdy + foy + fsy : fdy;
+        const float tn = sqrtf(tx * tx + ty * ty);
+        const float k_theta = inertia * P[19] * tn;
+        const float k_omega = inertia * (1.0f + P[18]) * sqrtf(P[19] * tn / P[18]);
+        const float torque = -k_theta * bound_angle(yaw - atan2f(ty, tx)) - k_omega * om;
+        // global_force = [ (fd + fo + fs) . R[:,0] ,  ko * (fo + fs) . R[:,1] - kd * body_velocity[1] ]
+        const float g0 = (fdx + fox + fsx) * cs + (fdy + foy + fsy) * sn;
+        const float g1 = P[16] * ((fox + fsx) * -sn + (foy + fsy) * cs) - P[17] * bvy;
+        npx = px + vx * a.dt; npy = py + vy * a.dt;
+        nyaw = bound_angle(yaw + om * a.dt);
+        nbx = bvx + g0 / mass * a.dt; nby = bvy + g1 / mass * a.dt;
+        nom = om + torque / inertia * a.dt;
+        const float sp = sqrtf(nbx * nbx + nby * nby);
+        if (sp > vd) { nbx = nbx / sp * vd; nby = nby / sp * vd; }
+        float s2, c2;
+        sincosf(nyaw, &s2, &c2);
+        nvx = c2 * nbx - s2 * nby; nvy = s2 * nbx + c2 * nby;
+    }
+    rb[0] = npx; rb[1] = npy; rb[2] = nyaw; rb[3] = nvx; rb[4] = nvy; rb[5] = nbx; rb[6] = nby; rb[7] = nom;
+    mem[0] = fdx; mem[1] = fdy;
+    if (a.write_row) {
+        float* s = a.S + ((long)w * a.rows + a.n) * a.as;
+        const long fs = a.fs;
+        s[0] = npx; s[fs] = npy; s[2 * fs] = nyaw; s[3 * fs] = nvx; s[4 * fs] = nvy; s[5 * fs] = nbx; s[6 * fs] = nby; s[7 * fs] = nom;
+    }
+}
+
+// check_actual_collisions_and_goal (social_nav_gym.py:107-118) + compute_reward_and_infos (social_nav_sim.py:986-1029):
+// distances at the CURRENT state (no swept test, `<=` for the collision), one lane per world.
+__global__ void k_actual_collision_reward(int W, int n, int rows, const float* S, long as, long fs, const float* robot, float T,
+                                          const float* gtime, float time_limit, float success_reward, float collision_penalty,
+                                          float discomfort_dist, float discomfort_factor, float* out)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    const float* rb = robot + (long)w * 13;
+    const float rpx = rb[0], rpy = rb[1], rr = rb[8], rgx = rb[10], rgy = rb[11];
+    float dmin = 10000.0f;
+    for (int i = 0; i < n; ++i) {
+        const float* s = S + ((long)w * rows + i) * as;
+        const float dx = s[0] - rpx, dy = s[fs] - rpy;
+        const float d = sqrtf(dx * dx + dy * dy) - s[8 * fs] - rr;
+        dmin = d < dmin ? d : dmin;
+    }
+    const int collision = dmin <= 0.0f;
+    const float ex = rpx - rgx, ey = rpy - rgy;
+    const int reaching = sqrtf(ex * ex + ey * ey) < rr;
+    float reward = 0.0f; int term = 0, trunc = 0, info = 0;
+    if (gtime[w] >= time_limit - 1.0f) { trunc = 1; info = 4; }
+    else if (collision) { reward = collision_penalty; term = 1; info = 3; }
+    else if (reaching) { reward = success_reward; term = 1; info = 2; }
+    else if (dmin < discomfort_dist) { reward = (dmin - discomfort_dist) * discomfort_factor * T; info = 1; }
+    float* o = out + (long)w * 7;
+    o[0] = (float)collision; o[1] = dmin; o[2] = (float)reaching; o[3] = reward;
+    o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
+}
+
+} // namespace
+
+extern "C" {
+
+int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
+                        const float* d_human_margin, float* d_robot_memory, float dt, void* stream)
+{
+    if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
+    if (w->W <= 0 || w->n <= 0 || !w->d_state || !w->d_robot) return fail(CS_ERR_ARG, "bad cs_worlds (a robot needs d_robot)");
+    if (w->layout != CS_LAYOUT_AOS && w->layout != CS_LAYOUT_SOA) return fail(CS_ERR_ARG, "bad layout");
+    const float* hm = d_human_margin ? d_human_margin : w->d_safety;
+    if (!hm) return fail(CS_ERR_ARG, "no human margins");
+    if (robot_type == CS_ORCA) return csimpl::orca_robot_launch(w, robot_margin, hm, dt, (hipStream_t)stream);
+    if (robot_type < 0 || robot_type > 8)
+        return fail(CS_ERR_TYPE, "The robot motion model '" + std::to_string(robot_type) + "' does not exist");
+    if (!robot_params || !d_robot_memory) return fail(CS_ERR_ARG, "null argument");
+    if (w->O < 0 || (w->O > 0 && (!w->d_obstacles || w->Smax <= 0))) return fail(CS_ERR_ARG, "bad obstacle description");
+    RArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = w->W; a.n = w->n; a.robot_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0; a.rows = w->n + a.robot_row;
+    a.write_row = a.robot_row && w->type != CS_ORCA;   // an ORCA crowd's simulator sees the moved robot only after its doStep (:389)
+    a.O = w->O; a.Smax = w->Smax; a.type = robot_type; a.obstacles_shared = (w->flags & CS_OBSTACLES_SHARED) ? 1 : 0;
+    a.dt = dt; a.robot_margin = robot_margin;
+    std::memcpy(a.P, robot_params, sizeof(a.P));
+    a.S = w->d_state;
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * a.rows; }
+    a.hmargin = hm; a.robot = w->d_robot; a.memory = d_robot_memory; a.obstacles = w->d_obstacles;
+    const int wpb = 4;
+    hipLaunchKernelGGL(k_robot_model_step, dim3((w->W + wpb - 1) / wpb), dim3(64 * wpb), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_actual_collision_reward(const cs_worlds* w, float T, const float* d_global_time, const float* reward_cfg, float* d_out,
+                               void* stream)
+{
+    if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
+    if (w->W <= 0 || w->n <= 0 || !w->d_state) return fail(CS_ERR_ARG, "bad cs_worlds");
+    if (w->layout != CS_LAYOUT_AOS && w->layout != CS_LAYOUT_SOA) return fail(CS_ERR_ARG, "bad layout");
+    if (!d_global_time || !reward_cfg || !d_out || !w->d_robot) return fail(CS_ERR_ARG, "null argument");
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    long as, fs;
+    if (w->layout == CS_LAYOUT_AOS) { as = 13; fs = 1; } else { as = 1; fs = (long)w->W * rows; }
+    const int block = 64;
+    hipLaunchKernelGGL(k_actual_collision_reward, dim3((w->W + block - 1) / block), dim3(block), 0, (hipStream_t)stream, w->W, w->n,
+                       rows, w->d_state, as, fs, w->d_robot, T, d_global_time, reward_cfg[0], reward_cfg[1], reward_cfg[2],
+                       reward_cfg[3], reward_cfg[4], d_out);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+} // extern "C"

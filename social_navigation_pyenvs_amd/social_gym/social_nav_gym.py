@@ -225,11 +225,19 @@ class SocialNavGym(_EnvBase, SocialNavSim):
         return self.compute_humans_observable_state(), reward, terminated, truncated, {0: info}
 
     def imitation_learning_step(self):
-        raise NotImplementedError("imitation learning drives the robot with a human motion model (motion_model_manager.py:"
-                                  "615-653), which is outside the crowd-step hot path of this build")
-
-    def set_human_motion_model_as_robot_policy(self, *a, **k):
-        raise NotImplementedError("see imitation_learning_step")
+        """One environment step with the robot following a human motion model (:252-274): reward and info come from the
+        ACTUAL state at the end of the update."""
+        self.states.append([self.robot.get_full_state(), [h.get_full_state() for h in self.humans]])
+        # time_step_factor x { update_robot(t, dt) ; update_humans(t, dt) } on the device, one read-back
+        self.motion_model_manager.imitation_block(self.time_step, self.time_step_factor)
+        for _ in range(self.time_step_factor):
+            self.global_time += self.time_step
+        ob = self.compute_humans_observable_state()
+        collision, dmin, reaching_goal = self.check_actual_collisions_and_goal()
+        reward, terminated, truncated, info = self.compute_reward_and_infos(collision, dmin, reaching_goal, self.global_time,
+                                                                            self.robot_time_step)
+        self.updated = True
+        return ob, reward, terminated, truncated, {0: info}
 
     def render(self):
         return None
@@ -437,6 +445,44 @@ class BatchedSocialNavGym:
             dl["counter"].masked_fill_(done, 0)
         torch.index_select(dl["clock"], 0, dl["counter"].clamp_(max=dl["clock"].numel() - 1), out=dl["gtime"])
         return self.observe_device(), reward, terminated, truncated, info
+
+    # ------------------------------------------------------------------ imitation learning, W worlds at once
+    def set_human_motion_model_as_robot_policy(self, policy_name, runge_kutta=False, safety_space=0.0):
+        """Every world's robot follows a human motion model (SocialNavGym.set_human_motion_model_as_robot_policy,
+        social_nav_sim.py:862-873); call after ``reset``.  ``safety_space``: the value the Gym hands to set_safety_space
+        (motion_model_manager.py:147-170) -- pass the one used at ``reset``."""
+        from .. import scenarios as sc
+        from ..batched import HUMAN_MODELS
+
+        if runge_kutta:
+            raise NotImplementedError("RK45 integration is outside the MI355X crowd-step path (Euler only)")
+        if policy_name not in HUMAN_MODELS:
+            raise Exception(f"The robot motion model '{policy_name}' does not exist")
+        if self.cw is None:
+            raise RuntimeError("reset() first: the robot model is attached to the resident worlds")
+        cw, n = self.cw, self.n
+        hm = np.zeros((self.W, cw.rows), np.float32)
+        if policy_name == "orca":
+            hm[:] = 0.01 + safety_space          # robot_sim radii: radius + 0.01 (+ safety space) for humans and robot (:585-587)
+            cw.set_robot_model("orca", None, 0.01 + safety_space, hm)
+        else:
+            # human.safety_space as the single-agent force functions read it: only set_safety_space touches it (:151-153)
+            if safety_space > 0 and self._proto.human_policy != "orca":
+                hm[:, :n] = 0.01 + safety_space
+            cw.set_robot_model(policy_name, sc.default_params(policy_name), (0.01 + safety_space) if safety_space > 0 else 0.0, hm)
+        self.robot_motion_model_title = policy_name
+
+    def imitation_learning_step(self):
+        """SocialNavGym.imitation_learning_step (social_nav_gym.py:252-274) for every world: time_step_factor x
+        { update_robot ; update_humans }, then reward / termination from the ACTUAL distances of the new state.
+        Returns (obs, reward [W], terminated [W], truncated [W], info_code [W])."""
+        if getattr(self.cw, "robot_model", None) is None:
+            raise AttributeError("set_human_motion_model_as_robot_policy has not been called")
+        self.cw.imitation_block(self.time_step, self.time_step_factor)
+        for _ in range(self.time_step_factor):
+            self.global_time += np.float32(self.time_step)
+        out = self.cw.actual_collision_reward(self.robot_time_step, self.global_time, self.reward_cfg)
+        return self.observe(), out[:, 3].copy(), out[:, 4] > 0, out[:, 5] > 0, out[:, 6].astype(np.int32)
 
     def observe(self):
         S = self.cw.get_states()[:, :self.n]

@@ -97,9 +97,19 @@ class SocialNavSim:
                                           h.get("des_speed", 0.9), h.get("group_id", -1)))
         if self.motion_model == "orca":
             self.parallelize_humans = False
+        # a robot that follows a human motion model keeps it across resets (:174-179)
+        previous = getattr(self, "motion_model_manager", None)
+        robot_model = previous.robot_motion_model_title if previous is not None else None
+        robot_rk = previous.robot_runge_kutta if robot_model is not None else False
+        if robot_model is None and getattr(self, "_pending_robot_model", None) is not None:
+            robot_model, robot_rk = self._pending_robot_model   # asked for before the first world existed
         self.motion_model_manager = MotionModelManager(self.motion_model, self.robot_visible, self.runge_kutta, self.humans,
                                                        self.robot, self.walls, parallelize=self.parallelize_humans)
         self.robot_controlled = False
+        if robot_model is not None:
+            self.motion_model_manager.set_robot_motion_model(robot_model, robot_rk)
+            self.robot_crowdnav_policy = False
+            self.robot_controlled = True
         # sticky, as in the reference (:183-185): once a parallel-traffic scenario was generated on this
         # object, every later reset keeps the respawn rule switched on
         if getattr(self, "parallel_traffic_humans_respawn", False):
@@ -314,6 +324,15 @@ class SocialNavSim:
             else:
                 out.append(ObservableState(hs[0], hs[1], hs[2], hs[3], self.humans[i].radius))
         return out
+
+    def set_human_motion_model_as_robot_policy(self, policy_name, runge_kutta):
+        """The robot moves towards its goal with a human motion model (:862-873); used by imitation learning."""
+        if getattr(self, "motion_model_manager", None) is None:   # no world yet (the Gym builds it at the first reset)
+            if runge_kutta:
+                raise NotImplementedError("RK45 integration is outside the MI355X crowd-step path (Euler only)")
+            self._pending_robot_model = (policy_name, runge_kutta)
+            return
+        self.motion_model_manager.set_robot_motion_model(policy_name, runge_kutta)
 
     def collision_detection_and_reaching_goal(self, action, time_step):
         """Swept robot-human test over `time_step` with the humans' current velocities (:949-984)."""

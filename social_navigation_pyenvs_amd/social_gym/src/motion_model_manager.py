@@ -328,16 +328,89 @@ class MotionModelManager:
                 self.safety_space[:] = safety_space
             else:
                 raise NotImplementedError(f"Model {self.motion_model_title} is not implemented for humans")
-        if self.robot_motion_model_title is not None:
-            raise NotImplementedError("robot motion models (imitation learning) are outside the accelerated path")
+        if self.robot_motion_model_title is not None:   # robot safety space (:160-170)
+            if "sfm" in self.robot_motion_model_title:
+                self.robot.safety_space = 0.01 + safety_space
+                if self.parallel and self.consider_robot:
+                    self.safety_space[len(self.humans)] = 0.01 + safety_space
+            elif self.robot_motion_model_title == "orca":
+                # robot_sim.setAgentRadius(i, radius + 0.01 + safety_space) for the humans AND the robot of the robot's simulator
+                self._robot_sim_margin = 0.01 + safety_space
+            else:
+                raise NotImplementedError(f"Model {self.motion_model_title} is not implemented for robot")
 
-    # ------------------------------------------------------------------ explicitly out of scope
+    # ------------------------------------------------------------------ the robot under a human motion model (:552-653)
     def set_robot_motion_model(self, motion_model_title: str, runge_kutta: bool):
-        raise NotImplementedError("robot SFM / ORCA policies (motion_model_manager.py:552-687) are not part of the "
-                                  "crowd-step hot path; drive the robot with actions through SocialNavGym.step")
+        """The robot follows one of the human motion models ("sfm_helbing" ... "hsfm_new_moussaid", "orca"); Euler only."""
+        if motion_model_title not in SFMS + ["orca"]:
+            if motion_model_title == "sfm_roboticsupo":
+                raise NotImplementedError("sfm_roboticsupo is outside this build (DESIGN.md §9)")
+            raise Exception(f"The robot motion model '{motion_model_title}' does not exist")
+        if runge_kutta:
+            raise NotImplementedError("RK45 integration is outside the MI355X crowd-step path (Euler only)")
+        self.robot_runge_kutta = runge_kutta
+        self.robot_motion_model_title = motion_model_title
+        self.robot_orca = motion_model_title == "orca"
+        self.robot.orca = self.robot_orca
+        self.robot_headed = motion_model_title.startswith("hsfm")
+        self.robot.headed = self.robot_headed
+        self.robot_include_mass = not self.robot_orca
+        self._robot_sim_margin = 0.01      # addAgent(..., radius + 0.01, ...) of the robot's own simulator (:585-587)
+        if not hasattr(self.robot, "desired_force"):
+            self.robot.desired_force = np.zeros(2, dtype=PRECISION)
+        if not self.robot_orca:
+            self.robot.set_parameters(motion_model_title)
+
+    def _device_with_robot_model(self) -> CrowdWorlds:
+        if self.robot_motion_model_title is None:
+            raise AttributeError("set_robot_motion_model has not been called")
+        cw = self._device()
+        n = len(self.humans)
+        if self.robot_orca:
+            hm = np.full(cw.rows, self._robot_sim_margin, dtype=np.float32)
+            verts = getattr(self, "_orca_vertices", None)
+            if verts is None and self.walls:
+                from ...rvo2 import process_obstacles
+                verts = process_obstacles([list(w.vertices) for w in self.walls])
+            cw.set_robot_model("orca", None, self._robot_sim_margin, hm, orca_vertices=verts)
+        else:
+            hm = np.zeros(cw.rows, dtype=np.float32)
+            hm[:n] = [h.safety_space for h in self.humans]
+            cw.set_robot_model(self.robot_motion_model_title, self.robot.get_parameters(self.robot_motion_model_title),
+                               self.robot.safety_space, hm)
+            cw.d_robot_memory.upload(np.asarray(self.robot.desired_force, dtype=np.float32).reshape(1, 2), cw.stream)
+        return cw
+
+    def _readback_robot(self, cw: CrowdWorlds):
+        rb = cw.get_robot()[0].astype(PRECISION)
+        self.robot.position = rb[0:2].copy()
+        self.robot.linear_velocity = rb[3:5].copy()
+        if not self.robot_orca:
+            self.robot.yaw = float(rb[2])
+            self.robot.body_velocity = rb[5:7].copy()
+            self.robot.angular_velocity = float(rb[7])
+            self.robot.desired_force = cw.d_robot_memory.download(cw.stream)[0].astype(PRECISION)
 
     def update_robot(self, t, dt, just_velocities=False):
-        raise NotImplementedError("see set_robot_motion_model")
+        """One substep of the robot under its motion model (:615-653)."""
+        if just_velocities:
+            raise NotImplementedError("just_velocities (robot and environment sampled at different rates, social_nav_sim.py:"
+                                      "521-524) is a SocialNavSim.run_live feature outside the Gym path")
+        cw = self._device_with_robot_model()
+        cw.robot_model_step(dt)
+        self._readback_robot(cw)
+
+    def imitation_block(self, dt: float, n_substeps: int):
+        """``n_substeps`` x { update_robot(t, dt) ; update_humans(t, dt) } without leaving the device -- the loop of
+        SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263)."""
+        cw = self._device_with_robot_model()
+        cw.imitation_block(dt, n_substeps)
+        self._readback(cw)
+        self._readback_robot(cw)
+        if self.orca and self.consider_robot:  # set_state_orca(robot) after the last doStep (:389)
+            n = len(self.humans)
+            self.states[n, 0:2] = self.robot.position
+            self.states[n, 3:5] = self.robot.linear_velocity
 
     def update_robot_pose(self, dt: float):
         self.robot.position += self.robot.linear_velocity * dt

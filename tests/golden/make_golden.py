@@ -673,10 +673,94 @@ def gen_g10_social_momentum():
     print("g10_social_momentum:", len(cases), "cases ->", save_cases("g10_social_momentum", cases))
 
 
+def robot_row(robot):
+    return np.array([*robot.position, robot.yaw, *robot.linear_velocity, *robot.body_velocity, robot.angular_velocity,
+                     robot.radius, robot.mass, *robot.goals[0], robot.desired_speed, robot.safety_space,
+                     *np.asarray(robot.desired_force, dtype=float)], dtype=np.float64)
+
+
+def gen_g11_imitation():
+    """The robot driven by a human motion model (set_human_motion_model_as_robot_policy + imitation_learning_step,
+    social_nav_gym.py:252-274, motion_model_manager.py:552-653).  Two families:
+      gym   - SocialNavGym episodes of imitation_learning_step() for the nine SFM / HSFM robot models (no walls in the Gym
+              scenarios), robot visible or not, with / without a safety space;
+      walls - manager level: update_robot + update_humans substeps in a custom scene with walls (obstacle force of the robot).
+    The ORCA robot model needs rvo2 (absent) and is not recordable."""
+    cases = []
+    seed = 0
+    human_models = ["sfm_helbing", "hsfm_new_guo", "hsfm_farina", "sfm_moussaid", "sfm_guo"]
+    scenarios = ["circle_crossing", "hybrid_scenario", "parallel_traffic"]
+    for rmodel in SFMS:
+        for robot_visible in (False, True):
+            seed += 1
+            rng = np.random.default_rng(110_000 + seed)
+            hmodel = human_models[seed % len(human_models)]
+            scen = scenarios[seed % len(scenarios)]
+            env, _ = make_env(hmodel, scen, 5, robot_visible, headed_obs=bool(seed % 2) and hmodel.startswith("hsfm"))
+            env.set_human_motion_model_as_robot_policy(rmodel, False)
+            if seed % 3 == 0:
+                env.set_safety_space(0.1)
+            phase = ("test", "val", "train")[seed % 3]
+            test_case = int(rng.integers(0, 90))
+            ob, info = env.reset(phase=phase, test_case=test_case)
+            mm = env.motion_model_manager
+            obs, rewards, terms, truncs, infos, dmins = [ob_to_array(ob)], [], [], [], [], []
+            robots = [robot_row(env.robot)]
+            mm_states, mm_goals = [mm.states.copy()], [mm.goals.copy()]
+            for k in range(24):
+                ob, r, term, trunc, info = env.imitation_learning_step()
+                obs.append(ob_to_array(ob)); rewards.append(float(r)); terms.append(bool(term)); truncs.append(bool(trunc))
+                infos.append(type(info[0]).__name__)
+                dmins.append(float(getattr(info[0], "min_dist", np.nan)))
+                robots.append(robot_row(env.robot))
+                mm_states.append(mm.states.copy()); mm_goals.append(mm.goals.copy())
+            cases.append(dict(family="gym", robot_model=rmodel, model=hmodel, scenario=scen, robot_visible=robot_visible,
+                              phase=phase, test_case=test_case, human_num=5, safety_space=float(env.safety_space),
+                              headed_obs=bool(seed % 2) and hmodel.startswith("hsfm"),
+                              respawn=bool(mm.parallel_traffic_humans_respawn),
+                              obs=np.array(obs), rewards=np.array(rewards), terminated=np.array(terms),
+                              truncated=np.array(truncs), infos=infos, dmins=np.array(dmins), robots=np.array(robots),
+                              mm_states=np.array(mm_states), mm_goals=np.array(mm_goals), mm_safety=mm.safety_space.copy(),
+                              human_safety=np.array([h.safety_space for h in mm.humans], dtype=float),
+                              robot_params=env.robot.get_parameters(rmodel), global_time=float(env.global_time)))
+            env.parallel_traffic_humans_respawn = False
+    for rmodel in SFMS:
+        for robot_visible in (False, True):
+            seed += 1
+            rng = np.random.default_rng(110_000 + seed)
+            hmodel = human_models[seed % len(human_models)]
+            n = int(rng.integers(3, 9))
+            walls = my_walls(rng)
+            robot = {"pos": [float(rng.uniform(-4.5, -3.5)), float(rng.uniform(-1, 1))], "yaw": float(rng.uniform(-0.5, 0.5)),
+                     "radius": 0.3, "goals": [[float(rng.uniform(3.5, 4.5)), float(rng.uniform(-1, 1))]]}
+            cfg = crossing_config(rng, hmodel, n, 3.5, walls=walls, robot=robot, robot_visible=robot_visible, attrs=bool(seed % 2))
+            sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=True)
+            sim.set_human_motion_model_as_robot_policy(rmodel, False)
+            mm = sim.motion_model_manager
+            if seed % 3 == 0:
+                mm.set_safety_space(0.07)
+            robots = [robot_row(sim.robot)]
+            mm_states, mm_goals = [mm.states.copy()], [mm.goals.copy()]
+            nsub = 200
+            for k in range(nsub):
+                mm.update_robot(k * DT, DT)
+                mm.update_humans(k * DT, DT)
+                robots.append(robot_row(sim.robot))
+                if (k + 1) % 20 == 0:
+                    mm_states.append(mm.states.copy()); mm_goals.append(mm.goals.copy())
+            cases.append(dict(family="walls", robot_model=rmodel, model=hmodel, robot_visible=robot_visible, n=n,
+                              walls=walls_to_array(walls), robots=np.array(robots), mm_states=np.array(mm_states),
+                              mm_goals=np.array(mm_goals), mm_safety=mm.safety_space.copy(), mm_params=mm.params.copy(),
+                              human_safety=np.array([h.safety_space for h in mm.humans], dtype=float),
+                              all_params_equal=bool(mm.all_equal_humans),
+                              robot_params=sim.robot.get_parameters(rmodel), nsub=nsub))
+    print("g11_imitation:", len(cases), "cases ->", save_cases("g11_imitation", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
               g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
-              g10_social_momentum=gen_g10_social_momentum)
+              g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
