@@ -412,6 +412,33 @@ class MotionModelManager:
             self.states[n, 0:2] = self.robot.position
             self.states[n, 3:5] = self.robot.linear_velocity
 
+    # ------------------------------------------------------------------ robot state access (:520-550)
+    def get_robot_state(self, include_goal=True, headed=False):
+        """[x, y, yaw, (B)Vx, (B)Vy, Omega, Gx, Gy] with the goal; without it [x, y, yaw, BVx, BVy, Omega] (headed) or
+        [x, y, Vx, Vy]."""
+        r = self.robot
+        v = r.body_velocity if headed else r.linear_velocity
+        if include_goal:
+            return np.array([r.position[0], r.position[1], r.yaw, v[0], v[1], r.angular_velocity, r.goals[0][0], r.goals[0][1]], dtype=PRECISION)
+        if headed:
+            return np.array([r.position[0], r.position[1], r.yaw, v[0], v[1], r.angular_velocity], dtype=PRECISION)
+        return np.array([r.position[0], r.position[1], v[0], v[1]], dtype=PRECISION)
+
+    def set_robot_state(self, state):
+        """Inverse of get_robot_state(include_goal=True, headed=robot.headed); rewinds the goal list to (Gx, Gy)."""
+        r = self.robot
+        r.position[0], r.position[1], r.yaw = state[0], state[1], state[2]
+        if not r.headed:
+            r.linear_velocity[0], r.linear_velocity[1] = state[3], state[4]
+        else:
+            r.body_velocity[0], r.body_velocity[1] = state[3], state[4]
+        r.angular_velocity = state[5]
+        self.rewind_goals(r, [state[6], state[7]])
+        if self.consider_robot and self.orca:  # set_state_orca(robot): the crowd simulator's copy of the robot
+            n = len(self.humans)
+            self.states[n, 0:2] = r.position
+            self.states[n, 3:5] = r.linear_velocity
+
     def update_robot_pose(self, dt: float):
         self.robot.position += self.robot.linear_velocity * dt
         self.robot.yaw += self.robot.angular_velocity * dt

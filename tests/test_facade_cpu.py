@@ -159,3 +159,32 @@ def test_state_records_flatten_like_the_reference():
     assert fs + ob == (1, 2, 3, 4, 0.3, 5, 6, 1.0, 0.5, 7, 8, 9, 10, 0.3)   # self_state + human_state, as the policies flatten it
     assert str(ob) == "7 8 9 10 0.3"
     JointState(fs, [ob])
+
+
+def test_robot_state_access_and_robot_motion_model_setup():
+    """get_robot_state / set_robot_state (motion_model_manager.py:520-550) and the bookkeeping of set_robot_motion_model
+    (:552-589) and of the robot half of set_safety_space (:160-170): host logic, no GPU."""
+    env = make_env("sfm_helbing", "circle_crossing", 5, True)
+    env.reset(phase="test", test_case=2)
+    mm = env.motion_model_manager
+    env.robot.linear_velocity[:] = [0.3, -0.2]
+    st = mm.get_robot_state()
+    np.testing.assert_allclose(st, [*env.robot.position, env.robot.yaw, 0.3, -0.2, 0.0, *env.robot.goals[0]])
+    assert mm.get_robot_state(include_goal=False, headed=False).shape == (4,) and mm.get_robot_state(include_goal=False, headed=True).shape == (6,)
+    st[0:2] += 1.0
+    mm.set_robot_state(st)
+    np.testing.assert_allclose(env.robot.position, st[0:2])
+    with pytest.raises(Exception, match="does not exist"):
+        mm.set_robot_motion_model("nonsense", False)
+    with pytest.raises(NotImplementedError):
+        mm.set_robot_motion_model("sfm_helbing", True)            # RK45
+    env.set_human_motion_model_as_robot_policy("hsfm_new_guo", False)
+    assert mm.robot_motion_model_title == "hsfm_new_guo" and env.robot.headed and not env.robot.orca
+    assert env.robot.Ci == 120.0 and env.robot.k_lambda == 0.1    # robot.set_parameters(model)
+    mm.set_safety_space(0.2)
+    assert abs(env.robot.safety_space - 0.21) < 1e-12 and abs(mm.safety_space[5] - 0.21) < 1e-12
+    env.reset(phase="test", test_case=3)                           # the robot keeps its model across resets (social_nav_sim.py:174-179)
+    assert env.motion_model_manager is not mm and env.motion_model_manager.robot_motion_model_title == "hsfm_new_guo"
+    env.set_human_motion_model_as_robot_policy("orca", False)
+    env.motion_model_manager.set_safety_space(0.15)
+    assert env.robot.orca and abs(env.motion_model_manager._robot_sim_margin - 0.16) < 1e-12
