@@ -555,29 +555,50 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             if (obst != nullptr) {
                 for (int o = 0; o < a.O; ++o) {
                     // first argmin over the polygon's segments, on squared distances (same order)
-                    float best = 0.0f, bdx = 0.0f, bdy = 0.0f;
-                    bool have = false;
-                    for (int sg = 0; sg < a.Smax; ++sg) {
-                        float x1, y1, ex, ey, einv;
-                        if (a.seg_tab > 0) {
-                            const float4 e = lds_seg[sbase + o * a.Smax + sg];
-                            x1 = e.x; y1 = e.y; ex = e.z; ey = e.w;
-                            einv = lds_sinv[sbase + o * a.Smax + sg];
-                        } else {
+                    float best = INFINITY, bdx = 0.0f, bdy = 0.0f;   // the first slot always beats +inf: a first argmin
+                    if (a.seg_tab > 0) {
+                        // branch-free, four slots per trip (then two, then one): the LDS reads of a trip (uniform addresses,
+                        // broadcasts) are issued before its arithmetic; a NaN slot (zeros in the table, 1/|e|^2 = -1) gets the
+                        // reference's huge distance
+                        const float4* sgp = lds_seg + sbase + o * a.Smax;
+                        const float* sip = lds_sinv + sbase + o * a.Smax;
+                        auto trip = [&](int s0, auto width) {
+                            constexpr int NW = decltype(width)::value;
+                            float4 e[NW];
+                            float iv[NW];
+#pragma unroll
+                            for (int j = 0; j < NW; ++j) { e[j] = sgp[s0 + j]; iv[j] = sip[s0 + j]; }
+#pragma unroll
+                            for (int j = 0; j < NW; ++j) {
+                                const float t = ((px - e[j].x) * e[j].z + (py - e[j].y) * e[j].w) * iv[j];
+                                const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                                const float ddx = px - fmaf(ts, e[j].z, e[j].x), ddy = py - fmaf(ts, e[j].w, e[j].y);
+                                const float d = (iv[j] < 0.0f) ? 3.0e38f : fmaf(ddx, ddx, ddy * ddy);
+                                const bool better = d < best;
+                                best = better ? d : best;
+                                bdx = better ? ddx : bdx;
+                                bdy = better ? ddy : bdy;
+                            }
+                        };
+                        int s0 = 0;
+                        for (; s0 + 4 <= a.Smax; s0 += 4) trip(s0, std::integral_constant<int, 4>{});
+                        if (s0 + 2 <= a.Smax) { trip(s0, std::integral_constant<int, 2>{}); s0 += 2; }
+                        if (s0 < a.Smax) trip(s0, std::integral_constant<int, 1>{});
+                    } else {
+                        for (int sg = 0; sg < a.Smax; ++sg) {
                             const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)o * a.Smax + sg) * 4);
-                            x1 = seg.x; y1 = seg.y; ex = seg.z - seg.x; ey = seg.w - seg.y;
-                            einv = isnan(seg.x) ? -1.0f : rcp_fast(fmaf(ex, ex, ey * ey));
+                            const float x1 = seg.x, y1 = seg.y, ex = seg.z - seg.x, ey = seg.w - seg.y;
+                            float d, ddx = 0.0f, ddy = 0.0f;
+                            if (isnan(seg.x)) {
+                                d = 3.0e38f; // NaN slot: the reference stores iinfo(int64).max as the distance (:247)
+                            } else {
+                                const float t = ((px - x1) * ex + (py - y1) * ey) * rcp_fast(fmaf(ex, ex, ey * ey));
+                                const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                                ddx = px - fmaf(ts, ex, x1); ddy = py - fmaf(ts, ey, y1);
+                                d = fmaf(ddx, ddx, ddy * ddy);
+                            }
+                            if (d < best) { best = d; bdx = ddx; bdy = ddy; }
                         }
-                        float d, ddx = 0.0f, ddy = 0.0f;
-                        if (einv < 0.0f) {
-                            d = 3.0e38f; // NaN slot: the reference stores iinfo(int64).max as the distance (:247)
-                        } else {
-                            const float t = ((px - x1) * ex + (py - y1) * ey) * einv;
-                            const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
-                            ddx = px - fmaf(ts, ex, x1); ddy = py - fmaf(ts, ey, y1);
-                            d = fmaf(ddx, ddx, ddy * ddy);
-                        }
-                        if (!have || d < best) { best = d; bdx = ddx; bdy = ddy; have = true; }
                     }
                     const float inv = rsq_fast(fmaxf(best, 1e-30f));
                     const float dist = best * inv;
@@ -1281,8 +1302,11 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     // at the 4-wave budget and stay on the run-time loop); 10 rows fit 128 VGPRs without spills in every model
     else if (lean && rows == 25) fn = crowded ? pick_kernel<64, 4, 25, true>(w->type, true) : pick_kernel<64, 1, 25, true>(w->type, true);
     else if (lean && rows == 10) fn = pick_kernel<64, 4, 10, true>(w->type, true);
-    else if (lean) fn = crowded ? pick_kernel<64, 4, 0, true>(w->type, true) : pick_kernel<64, 1, 0, true>(w->type, true);
-    else fn = crowded ? pick_kernel<64, 4, 0, false>(w->type, peq) : pick_kernel<64, 1, 0, false>(w->type, peq);
+    // the run-time partner loop (any other row count, walls, robot row) keeps the full register budget on every grid: its
+    // 128-VGPR build spills (7 VGPRs lean, 35 with walls) and measured 6-17 % slower on crowded grids (8192 x 50 + walls:
+    // 355 vs 304 us; 16384 x 30 Moussaid: 484 vs 402 us)
+    else if (lean) fn = pick_kernel<64, 1, 0, true>(w->type, true);
+    else fn = pick_kernel<64, 1, 0, false>(w->type, peq);
     // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
     // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
     size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +

@@ -43,10 +43,10 @@ if model == "orca":
     for k, nm in enumerate(names):
         print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
     sys.exit(0)
-if len(sys.argv) > 4 and sys.argv[4] == "circle":   # cfg2-style: circular crossing only, no respawn rule
+if len(sys.argv) > 4 and sys.argv[4] in ("circle", "walls"):   # cfg2-style: circular crossing only, no respawn rule; "walls": cfg5-style
     pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
     S, goals, P = sc.make_states(pos, yaw, g), g, np.tile(sc.default_params(model), (n, 1))
-    cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, layout="soa")
+    cw = CrowdWorlds(S, goals, P, None, sc.polygon_walls() if sys.argv[4] == "walls" else None, type=model, all_params_equal=True, layout="soa")
 else:
     S, goals, P, rb = sc.hybrid_worlds(W, n, model)
     cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
