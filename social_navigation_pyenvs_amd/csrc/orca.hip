@@ -312,46 +312,34 @@ __device__ int obstacle_lines(const float* V, const int* oi, int no, int T, int 
 
 // One ORCA half-plane (RVO2 Agent::computeNewVelocity, agent part): q = (x, y, vx, vy) of the neighbour,
 // R = combined radius.  Returns (point.x, point.y, direction.x, direction.y).
-__device__ __forceinline__ float4 orca_line(float px, float py, float vx, float vy, const float4 q, float R, float invT, float dt)
+// One agent-agent ORCA half-plane (RVO2 Agent::computeNewVelocity).  RVO2's three cases -- projection on the cut-off circle,
+// on a leg, and the collision case (cut-off circle of the time step) -- each take one square root and one reciprocal of
+// different arguments; the arguments are selected first, so a lane pays one IEEE sqrt and one IEEE divide whatever cases the
+// wavefront mixes, with the very same operations on the very same operands as the case it is in.  invDt = 1 / timeStep.
+__device__ __forceinline__ float4 orca_line(float px, float py, float vx, float vy, const float4 q, float R, float invT, float invDt)
 {
     const float rpx = q.x - px, rpy = q.y - py;
     const float rvx = vx - q.z, rvy = vy - q.w;
     const float distSq = rpx * rpx + rpy * rpy;
     const float RSq = R * R;
-    float dx, dy, ux, uy;
-    if (distSq > RSq) {
-        const float wx = rvx - invT * rpx, wy = rvy - invT * rpy;
-        const float wLenSq = wx * wx + wy * wy;
-        const float dot1 = wx * rpx + wy * rpy;
-        if (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq) {
-            const float wLen = sqrtf(wLenSq);
-            const float inv = 1.0f / wLen;
-            const float uwx = wx * inv, uwy = wy * inv;
-            dx = uwy; dy = -uwx;
-            const float s = R * invT - wLen;
-            ux = s * uwx; uy = s * uwy;
-        } else {
-            const float leg = sqrtf(distSq - RSq);
-            if (det2(rpx, rpy, wx, wy) > 0.0f) {
-                const float inv = 1.0f / distSq;
-                dx = (rpx * leg - rpy * R) * inv; dy = (rpx * R + rpy * leg) * inv;
-            } else {
-                const float inv = 1.0f / distSq;
-                dx = -(rpx * leg + rpy * R) * inv; dy = -(-rpx * R + rpy * leg) * inv;
-            }
-            const float dot2 = rvx * dx + rvy * dy;
-            ux = dot2 * dx - rvx; uy = dot2 * dy - rvy;
-        }
-    } else {
-        const float invDt = 1.0f / dt;
-        const float wx = rvx - invDt * rpx, wy = rvy - invDt * rpy;
-        const float wLen = sqrtf(wx * wx + wy * wy);
-        const float inv = 1.0f / wLen;
-        const float uwx = wx * inv, uwy = wy * inv;
-        dx = uwy; dy = -uwx;
-        const float s = R * invDt - wLen;
-        ux = s * uwx; uy = s * uwy;
-    }
+    const bool coll = !(distSq > RSq);
+    const float kT = coll ? invDt : invT;
+    const float wx = rvx - kT * rpx, wy = rvy - kT * rpy;
+    const float wLenSq = wx * wx + wy * wy;
+    const float dot1 = wx * rpx + wy * rpy;
+    const bool circ = coll || (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq);
+    const float root = sqrtf(circ ? wLenSq : distSq - RSq);   // |w|  or  the leg length
+    const float inv = 1.0f / (circ ? root : distSq);
+    // cut-off circle (of the time horizon, or of the time step when the discs overlap)
+    const float uwx = wx * inv, uwy = wy * inv;
+    const float sc = R * kT - root;
+    // legs
+    const bool left = det2(rpx, rpy, wx, wy) > 0.0f;
+    const float lx = left ? (rpx * root - rpy * R) * inv : -(rpx * root + rpy * R) * inv;
+    const float ly = left ? (rpx * R + rpy * root) * inv : -(-rpx * R + rpy * root) * inv;
+    const float dot2 = rvx * lx + rvy * ly;
+    const float dx = circ ? uwy : lx, dy = circ ? -uwx : ly;
+    const float ux = circ ? sc * uwx : dot2 * lx - rvx, uy = circ ? sc * uwy : dot2 * ly - rvy;
     return make_float4(vx + 0.5f * ux, vy + 0.5f * uy, dx, dy);
 }
 
@@ -482,11 +470,12 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
     OSTAMP(1);
 
     const float invT = 1.0f / time_horizon;
+    const float invDt = 1.0f / dt;
     float4 Lr[KF];
 #pragma unroll
     for (int k = 0; k < KF; ++k) {
         const int b = (k < cnt) ? __double2loint(key[k]) : row; // unused slots read my own row (finite, never used)
-        Lr[k] = orca_line(px, py, vx, vy, pv[b], my_r + rr[b], invT, dt);
+        Lr[k] = orca_line(px, py, vx, vy, pv[b], my_r + rr[b], invT, invDt);
     }
 
     OSTAMP(2);
@@ -655,9 +644,10 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
                     nobst = obstacle_lines(a.verts, lds_oi, no, TL, tid, px, py, vx, vy, r + margin, 1.0f / a.time_horizon_obst, L);
                 }
                 const float invT = 1.0f / a.time_horizon;
+                const float invDt = 1.0f / dt;
                 for (int k = 0; k < cnt; ++k) {
                     const int b = lds_ni[k * TL + tid];
-                    L.set(nobst + k, orca_line(px, py, vx, vy, pv[b], (r + margin) + rr[b], invT, dt));
+                    L.set(nobst + k, orca_line(px, py, vx, vy, pv[b], (r + margin) + rr[b], invT, invDt));
                 }
                 const int total = nobst + cnt;
                 const int failed = lp2(L, total, vmax, pvx, pvy, false, nvx, nvy);
@@ -814,11 +804,12 @@ __global__ __launch_bounds__(64) void k_orca_robot_step(const ORArgs a)
         nobst = obstacle_lines(a.verts, lds_oi, no, T, tid, px, py, vx, vy, r, 1.0f / a.time_horizon_obst, L);
     }
     const float invT = 1.0f / a.time_horizon;
+    const float invDt = 1.0f / a.dt;
     for (int k = 0; k < cnt; ++k) {
         const int b = lds_ni[k * T + tid];
         const float* s = Sw + (long)b * a.as;
         const float4 q = make_float4(s[0], s[a.fs], s[3 * a.fs], s[4 * a.fs]);
-        L.set(nobst + k, orca_line(px, py, vx, vy, q, r + (s[8 * a.fs] + a.hmargin[(long)w * a.rows + b]), invT, a.dt));
+        L.set(nobst + k, orca_line(px, py, vx, vy, q, r + (s[8 * a.fs] + a.hmargin[(long)w * a.rows + b]), invT, invDt));
     }
     const int total = nobst + cnt;
     float nvx, nvy;
