@@ -263,6 +263,20 @@ int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* rob
 int cs_actual_collision_reward(const cs_worlds* w, float T, const float* d_global_time, const float* reward_cfg /* host, 5 floats */,
                                float* d_out, void* stream);
 
+/*
+ * cs_update_humans_rk45  replaces MotionModelManager(runge_kutta=True).update_humans(t, dt) (motion_model_manager.py:374-384):
+ *   scipy.integrate.solve_ivp(f_rk45_headed | f_rk45_not_headed, (t, t + dt), y0, method='RK45') of every world, i.e. the
+ *   Dormand-Prince 5(4) pair with scipy's step-size control (rtol 1e-3, atol 1e-6, error norm over the whole world) around a
+ *   right-hand side with side effects (:500-550, :437-460): trial states are written with the speed clamp / angle wrap, goal
+ *   lists rotate at trial positions, the single-agent force functions of forces.py are used (with the pair force of the
+ *   lower index mirrored onto the higher one under CS_ALL_PARAMS_EQUAL, forces.py:130-151).
+ *   type 0..8; rows <= 64.  The robot row (CS_ROBOT_ROW) is a fixed entity for the whole call.
+ *   d_memory [W][n][2]: agent.desired_force between calls (kept within one radius of the goal, forces.py:12-16); zero it
+ *   when the humans are created.  d_nfev [W] or NULL: number of right-hand-side evaluations (2 + 6 per attempted step).
+ *   Updates rows (x, y, yaw, Vx, Vy, BVx, BVy, Omega, goal columns) and rotates d_goals in place.
+ */
+int cs_update_humans_rk45(const cs_worlds* w, float dt, float* d_memory, int32_t* d_nfev, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

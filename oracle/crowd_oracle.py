@@ -592,3 +592,165 @@ def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety,
         vel = np.array([[np.cos(yaw), -np.sin(yaw)], [np.sin(yaw), np.cos(yaw)]]) @ bvel
     r[0:2], r[2], r[3:5], r[5:7], r[7], r[14:16] = pos, yaw, vel, bvel, om, fd
     return r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RK45 integration of the crowd: MotionModelManager(runge_kutta=True).update_humans (motion_model_manager.py:374-384) =
+# scipy.integrate.solve_ivp(method="RK45", default rtol 1e-3 / atol 1e-6) around f_rk45_headed / f_rk45_not_headed (:500-550).
+# The right-hand side is NOT a pure function: it writes the trial state into the agents with the speed clamp and the angle
+# wrap (:88-103), rotates goal lists at trial positions (compute_forces :439-441), and uses the single-agent force functions
+# (stale desired force, Guo's un-averaged obstacle force; pairwise-mirrored social forces when all parameters are equal,
+# forces.py:130-151).  scipy is the reference's own dependency (1.15.3 in this image): the oracle calls it, with the
+# right-hand side restated here.  Pinned on tests/golden/g12_rk45.npz (rows and number of RHS evaluations).
+def _pair_force(kind, P, pi, vi, ri, pj, vj, rj):
+    """compute_pairwise_social_force(type, agent1 = i, agent2 = j) (forces.py:63-128); ri / rj = radius + safety_space."""
+    d = pi - pj
+    dn = np.linalg.norm(d)
+    n_ij = d / dn
+    rd = ri + rj - dn
+    if kind == 2:
+        iv = P[12] * (vi - vj) - n_ij
+        inorm = np.linalg.norm(iv)
+        i_ij = iv / inorm
+        th = _bound_angle(np.arctan2(n_ij[1], n_ij[0]) - np.arctan2(i_ij[1], i_ij[0]) + np.pi)
+        k = np.sign(th)
+        h_ij = np.array([-i_ij[1], i_ij[0]])
+        F = P[13] * inorm
+        dvh = np.dot(vj - vi, h_ij)
+        return -(P[9] * np.exp(-dn / F) * (np.exp(-(P[15] * F * th) ** 2) * i_ij + k * np.exp(-(P[14] * F * th) ** 2) * h_ij)
+                 + P[10] * max(0, rd) * i_ij + P[11] * max(0, rd) * dvh * h_ij)
+    t_ij = np.array([-n_ij[1], n_ij[0]])
+    dv = np.dot(vj - vi, t_ij)
+    if kind == 1:
+        return (P[1] * np.exp(rd / P[3]) + P[10] * max(0, rd)) * n_ij + (P[5] * np.exp(rd / P[7]) + P[11] * max(0, rd) * dv) * t_ij
+    return (P[1] * np.exp(rd / P[3]) + P[10] * max(0, rd)) * n_ij + P[11] * max(0, rd) * dv * t_ij
+
+
+class Rk45Crowd:
+    """State of one world between calls: rows [n, 16] = x, y, yaw, vx, vy, bvx, bvy, omega, radius, mass, gx, gy, desired_speed,
+    safety_space, desired_force_x, desired_force_y; goals [n, G, 2] NaN-padded lists; params [n, 20]."""
+
+    def __init__(self, rows, goals, params, model, all_equal, walls=None, robot=None):
+        self.rows = np.array(rows, dtype=np.float64)
+        self.goals = [[g.copy() for g in gl if not np.any(np.isnan(g))] for gl in np.asarray(goals, dtype=np.float64)]
+        self.P = np.asarray(params, dtype=np.float64)
+        self.model, self.all_equal = model, bool(all_equal)
+        self.headed = model.startswith("hsfm")
+        self.kind = 1 if model.endswith("guo") else (2 if model.endswith("moussaid") else 0)
+        self.torque_new = model.startswith("hsfm_new")
+        self.walls = walls if (walls is not None and len(walls)) else None
+        self.robot = None if robot is None or len(robot) == 0 else np.asarray(robot, dtype=np.float64)  # x, y, vx, vy, radius, safety
+        self.nfev = 0
+
+    def _set_state(self, y):
+        r = self.rows
+        n = len(r)
+        if self.headed:
+            Y = y.reshape(n, 6)
+            r[:, 0:2] = Y[:, 0:2]
+            for i in range(n):
+                r[i, 2] = _bound_angle(Y[i, 2])
+                bv = Y[i, 3:5]
+                sp = np.linalg.norm(bv)
+                r[i, 5:7] = bv / sp * r[i, 12] if sp > r[i, 12] else bv
+            r[:, 7] = Y[:, 5]
+        else:
+            Y = y.reshape(n, 4)
+            r[:, 0:2] = Y[:, 0:2]
+            for i in range(n):
+                v = Y[i, 2:4]
+                sp = np.linalg.norm(v)
+                r[i, 3:5] = v / sp * r[i, 12] if sp > r[i, 12] else v
+
+    def _forces(self):
+        r = self.rows
+        n = len(r)
+        obstacles = []
+        for i in range(n):
+            gl = self.goals[i]
+            if gl and np.linalg.norm(gl[0] - r[i, 0:2]) < r[i, 8]:   # update_goals (:66-70)
+                gl.append(gl.pop(0))
+            obstacles.append(closest_points(self.walls, r[i, 0:2]))
+            if self.headed:
+                c, s = np.cos(r[i, 2]), np.sin(r[i, 2])
+                r[i, 3:5] = np.array([[c, -s], [s, c]]) @ r[i, 5:7]
+        rs = r[:, 8] + r[:, 13]
+        ent_p = [r[i, 0:2] for i in range(n)]
+        ent_v = [r[i, 3:5] for i in range(n)]
+        ent_r = list(rs)
+        if self.robot is not None:
+            ent_p.append(self.robot[0:2]); ent_v.append(self.robot[2:4]); ent_r.append(self.robot[4] + self.robot[5])
+        fs = np.zeros((n, 2))
+        if self.all_equal:   # compute_all_social_forces: the pair force of the lower index, mirrored onto the higher one
+            for i in range(n):
+                for j in range(i + 1, len(ent_p)):
+                    f = _pair_force(self.kind, self.P[i], ent_p[i], ent_v[i], ent_r[i], ent_p[j], ent_v[j], ent_r[j])
+                    fs[i] += f
+                    if j != n:
+                        fs[j] -= f
+        else:
+            for i in range(n):
+                for j in range(len(ent_p)):
+                    if j != i:
+                        fs[i] += _pair_force(self.kind, self.P[i], ent_p[i], ent_v[i], ent_r[i], ent_p[j], ent_v[j], ent_r[j])
+        ydot = np.empty((n, 6 if self.headed else 4))
+        for i in range(n):
+            P = self.P[i]
+            pos, vel, radius, mass, vd = r[i, 0:2], r[i, 3:5], r[i, 8], r[i, 9], r[i, 12]
+            diff = self.goals[i][0] - pos
+            dist = np.linalg.norm(diff)
+            if dist > radius:
+                r[i, 14:16] = mass * (diff / dist * vd - vel) / P[0]
+            fd = r[i, 14:16]
+            fo = np.zeros(2)
+            for o in obstacles[i]:
+                d = pos - o
+                dn = np.linalg.norm(d)
+                n_iw = d / dn
+                t_iw = np.array([-n_iw[1], n_iw[0]])
+                dv = -np.dot(vel, t_iw)
+                rd = rs[i] - dn
+                if self.kind == 1:
+                    fo += (P[2] * np.exp(rd / P[4]) + P[10] * max(0, rd)) * n_iw + (-P[6] * np.exp(rd / P[8]) - P[11] * max(0, rd)) * dv * t_iw
+                else:
+                    fo += (P[2] * np.exp(rd / P[4]) + P[10] * max(0, rd)) * n_iw - P[11] * max(0, rd) * dv * t_iw
+            if obstacles[i] and self.kind != 1:
+                fo /= len(obstacles[i])
+            if not self.headed:
+                gf = fd + fo + fs[i]
+                ydot[i] = [vel[0], vel[1], gf[0] / mass, gf[1] / mass]
+            else:
+                inertia = 0.5 * mass * radius * radius
+                tot = fd + fo + fs[i] if self.torque_new else fd
+                tn = np.linalg.norm(tot)
+                k_theta = inertia * P[19] * tn
+                k_omega = inertia * (1 + P[18]) * np.sqrt(P[19] * tn / P[18])
+                torque = -k_theta * _bound_angle(r[i, 2] - np.arctan2(tot[1], tot[0])) - k_omega * r[i, 7]
+                c, s = np.cos(r[i, 2]), np.sin(r[i, 2])
+                R = np.array([[c, -s], [s, c]])
+                g0 = np.dot(fd + fo + fs[i], R[:, 0])
+                g1 = P[16] * np.dot(fo + fs[i], R[:, 1]) - P[17] * r[i, 6]
+                bv = r[i, 5:7]
+                ydot[i] = [np.dot(R[0, :], bv), np.dot(R[1, :], bv), r[i, 7], g0 / mass, g1 / mass, torque / inertia]
+        return ydot.ravel()
+
+    def rhs(self, t, y):
+        self.nfev += 1
+        self._set_state(y)
+        return self._forces()
+
+    def update_humans(self, t, dt):
+        from scipy.integrate import solve_ivp
+
+        r = self.rows
+        self.nfev = 0
+        y0 = (r[:, [0, 1, 2, 5, 6, 7]] if self.headed else r[:, [0, 1, 3, 4]]).ravel().copy()
+        sol = solve_ivp(self.rhs, (t, t + dt), y0, method="RK45")
+        self._set_state(sol.y[:, -1])
+        if self.headed:
+            for i in range(len(r)):
+                c, s = np.cos(r[i, 2]), np.sin(r[i, 2])
+                r[i, 3:5] = np.array([[c, -s], [s, c]]) @ r[i, 5:7]
+        for i in range(len(r)):
+            r[i, 10:12] = self.goals[i][0]
+        return self.nfev

@@ -231,6 +231,24 @@ class CrowdWorlds:
                                         C.c_float(max_distance), C.c_void_p(out.ptr), C.c_void_p(self.stream)))
         return out.download(self.stream)
 
+    # ------------------------------------------------------------------ RK45 integration (runge_kutta=True)
+    def update_humans_rk45(self, dt: float, desired_force=None) -> np.ndarray:
+        """MotionModelManager(runge_kutta=True).update_humans(t, dt) (motion_model_manager.py:374-384) of every world: one
+        adaptive RK45 solve over dt, in place.  ``desired_force`` [W, n, 2]: the humans' desired_force attributes to start
+        from (None = what the previous call left, zeros at first).  Returns the number of right-hand-side evaluations [W]."""
+        if self.type > 8:
+            raise ValueError(f"Type {self.type} does not exist for this implementation")
+        mem = getattr(self, "d_rk_memory", None)
+        if mem is None:
+            mem = self.d_rk_memory = DeviceBuffer.from_numpy(np.zeros((self.W, self.n, 2), np.float32))
+        if desired_force is not None:
+            mem.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(desired_force, dtype=np.float32), (self.W, self.n, 2))), self.stream)
+        d = self.descriptor(respawn=False)
+        nfev = self._buffer("rk_nfev", (self.W,), np.int32)
+        check(_lib.load().cs_update_humans_rk45(C.byref(d), C.c_float(dt), C.c_void_p(mem.ptr), C.c_void_p(nfev.ptr),
+                                                C.c_void_p(self.stream)))
+        return nfev.download(self.stream)
+
     # ------------------------------------------------------------------ the robot under a human motion model
     def set_robot_model(self, model, params=None, margin=0.0, human_margin=None, orca_vertices=None) -> None:
         """MotionModelManager.set_robot_motion_model (motion_model_manager.py:552-589) for every world: the robot rows are

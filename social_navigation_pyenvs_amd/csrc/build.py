@@ -9,7 +9,7 @@ CSRC = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(CSRC)
 ROOT = os.path.dirname(PKG)
 LIB_PATH = os.path.join(PKG, "libcrowdstep.so")
-SOURCES = ["crowdstep.hip", "orca.hip", "lookahead.hip", "generate.hip", "laser.hip", "social_momentum.hip", "robot_model.hip"]
+SOURCES = ["crowdstep.hip", "orca.hip", "lookahead.hip", "generate.hip", "laser.hip", "social_momentum.hip", "robot_model.hip", "rk45.hip"]
 ARCH = "gfx950"
 
 

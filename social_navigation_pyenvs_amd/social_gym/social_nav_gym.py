@@ -455,7 +455,7 @@ class BatchedSocialNavGym:
         from ..batched import HUMAN_MODELS
 
         if runge_kutta:
-            raise NotImplementedError("RK45 integration is outside the MI355X crowd-step path (Euler only)")
+            raise NotImplementedError("RK45 integration of the ROBOT is not built (the crowd has it: cs_update_humans_rk45)")
         if policy_name not in HUMAN_MODELS:
             raise Exception(f"The robot motion model '{policy_name}' does not exist")
         if self.cw is None:

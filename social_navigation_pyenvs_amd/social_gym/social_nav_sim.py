@@ -329,7 +329,7 @@ class SocialNavSim:
         """The robot moves towards its goal with a human motion model (:862-873); used by imitation learning."""
         if getattr(self, "motion_model_manager", None) is None:   # no world yet (the Gym builds it at the first reset)
             if runge_kutta:
-                raise NotImplementedError("RK45 integration is outside the MI355X crowd-step path (Euler only)")
+                raise NotImplementedError("RK45 integration of the ROBOT is not built (the crowd has it: cs_update_humans_rk45)")
             self._pending_robot_model = (policy_name, runge_kutta)
             return
         self.motion_model_manager.set_robot_motion_model(policy_name, runge_kutta)

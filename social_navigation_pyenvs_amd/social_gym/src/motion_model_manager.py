@@ -45,8 +45,6 @@ class MotionModelManager:
         self.orca = False
         self.sm = False
         self.sf = False
-        if runge_kutta:
-            raise NotImplementedError("RK45 integration is outside the MI355X crowd-step path (Euler only)")
         self.parallel_traffic_humans_respawn = False
         self.respawn_bounds = None
         self._cw = None
@@ -242,6 +240,18 @@ class MotionModelManager:
     def update_humans(self, t: float, dt: float, post_update=True):
         """One substep of every human (:354-422): Euler SFM / HSFM, or ORCA; parallel-traffic respawn when
         ``post_update``."""
+        if self.runge_kutta and not (self.orca or self.sm):   # RK45 of the SFM / HSFM crowd (:374-384); ORCA is Euler only
+            if post_update and self.parallel_traffic_humans_respawn:
+                raise NotImplementedError("RK45 integration with the parallel-traffic respawn rule is not built")
+            cw = self._device(respawn=False)
+            if not hasattr(self, "_desired_force"):   # agent.desired_force of the single-agent force functions (forces.py:12-16)
+                self._desired_force = np.zeros((len(self.humans), 2), dtype=PRECISION)
+            self.rk45_nfev = int(cw.update_humans_rk45(dt, desired_force=self._desired_force[None])[0])
+            self._readback(cw)
+            self._desired_force = cw.d_rk_memory.download(cw.stream)[0].astype(PRECISION)
+            for i, h in enumerate(self.humans):
+                h.desired_force = self._desired_force[i]
+            return
         cw = self._device(respawn=bool(post_update and self.parallel_traffic_humans_respawn))
         cw.step(dt, 1, None)
         self._readback(cw)
@@ -253,6 +263,9 @@ class MotionModelManager:
     def update_humans_block(self, dt: float, n_substeps: int, action=None, unicycle=False):
         """``n_substeps`` x { robot.step(action, dt) ; update_humans(t, dt) } fused in one launch -- the loop of
         SocialNavGym.step (social_nav_gym.py:240-245).  ``action``: (vx, vy) or (v, r) for a unicycle robot."""
+        if self.runge_kutta and not (self.orca or self.sm):
+            raise NotImplementedError("the fused Gym block is Euler (SocialNavGym never sets runge_kutta, social_nav_gym.py:141-143); "
+                                      "call update_humans(t, dt) for RK45")
         cw = self._device()
         cw.unicycle = bool(unicycle)
         act = None if action is None else np.asarray(action, dtype=np.float32).reshape(1, 2)
@@ -347,7 +360,7 @@ class MotionModelManager:
                 raise NotImplementedError("sfm_roboticsupo is outside this build (DESIGN.md §9)")
             raise Exception(f"The robot motion model '{motion_model_title}' does not exist")
         if runge_kutta:
-            raise NotImplementedError("RK45 integration is outside the MI355X crowd-step path (Euler only)")
+            raise NotImplementedError("RK45 integration of the ROBOT is not built (the crowd has it: cs_update_humans_rk45)")
         self.robot_runge_kutta = runge_kutta
         self.robot_motion_model_title = motion_model_title
         self.robot_orca = motion_model_title == "orca"

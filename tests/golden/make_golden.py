@@ -757,10 +757,72 @@ def gen_g11_imitation():
     print("g11_imitation:", len(cases), "cases ->", save_cases("g11_imitation", cases))
 
 
+def humans_snapshot(mm):
+    hs = mm.humans
+    gmax = max(len(h.goals) for h in hs)
+    g = np.full((len(hs), gmax, 2), np.nan)
+    for i, h in enumerate(hs):
+        g[i, :len(h.goals)] = np.array(h.goals, dtype=float)
+    rows = np.array([[*h.position, h.yaw, *h.linear_velocity, *h.body_velocity, h.angular_velocity, h.radius, h.mass,
+                      *h.goals[0], h.desired_speed, h.safety_space, *np.asarray(h.desired_force, dtype=float)] for h in hs], dtype=float)
+    return rows, g
+
+
+def gen_g12_rk45():
+    """MotionModelManager(runge_kutta=True).update_humans(t, dt) (motion_model_manager.py:374-384, 500-550): scipy's RK45 around
+    the single-agent force functions, whose right-hand side clamps velocities, switches goals and keeps stale desired forces.
+    Records rows before / after every call and the number of right-hand-side evaluations (pins the step-size control)."""
+    cases = []
+    seed = 0
+    for t, model in enumerate(SFMS):
+        for n, radius, dt, calls in ((4, 2.0, DT, 40), (9, 2.6, 0.25, 10), (16, 3.2, DT, 30)):
+            seed += 1
+            rng = np.random.default_rng(120_000 + seed)
+            walls = my_walls(rng) if seed % 2 else None
+            robot_visible = seed % 3 == 0
+            robot = None
+            if robot_visible:
+                robot = {"pos": [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1))], "yaw": 0.0, "radius": 0.3, "goals": [[4.0, 4.0]]}
+            cfg = crossing_config(rng, model, n, radius, walls=walls, robot=robot, robot_visible=robot_visible, attrs=bool(seed % 4 == 1))
+            cfg["runge_kutta"] = True
+            sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=False)
+            mm = sim.motion_model_manager
+            assert mm.runge_kutta
+            if seed % 5 == 0:
+                mm.set_safety_space(0.05)
+            if robot_visible:
+                sim.robot.linear_velocity = np.array([0.3, 0.2])
+            counter = {"n": 0}
+            for name in ("f_rk45_headed", "f_rk45_not_headed"):
+                orig = getattr(mm, name)
+                def wrapped(tt, y, _o=orig):
+                    counter["n"] += 1
+                    return _o(tt, y)
+                setattr(mm, name, wrapped)
+            warm = int(round(0.45 * radius / dt))
+            for k in range(warm):
+                mm.update_humans(k * dt, dt)
+            rows, goals, nfev = [], [], []
+            r0, g0 = humans_snapshot(mm)
+            rows.append(r0); goals.append(g0)
+            for k in range(calls):
+                counter["n"] = 0
+                mm.update_humans((warm + k) * dt, dt)
+                r1, g1 = humans_snapshot(mm)
+                rows.append(r1); goals.append(g1); nfev.append(counter["n"])
+            rb = np.zeros(0)
+            if robot_visible:
+                rb = np.array([*sim.robot.position, *sim.robot.linear_velocity, sim.robot.radius, sim.robot.safety_space], dtype=float)
+            cases.append(dict(model=model, type=t, n=n, dt=dt, robot_visible=robot_visible, all_params_equal=bool(mm.all_equal_humans),
+                              walls=walls_to_array(walls) if walls else np.zeros((0, 1, 2, 2)), rows=np.array(rows), goals=np.array(goals),
+                              nfev=np.array(nfev), robot=rb, params=np.array([h.get_parameters(model) for h in mm.humans])))
+    print("g12_rk45:", len(cases), "cases ->", save_cases("g12_rk45", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
               g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
-              g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation)
+              g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

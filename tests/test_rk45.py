@@ -1,0 +1,179 @@
+"""RK45 integration of the crowd (MotionModelManager(runge_kutta=True).update_humans).  Golden G12 was
+recorded from the reference (tests/golden/make_golden.py gen_g12_rk45): rows before / after every call and the number of
+right-hand-side evaluations, which pins scipy's step-size control."""
+import numpy as np
+import pytest
+
+from golden_io import load_cases
+from oracle import crowd_oracle as orc
+
+
+def test_oracle_rk45_matches_reference_g12():
+    """scipy's solve_ivp around the restated right-hand side, call by call from the recorded state."""
+    worst = 0.0
+    for ci, c in enumerate(load_cases("g12_rk45")):
+        for k in range(0, len(c["nfev"]), 3):
+            sim = orc.Rk45Crowd(c["rows"][k], c["goals"][k], c["params"], c["model"], c["all_params_equal"], c["walls"], c["robot"])
+            nf = sim.update_humans(0.0, c["dt"])
+            assert nf == c["nfev"][k], (ci, k, nf, c["nfev"][k])
+            err = np.max(np.abs(sim.rows - c["rows"][k + 1]))
+            worst = max(worst, err)
+            got_goals = np.full_like(c["goals"][k + 1], np.nan)
+            for i, gl in enumerate(sim.goals):
+                got_goals[i, :len(gl)] = gl
+            np.testing.assert_array_equal(got_goals, c["goals"][k + 1])
+    assert worst < 1e-8, worst
+
+
+def _worlds(c, k):
+    rows, goals = c["rows"][k], c["goals"][k]
+    n = c["n"]
+    S = np.zeros((n + int(c["robot_visible"]), 13), np.float32)
+    S[:n] = rows[:, :13]
+    safety = np.zeros(len(S), np.float32)
+    safety[:n] = rows[:, 13]
+    if c["robot_visible"]:
+        rb = c["robot"]
+        S[n, 0:2], S[n, 3:5], S[n, 8], S[n, 9], S[n, 12] = rb[0:2], rb[2:4], rb[4], 80.0, 1.0
+        safety[n] = rb[5]
+    return S, goals, safety
+
+
+def _run_case_call(c, k):
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    S, goals, safety = _worlds(c, k)
+    walls = c["walls"] if c["walls"].shape[0] else None
+    cw = CrowdWorlds(S, goals, c["params"], safety, walls, type=c["model"], all_params_equal=c["all_params_equal"],
+                     robot_row=c["robot_visible"])
+    nfev = cw.update_humans_rk45(c["dt"], desired_force=c["rows"][k][:, 14:16])
+    return cw, int(nfev[0])
+
+
+@pytest.mark.gpu
+def test_rk45_kernel_matches_reference_g12_substep_sized_calls():
+    """dt = 0.0125 (the simulator's sampling time): cs_update_humans_rk45 call by call from the recorded state, float32 kernel
+    vs the float64 reference -- the same number of right-hand-side evaluations (= the same accept / reject decisions and step
+    sizes, including calls with rejected steps) and the same rows to 1e-5, in at least 99 % of the calls."""
+    calls = other = 0
+    for ci, c in enumerate(load_cases("g12_rk45")):
+        if c["dt"] > 0.1:
+            continue
+        n = c["n"]
+        for k in range(len(c["nfev"])):
+            cw, nfev = _run_case_call(c, k)
+            got, ref = cw.get_states()[0][:n], c["rows"][k + 1]
+            err = np.max(np.abs(got[:, [0, 1, 3, 4]] - ref[:, [0, 1, 3, 4]]))
+            calls += 1
+            if nfev != c["nfev"][k]:   # an error estimate on the accept / reject edge (stiff wall contact): another step sequence
+                other += 1
+                assert err < 5e-3 and c["nfev"][k] > 8, (ci, c["model"], k, nfev, c["nfev"][k], err)
+                continue
+            assert err < 1e-5, (ci, c["model"], n, k, err)
+            if c["model"].startswith("hsfm"):
+                dth = np.abs((got[:, 2] - ref[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+                assert np.max(dth) < 1e-4 and np.max(np.abs(got[:, 5:7] - ref[:, 5:7])) < 1e-4, (ci, k)
+                assert np.max(np.abs(got[:, 7] - ref[:, 7])) < 2e-3 * max(1.0, np.max(np.abs(ref[:, 7]))), (ci, k)
+            np.testing.assert_allclose(cw.get_goals()[0], c["goals"][k + 1], atol=1e-6)
+            np.testing.assert_allclose(got[:, 10:12], ref[:, 10:12], atol=1e-6)
+    assert calls >= 600 and other <= 0.01 * calls, (calls, other)
+
+
+@pytest.mark.gpu
+def test_rk45_kernel_matches_reference_g12_quarter_second_calls():
+    """dt = 0.25: 2 to 80 adaptive steps per call, some through stiff contacts (k1 = 1.2e5 N/m) where float32 rounding is
+    amplified inside one call and an error estimate near 1 flips an accept / reject decision.  Asserted: the step sequence
+    agrees in >= 80 % of the calls, those agree to 1e-4 in >= 70 % of them, and every call stays within what the solver's
+    own tolerance (rtol 1e-3) allows for a different step sequence."""
+    total = same = tight = 0
+    for ci, c in enumerate(load_cases("g12_rk45")):
+        if c["dt"] < 0.1:
+            continue
+        n = c["n"]
+        for k in range(len(c["nfev"])):
+            cw, nfev = _run_case_call(c, k)
+            got, ref = cw.get_states()[0][:n], c["rows"][k + 1]
+            err = np.max(np.abs(got[:, [0, 1]] - ref[:, [0, 1]]))
+            total += 1
+            same += int(nfev == c["nfev"][k])
+            tight += int(nfev == c["nfev"][k] and err < 1e-4)
+            assert err < 5e-2, (ci, c["model"], k, err, nfev, c["nfev"][k])
+            assert abs(nfev - c["nfev"][k]) <= max(12, 0.35 * c["nfev"][k]), (ci, k, nfev, c["nfev"][k])
+    assert same >= 0.8 * total and tight >= 0.7 * same, (total, same, tight)
+
+
+@pytest.mark.gpu
+def test_rk45_batch_of_worlds_and_layouts():
+    """W different worlds in one launch == one launch per world; SoA == AoS."""
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    cases = [c for c in load_cases("g12_rk45") if c["n"] == 9 and c["model"] == "hsfm_farina"]
+    c = cases[0]
+    ks = list(range(6))
+    Ss, Gs, Fs = zip(*[_worlds(c, k) for k in ks])
+    walls = c["walls"] if c["walls"].shape[0] else None
+    mem = np.stack([c["rows"][k][:, 14:16] for k in ks])
+    outs = {}
+    for layout in ("aos", "soa"):
+        cw = CrowdWorlds(np.stack(Ss), np.stack(Gs), c["params"], np.stack(Fs), walls, type=c["model"],
+                         all_params_equal=c["all_params_equal"], robot_row=c["robot_visible"], layout=layout)
+        nf = cw.update_humans_rk45(c["dt"], desired_force=mem)
+        outs[layout] = (cw.get_states(), nf)
+    np.testing.assert_array_equal(outs["aos"][0], outs["soa"][0])
+    np.testing.assert_array_equal(outs["aos"][1], outs["soa"][1])
+    for i, k in enumerate(ks):
+        cw = CrowdWorlds(Ss[i], Gs[i], c["params"], Fs[i], walls, type=c["model"], all_params_equal=c["all_params_equal"],
+                         robot_row=c["robot_visible"])
+        nf = cw.update_humans_rk45(c["dt"], desired_force=mem[i])
+        np.testing.assert_array_equal(cw.get_states()[0], outs["aos"][0][i])
+        assert nf[0] == outs["aos"][1][i]
+
+
+@pytest.mark.gpu
+def test_motion_model_manager_runge_kutta_facade_g12():
+    """MotionModelManager(..., runge_kutta=True).update_humans(t, dt) on HumanAgent objects rebuilt from the recorded rows
+    (scenes without walls), call by call."""
+    from social_navigation_pyenvs_amd.social_gym.src.agent import HumanAgent, RobotAgent
+    from social_navigation_pyenvs_amd.social_gym.src.motion_model_manager import MotionModelManager
+
+    done = 0
+    for ci, c in enumerate(load_cases("g12_rk45")):
+        if c["walls"].shape[0] or c["dt"] > 0.1:
+            continue
+        n = c["n"]
+        for k in (0, 7, 19):
+            rows, goals = c["rows"][k], c["goals"][k]
+            humans = []
+            for i in range(n):
+                gl = [list(g) for g in goals[i] if not np.any(np.isnan(g))]
+                h = HumanAgent(None, i, c["model"], list(rows[i, 0:2]), float(rows[i, 2]), gl, radius=float(rows[i, 8]),
+                               mass=float(rows[i, 9]), des_speed=float(rows[i, 12]))
+                h.linear_velocity[:] = rows[i, 3:5]
+                h.body_velocity[:] = rows[i, 5:7]
+                h.angular_velocity = float(rows[i, 7])
+                for name, val in zip(("relaxation_time", "Ai", "Aw", "Bi", "Bw", "Ci", "Cw", "Di", "Dw", "Ei", "k1", "k2", "agent_lambda",
+                                      "gamma", "ns", "ns1", "ko", "kd", "alpha", "k_lambda"), c["params"][i]):
+                    if hasattr(h, name):
+                        setattr(h, name, float(val))
+                humans.append(h)
+            robot = RobotAgent(None)
+            if c["robot_visible"]:
+                rb = c["robot"]
+                robot.position[:] = rb[0:2]
+                robot.linear_velocity[:] = rb[2:4]
+                robot.radius = float(rb[4])
+                robot.goals = [[4.0, 4.0]]
+            mm = MotionModelManager(c["model"], c["robot_visible"], True, humans, robot, [])
+            assert mm.all_equal_humans == c["all_params_equal"]
+            if rows[0, 13] > 0:
+                mm.set_safety_space(float(rows[0, 13]) - 0.01)
+            mm._desired_force = rows[:, 14:16].copy()
+            mm.update_humans(0.0, c["dt"])
+            ref = c["rows"][k + 1]
+            if mm.rk45_nfev != c["nfev"][k]:
+                continue
+            got = np.array([[*h.position, h.yaw, *h.linear_velocity, *h.body_velocity] for h in humans])
+            assert np.max(np.abs(got[:, [0, 1, 3, 4]] - ref[:, [0, 1, 3, 4]])) < 1e-5, (ci, k)
+            assert [list(map(float, g)) for g in humans[0].goals] == [list(g) for g in c["goals"][k + 1][0] if not np.any(np.isnan(g))]
+            done += 1
+    assert done >= 20
