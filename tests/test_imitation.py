@@ -258,3 +258,39 @@ def test_batched_imitation_matches_single_env(hmodel, rmodel, visible, safety):
             assert abs(r - rew[w]) < 1e-4 and t == bool(term[w]) and tr == bool(trunc[w])
             assert type(info[0]) is INFO_BY_CODE[int(code[w])] or isinstance(info[0], INFO_BY_CODE[int(code[w])])
         np.testing.assert_allclose(robots[w, [0, 1, 3, 4]], [*env.robot.position, *env.robot.linear_velocity], atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rmodel", [(1, "sfm_guo"), (64, "hsfm_new_moussaid"), (150, "sfm_helbing"), (150, "hsfm_farina")])
+def test_robot_model_kernel_edge_sizes_against_the_oracle(n, rmodel):
+    """One human, a full wavefront of humans, and more humans than lanes (the lane-strided social-force sum)."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rng = np.random.default_rng(n)
+    side = int(np.ceil(np.sqrt(n + 1)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    pts = (np.stack([gx.ravel(), gy.ravel()], -1)[:n + 1] - side / 2) * 1.2 + rng.uniform(-0.2, 0.2, (n + 1, 2))
+    S = np.zeros((1, n, 13), np.float32)
+    S[0, :, 0:2] = pts[:n]
+    S[0, :, 3:5] = rng.normal(0, 0.4, (n, 2))
+    S[0, :, 8], S[0, :, 9], S[0, :, 12] = rng.uniform(0.25, 0.4, n), 75.0, 1.0
+    goals = np.zeros((1, n, 1, 2), np.float32)
+    goals[0, :, 0] = -S[0, :, 0:2]
+    S[0, :, 10:12] = goals[0, :, 0]
+    row = np.zeros(16)
+    row[0:2], row[2], row[5:7], row[7] = pts[n], 0.4, [0.5, 0.1], 0.2
+    row[3:5] = [0.5 * np.cos(0.4) - 0.1 * np.sin(0.4), 0.5 * np.sin(0.4) + 0.1 * np.cos(0.4)] if rmodel.startswith("hsfm") else [0.3, 0.2]
+    row[8], row[9], row[10:12], row[12], row[13] = 0.3, 80.0, [side, side], 1.0, 0.02
+    row = row.astype(np.float32).astype(np.float64)
+    P = sc.default_params(rmodel)
+    hs = np.full(n, 0.015, np.float32)
+    # humans under ORCA so that they do not depend on SFM parameters; only the robot substep is compared
+    cw = CrowdWorlds(S, goals, None, np.zeros((1, n), np.float32), None, type="orca", robot=_robot13(row))
+    cw.set_robot_model(rmodel, P, 0.02, hs[None])
+    cw.robot_model_step(DT)
+    ref = orc.robot_model_substep(row, P.astype(np.float32).astype(np.float64), rmodel, S[0, :, 0:2].astype(np.float64),
+                                  S[0, :, 3:5].astype(np.float64), S[0, :, 8].astype(np.float64), hs.astype(np.float64), None, DT)
+    got = cw.get_robot()[0]
+    tol = 1e-3 if rmodel.endswith("moussaid") else 2e-6
+    assert np.max(np.abs(got[:8] - ref[:8])) < tol * max(1.0, np.max(np.abs(ref[:8]))), (got[:8], ref[:8])

@@ -177,3 +177,51 @@ def test_motion_model_manager_runge_kutta_facade_g12():
             assert [list(map(float, g)) for g in humans[0].goals] == [list(g) for g in c["goals"][k + 1][0] if not np.any(np.isnan(g))]
             done += 1
     assert done >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,model,robot", [(1, "sfm_helbing", False), (1, "hsfm_new_guo", True), (2, "sfm_moussaid", False),
+                                           (63, "hsfm_farina", True), (64, "sfm_guo", False)])
+def test_rk45_edge_sizes_against_the_oracle(n, model, robot):
+    """One human, and worlds that fill the wavefront (64 rows): kernel vs the scipy-based oracle from float32-rounded inputs."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rng = np.random.default_rng(n * 7 + int(robot))
+    side = int(np.ceil(np.sqrt(n + 1)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    pts = (np.stack([gx.ravel(), gy.ravel()], -1)[:n + 1] - side / 2) * 1.1 + rng.uniform(-0.15, 0.15, (n + 1, 2))
+    rows = np.zeros((n, 16))
+    rows[:, 0:2] = pts[:n]
+    rows[:, 2] = rng.uniform(-np.pi, np.pi, n)
+    rows[:, 5:7] = rng.normal(0, 0.3, (n, 2))
+    c, s = np.cos(rows[:, 2]), np.sin(rows[:, 2])
+    if model.startswith("hsfm"):
+        rows[:, 3] = c * rows[:, 5] - s * rows[:, 6]; rows[:, 4] = s * rows[:, 5] + c * rows[:, 6]
+    else:
+        rows[:, 3:5] = rng.normal(0, 0.3, (n, 2)); rows[:, 5:7] = 0
+    rows[:, 7] = rng.normal(0, 0.2, n) if model.startswith("hsfm") else 0.0
+    rows[:, 8], rows[:, 9], rows[:, 12], rows[:, 13] = 0.3, 75.0, 1.0, 0.01
+    goals = np.stack([-rows[:, 0:2] * 2 + 0.3, rows[:, 0:2]], 1)
+    rows[:, 10:12] = goals[:, 0]
+    rows = rows.astype(np.float32).astype(np.float64)
+    goals = goals.astype(np.float32).astype(np.float64)
+    P = np.tile(sc.default_params(model), (n, 1)).astype(np.float32)
+    rb = np.array([*pts[n], 0.2, -0.1, 0.3, 0.0], dtype=np.float32).astype(np.float64) if robot else np.zeros(0)
+    sim = orc.Rk45Crowd(rows, goals, P.astype(np.float64), model, True, None, rb)
+    nf_ref = sim.update_humans(0.0, 0.0125)
+    S = np.zeros((n + int(robot), 13), np.float32)
+    S[:n] = rows[:, :13]
+    safety = np.full(n + int(robot), 0.01, np.float32)
+    if robot:
+        S[n, 0:2], S[n, 3:5], S[n, 8], S[n, 9], S[n, 12] = rb[0:2], rb[2:4], rb[4], 80.0, 1.0
+        safety[n] = 0.0
+    cw = CrowdWorlds(S, goals, P, safety, None, type=model, all_params_equal=True, robot_row=robot)
+    nf = cw.update_humans_rk45(0.0125)
+    assert nf[0] == nf_ref
+    got = cw.get_states()[0][:n]
+    tol = 2e-3 if model.endswith("moussaid") else 1e-5
+    assert np.max(np.abs(got[:, [0, 1, 3, 4]] - sim.rows[:, [0, 1, 3, 4]])) < tol
+    with pytest.raises(ValueError, match="64 rows"):
+        CrowdWorlds(np.zeros((1, 65, 13), np.float32), np.zeros((1, 65, 1, 2), np.float32), np.zeros((65, 20), np.float32), None, None,
+                    type=model).update_humans_rk45(0.0125)
