@@ -251,6 +251,42 @@ def test_device_resident_step_equals_host_step_and_auto_resets():
     assert np.all(dev._dl["gtime"].cpu().numpy()[fresh] == 0)
 
 
+def test_device_resident_lookahead_feeds_one_batched_value_network_call():
+    """BatchedSocialNavGym.lookahead_device (cs_peek + cs_lookahead on resident tensors) == the host path of
+    crowd_nav.policy.cadrl.compute_rotated_states_and_reward on downloaded arrays; then a greedy decision loop entirely on the
+    GPU: look-ahead -> one batched (toy) value network call -> arg-max action -> step_device."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.crowd_nav.policy.cadrl import build_action_space_array, compute_rotated_states_and_reward
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W = 48
+    env = BatchedSocialNavGym(_config("circle_crossing", human_num=6), W)
+    env.reset(phase="val", first_case=5, device=True)
+    acts = build_action_space_array(1.0)
+    for _ in range(3):
+        env.step_device(torch.as_tensor(np.tile([[0.2, 0.6]], (W, 1)), dtype=torch.float32, device="cuda"))
+    rot, rew = env.lookahead_device(acts)
+    assert rot.is_cuda and rot.shape == (W, 81, 6, 13) and rew.shape == (W, 81)
+    cw = env.cw
+    nxt = cw.peek(env.robot_time_step)[:, :, [0, 1, 3, 4]]
+    cur = cw.get_states()[:, :6][:, :, [0, 1, 3, 4, 8]]
+    rob = cw.get_robot()[:, [0, 1, 3, 4, 8, 10, 11, 12, 2]]
+    hrot, hrew = compute_rotated_states_and_reward(acts, nxt, cur, rob, env.robot_time_step)
+    np.testing.assert_array_equal(rot.cpu().numpy(), hrot.astype(np.float32))
+    np.testing.assert_array_equal(rew.cpu().numpy(), hrew.astype(np.float32))
+    # greedy loop on the device: value = reward + a toy network (mean over humans of a linear map of the 13-column rows)
+    wts = torch.linspace(-0.05, 0.05, 13, device="cuda")
+    acts_d = torch.as_tensor(acts, dtype=torch.float32, device="cuda")
+    start = cw.d_robot.torch().view(W, 13)[:, 0:2].clone()
+    for _ in range(8):
+        rot, rew = env.lookahead_device(acts_d)
+        value = rew + 0.9 * (rot @ wts).mean(dim=2)          # ONE batched "model" call over [W, 81, N, 13]
+        best = value.argmax(dim=1)
+        env.step_device(acts_d.index_select(0, best))
+    moved = (cw.d_robot.torch().view(W, 13)[:, 0:2] - start).norm(dim=1)
+    assert torch.isfinite(moved).all() and (moved > 0).any()
+
+
 def test_more_than_64_humans_use_the_lane_per_world_kernel():
     """n <= 64 runs one wavefront per world, larger worlds one lane per world: both restate the same stream."""
     from social_navigation_pyenvs_amd.generators import generate_worlds
