@@ -286,64 +286,77 @@ __global__ __launch_bounds__(64) void k_generate(const GArgs a)
 
 // ------------------------------------------------------------------------------------------
 // One WAVEFRONT per world (n <= 64): the latency form, used for the masked auto-reset inside a device-resident loop.
-// Every lane runs the same random stream redundantly (MT19937 state in LDS, words read as wave-wide broadcasts, so all
-// lanes hold the same candidate), the twist is done cooperatively, lane j keeps placed human j in registers and the
-// rejection test against all placed humans is ONE instruction sequence + a wave vote instead of a serial loop.
+// MT19937 state in LDS (the current block and its successor, twisted cooperatively); attribute draws are read as wave-wide
+// broadcasts.  The rejection loops of the circular crossing and of the parallel traffic are SPECULATIVE: eight attempts of
+// the human being placed are evaluated at once, each from its own words of the stream by eight lanes that share the test
+// against the placed humans (kept in LDS); the first accepted attempt wins and the stream position moves to just behind
+// it, so a human mostly costs one round whatever its rejection count -- the slowest world of a batch no longer sets the
+// latency of a masked reset.
 // Same draws, same f64 expressions, same accept / reject decisions as k_generate above.
 // ------------------------------------------------------------------------------------------
 struct WMT {
-    uint32_t* s; // [624] in LDS
-    int pos;     // wave-uniform
+    uint32_t* cur; // [624] in LDS: the block the stream is in
+    uint32_t* nxt; // [624] in LDS: twist(cur), kept ready so that speculative attempts can read across the block boundary
+    int pos;       // wave-uniform index into cur; 624 <= pos < 1248 means "in nxt" until the next advance
 };
 
-__device__ void wmt_seed(WMT& m, uint32_t seed, int lane)
-{
-    if (lane == 0) { // the init_genrand recurrence is serial
-        uint32_t prev = seed;
-        m.s[0] = prev;
-        for (int i = 1; i < 624; ++i) {
-            prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i;
-            m.s[i] = prev;
-        }
-    }
-    m.pos = 624;
-    __syncthreads();
-}
-
-__device__ void wmt_twist(WMT& m, int lane)
+// nw = twist(old) (genrand's block update, out of place), cooperatively: chunks of 64 in increasing order -- element kk reads
+// old[kk], old[kk + 1] and either old[kk + 397] (kk < 227) or nw[kk - 227], written at least three chunks earlier
+__device__ void wmt_twist_from(const uint32_t* old, uint32_t* nw, int lane)
 {
     constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MATRIX_A = 0x9908b0dfu;
-    // chunks of 64 in increasing order keep the serial algorithm's old / new value pattern: element kk reads old[kk],
-    // old[kk + 1] (not yet rewritten: it belongs to this or a later chunk, and a chunk loads before it stores) and either
-    // old[kk + 397] (kk < 227) or new[kk - 227] (rewritten at least three chunks earlier)
     for (int k0 = 0; k0 < 623; k0 += 64) {
         const int kk = k0 + lane;
-        uint32_t v = 0;
         if (kk < 623) {
-            const uint32_t y = (m.s[kk] & UPPER) | (m.s[kk + 1] & LOWER);
-            v = m.s[kk < 227 ? kk + 397 : kk - 227] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+            const uint32_t y = (old[kk] & UPPER) | (old[kk + 1] & LOWER);
+            nw[kk] = (kk < 227 ? old[kk + 397] : nw[kk - 227]) ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
         }
-        __syncthreads();
-        if (kk < 623) m.s[kk] = v;
         __syncthreads();
     }
     if (lane == 0) {
-        const uint32_t y = (m.s[623] & UPPER) | (m.s[0] & LOWER);
-        m.s[623] = m.s[396] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
+        const uint32_t y = (old[623] & UPPER) | (nw[0] & LOWER);
+        nw[623] = nw[396] ^ (y >> 1) ^ ((y & 1u) ? MATRIX_A : 0u);
     }
-    m.pos = 0;
     __syncthreads();
 }
 
-__device__ uint32_t wmt_next(WMT& m, int lane)
+__device__ void wmt_seed(WMT& m, uint32_t seed, int lane)
 {
-    if (m.pos >= 624) wmt_twist(m, lane);
-    uint32_t y = m.s[m.pos++];
+    __syncthreads();
+    if (lane == 0) { // the init_genrand recurrence is serial
+        uint32_t prev = seed;
+        m.cur[0] = prev;
+        for (int i = 1; i < 624; ++i) {
+            prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i;
+            m.cur[i] = prev;
+        }
+    }
+    __syncthreads();
+    wmt_twist_from(m.cur, m.nxt, lane);
+    m.pos = 624;   // numpy leaves the seeded block exhausted: the first draw comes from its twist
+}
+
+__device__ void wmt_advance(WMT& m, int lane)   // the stream has left `cur`: make `nxt` current and prepare the block after it
+{
+    uint32_t* t = m.cur; m.cur = m.nxt; m.nxt = t;
+    m.pos -= 624;
+    __syncthreads();
+    wmt_twist_from(m.cur, m.nxt, lane);
+}
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;
     y ^= (y >> 18);
     return y;
+}
+
+__device__ uint32_t wmt_next(WMT& m, int lane)
+{
+    if (m.pos >= 624) wmt_advance(m, lane);
+    return mt_temper(m.cur[m.pos++]);
 }
 
 __device__ double wrnd(WMT& m, int lane)
@@ -352,25 +365,46 @@ __device__ double wrnd(WMT& m, int lane)
     return (a * 67108864.0 + b) / 9007199254740992.0;
 }
 
+// random_sample() number q of the stream counted from word index k0 (k0 < 624, read-ahead below 1248), without consuming it
+__device__ __forceinline__ double wmt_peek_double(const WMT& m, int k0, int q)
+{
+    const int k = k0 + 2 * q;
+    const uint32_t wa = (k < 624) ? m.cur[k] : m.nxt[k - 624];
+    const uint32_t wb = (k + 1 < 624) ? m.cur[k + 1] : m.nxt[k + 1 - 624];
+    const uint32_t a = mt_temper(wa) >> 5, b = mt_temper(wb) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+// np.linalg.norm((dx, dy)) < md, decided on the squares; the square root only inside the rounding band of the comparison
+__device__ __forceinline__ bool closer_than(double dx, double dy, double md)
+{
+    const double d2 = dx * dx + dy * dy, md2 = md * md;
+    bool c = d2 < md2;
+    if (fabs(d2 - md2) <= 1e-14 * md2) c = sqrt(d2) < md;
+    return c;
+}
+
 __global__ __launch_bounds__(64) void k_generate_wave(const GArgs a)
 {
-    __shared__ uint32_t s_mt[624];
-    __shared__ double s_rad[64], s_spd[64];
+    __shared__ uint32_t s_mt[2][624];
+    __shared__ double s_rad[64], s_spd[64], s_px[64], s_py[64], s_yaw[64];
     const int w = blockIdx.x, lane = threadIdx.x;
     if (a.mask != nullptr && a.mask[w] == 0) return; // block-uniform
     const cs_generator& g = a.g;
     const int n = g.n;
     const double pi = 3.141592653589793;
     WMT m;
-    m.s = s_mt;
+    m.cur = s_mt[0];
+    m.nxt = s_mt[1];
     m.pos = 624;
     const uint32_t seed = a.seeds[w];
     wmt_seed(m, seed, lane);
     int scenario = g.scenario;
     if (scenario == CS_SCN_HYBRID) {
         scenario = (wmt_next(m, lane) & 1u) ? CS_SCN_PARALLEL_TRAFFIC : CS_SCN_CIRCULAR_CROSSING;
-        __syncthreads();
-        wmt_seed(m, seed, lane);
+        // np.random.seed(seed) again (:156-157): the stream restarts at its first word, which is word 0 of the block the
+        // choice was just drawn from -- rewinding the position is the whole re-seeding
+        m.pos = 0;
     }
     const double R = g.circle_radius, L = g.traffic_length, H = g.traffic_height, rr = g.robot_radius;
     const bool insert_robot = g.insert_robot != 0;
@@ -405,53 +439,92 @@ __global__ __launch_bounds__(64) void k_generate_wave(const GArgs a)
             mx = 0.0 + R * cos(off + step * k); my = 0.0 + R * sin(off + step * k);
             myaw = insert_robot ? bound_angle_d((pi / 2.0) + step * k) : bound_angle_d(-pi + step * k);
         } else {
+            // speculative rejection sampling: the wavefront evaluates 8 attempts of human i at once, attempt a = lane / 8 from
+            // its own six words of the stream (read ahead without consuming them), its 8 lanes sharing the test against the
+            // placed humans (lane % 8 takes every eighth one).  The first attempt none of whose lanes found a collision wins
+            // and the stream moves to just behind it: the same draws and decisions as the sequential loop.
+            const int att = lane >> 3, sub = lane & 7;
             for (int i = 0; i < n && status == 0; ++i) {
                 const double ri = s_rad[i], si = s_spd[i];
                 bool placed = false;
-                for (int t = 0; t < g.max_tries; ++t) {
-                    const double angle = wrnd(m, lane) * pi * 2.0;
-                    const double nx = (wrnd(m, lane) - 0.5) * si;
-                    const double ny = (wrnd(m, lane) - 0.5) * si;
+                for (int t0 = 0; t0 < g.max_tries && !placed; t0 += 8) {
+                    if (m.pos >= 624) wmt_advance(m, lane);
+                    const int base = m.pos, k0 = base + 6 * att;
+                    const double angle = wmt_peek_double(m, k0, 0) * pi * 2.0;
+                    const double nx = (wmt_peek_double(m, k0, 1) - 0.5) * si;
+                    const double ny = (wmt_peek_double(m, k0, 2) - 0.5) * si;
                     double sa, ca;
                     sincos(angle, &sa, &ca); // one range reduction for both (same values as cos() and sin(): G6 parity)
                     const double x = 0.0 + R * ca + nx, y = 0.0 + R * sa + ny;
-                    const double md = ri + myrad + 0.2;
-                    const bool hit = lane < i && (norm2d(x - mx, y - my) < md || norm2d(x - (-mx + 0.0), y - (-my + 0.0)) < md);
-                    bool collide = __builtin_amdgcn_ballot_w64(hit) != 0;
-                    if (insert_robot && (norm2d(x - rpx, y - rpy) < ri + rr + 0.2 || norm2d(x - rgx, y - rgy) < ri + rr + 0.2))
-                        collide = true;
-                    if (!collide) {
-                        if (lane == i) { mx = x; my = y; myaw = bound_angle_d(pi + angle); }
-                        placed = true;
-                        break;
+                    bool collide = t0 + att >= g.max_tries;
+                    for (int j = sub; j < i; j += 8) {
+                        const double qx = s_px[j], qy = s_py[j], md = ri + s_rad[j] + 0.2;
+                        collide |= closer_than(x - qx, y - qy, md) || closer_than(x - (-qx + 0.0), y - (-qy + 0.0), md);
                     }
+                    if (insert_robot && sub == 0)
+                        collide |= closer_than(x - rpx, y - rpy, ri + rr + 0.2) || closer_than(x - rgx, y - rgy, ri + rr + 0.2);
+                    const unsigned long long bad = __builtin_amdgcn_ballot_w64(collide);
+                    int win = -1;
+                    for (int q = 7; q >= 0; --q) if (((bad >> (8 * q)) & 0xFFull) == 0) win = q;
+                    if (win >= 0) {
+                        if (lane == 8 * win) { s_px[i] = x; s_py[i] = y; s_yaw[i] = bound_angle_d(pi + angle); }
+                        m.pos = base + 6 * (win + 1);
+                        placed = true;
+                    } else {
+                        m.pos = base + 6 * 8;
+                    }
+                    __syncthreads();
                 }
                 if (!placed) status = 1;
             }
+            if (lane < n) { mx = s_px[lane]; my = s_py[lane]; myaw = s_yaw[lane]; }
         }
     } else if (scenario == CS_SCN_PARALLEL_TRAFFIC) {
         rpx = -(L / 2.0) + 1.0; rpy = 0.0; ryaw = 0.0; rgx = (L / 2.0) - 1.0; rgy = 0.0;
         double area = 0.0;
         for (int i = 0; i < n; ++i) area += pi * (s_rad[i] * s_rad[i]);
         if (area > L * H * 0.4) status = 2;
-        for (int i = 0; i < n && status == 0; ++i) {
+        const int att = lane >> 3, sub = lane & 7;
+        for (int i = 0; i < n && status == 0; ++i) {   // speculative, four words per attempt (see the circular crossing)
             const double ri = s_rad[i];
+            const double lo = -(L / 2.0) + ri, hi = L / 2.0 - ri;
             bool placed = false;
-            for (int t = 0; t < g.max_tries; ++t) {
-                const double lo = -(L / 2.0) + ri, hi = L / 2.0 - ri;
-                const double x = (hi - lo) * wrnd(m, lane) + lo;
-                const double y = (wrnd(m, lane) - 0.5) * H;
-                const bool hit = lane < i && (norm2d(x - mx, y - my) - ri - myrad - 0.1 < 0.0);
-                bool collide = __builtin_amdgcn_ballot_w64(hit) != 0;
-                if (insert_robot && norm2d(x - rpx, y - rpy) - ri - rr - 0.1 < 0.0) collide = true;
-                if (!collide) {
-                    if (lane == i) { mx = x; my = y; myaw = bound_angle_d(-pi); }
-                    placed = true;
-                    break;
+            for (int t0 = 0; t0 < g.max_tries && !placed; t0 += 8) {
+                if (m.pos >= 624) wmt_advance(m, lane);
+                const int base = m.pos, k0 = base + 4 * att;
+                const double x = (hi - lo) * wmt_peek_double(m, k0, 0) + lo;
+                const double y = (wmt_peek_double(m, k0, 1) - 0.5) * H;
+                bool collide = t0 + att >= g.max_tries;
+                for (int j = sub; j < i; j += 8) {
+                    // norm(...) - ri - radius_j - 0.1 < 0, decided on the squares outside the rounding band of that expression
+                    const double dx = x - s_px[j], dy = y - s_py[j], rj = s_rad[j];
+                    const double d2 = dx * dx + dy * dy, T = ri + rj + 0.1, T2 = T * T;
+                    bool c = d2 < T2;
+                    if (fabs(d2 - T2) <= 1e-12 * T2) c = norm2d(dx, dy) - ri - rj - 0.1 < 0.0;
+                    collide |= c;
                 }
+                if (insert_robot && sub == 0) {
+                    const double dx = x - rpx, dy = y - rpy;
+                    const double d2 = dx * dx + dy * dy, T = ri + rr + 0.1, T2 = T * T;
+                    bool c = d2 < T2;
+                    if (fabs(d2 - T2) <= 1e-12 * T2) c = norm2d(dx, dy) - ri - rr - 0.1 < 0.0;
+                    collide |= c;
+                }
+                const unsigned long long bad = __builtin_amdgcn_ballot_w64(collide);
+                int win = -1;
+                for (int q = 7; q >= 0; --q) if (((bad >> (8 * q)) & 0xFFull) == 0) win = q;
+                if (win >= 0) {
+                    if (lane == 8 * win) { s_px[i] = x; s_py[i] = y; s_yaw[i] = bound_angle_d(-pi); }
+                    m.pos = base + 4 * (win + 1);
+                    placed = true;
+                } else {
+                    m.pos = base + 4 * 8;
+                }
+                __syncthreads();
             }
             if (!placed) status = 1;
         }
+        if (lane < n) { mx = s_px[lane]; my = s_py[lane]; myaw = s_yaw[lane]; }
     } else {
         rpx = 0.0; rpy = 0.0 - R; ryaw = pi / 2.0; rgx = 0.0; rgy = 0.0 + R;
         const double inner = R - 3.0;
