@@ -277,6 +277,18 @@ int cs_actual_collision_reward(const cs_worlds* w, float T, const float* d_globa
  */
 int cs_update_humans_rk45(const cs_worlds* w, float dt, float* d_memory, int32_t* d_nfev, void* stream);
 
+/*
+ * cs_gym_bookkeeping  the host bookkeeping of SocialNavGym between two steps, for W worlds on the device (one lane per world):
+ *   typed copies of cs_collision_reward's rows (d_out [W][7] -> d_reward [W], d_terminated / d_truncated [W] bytes 0 / 1,
+ *   d_info [W]); the per-world step counter and global_time = clock[counter] (social_nav_gym.py:244 accumulates time_step in
+ *   float32: the caller tabulates those sums in d_clock [clock_len]); with auto_reset, d_mask [W] = episode ended, the counter
+ *   of such a world restarts at 0 and its seed moves on by W (the next unused seed of its arithmetic sequence) -- the inputs
+ *   of the masked cs_generate_worlds that follows.
+ */
+int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, float* d_global_time,
+                       const float* d_clock, int clock_len, int auto_reset, float* d_reward, uint8_t* d_terminated,
+                       uint8_t* d_truncated, int32_t* d_info, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

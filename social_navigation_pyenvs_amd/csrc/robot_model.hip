@@ -232,6 +232,30 @@ __global__ void k_actual_collision_reward(int W, int n, int rows, const float* S
     o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
 }
 
+// Episode bookkeeping of a vectorised Gym loop, one lane per world: what SocialNavGym does on the host between two steps
+// (social_nav_gym.py:244 global_time += time_step, time_step_factor times -- the float32 sums are tabulated in `clock`;
+// :135-197 the next reset of a finished world draws the next unused seed) plus the typed copies of the reward kernel's
+// output row, so that a step of BatchedSocialNavGym.step_device needs no element-wise torch op.
+__global__ void k_gym_bookkeeping(int W, const float* out7, int* counter, unsigned* seeds, int* mask, float* gtime, const float* clock,
+                                  int clock_len, int auto_reset, float* reward, unsigned char* terminated, unsigned char* truncated,
+                                  int* info)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    const float* o = out7 + (long)w * 7;
+    const bool term = o[4] > 0.0f, trunc = o[5] > 0.0f;
+    reward[w] = o[3]; terminated[w] = term ? 1 : 0; truncated[w] = trunc ? 1 : 0; info[w] = (int)o[6];
+    int c = counter[w] + 1;
+    if (auto_reset) {
+        const bool done = term || trunc;
+        mask[w] = done ? 1 : 0;
+        if (done) { seeds[w] += (unsigned)W; c = 0; }   // every world walks its own arithmetic sequence of seeds
+    }
+    c = c < clock_len - 1 ? c : clock_len - 1;
+    counter[w] = c;
+    gtime[w] = clock[c];
+}
+
 } // namespace
 
 extern "C" {
@@ -279,6 +303,21 @@ int cs_actual_collision_reward(const cs_worlds* w, float T, const float* d_globa
     hipLaunchKernelGGL(k_actual_collision_reward, dim3((w->W + block - 1) / block), dim3(block), 0, (hipStream_t)stream, w->W, w->n,
                        rows, w->d_state, as, fs, w->d_robot, T, d_global_time, reward_cfg[0], reward_cfg[1], reward_cfg[2],
                        reward_cfg[3], reward_cfg[4], d_out);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, float* d_global_time,
+                       const float* d_clock, int clock_len, int auto_reset, float* d_reward, uint8_t* d_terminated,
+                       uint8_t* d_truncated, int32_t* d_info, void* stream)
+{
+    if (W <= 0 || clock_len <= 0) return fail(CS_ERR_ARG, "W and clock_len must be positive");
+    if (!d_out || !d_counter || !d_global_time || !d_clock || !d_reward || !d_terminated || !d_truncated || !d_info)
+        return fail(CS_ERR_ARG, "null argument");
+    if (auto_reset && (!d_seeds || !d_mask)) return fail(CS_ERR_ARG, "auto_reset needs the seeds and the mask");
+    const int block = 64;
+    hipLaunchKernelGGL(k_gym_bookkeeping, dim3((W + block - 1) / block), dim3(block), 0, (hipStream_t)stream, W, d_out, d_counter,
+                       d_seeds, d_mask, d_global_time, d_clock, clock_len, auto_reset, d_reward, d_terminated, d_truncated, d_info);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

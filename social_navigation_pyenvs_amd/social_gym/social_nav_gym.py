@@ -395,7 +395,11 @@ class BatchedSocialNavGym:
                 t = t + np.float32(self.time_step)
             clock[k] = t
         dl = dict(cw=self.cw, clock=torch.as_tensor(clock, device="cuda"),
-                  counter=torch.zeros(W, dtype=torch.int64, device="cuda"),
+                  counter=torch.zeros(W, dtype=torch.int32, device="cuda"),
+                  parity=0,
+                  results=[(torch.zeros(W, dtype=torch.float32, device="cuda"), torch.zeros(W, dtype=torch.bool, device="cuda"),
+                            torch.zeros(W, dtype=torch.bool, device="cuda"), torch.zeros(W, dtype=torch.int32, device="cuda"))
+                           for _ in range(2)],
                   gtime=torch.zeros(W, dtype=torch.float32, device="cuda"),
                   seeds=torch.as_tensor(self._seeds_host.astype(np.int64), device="cuda").to(torch.int32),
                   mask=torch.zeros(W, dtype=torch.int32, device="cuda"),
@@ -424,7 +428,9 @@ class BatchedSocialNavGym:
 
         dl = self._device_loop_state()
         cw = self.cw
-        a = actions.to(device="cuda", dtype=torch.float32).contiguous()
+        a = actions
+        if a.dtype != torch.float32 or not a.is_cuda or not a.is_contiguous():
+            a = a.to(device="cuda", dtype=torch.float32).contiguous()
         d = cw.descriptor()
         cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
         lib = _lib.load()
@@ -433,17 +439,19 @@ class BatchedSocialNavGym:
                                            C.c_void_p(cw.stream)))
         _lib.check(lib.cs_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(a.data_ptr()),
                                C.c_void_p(cw.stream)))
-        out = dl["out"]
-        reward, terminated, truncated = out[:, 3].clone(), out[:, 4] > 0, out[:, 5] > 0
-        info = out[:, 6].to(torch.int32)
-        dl["counter"] += 1
+        # typed results of this step (two sets, alternating: the tensors of the previous step stay valid for one more call),
+        # step counter, float32 clock, reset mask and next seeds in ONE small launch instead of a dozen element-wise torch ops
+        res = dl["results"][dl["parity"]]
+        dl["parity"] ^= 1
+        reward, terminated, truncated, info = res
+        _lib.check(lib.cs_gym_bookkeeping(C.c_int(self.W), C.c_void_p(dl["out"].data_ptr()), C.c_void_p(dl["counter"].data_ptr()),
+                                          C.c_void_p(dl["seeds"].data_ptr()), C.c_void_p(dl["mask"].data_ptr()),
+                                          C.c_void_p(dl["gtime"].data_ptr()), C.c_void_p(dl["clock"].data_ptr()),
+                                          C.c_int(dl["clock"].numel()), C.c_int(int(bool(auto_reset))),
+                                          C.c_void_p(reward.data_ptr()), C.c_void_p(terminated.data_ptr()),
+                                          C.c_void_p(truncated.data_ptr()), C.c_void_p(info.data_ptr()), C.c_void_p(cw.stream)))
         if auto_reset:
-            done = terminated | truncated
-            dl["mask"].copy_(done)
-            dl["seeds"] += dl["mask"] * self.W               # every world walks its own arithmetic sequence of seeds
             gen.generate_worlds_device(cw, dl["gen"], dl["seeds"], dl["mask"])
-            dl["counter"].masked_fill_(done, 0)
-        torch.index_select(dl["clock"], 0, dl["counter"].clamp_(max=dl["clock"].numel() - 1), out=dl["gtime"])
         return self.observe_device(), reward, terminated, truncated, info
 
     def lookahead_device(self, action_space):
