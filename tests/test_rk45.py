@@ -121,6 +121,11 @@ def test_rk45_batch_of_worlds_and_layouts():
         outs[layout] = (cw.get_states(), nf)
     np.testing.assert_array_equal(outs["aos"][0], outs["soa"][0])
     np.testing.assert_array_equal(outs["aos"][1], outs["soa"][1])
+    cw = CrowdWorlds(np.stack(Ss), np.stack(Gs), np.tile(c["params"], (len(ks), 1, 1)), np.stack(Fs), walls, type=c["model"],
+                     all_params_equal=c["all_params_equal"], robot_row=c["robot_visible"])   # per-world parameter blocks
+    nf = cw.update_humans_rk45(c["dt"], desired_force=mem)
+    np.testing.assert_array_equal(cw.get_states(), outs["aos"][0])
+    np.testing.assert_array_equal(nf, outs["aos"][1])
     for i, k in enumerate(ks):
         cw = CrowdWorlds(Ss[i], Gs[i], c["params"], Fs[i], walls, type=c["model"], all_params_equal=c["all_params_equal"],
                          robot_row=c["robot_visible"])
