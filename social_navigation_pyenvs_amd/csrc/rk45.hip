@@ -101,7 +101,6 @@ __global__ __launch_bounds__(64) void k_rk45_step(const KArgsRk a)
     const int w = blockIdx.x, lane = threadIdx.x;
     const int n = a.n, rows = a.rows;
     const bool human = lane < n;
-    const bool robot_row = (a.flags & CS_ROBOT_ROW) != 0;
     const bool all_equal = (a.flags & CS_ALL_PARAMS_EQUAL) != 0;
     const int kind = a.type % 3;
     const bool torque_new = a.type >= CS_HSFM_NEW;
