@@ -151,6 +151,11 @@ def cpu_baseline(args, host, type_id):
 
 def main():
     args = parse()
+    # stdout carries ONE JSON line and nothing else: native libraries (RCCL prints a version banner from C when NCCL_DEBUG
+    # asks for it) write to file descriptor 1 directly, so everything but the final line is sent to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +172,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.force_dist and world_size == 1:   # rehearsal of the RCCL barrier path without a launcher
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world_size and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world_size}", file=sys.stderr)
@@ -271,7 +279,10 @@ def main():
         if not args.no_cpu_baseline and args.model != "orca" and world_size == 1:  # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
