@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per agent-substep, f32 (SURVEY.md §8d / BASELINE.md §4)
 ALG_BYTES = {"sfm": 52, "hsfm": 76, "orca": 48}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
-# HBM-side bytes per agent per LAUNCH from rocprofv3 PMC passes of this very command (profiles/r1g_pmc_traffic.txt,
+# HBM-side bytes per agent per LAUNCH from rocprofv3 PMC passes of this very command (profiles/r1i_pmc_traffic.txt (first measured in r1g),
 # method in profiles/r1c_pmc_traffic.md): (FETCH_SIZE 5511.1 KB + WRITE_SIZE 4505.9 KB) / (4096 x 25 agents);
 # independent of the number of fused substeps.  FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950
 # (reads 0.87x the 64 B/agent the code loads).
