@@ -72,3 +72,19 @@ def test_header_is_plain_c_and_generator_struct_matches():
     assert sizes[3] == cs_generator.robot_desired_speed.offset
     assert sizes[4] == cs_worlds.d_world_flags.offset
     assert sizes[5] == cs_worlds.d_orca_vertices.offset
+
+
+def test_integration_doc_stub_matches_the_struct():
+    """The ctypes stub INTEGRATION.md shows a maintainer is the header's cs_worlds, field for field."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd._lib import cs_worlds
+
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class cs_worlds\(C\.Structure\):.*?\n(    _fields_ = \[.*?\])\n", src, re.S)
+    assert m, "stub not found"
+    ns = {"C": C}
+    exec("class stub(C.Structure):\n" + m.group(1), ns)
+    stub = ns["stub"]
+    assert [(f[0], f[1]) for f in stub._fields_] == [(f[0], f[1]) for f in cs_worlds._fields_]
+    assert C.sizeof(stub) == C.sizeof(cs_worlds)
