@@ -744,7 +744,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
 // robot's computeNeighbors + computeNewVelocity + update: one lane per world, the generic LDS-column code above.
 // The robot's preferred velocity is update_goals_orca(robot) of its current position (:134-141).
 struct ORArgs {
-    int W, n, rows, robot_row, write_row, K, KO, nv;
+    int W, n, rows, robot_row, write_row, K, KO, nv, wpb;
     float dt, neighbor_dist, time_horizon, time_horizon_obst, robot_margin;
     float* S; long as, fs;
     const float* hmargin;   // [W][rows]
@@ -763,8 +763,8 @@ __global__ __launch_bounds__(64) void k_orca_robot_step(const ORArgs a)
     int* lds_ni = reinterpret_cast<int*>(lds_nd + a.K * T);          // [K][T]
     float* lds_od = reinterpret_cast<float*>(lds_ni + a.K * T);      // [KO][T]
     int* lds_oi = reinterpret_cast<int*>(lds_od + a.KO * T);         // [KO][T]
-    const int w = blockIdx.x * T + tid;
-    if (w >= a.W) return;
+    const int w = blockIdx.x * a.wpb + tid;
+    if (tid >= a.wpb || w >= a.W) return;
     float* rb = a.robot + (long)w * 13;
     float px = rb[0], py = rb[1], vx = rb[3], vy = rb[4];
     const float r = rb[8] + a.robot_margin, gx = rb[10], gy = rb[11], vmax = rb[12];
@@ -900,7 +900,11 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
     const size_t shmem = (size_t)(a.K + a.KO) * 64 * (2 * sizeof(float4) + 2 * sizeof(float));
     if (shmem > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_orca_robot_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(k_orca_robot_step, dim3((w->W + 63) / 64), dim3(64), shmem, stream, a);
+    // one lane per world, 16 worlds per wavefront: the linear programme is a serial, divergent chain per lane (one launch costs
+    // about one ORCA substep, ~55 us, whatever the packing: 64 / 32 / 16 / 8 worlds per wavefront measured 1.27 / 1.24 / 1.18 /
+    // 1.18 ms per 20-substep imitation step at 4096 worlds), so the packing only has to reach every CU
+    a.wpb = 16;
+    hipLaunchKernelGGL(k_orca_robot_step, dim3((w->W + a.wpb - 1) / a.wpb), dim3(64), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
