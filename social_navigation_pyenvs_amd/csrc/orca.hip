@@ -824,6 +824,55 @@ __global__ __launch_bounds__(64) void k_orca_robot_step(const ORArgs a)
     }
 }
 
+
+// The same for the reference's defaults (maxNeighbors = 10) without walls: the register-resident solve of the crowd kernel
+// (orca_velocity_fast10), one lane per world, the humans' rows of the block's worlds staged in LDS by all 64 lanes.
+__global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, ent = a.n + 1;                       // the humans and the robot itself as the last row
+    float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [wpb][ent] x, y, vx, vy
+    float* lds_rr = reinterpret_cast<float*>(lds_pv + a.wpb * ent);  // [wpb][ent] radius + margin
+    const int w0 = blockIdx.x * a.wpb;
+    for (int k = tid; k < a.wpb * a.n; k += 64) {
+        const int wl = k / a.n, b = k - wl * a.n, w = w0 + wl;
+        if (w < a.W) {
+            const float* s = a.S + ((long)w * a.rows + b) * a.as;
+            lds_pv[wl * ent + b] = make_float4(s[0], s[a.fs], s[3 * a.fs], s[4 * a.fs]);
+            lds_rr[wl * ent + b] = s[8 * a.fs] + a.hmargin[(long)w * a.rows + b];
+        }
+    }
+    const int w = w0 + tid;
+    const bool mine = tid < a.wpb && w < a.W;
+    float px = 0, py = 0, vx = 0, vy = 0, r = 1, gx = 0, gy = 0, vmax = 1;
+    float* rb = a.robot + (long)(mine ? w : 0) * 13;
+    if (mine) {
+        px = rb[0]; py = rb[1]; vx = rb[3]; vy = rb[4];
+        r = rb[8] + a.robot_margin; gx = rb[10]; gy = rb[11]; vmax = rb[12];
+        lds_pv[tid * ent + a.n] = make_float4(px, py, vx, vy);
+        lds_rr[tid * ent + a.n] = r;
+    }
+    __syncthreads();
+    if (!mine) return;
+    float pvx, pvy;
+    {
+        const float ddx = gx - px, ddy = gy - py;
+        const float nrm = sqrtf(ddx * ddx + ddy * ddy);
+        if (nrm > vmax) { pvx = ddx / nrm; pvy = ddy / nrm; } else { pvx = ddx; pvy = ddy; }
+    }
+    float nvx, nvy;
+    unsigned long long ost_last = 0;
+    orca_velocity_fast10(lds_pv + tid * ent, lds_rr + tid * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
+                         a.time_horizon, a.dt, nvx, nvy, nullptr, ost_last);
+    vx = nvx; vy = nvy;
+    px += vx * a.dt; py += vy * a.dt;
+    rb[0] = px; rb[1] = py; rb[3] = vx; rb[4] = vy;
+    if (a.write_row) {
+        float* s = a.S + ((long)w * a.rows + a.n) * a.as;
+        s[0] = px; s[a.fs] = py; s[3 * a.fs] = vx; s[4 * a.fs] = vy;
+    }
+}
+
 } // namespace
 
 namespace csimpl {
@@ -904,6 +953,12 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
     // about one ORCA substep, ~55 us, whatever the packing: 64 / 32 / 16 / 8 worlds per wavefront measured 1.27 / 1.24 / 1.18 /
     // 1.18 ms per 20-substep imitation step at 4096 worlds), so the packing only has to reach every CU
     a.wpb = 16;
+    if (a.K == 10 && a.nv == 0 && a.n + 1 <= 128) {   // the reference's defaults, no walls: register-resident solve
+        const size_t sh = (size_t)a.wpb * (a.n + 1) * (sizeof(float4) + sizeof(float));
+        hipLaunchKernelGGL(k_orca_robot_step_fast, dim3((w->W + a.wpb - 1) / a.wpb), dim3(64), sh, stream, a);
+        HIP_TRY(hipGetLastError());
+        return CS_OK;
+    }
     hipLaunchKernelGGL(k_orca_robot_step, dim3((w->W + a.wpb - 1) / a.wpb), dim3(64), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
