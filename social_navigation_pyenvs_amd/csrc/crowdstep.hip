@@ -1305,8 +1305,10 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     // the run-time partner loop (any other row count, walls, robot row) keeps the full register budget on every grid: its
     // 128-VGPR build spills (7 VGPRs lean, 35 with walls) and measured 6-17 % slower on crowded grids (8192 x 50 + walls:
     // 355 vs 304 us; 16384 x 30 Moussaid: 484 vs 402 us)
-    else if (lean) fn = pick_kernel<64, 1, 0, true>(w->type, true);
-    else fn = pick_kernel<64, 1, 0, false>(w->type, peq);
+    // (budget of THREE waves per SIMD, 168 VGPRs: the walls build needs exactly that many, and a build that tips over to
+    // 169 runs at two waves per SIMD and 18 % slower -- with the cap a future compiler spills a register instead)
+    else if (lean) fn = pick_kernel<64, 3, 0, true>(w->type, true);
+    else fn = pick_kernel<64, 3, 0, false>(w->type, peq);
     // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
     // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
     size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
