@@ -581,6 +581,10 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             }
                         };
                         int s0 = 0;
+                        // polygons of up to six slots (triangles to hexagons) in ONE trip: all their LDS reads are in flight together
+                        if (a.Smax == 5) { trip(0, std::integral_constant<int, 5>{}); s0 = 5; }
+                        else if (a.Smax == 6) { trip(0, std::integral_constant<int, 6>{}); s0 = 6; }
+                        else if (a.Smax == 3) { trip(0, std::integral_constant<int, 3>{}); s0 = 3; }
                         for (; s0 + 4 <= a.Smax; s0 += 4) trip(s0, std::integral_constant<int, 4>{});
                         if (s0 + 2 <= a.Smax) { trip(s0, std::integral_constant<int, 2>{}); s0 += 2; }
                         if (s0 < a.Smax) trip(s0, std::integral_constant<int, 1>{});
