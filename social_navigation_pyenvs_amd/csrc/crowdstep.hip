@@ -272,10 +272,10 @@ constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one 
 //            are exactly two waves per SIMD and the spill-free build is 6 % faster; at 16384 x 25 the 4-wave build is 7 % faster
 //   ROWS_CT = rows per world known at compile time (0: read from the arguments): the partner-group loop unrolls and
 //            its ~9 scalar branches per substep (~24 cycles of wave latency each) disappear
-//   LEAN   = pair-once build for the plain crowd batch: no walls, no robot row, goal lists of <= 2 entries, state
+//   LEAN   = 1 / 2: pair-once build for the plain crowd batch: no walls (1) or walls kept (2), no robot row, goal lists of <= 2 entries, state
 //            committed in place -- the wall / robot / goal-list-in-memory code and their branches are compiled out and
 //            the goal switch is predicated
-template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, bool LEAN>
+template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, int LEAN>
 __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -362,12 +362,12 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     }
     const float inv_O = a.O > 0 ? 1.0f / (float)a.O : 0.0f;
     const float* obst = nullptr;
-    if (!LEAN && a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
+    if (LEAN != 1 && a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
     // wall segments are constant over the launch: stage (x1, y1, e, 1/|e|^2) in LDS once instead of re-loading and
     // re-deriving them in every substep (3 polygons x 5 segments cost as much as the whole 50-agent pair loop otherwise)
-    const int nseg = LEAN ? 0 : a.O * a.Smax;
+    const int nseg = LEAN == 1 ? 0 : a.O * a.Smax;
     const int sbase = (a.flags & CS_OBSTACLES_SHARED) ? 0 : lw * nseg;
-    for (int i = tid; i < (LEAN ? 0 : a.seg_tab); i += T) {
+    for (int i = tid; i < (LEAN == 1 ? 0 : a.seg_tab); i += T) {
         const int lwi = i / (nseg > 0 ? nseg : 1);
         const long wi = (long)blockIdx.x * a.wpb + lwi;
         float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1215,13 +1215,13 @@ __global__ void k_transpose_state(const float* src, float* dst, long total_rows,
 // ------------------------------------------------------------------------------------------
 using kfn = void (*)(const KArgs);
 
-template <int MAXT, int OCC, int ROWS_CT, bool LEAN>
+template <int MAXT, int OCC, int ROWS_CT, int LEAN>
 kfn pick_kernel(int type, bool peq)
 {
 #define CS_CASE(SOC, HD)                                                                                      \
-    if constexpr (LEAN) return (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, true>;                      \
-    else return peq ? (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, false>                               \
-                    : (kfn)k_sfm_step<SOC, HD, false, MAXT, OCC, ROWS_CT, false>;
+    if constexpr (LEAN != 0) return (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, LEAN>;                      \
+    else return peq ? (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, 0>                               \
+                    : (kfn)k_sfm_step<SOC, HD, false, MAXT, OCC, ROWS_CT, 0>;
     switch (type) {
         case 0: CS_CASE(0, 0) case 1: CS_CASE(1, 0) case 2: CS_CASE(2, 0)
         case 3: CS_CASE(0, 1) case 4: CS_CASE(1, 1) case 5: CS_CASE(2, 1)
@@ -1299,20 +1299,22 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     const bool crowded = g.block == 64 && g.grid > 2 * 1024;
     // the plain crowd batch (what Gym scenarios and the bench step): pair-once, no walls, no robot row, <= 2 goal slots,
     // committed in place -> the lean build; 25 rows per world also has its partner groups unrolled at compile time
-    const bool lean = peq && g.block == 64 && w->O == 0 && !(w->flags & CS_ROBOT_ROW) && w->G <= 2 && mode == M_COMMIT_GOALS;
+    const bool lean_w = peq && g.block == 64 && !(w->flags & CS_ROBOT_ROW) && w->G <= 2 && mode == M_COMMIT_GOALS;   // walls allowed
+    const bool lean = lean_w && w->O == 0;
     kfn fn;
-    if (g.block != 64) fn = pick_kernel<1024, 1, 0, false>(w->type, peq);
+    if (g.block != 64) fn = pick_kernel<1024, 1, 0, 0>(w->type, peq);
     // compile-time row counts of the BASELINE.json configurations with 25 and 10 humans (50 rows unrolled spill 30-47 VGPRs
     // at the 4-wave budget and stay on the run-time loop); 10 rows fit 128 VGPRs without spills in every model
-    else if (lean && rows == 25) fn = crowded ? pick_kernel<64, 4, 25, true>(w->type, true) : pick_kernel<64, 1, 25, true>(w->type, true);
-    else if (lean && rows == 10) fn = pick_kernel<64, 4, 10, true>(w->type, true);
+    else if (lean && rows == 25) fn = crowded ? pick_kernel<64, 4, 25, 1>(w->type, true) : pick_kernel<64, 1, 25, 1>(w->type, true);
+    else if (lean && rows == 10) fn = pick_kernel<64, 4, 10, 1>(w->type, true);
     // the run-time partner loop (any other row count, walls, robot row) keeps the full register budget on every grid: its
     // 128-VGPR build spills (7 VGPRs lean, 35 with walls) and measured 6-17 % slower on crowded grids (8192 x 50 + walls:
     // 355 vs 304 us; 16384 x 30 Moussaid: 484 vs 402 us)
     // (budget of THREE waves per SIMD, 168 VGPRs: the walls build needs exactly that many, and a build that tips over to
     // 169 runs at two waves per SIMD and 18 % slower -- with the cap a future compiler spills a register instead)
-    else if (lean) fn = pick_kernel<64, 3, 0, true>(w->type, true);
-    else fn = pick_kernel<64, 3, 0, false>(w->type, peq);
+    else if (lean) fn = pick_kernel<64, 3, 0, 1>(w->type, true);
+    else if (lean_w) fn = pick_kernel<64, 3, 0, 2>(w->type, true);   // the lean build that keeps the walls (cfg5's shard)
+    else fn = pick_kernel<64, 3, 0, 0>(w->type, peq);
     // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
     // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
     size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
