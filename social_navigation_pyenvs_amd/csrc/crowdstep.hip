@@ -1303,8 +1303,8 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     const bool lean = lean_w && w->O == 0;
     kfn fn;
     if (g.block != 64) fn = pick_kernel<1024, 1, 0, 0>(w->type, peq);
-    // compile-time row counts of the BASELINE.json configurations with 25 and 10 humans (50 rows unrolled spill 30-47 VGPRs
-    // at the 4-wave budget and stay on the run-time loop); 10 rows fit 128 VGPRs without spills in every model
+    // compile-time row counts of the BASELINE.json configurations with 25, 10 and 50 humans (50 rows unrolled spill 30-47 VGPRs
+    // at the 4-wave budget: they are built for three waves per SIMD); 10 rows fit 128 VGPRs without spills in every model
     else if (lean && rows == 25) fn = crowded ? pick_kernel<64, 4, 25, 1>(w->type, true) : pick_kernel<64, 1, 25, 1>(w->type, true);
     else if (lean && rows == 10) fn = pick_kernel<64, 4, 10, 1>(w->type, true);
     // the run-time partner loop (any other row count, walls, robot row) keeps the full register budget on every grid: its
@@ -1312,6 +1312,8 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     // 355 vs 304 us; 16384 x 30 Moussaid: 484 vs 402 us)
     // (budget of THREE waves per SIMD, 168 VGPRs: the walls build needs exactly that many, and a build that tips over to
     // 169 runs at two waves per SIMD and 18 % slower -- with the cap a future compiler spills a register instead)
+    // 50 rows (cfg5) unrolled within the three-wave budget: 182 -> 176 us without walls, 266 -> 260 us with them
+    else if (lean_w && rows == 50) fn = lean ? pick_kernel<64, 3, 50, 1>(w->type, true) : pick_kernel<64, 3, 50, 2>(w->type, true);
     else if (lean) fn = pick_kernel<64, 3, 0, 1>(w->type, true);
     else if (lean_w) fn = pick_kernel<64, 3, 0, 2>(w->type, true);   // the lean build that keeps the walls (cfg5's shard)
     else fn = pick_kernel<64, 3, 0, 0>(w->type, peq);

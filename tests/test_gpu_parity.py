@@ -236,7 +236,7 @@ def test_bad_type_raises_value_error():
 
 
 @pytest.mark.parametrize("rows_case", [(1, False), (2, False), (1, True), (3, False), (4, True), (7, False), (21, True),
-                                       (31, True), (32, False), (33, False), (63, True), (64, False)])
+                                       (31, True), (32, False), (33, False), (50, False), (63, True), (64, False)])
 def test_pair_once_loop_world_sizes(rows_case):
     """Edge sizes of the pair-once loop (ring distance (rows-1)/2, antipodal partner for even rows, several worlds per
     wavefront with the padded LDS pitch, worlds that fill the wavefront): dense random worlds, all 9 types,
