@@ -344,24 +344,16 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
 }
 
 // linearProgram3 on ten register-resident lines (no static obstacles): the same operations in the same order as lp3() /
-// lp2() / lp1() above.  The walk over the violated lines i is a wave-uniform runtime loop (line i is picked with selects); the
+// lp2() / lp1() above.  The walk over the violated lines i is a wave-uniform runtime loop (line i is read from an LDS copy); the
 // projected lines j < i and linearProgram2 / linearProgram1 over them are statically unrolled and guarded by the uniform j < i.
 // RVO2 drops a projected line whose source line is parallel to line i and points the same way: here it keeps its slot and a
 // cleared bit in `pvalid`, and every loop skips it, which visits the surviving lines in the same order.
-__device__ __forceinline__ float4 pick10(const float4 (&A)[10], int i)
-{
-    float4 r = A[0];
-#pragma unroll
-    for (int k = 1; k < 10; ++k) if (i == k) r = A[k];
-    return r;
-}
-
-__device__ void lp3_fast10(const float4 (&Lr)[10], int cnt, int failed, float vmax, float& rx, float& ry)
+__device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int failed, float vmax, float& rx, float& ry)
 {
     float distance = 0.0f;
 #pragma nounroll
     for (int i = 0; i < 10; ++i) {
-        const float4 li = pick10(Lr, i);
+        const float4 li = L.get(i);   // line i by its run-time index: from the LDS copy (a register array indexed at run time goes to scratch memory, ~10x the latency)
         const bool act = (i >= failed) && (i < cnt) && (det2(li.z, li.w, li.x - rx, li.y - ry) > distance);
         if (__builtin_amdgcn_ballot_w64(act) == 0) continue;
         float4 Pr[9];
@@ -401,32 +393,30 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], int cnt, int failed, float vm
                     const float sq = sqrtf(fmaxf(disc, 0.0f));
                     float tL = -dot - sq, tR = -dot + sq;
 #pragma unroll
-                    for (int m = 0; m < k; ++m) {
+                    for (int m = 0; m < k; ++m) {   // branch-free: the divisions of all m are independent and overlap
                         const float4 lm = Pr[m];
                         const float den = det2(lk.z, lk.w, lm.z, lm.w);
                         const float num = det2(lm.z, lm.w, lk.x - lm.x, lk.y - lm.y);
-                        if ((pvalid >> m) & 1u) {
-                            if (fabsf(den) <= RVO_EPSILON) {
-                                if (num < 0.0f) ok = false;
-                            } else if (ok) {
-                                const float t = num / den;
-                                if (den >= 0.0f) tR = fminf(tR, t); else tL = fmaxf(tL, t);
-                                if (tL > tR) ok = false;
-                            }
-                        }
+                        const float t = num / den;
+                        const bool live = ((pvalid >> m) & 1u) != 0;
+                        const bool par = fabsf(den) <= RVO_EPSILON;
+                        const bool upd = live && !par && ok;             // (after a failure RVO2 has already returned)
+                        const float nR = (den >= 0.0f) ? fminf(tR, t) : tR, nL = (den >= 0.0f) ? tL : fmaxf(tL, t);
+                        tR = upd ? nR : tR; tL = upd ? nL : tL;
+                        ok = ok && !(live && par && num < 0.0f) && !(upd && tL > tR);
                     }
                     const float t = (ox * lk.z + oy * lk.w > 0.0f) ? tR : tL;
-                    if (viol) {
-                        if (ok) { qx = lk.x + t * lk.z; qy = lk.y + t * lk.w; }
-                        else fail2 = true;
-                    }
+                    const bool set = viol && ok;
+                    qx = set ? lk.x + t * lk.z : qx;
+                    qy = set ? lk.y + t * lk.w : qy;
+                    fail2 = fail2 || (viol && !ok);
                 }
             }
         }
-        if (act) {
-            if (!fail2) { rx = qx; ry = qy; }   // a failed linearProgram2 leaves the result where it was
-            distance = det2(li.z, li.w, li.x - rx, li.y - ry);
-        }
+        const bool take = act && !fail2;           // a failed linearProgram2 leaves the result where it was
+        rx = take ? qx : rx;
+        ry = take ? qy : ry;
+        distance = act ? det2(li.z, li.w, li.x - rx, li.y - ry) : distance;
     }
 }
 
@@ -441,7 +431,7 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], int cnt, int failed, float vm
 //    registers too (lp3_fast10).
 __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
                                      float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
-                                     float time_horizon, float dt, float& nvx, float& nvy,
+                                     float time_horizon, float dt, const Lines& L, float& nvx, float& nvy,
                                      unsigned long long* g_ost, unsigned long long& g_ost_last)
 {
     constexpr int KF = 10;
@@ -499,29 +489,31 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
             const float sq = sqrtf(fmaxf(disc, 0.0f));
             float tL = -dot - sq, tR = -dot + sq;
 #pragma unroll
-            for (int j = 0; j < i; ++j) {
+            for (int j = 0; j < i; ++j) {   // branch-free: the divisions of all j are independent and overlap
                 const float4 lj = Lr[j];
                 const float den = det2(ln.z, ln.w, lj.z, lj.w);
                 const float num = det2(lj.z, lj.w, ln.x - lj.x, ln.y - lj.y);
-                if (fabsf(den) <= RVO_EPSILON) {
-                    if (num < 0.0f) ok = false;          // parallel and on the wrong side: infeasible
-                } else if (ok) {                         // (after a failure RVO2 has already returned)
-                    const float t = num / den;
-                    if (den >= 0.0f) tR = fminf(tR, t); else tL = fmaxf(tL, t);
-                    if (tL > tR) ok = false;
-                }
+                const float t = num / den;
+                const bool par = fabsf(den) <= RVO_EPSILON;
+                const bool upd = !par && ok;                     // (after a failure RVO2 has already returned)
+                const float nR = (den >= 0.0f) ? fminf(tR, t) : tR, nL = (den >= 0.0f) ? tL : fmaxf(tL, t);
+                tR = upd ? nR : tR; tL = upd ? nL : tL;
+                ok = ok && !(par && num < 0.0f) && !(upd && tL > tR);   // parallel and on the wrong side, or an empty interval
             }
             float t = ln.z * (pvx - ln.x) + ln.w * (pvy - ln.y);
-            if (t < tL) t = tL; else if (t > tR) t = tR;
-            if (viol) {
-                if (ok) { rx = ln.x + t * ln.z; ry = ln.y + t * ln.w; }
-                else { failed = i; done = true; }
-            }
+            t = (t < tL) ? tL : ((t > tR) ? tR : t);
+            const bool set = viol && ok, bad = viol && !ok;
+            rx = set ? ln.x + t * ln.z : rx;
+            ry = set ? ln.y + t * ln.w : ry;
+            failed = bad ? i : failed;
+            done = done || bad;
         }
     }
     OSTAMP(3);
     if (__builtin_amdgcn_ballot_w64(failed < cnt) != 0) { // some lane's programme is infeasible: linearProgram3
-        lp3_fast10(Lr, cnt, failed, vmax, rx, ry);
+#pragma unroll
+        for (int k = 0; k < KF; ++k) L.set(k, Lr[k]);
+        lp3_fast10(Lr, L, cnt, failed, vmax, rx, ry);
     }
     OSTAMP(4);
     nvx = rx; nvy = ry;
@@ -535,13 +527,14 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
     const int T = blockDim.x;
     const int K = a.K;
     const int KL = FAST10 ? 0 : a.K + a.KO;                          // lines per agent: obstacle lines first, then agents
+    const int KLL = FAST10 ? 10 : KL;                                // FAST10 keeps a copy of its ten lines for LP3's run-time line index
     // per-lane columns are TL = wpb * rows lanes wide (the lanes that hold an agent: 50 of 64 for 25-agent worlds); the
     // register-resident build (FAST10) keeps lines, projected lines and neighbour keys in registers and has no columns at all
     const int TL = a.wpb * a.rows;
     const int KN = FAST10 ? 0 : K;
     float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [2][T] x, y, vx, vy
     float4* lds_L = lds_pv + 2 * T;                                  // [KL][TL] ORCA lines
-    float4* lds_P = lds_L + KL * TL;                                 // [KL][TL] LP3 projection lines
+    float4* lds_P = lds_L + KLL * TL;                                // [KL][TL] LP3 projection lines
     float* lds_r = reinterpret_cast<float*>(lds_P + KL * TL);        // [T] radius + margin
     float* lds_nd = lds_r + T;                                       // [KN][TL] neighbour distSq
     int* lds_ni = reinterpret_cast<int*>(lds_nd + KN * TL);          // [KN][TL] neighbour row
@@ -611,7 +604,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
             float nvx, nvy;
             if constexpr (FAST10) {
                 orca_velocity_fast10(pv, rr, rows, row, px, py, vx, vy, r + margin, vmax, pvx, pvy, a.neighbor_dist,
-                                     a.time_horizon, dt, nvx, nvy, g_ost, g_ost_last);
+                                     a.time_horizon, dt, L, nvx, nvy, g_ost, g_ost_last);
             } else {
                 // ---- Agent::computeNeighbors / insertAgentNeighbor (index order; strict <, ties keep order)
                 int cnt = 0;
@@ -833,6 +826,7 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
     const int tid = threadIdx.x, ent = a.n + 1;                       // the humans and the robot itself as the last row
     float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [wpb][ent] x, y, vx, vy
     float* lds_rr = reinterpret_cast<float*>(lds_pv + a.wpb * ent);  // [wpb][ent] radius + margin
+    float4* lds_ln = reinterpret_cast<float4*>(lds_rr + ((a.wpb * ent + 3) & ~3));   // [10][64] the lanes' ORCA lines for LP3
     const int w0 = blockIdx.x * a.wpb;
     for (int k = tid; k < a.wpb * a.n; k += 64) {
         const int wl = k / a.n, b = k - wl * a.n, w = w0 + wl;
@@ -862,8 +856,9 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
     }
     float nvx, nvy;
     unsigned long long ost_last = 0;
+    const Lines L{lds_ln, 64, tid};
     orca_velocity_fast10(lds_pv + tid * ent, lds_rr + tid * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
-                         a.time_horizon, a.dt, nvx, nvy, nullptr, ost_last);
+                         a.time_horizon, a.dt, L, nvx, nvy, nullptr, ost_last);
     vx = nvx; vy = nvy;
     px += vx * a.dt; py += vy * a.dt;
     rb[0] = px; rb[1] = py; rb[3] = vx; rb[4] = vy;
@@ -912,7 +907,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     const bool fast10 = a.K == 10 && a.nv == 0; // the register-resident solve has no obstacle lines
     const int TL = a.wpb * rows;                // lanes that hold an agent: the width of the per-lane LDS columns
     const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
-                         (fast10 ? 0 : (size_t)(a.K + a.KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
+                         (fast10 ? (size_t)10 * TL * sizeof(float4) : (size_t)(a.K + a.KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
     if (shmem > 160 * 1024) return fail(CS_ERR_ARG, "ORCA worlds of this many rows need max_neighbors = 10 and no static obstacles "
                                                     "(the per-agent line columns do not fit the LDS)");
     auto launch = [&](auto kernel) -> int {
@@ -954,7 +949,7 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
     // 1.18 ms per 20-substep imitation step at 4096 worlds), so the packing only has to reach every CU
     a.wpb = 16;
     if (a.K == 10 && a.nv == 0 && a.n + 1 <= 128) {   // the reference's defaults, no walls: register-resident solve
-        const size_t sh = (size_t)a.wpb * (a.n + 1) * (sizeof(float4) + sizeof(float));
+        const size_t sh = (size_t)a.wpb * (a.n + 1) * sizeof(float4) + (size_t)(((a.wpb * (a.n + 1)) + 3) & ~3) * sizeof(float) + 10 * 64 * sizeof(float4);
         hipLaunchKernelGGL(k_orca_robot_step_fast, dim3((w->W + a.wpb - 1) / a.wpb), dim3(64), sh, stream, a);
         HIP_TRY(hipGetLastError());
         return CS_OK;
