@@ -296,6 +296,11 @@ int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void*
 /* kernel launch geometry the library would use for `w` (diagnostics / DESIGN.md numbers) */
 int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_per_block);
 
+/* Name of the kernel build the library runs for `w` (diagnostics; the parity tests assert through it that the build a
+ * published number comes from is the build they compared with the oracle).  entry: 0 = cs_step, 1 = cs_update_humans_parallel
+ * with d_out != d_state, 2 = cs_peek.  buf receives e.g. "k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2". */
+int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
     "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry", "cs_lookahead",
     "cs_generate_scratch_bytes", "cs_generate_worlds", "cs_laser_scan", "cs_robot_model_step", "cs_actual_collision_reward",
-    "cs_update_humans_rk45", "cs_gym_bookkeeping",
+    "cs_update_humans_rk45", "cs_gym_bookkeeping", "cs_step_variant",
 ]
 
 
@@ -56,6 +56,40 @@ class cs_worlds(C.Structure):
 
 
 _lib = None
+hip_runtime_path = None  # the libamdhip64 this process uses (None: whatever the dynamic loader resolves, i.e. /opt/rocm)
+
+
+def _preload_hip_runtime() -> None:
+    """ONE HIP runtime per process, whatever the import order.  PyTorch-ROCm bundles its own libamdhip64.so (+ HSA
+    runtime) under torch/lib, with the same SONAME (libamdhip64.so.7) as the system one libcrowdstep.so is linked
+    against.  If libcrowdstep.so came first and pulled /opt/rocm's copy, a later `import torch` would load the bundled
+    one as well: two runtimes, two device contexts, pointers of one invalid in the other.  So when torch is installed
+    its bundled runtime is loaded first (RTLD_GLOBAL): the loader then binds libcrowdstep.so's NEEDED libamdhip64.so.7
+    to it by SONAME, and torch, whenever it is imported, finds the very same file already mapped.
+    CROWDSTEP_HIP_RUNTIME = "system" (never preload) | "torch" (default when torch is installed) | a path."""
+    global hip_runtime_path
+    choice = os.environ.get("CROWDSTEP_HIP_RUNTIME", "torch")
+    if choice == "system":
+        return
+    path = choice if os.path.sep in choice else None
+    if path is None:
+        import importlib.util
+        import sys
+
+        if "torch" in sys.modules:   # already imported: its runtime is mapped, the SONAME match does the rest
+            return
+        try:
+            spec = importlib.util.find_spec("torch")   # locates the package without importing it
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if not os.path.exists(cand):
+            return
+        path = cand
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    hip_runtime_path = path
 
 
 def load():
@@ -67,6 +101,7 @@ def load():
         raise CrowdstepError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the crowd stepper.")
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.cs_last_error.restype = C.c_char_p
     for name in ABI_SYMBOLS:

@@ -344,3 +344,11 @@ class CrowdWorlds:
         g, b, wpb = C.c_int(), C.c_int(), C.c_int()
         check(_lib.load().cs_launch_geometry(C.byref(d), C.byref(g), C.byref(b), C.byref(wpb)))
         return g.value, b.value, wpb.value
+
+    def step_variant(self, entry: str = "step") -> str:
+        """Name of the kernel build the library runs for these worlds (cs_step_variant): "step" = cs_step,
+        "update" = cs_update_humans_parallel out of place, "peek" = cs_peek."""
+        d = self.descriptor(respawn=False if entry != "step" else None)
+        buf = C.create_string_buffer(256)
+        check(_lib.load().cs_step_variant(C.byref(d), C.c_int({"step": 0, "update": 1, "peek": 2}[entry]), buf, C.c_size_t(256)))
+        return buf.value.decode()

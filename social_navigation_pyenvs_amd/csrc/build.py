@@ -1,16 +1,31 @@
-"""Build libcrowdstep.so (HIP, gfx950) in-tree with hipcc.  No CPU fallback is ever built."""
+"""Build libcrowdstep.so (HIP, gfx950) in-tree with hipcc.  No CPU fallback is ever built.
+
+The rebuild is keyed on CONTENT, not on mtimes: every translation unit is compiled to an object under csrc/.build/ whose
+key is sha256(source + the headers it includes + flags); the library carries the combined key (`cs_build_id()`), and
+`libcrowdstep.so.manifest.json` beside it records the per-file keys.  `status()` tells whether the library on disk was
+built from the sources on disk -- tests/test_abi_cpu.py fails when it was not.
+"""
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(CSRC)
 ROOT = os.path.dirname(PKG)
 LIB_PATH = os.path.join(PKG, "libcrowdstep.so")
-SOURCES = ["crowdstep.hip", "orca.hip", "lookahead.hip", "generate.hip", "laser.hip", "social_momentum.hip", "robot_model.hip", "rk45.hip"]
+MANIFEST_PATH = LIB_PATH + ".manifest.json"
+OBJ_DIR = os.path.join(CSRC, ".build")
+SOURCES = ["crowdstep.hip", "orca.hip", "lookahead.hip", "generate.hip", "laser.hip", "social_momentum.hip", "robot_model.hip",
+           "rk45.hip", "gymstep.hip", "bigworld.hip"]
 ARCH = "gfx950"
+# -fno-slp-vectorize: v_pk_*_f32 has no throughput advantage over two scalar ops on gfx950 (measured,
+# tools/valu_microbench.hip) and packing costs ~2 v_mov per partner in the pair loop
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
 
 
 def hipcc_path() -> str:
@@ -20,28 +35,103 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: the crowd stepper only exists as a HIP library for gfx950")
 
 
+def _sources() -> list[str]:
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _headers() -> list[str]:
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp", ".inc")))
+    return hs + [os.path.join(ROOT, "include", "crowdstep.h")]
+
+
+def _sha(paths: list[str], extra: str = "") -> str:
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(extra.encode())
+    return h.hexdigest()
+
+
+def source_keys(extra_flags: list[str] | None = None) -> dict:
+    """Per-file content keys and the combined build id of the sources on disk."""
+    flags = " ".join(FLAGS + (extra_flags or []))
+    hdr = _sha(_headers())
+    files = {s: _sha([os.path.join(CSRC, s)], hdr + flags) for s in _sources()}
+    build_id = hashlib.sha256(json.dumps(files, sort_keys=True).encode()).hexdigest()[:32]
+    return {"files": files, "build_id": build_id, "flags": flags}
+
+
+def status() -> dict:
+    """{'exists', 'fresh', 'build_id' (sources), 'lib_build_id' (manifest beside the library)}"""
+    keys = source_keys()
+    out = {"exists": os.path.exists(LIB_PATH), "fresh": False, "build_id": keys["build_id"], "lib_build_id": None}
+    if out["exists"] and os.path.exists(MANIFEST_PATH):
+        try:
+            out["lib_build_id"] = json.load(open(MANIFEST_PATH)).get("build_id")
+        except Exception:
+            pass
+    out["fresh"] = out["exists"] and out["lib_build_id"] == keys["build_id"]
+    return out
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in os.listdir(CSRC) if s.endswith((".hip", ".h", ".hpp"))]
-    deps.append(os.path.join(ROOT, "include", "crowdstep.h"))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return not status()["fresh"]
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags: list[str] | None = None, jobs: int | None = None) -> str:
+    """Compile what changed and link.  Returns the library path; `build.last_action` says 'compiled' or 'reused'."""
+    global last_action
+    keys = source_keys(extra_flags)
+    if extra_flags:   # diagnostic builds (e.g. -DCS_STAMPS) never claim to be the product build
+        keys["build_id"] = "diag-" + keys["build_id"][:27]
+    if not force and not extra_flags and status()["fresh"]:
+        last_action = "reused"
         return LIB_PATH
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    # -fno-slp-vectorize: v_pk_*_f32 has no throughput advantage over two scalar ops on gfx950 (measured,
-    # tools/valu_microbench.hip) and packing costs ~2 v_mov per partner in the pair loop
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + srcs + (extra_flags or [])
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = hipcc_path()
+    todo = []
+    objs = []
+    for s, key in keys["files"].items():
+        obj = os.path.join(OBJ_DIR, s + ".o")
+        objs.append(obj)
+        keyfile = obj + ".key"
+        have = open(keyfile).read().strip() if os.path.exists(keyfile) and os.path.exists(obj) else None
+        if force or have != key:
+            todo.append((s, obj, keyfile, key))
+
+    def compile_one(item):
+        s, obj, keyfile, key = item
+        cmd = [hipcc] + FLAGS + (extra_flags or []) + ["-I", os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(keyfile, "w") as f:
+            f.write(key)
+
+    jobs = jobs or min(len(todo) or 1, max(1, (os.cpu_count() or 2) - 1), 8)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(compile_one, todo))
+    idsrc = os.path.join(OBJ_DIR, "build_id.cpp")
+    with open(idsrc, "w") as f:
+        f.write('extern "C" const char* cs_build_id(void) { return "%s"; }\n' % keys["build_id"])
+    idobj = os.path.join(OBJ_DIR, "build_id.o")
+    subprocess.check_call(["g++", "-O1", "-fPIC", "-c", idsrc, "-o", idobj])
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs + [idobj]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(MANIFEST_PATH, "w") as f:
+        json.dump(keys, f, indent=1, sort_keys=True)
+    last_action = f"compiled ({len(todo)} of {len(objs)} translation units)"
     return LIB_PATH
 
 
+last_action = "none"
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build(force="--force" in sys.argv, verbose=True), last_action)

@@ -22,6 +22,8 @@ extern unsigned long long* g_stamp_buf; // diagnostic build only (tools/stamp_pr
 
 // ORCA branch (orca.hip)
 int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);
+// name of the k_orca_step build orca_launch would run for `w` (cs_step_variant)
+int orca_variant(const cs_worlds* w, char* buf, size_t buflen);
 // the robot's own ORCA model, one doStep of the robot per world (orca.hip; cs_robot_model_step with CS_ORCA)
 int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream);
 // social-momentum branch (social_momentum.hip)

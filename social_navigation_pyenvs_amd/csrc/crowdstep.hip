@@ -1271,6 +1271,46 @@ void strides(const cs_worlds* w, int rows, long& as, long& fs)
     else { as = 1; fs = (long)w->W * rows; }
 }
 
+// Which instantiation of k_sfm_step a launch runs.  One function decides it for launch_step and for cs_step_variant (the
+// diagnostic entry the parity tests use to assert that every benched build is the one they compared with the oracle).
+struct Variant { int maxt, occ, rows_ct, lean; bool peq; };
+
+Variant select_variant(const cs_worlds* w, int mode, const Geometry& g)
+{
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
+    // 256 CUs x 4 SIMDs: more than two one-wave blocks per SIMD -> the 4-waves-per-SIMD register budget pays
+    const bool crowded = g.block == 64 && g.grid > 2 * 1024;
+    // the plain crowd batch (what Gym scenarios and the bench step): pair-once, no walls, no robot row, <= 2 goal slots,
+    // committed in place -> the lean build; 25 rows per world also has its partner groups unrolled at compile time
+    const bool lean_w = peq && g.block == 64 && !(w->flags & CS_ROBOT_ROW) && w->G <= 2 && mode == M_COMMIT_GOALS;   // walls allowed
+    const bool lean = lean_w && w->O == 0;
+    if (g.block != 64) return Variant{1024, 1, 0, 0, peq};
+    // compile-time row counts of the BASELINE.json configurations with 25, 10 and 50 humans (50 rows unrolled spill 30-47 VGPRs
+    // at the 4-wave budget: they are built for three waves per SIMD); 10 rows fit 128 VGPRs without spills in every model
+    if (lean && rows == 25) return Variant{64, crowded ? 4 : 1, 25, 1, true};
+    if (lean && rows == 10) return Variant{64, 4, 10, 1, true};
+    // the run-time partner loop (any other row count, walls, robot row) keeps the full register budget on every grid: its
+    // 128-VGPR build spills (7 VGPRs lean, 35 with walls) and measured 6-17 % slower on crowded grids (8192 x 50 + walls:
+    // 355 vs 304 us; 16384 x 30 Moussaid: 484 vs 402 us)
+    // (budget of THREE waves per SIMD, 168 VGPRs: the walls build needs exactly that many, and a build that tips over to
+    // 169 runs at two waves per SIMD and 18 % slower -- with the cap a future compiler spills a register instead)
+    // 50 rows (cfg5) unrolled within the three-wave budget: 182 -> 176 us without walls, 266 -> 260 us with them
+    if (lean_w && rows == 50) return Variant{64, 3, 50, lean ? 1 : 2, true};
+    if (lean) return Variant{64, 3, 0, 1, true};
+    if (lean_w) return Variant{64, 3, 0, 2, true};   // the lean build that keeps the walls (cfg5's shard)
+    return Variant{64, 3, 0, 0, peq};
+}
+
+kfn variant_kernel(const Variant& v, int type)
+{
+#define CS_V(MT, OC, RC, LN) if (v.maxt == MT && v.occ == OC && v.rows_ct == RC && v.lean == LN) return pick_kernel<MT, OC, RC, LN>(type, v.peq);
+    CS_V(1024, 1, 0, 0) CS_V(64, 1, 25, 1) CS_V(64, 4, 25, 1) CS_V(64, 4, 10, 1) CS_V(64, 3, 50, 1) CS_V(64, 3, 50, 2)
+    CS_V(64, 3, 0, 1) CS_V(64, 3, 0, 2) CS_V(64, 3, 0, 0)
+#undef CS_V
+    return nullptr;
+}
+
 int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, const float* d_action,
                 float* d_peek, hipStream_t stream)
 {
@@ -1294,29 +1334,10 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
 #ifdef CS_STAMPS
     a.stamps = g_stamp_buf;
 #endif
-    const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
-    // 256 CUs x 4 SIMDs: more than two one-wave blocks per SIMD -> the 4-waves-per-SIMD register budget pays
-    const bool crowded = g.block == 64 && g.grid > 2 * 1024;
-    // the plain crowd batch (what Gym scenarios and the bench step): pair-once, no walls, no robot row, <= 2 goal slots,
-    // committed in place -> the lean build; 25 rows per world also has its partner groups unrolled at compile time
-    const bool lean_w = peq && g.block == 64 && !(w->flags & CS_ROBOT_ROW) && w->G <= 2 && mode == M_COMMIT_GOALS;   // walls allowed
-    const bool lean = lean_w && w->O == 0;
-    kfn fn;
-    if (g.block != 64) fn = pick_kernel<1024, 1, 0, 0>(w->type, peq);
-    // compile-time row counts of the BASELINE.json configurations with 25, 10 and 50 humans (50 rows unrolled spill 30-47 VGPRs
-    // at the 4-wave budget: they are built for three waves per SIMD); 10 rows fit 128 VGPRs without spills in every model
-    else if (lean && rows == 25) fn = crowded ? pick_kernel<64, 4, 25, 1>(w->type, true) : pick_kernel<64, 1, 25, 1>(w->type, true);
-    else if (lean && rows == 10) fn = pick_kernel<64, 4, 10, 1>(w->type, true);
-    // the run-time partner loop (any other row count, walls, robot row) keeps the full register budget on every grid: its
-    // 128-VGPR build spills (7 VGPRs lean, 35 with walls) and measured 6-17 % slower on crowded grids (8192 x 50 + walls:
-    // 355 vs 304 us; 16384 x 30 Moussaid: 484 vs 402 us)
-    // (budget of THREE waves per SIMD, 168 VGPRs: the walls build needs exactly that many, and a build that tips over to
-    // 169 runs at two waves per SIMD and 18 % slower -- with the cap a future compiler spills a register instead)
-    // 50 rows (cfg5) unrolled within the three-wave budget: 182 -> 176 us without walls, 266 -> 260 us with them
-    else if (lean_w && rows == 50) fn = lean ? pick_kernel<64, 3, 50, 1>(w->type, true) : pick_kernel<64, 3, 50, 2>(w->type, true);
-    else if (lean) fn = pick_kernel<64, 3, 0, 1>(w->type, true);
-    else if (lean_w) fn = pick_kernel<64, 3, 0, 2>(w->type, true);   // the lean build that keeps the walls (cfg5's shard)
-    else fn = pick_kernel<64, 3, 0, 0>(w->type, peq);
+    const Variant v = select_variant(w, mode, g);
+    const bool peq = v.peq;
+    const kfn fn = variant_kernel(v, w->type);
+    if (!fn) return fail(CS_ERR_ARG, "no kernel build for this variant");
     // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
     // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
     size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
@@ -1471,6 +1492,26 @@ int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void*
 #ifdef CS_STAMPS
 int cs_debug_set_stamp_buffer(void* d_buf) { g_stamp_buf = (unsigned long long*)d_buf; return CS_OK; }
 #endif
+
+int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)
+{
+    if (!w || !buf || buflen == 0) return fail(CS_ERR_ARG, "null argument");
+    if (entry < 0 || entry > 2) return fail(CS_ERR_ARG, "entry must be 0 (cs_step), 1 (cs_update_humans_parallel, out of place) or 2 (cs_peek)");
+    if (w->type == CS_ORCA) return csimpl::orca_variant(w, buf, buflen);
+    if (w->type == CS_SOCIAL_MOMENTUM) { std::snprintf(buf, buflen, "k_sm_step"); return CS_OK; }
+    int rc = check_worlds(w);
+    if (rc) return rc;
+    Geometry g;
+    rc = geometry(w, g);
+    if (rc) return rc;
+    int mode = entry == 2 ? (int)M_PEEK : (int)M_COMMIT_GOALS;
+    if (entry == 1) mode |= M_MUTATE_INPUT;
+    if (entry != 1 && (w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
+    const Variant v = select_variant(w, mode, g);
+    std::snprintf(buf, buflen, "k_sfm_step<SOC=%d,HEADED=%d,PEQ=%d,MAXT=%d,OCC=%d,ROWS_CT=%d,LEAN=%d> grid=%d block=%d wpb=%d",
+                  w->type % 3, w->type / 3, v.peq ? 1 : 0, v.maxt, v.occ, v.rows_ct, v.lean, g.grid, g.block, g.wpb);
+    return CS_OK;
+}
 
 int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_per_block)
 {

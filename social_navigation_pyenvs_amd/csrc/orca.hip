@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "common.h"
@@ -922,6 +923,16 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     else rc = fast10 ? launch(k_orca_step<true, 512>) : launch(k_orca_step<false, 512>);
     if (rc != CS_OK) return rc;
     HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int orca_variant(const cs_worlds* w, char* buf, size_t buflen)
+{
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    const int T = rows <= 64 ? 64 : (rows <= 256 ? 256 : 512);
+    const bool fast10 = w->orca_max_neighbors == 10 && w->orca_n_vertices == 0;
+    const int wpb = rows <= 64 ? 64 / rows : 1;
+    std::snprintf(buf, buflen, "k_orca_step<FAST10=%d,MAXT=%d> grid=%d block=%d wpb=%d", fast10 ? 1 : 0, T, (w->W + wpb - 1) / wpb, T, wpb);
     return CS_OK;
 }
 

@@ -28,9 +28,10 @@ def world_shard(rank: int, world_size: int, worlds_per_gpu: int, total_worlds: i
 
 
 def shard_seed(first_world_id: int, base_seed: int = 1000) -> int:
-    """Seed of a rank's generator stream: worlds are seeded by their GLOBAL id, so a world's scenario does not
-    depend on how many GPUs the batch is spread over."""
-    return base_seed + first_world_id
+    """Seed for a rank's worlds: the SAME base seed on every rank.  scenarios.* key every draw by (seed, global world
+    id) -- pass `first_world=first_world_id` to them -- so a world's scenario does not depend on the shard boundaries or
+    on how many GPUs the batch is spread over.  (`first_world_id` is accepted for symmetry and deliberately unused.)"""
+    return base_seed
 
 
 def max_over_ranks(value: float, dist=None, device=None) -> float:

@@ -355,8 +355,8 @@ class BatchedSocialNavGym:
                             robot_mass=robot.mass, robot_desired_speed=robot.desired_speed)
         self._gen_scenario, self._seeds_host = scenario, seeds
         status, scn = gen.generate_worlds(self.cw, scenario, seeds, **self._gen_kw)
-        if traffic and not np.any(scn == gen.SCENARIOS["parallel_traffic"]):
-            self.cw.respawn_bounds = None  # a hybrid batch that drew no traffic world: same descriptor as the host path
+        # (the respawn rule stays armed for a hybrid batch even when it drew no traffic world: d_world_flags gates it per
+        #  world, and step_device's auto-reset may regenerate any world as a traffic world later)
         if model == "orca":  # RVO2 preferred velocity lives in columns 5:7 (set_state_orca, motion_model_manager.py:105-123)
             S = self.cw.get_states()
             d = S[:, :n, 10:12] - S[:, :n, 0:2]
@@ -381,9 +381,9 @@ class BatchedSocialNavGym:
             raise RuntimeError("step_device needs a world batch generated on the device: reset(..., device=True)")
         try:
             torch.zeros(1, device="cuda")
-        except RuntimeError as e:  # torch ships its own HIP / HSA runtime; the first one loaded owns the device
-            raise _lib.CrowdstepError("torch cannot see the GPU in this process: `import torch` BEFORE the first crowdstep "
-                                      f"object is created so both share one HIP runtime ({e})") from e
+        except RuntimeError as e:  # _lib.load() maps torch's bundled HIP runtime for both, whatever the import order
+            raise _lib.CrowdstepError("torch cannot see the GPU in this process (HIP runtime in use: "
+                                      f"{_lib.hip_runtime_path or 'system'}; CROWDSTEP_HIP_RUNTIME=system forces two runtimes): {e}") from e
         W = self.W
         # global_time is accumulated in float32, time_step_factor additions of time_step per step (social_nav_gym.py:244):
         # the same sequence as a table indexed by the per-world step counter

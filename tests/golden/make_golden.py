@@ -19,6 +19,8 @@ reference produced) is written to the ``.npz`` fixtures.  Groups (SURVEY.md §8c
   g7_respawn  parallel-traffic respawn (state just before / after)
   g8_lookahead  compute_rotated_states_and_reward (CADRL / SARL 81-action look-ahead)
   g9_laser    LaserSensor.get_laser_measurements (social_gym/src/sensors.py:51-66)
+  g13_block_sizes  20-substep blocks at the row counts of the BASELINE.json configurations (10, 25 traffic, 50, 50 + walls +
+              immobile humans), all nine models: the shapes the shape-specialised kernel builds run on
   g10_social_momentum  MotionModelManager("social_momentum").update_humans single steps (motion_model_manager.py:395-404,
               social_gym/src/social_momentum.py)
 """
@@ -819,10 +821,74 @@ def gen_g12_rk45():
     print("g12_rk45:", len(cases), "cases ->", save_cases("g12_rk45", cases))
 
 
+# ----------------------------------------------------------------------------- G13 blocks at the BASELINE.json sizes
+def gen_g13_block_sizes():
+    """20-substep blocks (= one Gym step) through MotionModelManager.update_humans at the row counts of the BASELINE.json
+    configurations, all nine models, all_equal_humans worlds with goal lists of two entries -- the shapes the shape-specialised
+    builds of the step kernel run on (SURVEY.md §8c asks for N in {5, 10, 25, 50}; G2 holds 5, 8 and 25):
+      n10        10 humans, dense crossing                                   (configs[1]: 4096 x 10 SFM circle crossing)
+      n25_traffic 25 humans, the reference's parallel-traffic generator with respawns inside the window   (configs[2], odd worlds)
+      n50        50 humans, dense crossing                                   (configs[4] without obstacles)
+      n50_walls_static  50 humans of which 3 immobile (desired speed 0, radius 0.8, goal = own position, as
+                 circular_crossing_with_static_obstacles builds them, social_nav_sim.py:381-387) + 3 polygon walls   (configs[4])"""
+    cases = []
+    seed = 0
+    for t, model in enumerate(SFMS):
+        for kind, n, radius, warm in (("n10", 10, 2.8, 100), ("n50", 50, 6.0, 110), ("n50_walls_static", 50, 6.4, 110)):
+            seed += 1
+            rng = np.random.default_rng(130_000 + seed)
+            walls = my_walls(rng) if kind == "n50_walls_static" else None
+            cfg = crossing_config(rng, model, n, radius, walls=walls)
+            if kind == "n50_walls_static":
+                for i in range(3):
+                    h = cfg["humans"][i]
+                    ang = 2.1 * i + 1.35          # half way between the walls of my_walls (at 2.1 k + 0.3), clear of them
+                    h["pos"] = [float(2.4 * math.cos(ang)), float(2.4 * math.sin(ang))]
+                    h["goals"] = [list(h["pos"]), list(h["pos"])]
+                    h["des_speed"] = 0.0
+                    h["radius"] = 0.8
+            sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=True)
+            mm = sim.motion_model_manager
+            for k in range(warm):
+                mm.update_humans(0, DT)
+            before = mm_snapshot(mm)
+            for k in range(20):
+                mm.update_humans(0, DT)
+            after = mm_snapshot(mm)
+            cases.append(dict(kind=kind, model=model, type=t, n=n, dt=DT, n_substeps=20,
+                              all_params_equal=bool(mm.all_equal_humans), respawn=False,
+                              **{f"in_{k}": v for k, v in before.items()},
+                              out_states=after["states"], out_goals=after["goals"]))
+        # the reference's own parallel-traffic generator at 25 humans, respawns inside the 20-substep window
+        seed += 1
+        np.random.seed(1300 + seed)
+        kw = {"insert_robot": False, "human_policy": model, "headless": True, "runge_kutta": False, "n_actors": 25,
+              "traffic_length": 14, "traffic_height": 3}
+        sim = ns.sim.SocialNavSim(kw, scenario="parallel_traffic", parallelize_humans=True)
+        mm = sim.motion_model_manager
+        for k in range(60):
+            mm.update_humans(0, DT)
+        for i in (2, 11, 19):
+            mm.states[i, 0] = mm.goals[i, 0, 0] + 3.0 + 0.015 * (i + 1)
+            mm.humans[i].set_state(mm.states[i, 0:8])
+        before = mm_snapshot(mm)
+        for k in range(20):
+            mm.update_humans(0, DT)
+        after = mm_snapshot(mm)
+        cases.append(dict(kind="n25_traffic", model=model, type=t, n=25, dt=DT, n_substeps=20,
+                          all_params_equal=bool(mm.all_equal_humans), respawn=bool(mm.parallel_traffic_humans_respawn),
+                          respawn_bounds=[float(x) for x in mm.respawn_bounds],
+                          **{f"in_{k}": v for k, v in before.items()},
+                          out_states=after["states"], out_goals=after["goals"]))
+        sim.parallel_traffic_humans_respawn = False
+    print("g13_block_sizes:", len(cases), "cases ->", save_cases("g13_block_sizes", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
               g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
-              g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45)
+              g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45,
+              g13_block_sizes=gen_g13_block_sizes)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -24,6 +24,27 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert lib.cs_abi_version() >= 1
 
 
+def test_library_on_disk_was_built_from_the_sources_on_disk():
+    """The rebuild is keyed on a content hash of csrc/* + include/*: the id the LOADED library reports (cs_build_id) must
+    be the hash of the sources in the tree, so a stale prebuilt .so cannot pass for the current code."""
+    import ctypes as C
+
+    import __graft_entry__ as g
+
+    g.build()
+    from social_navigation_pyenvs_amd import _lib
+    from social_navigation_pyenvs_amd.csrc import build as hb
+
+    st = hb.status()
+    assert st["exists"] and st["fresh"], st
+    lib = _lib.load()
+    lib.cs_build_id.restype = C.c_char_p
+    assert lib.cs_build_id().decode() == st["build_id"]
+    # and the key really follows the content: a changed source gives a different id
+    keys = hb.source_keys()
+    assert hb.source_keys(["-DX"])["build_id"] != keys["build_id"]
+
+
 def test_struct_layout_matches_header():
     import ctypes as C
 

@@ -31,8 +31,7 @@ def test_gym_step_loop_g3_per_step():
 
     worst = 0.0
     for ci, c in enumerate(load_cases("g3_gym")):
-        if np.max(np.abs(c["mm_states"][..., 7])) > 1e3:
-            continue
+        assert np.max(np.abs(c["mm_states"][..., 7])) < 1e3   # no Gym fixture is in the diverged-omega regime: none is skipped
         env = make_env(c["model"], c["scenario"], c["human_num"], c["robot_visible"], c["headed_obs"])
         if c["safety_space"] > 0:
             env.set_safety_space(c["safety_space"])
@@ -68,7 +67,7 @@ def test_gym_free_running_first_steps_g3():
     from social_navigation_pyenvs_amd.crowd_nav.utils.action import ActionXY
 
     for c in load_cases("g3_gym"):
-        if c["model"].endswith("moussaid") or np.max(np.abs(c["mm_states"][..., 7])) > 1e3:
+        if c["model"].endswith("moussaid"):   # sign(theta ~ 0) at rest: no free-running parity
             continue
         env = make_env(c["model"], c["scenario"], c["human_num"], c["robot_visible"], c["headed_obs"])
         if c["safety_space"] > 0:
@@ -106,15 +105,23 @@ def test_update_humans_parallel_array_seam_g1():
     """The reference signature, numpy float64 in / out, in-place side effects."""
     from social_navigation_pyenvs_amd.social_gym.src.forces_parallel import update_humans_parallel
 
+    from oracle import crowd_oracle as orc
+    from parity_util import compare_rows, f32
+
     for c in load_cases("g1_episode")[::6]:
-        if c["type"] % 3 == 2 or np.max(np.abs(c["state_out"][:, 7])) > 1e3:
-            continue
         S, G = c["state_in"].copy(), c["goals_in"].copy()
-        out = update_humans_parallel(c["type"], S, G, c.get("obstacles"), c["params"], c["dt"], c["safety"],
-                                     c["all_params_equal"], c["last_is_robot"])
+        with np.errstate(over="ignore"):
+            out = update_humans_parallel(c["type"], S, G, c.get("obstacles"), c["params"], c["dt"], c["safety"],
+                                         c["all_params_equal"], c["last_is_robot"])
+            om_in = f32(c["state_in"])[:, 7].astype(np.float64)
         n = c["n"]
         assert out.dtype == np.float64 and out.shape == c["state_out"].shape
-        assert np.max(np.abs(out[:n, [0, 1, 3, 4]] - c["state_out"][:n, [0, 1, 3, 4]])) < 1e-5
+        ref = c["state_out"]
+        if c["type"] % 3 == 2:   # Moussaid: against the f64 oracle from the same f32-rounded inputs (sign() discontinuity)
+            up = lambda a: None if a is None else f32(a).astype(np.float64)
+            ref, _, _ = orc.update_humans(c["type"], up(c["state_in"]), up(c["goals_in"]), up(c.get("obstacles")), up(c["params"]),
+                                          c["dt"], up(c["safety"]), c["all_params_equal"], c["last_is_robot"])
+        compare_rows(out[:n], ref[:n], om_in[:n], c["dt"], 1e-5, c["type"] >= 3, f"array seam type {c['type']}")
         np.testing.assert_array_equal(G, c["goals_out"])                  # rotated in place, full precision kept
         assert np.max(np.abs(S[:n, 10:12] - c["state_in_after"][:n, 10:12])) < 1e-6
     with pytest.raises(ValueError):

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import crowd_oracle as orc
+from parity_util import record
 
 pytestmark = pytest.mark.gpu
 
@@ -15,39 +16,67 @@ def _worlds(cfg):
         W, n, model = 4096, 10, "sfm_helbing"
         pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
         S, goals, P, rb, rw, walls = sc.make_states(pos, yaw, g), g, np.tile(sc.default_params(model), (n, 1)), None, None, None
-    elif cfg == "cfg3":    # 4096 worlds x 25-agent HSFM hybrid scenario
-        W, n, model = 4096, 25, "hsfm_farina"
+    elif cfg in ("cfg3", "cfg3x4"):    # 4096 (16384: four waves per SIMD) worlds x 25-agent HSFM hybrid scenario
+        W, n, model = (4096 if cfg == "cfg3" else 16384), 25, "hsfm_farina"
         S, goals, P, rb = sc.hybrid_worlds(W, n, model)
         rw, walls = (np.arange(W) % 2 == 1).astype(np.int32), None
     else:                  # one GPU's shard of cfg5: 8192 worlds x 50-agent HSFM + static obstacles (both flavours)
         W, n, model = 8192, 50, "hsfm_farina"  # (hsfm_new* blows up |omega| to 1e108 in the f64 reference itself here)
-        pos, yaw, g = sc.circular_crossing(W, n, 14.0, 1000)
-        S, goals = sc.make_states(pos, yaw, g), g
-        S[:, :3, 12] = 0.0                      # three immobile "obstacle" humans, larger radius, goal = own position
-        S[:, :3, 8] = 0.8
-        goals[:, :3, 0] = S[:, :3, 0:2]; goals[:, :3, 1] = S[:, :3, 0:2]; S[:, :3, 10:12] = S[:, :3, 0:2]
-        P, rb, rw, walls = np.tile(sc.default_params(model), (n, 1)), None, None, sc.polygon_walls()
+        S, goals, P, walls = sc.static_obstacle_worlds(W, n, model)
+        rb, rw = None, None
     return W, n, model, S.astype(np.float32), goals.astype(np.float32), P.astype(np.float32), rb, rw, walls
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5shard"])
+# the kernel build behind each published number (crowdstep.hip select_variant); asserted so that a dispatch change cannot
+# silently un-test a build
+VARIANT = {"cfg2": "MAXT=64,OCC=4,ROWS_CT=10,LEAN=1", "cfg3": "MAXT=64,OCC=1,ROWS_CT=25,LEAN=1",
+           "cfg3x4": "MAXT=64,OCC=4,ROWS_CT=25,LEAN=1", "cfg5shard": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=2"}
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg3x4", "cfg5shard"])
 def test_full_size_properties(cfg):
     from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
 
     W, n, model, S, goals, P, rb, rw, walls = _worlds(cfg)
     peq = True
+    t = SFMS.index(model)
+    w64 = None if walls is None else walls.astype(np.float32).astype(np.float64)
+
+    def make(sel, layout="soa"):
+        return CrowdWorlds(S[sel], goals[sel], P, None, walls, type=model, all_params_equal=peq, respawn_bounds=rb,
+                           respawn_worlds=None if rw is None else rw[sel], layout=layout)
 
     def run(sel, nsub=20, steps=3):
-        cw = CrowdWorlds(S[sel], goals[sel], P, None, walls, type=model, all_params_equal=peq, respawn_bounds=rb,
-                         respawn_worlds=None if rw is None else rw[sel], layout="soa")
+        cw = make(sel)
         for _ in range(steps):
             cw.step(0.0125, nsub)
         return cw.get_states(), cw.get_goals()
 
+    def oracle_block(w, S0, g0, nsub):
+        respawn = rw is not None and bool(rw[w])
+        rp = (rb[0], rb[1], 0.0) if respawn else (0.0, 0.0, 0.0)
+        return orc.step_block(t, S0[w].astype(np.float64), g0[w].astype(np.float64), w64, P.astype(np.float64), 0.0125, nsub,
+                              np.zeros(n), peq, respawn=respawn, respawn_par=rp)
+
+    rng = np.random.default_rng(0)
+    # (0) THE BUILD THE PUBLISHED NUMBER COMES FROM, through cs_step (mode == commit goals in place), against the f64 oracle on
+    #     sampled worlds: one substep and one Gym step (20 fused substeps) from the initial state
+    cw = make(np.arange(W))
+    assert VARIANT[cfg] in cw.step_variant(), cw.step_variant()
+    sample = rng.choice(W, 12, replace=False)
+    for nsub, tol in ((1, 1e-5), (20, 5e-5)):
+        cw = make(np.arange(W))
+        cw.step(0.0125, nsub)
+        out, gout = cw.get_states(), cw.get_goals()
+        for w in sample:
+            ref, ref_goals, _ = oracle_block(w, S, goals, nsub)
+            err = np.max(np.abs(out[w][:, [0, 1, 3, 4]] - ref[:, [0, 1, 3, 4]]))
+            assert err < tol, (cfg, "cs_step", nsub, int(w), err)
+            record(f"full size {cfg} {nsub} substep(s) through cs_step (GPU vs f64 oracle)", err)
+            assert np.max(np.abs(np.nan_to_num(gout[w]) - np.nan_to_num(ref_goals))) < 1e-4
     full, gfull = run(np.arange(W))
     assert np.all(np.isfinite(full[..., :8]))
     # (1) composition invariance, bitwise: a permuted half-batch gives the same rows for the same worlds
-    rng = np.random.default_rng(0)
     sel = rng.permutation(W)[: W // 2 + 3]
     part, gpart = run(sel)
     np.testing.assert_array_equal(part, full[sel])
@@ -57,15 +86,24 @@ def test_full_size_properties(cfg):
     assert np.all(sp <= S[..., 12] * (1 + 1e-5) + 1e-6)
     # (3) things that must not change: radius, mass, desired speed
     np.testing.assert_array_equal(full[..., [8, 9, 12]], S[..., [8, 9, 12]])
-    # (4) sampled worlds against the f64 oracle, one substep from the evolved state
+    # (4) sampled worlds against the f64 oracle from the EVOLVED state (three Gym steps in): one more Gym step through cs_step
+    #     (the same lean build), and one substep through the array seam (the generic build)
+    cw = CrowdWorlds(full, gfull, P, None, walls, type=model, all_params_equal=peq, respawn_bounds=rb, respawn_worlds=rw, layout="soa")
+    assert VARIANT[cfg] in cw.step_variant()
+    cw.step(0.0125, 20)
+    out20 = cw.get_states()
     cw = CrowdWorlds(full, gfull, P, None, walls, type=model, all_params_equal=peq, layout="aos")
     out = cw.get_states(cw.update_humans_parallel(0.0125, in_place=False))
     for w in rng.choice(W, 12, replace=False):
-        ref, _, _ = orc.update_humans(SFMS.index(model), full[w].astype(np.float64), gfull[w].astype(np.float64),
-                                      None if walls is None else walls.astype(np.float32).astype(np.float64),
+        ref, _, _ = orc.update_humans(t, full[w].astype(np.float64), gfull[w].astype(np.float64), w64,
                                       P.astype(np.float64), 0.0125, np.zeros(n), peq, False)
         err = np.max(np.abs(out[w][:, [0, 1, 3, 4]] - ref[:, [0, 1, 3, 4]]))
         assert err < 1e-5, (cfg, int(w), err)
+        ref20, _, _ = oracle_block(w, full, gfull, 20)
+        err = np.max(np.abs(out20[w][:, [0, 1, 3, 4]] - ref20[:, [0, 1, 3, 4]]))
+        respawned = rw is not None and bool(rw[w])
+        assert err < (3e-4 if respawned else 5e-5), (cfg, "evolved + 20", int(w), err)
+        record(f"full size {cfg} 20 substeps from the evolved state (GPU vs f64 oracle)", err)
 
 
 def test_fused_block_equals_repeated_single_substeps_bitwise():

@@ -330,3 +330,43 @@ def test_motion_model_manager_orca_with_walls():
     got = np.array([[*h.position, *h.linear_velocity] for h in humans])
     np.testing.assert_allclose(got, ref[0][:, [0, 1, 3, 4]], atol=2e-5)
     assert got[0, 1] > 0.5 + 0.3    # the human heading into the box from above is still outside it
+
+
+def test_orca_cfg4_full_size():
+    """BASELINE.json configs[3] at its full size: 4096 worlds x 25-agent ORCA circular crossing (R = 7, neighborDist 10,
+    maxNeighbors 10, tau 5, radius 0.31, maxSpeed 1), three Gym steps of 20 fused substeps.  Size-independent properties:
+    a permuted half-batch reproduces its worlds bit for bit (composition invariance), speeds respect maxSpeed; and 12 sampled
+    worlds equal the C restatement bit for bit over the 60 substeps (the register-resident LP2 / LP3 build, k_orca_step<FAST10>)."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n = 4096, 25
+    pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
+    S = sc.make_states(pos, yaw, g).astype(np.float32)
+    g = g.astype(np.float32)
+    d = g[:, :, 0] - S[:, :, 0:2]
+    S[:, :, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    margin = np.full((W, n), 0.01, np.float32)
+
+    def run(sel):
+        cw = CrowdWorlds(S[sel], g[sel], None, margin[sel], None, type="orca", layout="soa")
+        assert "k_orca_step<FAST10=1,MAXT=64>" in cw.step_variant(), cw.step_variant()
+        for _ in range(3):
+            cw.step(0.0125, 20)
+        return cw.get_states(), cw.get_goals()
+
+    full, gfull = run(np.arange(W))
+    assert np.all(np.isfinite(full[..., :8]))
+    rng = np.random.default_rng(4)
+    sel = rng.permutation(W)[: W // 2 + 1]
+    part, gpart = run(sel)
+    np.testing.assert_array_equal(part, full[sel])
+    np.testing.assert_array_equal(gpart, gfull[sel])
+    assert np.all(np.linalg.norm(full[..., 3:5], axis=-1) <= S[..., 12] + 5e-2)
+    sample = np.sort(rng.choice(W, 12, replace=False))
+    ref, rg = S[sample], g[sample]
+    for _ in range(3):
+        ref, rg, _ = orc.orca_step_block(ref, rg, margin[sample], 0.0125, 20)
+    cols = [0, 1, 3, 4, 5, 6, 10, 11]
+    np.testing.assert_array_equal(full[sample][..., cols], ref[..., cols])
+    np.testing.assert_array_equal(gfull[sample], rg)

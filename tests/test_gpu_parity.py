@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
  (a) the golden vectors the reference produced and (b) the pinned oracle on the same seeded inputs.
+Every fixture is compared (column rules in tests/parity_util.py); how many cases meet 1e-5 goes to
+gpurun_out/parity_report.json.
 
 Tolerances (absolute, on positions / velocities, per step from re-synchronised state):
   * 1e-5  realistic mid-episode states (north_star bar)         -> g1_episode, g2 blocks use 5e-5
@@ -13,18 +15,21 @@ import pytest
 
 from golden_io import load_cases
 from oracle import crowd_oracle as orc
+from parity_util import compare_rows, f32, record
 
 pytestmark = pytest.mark.gpu
 
 TOL = {"g1_direct": 5e-5, "g1_episode": 1e-5}
 PV = [0, 1, 3, 4]
+# rows whose heading float32 cannot hold (|omega_in * dt| > 1e4 rad: the reference's own omega has diverged): one row in each
+# of g1_episode cases 82, 83, 106, 107; everything else -- the 33 hsfm_new* g1_direct cases with |omega_out| up to 4e6
+# included -- is compared in full (tests/parity_util.py)
+LOST_HEADING_ROWS = {"g1_direct": 0, "g1_episode": 4}
 
 
-def f32(a):
-    return None if a is None else np.asarray(a, dtype=np.float32)
-
-
-def f32_comparable(c, key_in="state_in", key_out="state_out"):
+def tame(c, key_in="state_in", key_out="state_out"):
+    """Fixtures outside the regime in which the reference's explicit Euler on omega has diverged (|omega| >= 1e3).  Used only to
+    pick cases for SECONDARY checks (layout / batching equivalences); the parity tests compare every fixture."""
     return bool(np.all(np.isfinite(c[key_out])) and np.max(np.abs(c[key_out][:, 7])) < 1e3
                 and np.max(np.abs(c[key_in][:, 7])) < 1e3)
 
@@ -48,37 +53,38 @@ def oracle_from_f32(c, dtype=np.float64):
 
 @pytest.mark.parametrize("group", ["g1_direct", "g1_episode"])
 def test_single_substep_vs_golden_and_oracle(group):
-    worst = 0.0
+    lost = 0
     for k, c in enumerate(load_cases(group)):
-        if not f32_comparable(c):
-            continue
         cw, got = run_single(c)
         n = c["n"]
+        headed = c["type"] >= 3
+        with np.errstate(over="ignore"):
+            om_in = f32(c["state_in"])[:n, 7].astype(np.float64)
         ref64, s_after, goals_after = oracle_from_f32(c)
-        err_o = np.max(np.abs(got[:n, PV] - ref64[:n, PV]))
-        assert err_o < TOL[group], f"{group} case {k} type {c['type']} vs oracle: {err_o}"
-        # every dynamic column, relative (theta / omega of HSFM included)
-        scale = np.maximum(1.0, np.abs(ref64[:n, :8]))
-        assert np.max(np.abs(got[:n, :8] - ref64[:n, :8]) / scale) < 2e-4, f"{group} case {k}"
+        # every dynamic column against the f64 oracle run from the same f32-rounded inputs
+        err_o, u = compare_rows(got[:n], ref64[:n], om_in, c["dt"], TOL[group], headed, f"{group} case {k} type {c['type']} vs oracle")
+        lost += u
+        record(f"{group} (GPU vs f64 oracle, same f32 inputs)", err_o, unrepresentable_rows=u)
         if c["type"] % 3 != 2:  # continuous models: straight against what the reference returned
-            err_g = np.max(np.abs(got[:n, PV] - c["state_out"][:n, PV]))
-            assert err_g < TOL[group], f"{group} case {k} type {c['type']} vs golden: {err_g}"
-            worst = max(worst, err_g)
+            err_g, _ = compare_rows(got[:n], c["state_out"][:n], om_in, c["dt"], TOL[group], headed,
+                                    f"{group} case {k} type {c['type']} vs golden")
+            record(f"{group} (GPU vs golden, continuous models)", err_g)
         # integer / control-flow work is exact: rotated goals, goal columns, robot row, constants
         np.testing.assert_array_equal(cw.get_goals()[0], f32(c["goals_out"]))
         np.testing.assert_array_equal(got[:, 8:13], f32(c["state_out"])[:, 8:13])
         if c["last_is_robot"]:
-            np.testing.assert_array_equal(got[n], f32(c["state_in"])[n])
+            with np.errstate(over="ignore"):
+                np.testing.assert_array_equal(got[n], f32(c["state_in"])[n])
         # in-place side effects on the input rows (goal columns; refreshed linear velocity)
         s_in = cw.get_states()[0]
         np.testing.assert_array_equal(s_in[:n, 10:12], f32(c["state_in_after"])[:n, 10:12])
-        if c["type"] >= 3:
+        if headed:
             assert np.max(np.abs(s_in[:n, 3:5] - c["state_in_after"][:n, 3:5])) < 1e-5
-    print(group, "worst |err| vs golden", worst)
+    assert lost == LOST_HEADING_ROWS[group], lost
 
 
 def test_soa_layout_and_in_place_match_aos_bitwise():
-    cases = [c for c in load_cases("g1_episode") if f32_comparable(c)][::7]
+    cases = [c for c in load_cases("g1_episode") if tame(c)][::7]
     for c in cases:
         _, a = run_single(c, "aos", in_place=False)
         _, b = run_single(c, "soa", in_place=False)
@@ -104,7 +110,7 @@ def test_many_worlds_per_wave_vs_oracle(W):
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
     rng = np.random.default_rng(W)
-    picks = [c for c in load_cases("g1_episode") if f32_comparable(c) and c["type"] % 3 != 2][::5]
+    picks = [c for c in load_cases("g1_episode") if tame(c) and c["type"] % 3 != 2][::5]
     for c in picks:
         S, goals = _perturbed_batch(c, W, rng)
         obs = f32(c.get("obstacles"))
@@ -125,23 +131,51 @@ def test_many_worlds_per_wave_vs_oracle(W):
             assert err < 1e-5, f"W={W} world {w} type {c['type']} n {n}: {err}"
 
 
-def test_block_of_20_substeps_g2():
+def _block_reference(c, nsub):
+    up = lambda key: None if key not in c else f32(c[key]).astype(np.float64)
+    rp = (c["respawn_bounds"] + [0.0]) if c["respawn"] else (0.0, 0.0, 0.0)
+    return orc.step_block(c["type"], up("in_states"), up("in_goals"), up("in_obstacles"), up("in_params"), c["dt"], nsub,
+                          up("in_safety"), c["all_params_equal"], respawn=c["respawn"], respawn_par=rp)
+
+
+def _block_worlds(c):
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
-    worst = 0.0
-    for k, c in enumerate(load_cases("g2_block")):
-        if not f32_comparable(c, "in_states", "out_states"):
+    return CrowdWorlds(f32(c["in_states"]), f32(c["in_goals"]), f32(c["in_params"]), f32(c["in_safety"]),
+                       f32(c.get("in_obstacles")), type=c["type"], all_params_equal=c["all_params_equal"],
+                       respawn_bounds=c["respawn_bounds"] if c["respawn"] else None)
+
+
+# the kernel build cs_step must pick for each G13 kind (crowdstep.hip select_variant): the builds the published numbers come from
+G13_VARIANT = {"n10": "MAXT=64,OCC=4,ROWS_CT=10,LEAN=1", "n25_traffic": "MAXT=64,OCC=1,ROWS_CT=25,LEAN=1",
+               "n50": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=1", "n50_walls_static": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=2"}
+
+
+@pytest.mark.parametrize("group", ["g2_block", "g13_block_sizes"])
+def test_block_of_20_substeps(group):
+    """20 fused substeps (cs_step, the lean / shape-specialised builds included) against the golden blocks the reference
+    produced and against the f64 oracle from the same f32 inputs.  No fixture is skipped: a block in which the reference's own
+    omega diverges (|omega| >= 1e3 inside the window: hsfm_new* humans pressed together by a respawn) amplifies any rounding
+    beyond comparison over 20 substeps -- it is compared on its first substep instead, column by column."""
+    first_only = 0
+    for k, c in enumerate(load_cases(group)):
+        headed = c["type"] >= 3
+        cw = _block_worlds(c)
+        if group == "g13_block_sizes":
+            assert G13_VARIANT[c["kind"]] in cw.step_variant(), (c["kind"], cw.step_variant())
+        ref, ref_goals, _ = _block_reference(c, c["n_substeps"])
+        om_in = f32(c["in_states"])[:, 7].astype(np.float64)
+        wild = max(np.max(np.abs(ref[:, 7])), np.max(np.abs(c["out_states"][:, 7])), np.max(np.abs(om_in))) >= 1e3
+        what = f"{group} case {k} {c['kind']} {c['model']}"
+        if wild:
+            first_only += 1
+            ref1, _, _ = _block_reference(c, 1)
+            cw.step(c["dt"], 1)
+            err, _ = compare_rows(cw.get_states()[0], ref1, om_in, c["dt"], 1e-5, headed, what + " (first substep)")
+            record(f"{group} first substep of diverging blocks (GPU vs f64 oracle)", err)
             continue
-        cw = CrowdWorlds(f32(c["in_states"]), f32(c["in_goals"]), f32(c["in_params"]), f32(c["in_safety"]),
-                         f32(c.get("in_obstacles")), type=c["type"], all_params_equal=c["all_params_equal"],
-                         respawn_bounds=c["respawn_bounds"] if c["respawn"] else None)
         cw.step(c["dt"], c["n_substeps"])
         got = cw.get_states()[0]
-        up = lambda key: None if key not in c else f32(c[key]).astype(np.float64)
-        rp = (c["respawn_bounds"] + [0.0]) if c["respawn"] else (0.0, 0.0, 0.0)
-        ref, ref_goals, _ = orc.step_block(c["type"], up("in_states"), up("in_goals"), up("in_obstacles"),
-                                           up("in_params"), c["dt"], c["n_substeps"], up("in_safety"),
-                                           c["all_params_equal"], respawn=c["respawn"], respawn_par=rp)
         # 20 stiff substeps amplify f32 rounding; SURVEY.md G2 allows 5e-5 (Moussaid: from same inputs).
         # A respawned human is placed exactly at contact distance (max_x + 2 r) of the right-most one,
         # where dF/dx = A/B = 25 kN/m: f32 rounding of that position grows ~4x per substep -> 3e-4.
@@ -149,17 +183,18 @@ def test_block_of_20_substeps_g2():
         if c["respawn"]:
             tol = max(tol, 3e-4)
         err = np.max(np.abs(got[:, PV] - ref[:, PV]))
-        assert err < tol, f"g2 case {k} {c['kind']} {c['model']}: {err}"
+        assert err < tol, f"{what}: {err}"
+        record(f"{group} 20 substeps (GPU vs f64 oracle, same f32 inputs)", err)
         if c["type"] % 3 != 2:
             errg = np.max(np.abs(got[:, PV] - c["out_states"][:, PV]))
-            assert errg < max(1e-4, 2 * tol), f"g2 case {k} vs golden: {errg}"
-            worst = max(worst, errg)
+            assert errg < max(1e-4, 2 * tol), f"{what} vs golden: {errg}"
+            record(f"{group} 20 substeps (GPU vs golden, continuous models)", errg)
         g = cw.get_goals()[0]
         assert np.max(np.abs(np.nan_to_num(g) - np.nan_to_num(ref_goals))) < 1e-4
         if c["respawn"]:  # respawned rows land exactly on the bound rule
             moved = np.abs(c["out_states"][:, 0] - c["in_states"][:, 0]) > 1.0
             assert np.array_equal(moved, np.abs(got[:, 0] - f32(c["in_states"])[:, 0]) > 1.0)
-    print("g2 worst vs golden", worst)
+    assert first_only <= {"g2_block": 1, "g13_block_sizes": 2}[group], first_only
 
 
 def test_respawn_g7_with_and_without_robot():
@@ -235,8 +270,8 @@ def test_bad_type_raises_value_error():
         CrowdWorlds(f32(c["state_in"]), f32(c["goals_in"]), f32(c["params"]), type=11)  # 0..8 SFM/HSFM, 9 ORCA, 10 social momentum
 
 
-@pytest.mark.parametrize("rows_case", [(1, False), (2, False), (1, True), (3, False), (4, True), (7, False), (21, True),
-                                       (31, True), (32, False), (33, False), (50, False), (63, True), (64, False)])
+@pytest.mark.parametrize("rows_case", [(1, False), (2, False), (1, True), (3, False), (4, True), (7, False), (10, False), (16, False),
+                                       (21, True), (25, False), (31, True), (32, False), (33, False), (50, False), (63, True), (64, False)])
 def test_pair_once_loop_world_sizes(rows_case):
     """Edge sizes of the pair-once loop (ring distance (rows-1)/2, antipodal partner for even rows, several worlds per
     wavefront with the padded LDS pitch, worlds that fill the wavefront): dense random worlds, all 9 types,

@@ -29,36 +29,37 @@ def test_single_substep_f64(group):
     print(group, "worst rel err", worst)
 
 
-def f32_comparable(c):
-    """Cases on which an f32 run can be compared with the f64 reference at all: the reference's
-    own state must not have diverged (hsfm_new* with agents pushed into walls blows |omega| up to
-    1e11..1e38 in two episode fixtures; theta = wrap(theta + omega*dt) is then noise)."""
-    return bool(np.all(np.isfinite(c["state_out"])) and np.max(np.abs(c["state_out"][:, 7])) < 1e3
-                and np.max(np.abs(c["state_in"][:, 7])) < 1e3)
-
-
 # g1_direct holds deliberately extreme synthetic states (overlaps up to 0.5 m, forces to 1e7 N):
 # f32 rounding of those stiff forces reaches 1.3e-5 on one case; realistic mid-episode states
 # (g1_episode) stay below 1e-6.  The north_star bar (1e-5) is asserted on the episode group.
+LOST_HEADING_ROWS_G1_EPISODE = 4   # rows (one per case) with |omega_in * dt| > 1e4 rad in cases 82, 83, 106, 107
 F32_TOL_BY_GROUP = {"g1_direct": 5e-5, "g1_episode": F32_TOL}
 
 
 @pytest.mark.parametrize("group", ["g1_direct", "g1_episode"])
 def test_single_substep_f32_oracle_within_tolerance(group):
     """The f32 instantiation of the oracle (what the HIP kernel mirrors) stays within 1e-5 of the
-    f64 reference on pos/vel for the continuous models, from f32-rounded inputs."""
+    f64 reference on pos/vel, from f32-rounded inputs.  EVERY fixture is compared, column by column
+    (tests/parity_util.py): positions and body velocities always, heading-dependent columns within what float32 holds
+    of theta + omega * dt, omega relatively -- the hsfm_new* cases whose |omega_out| reaches 1e3 .. 4e6 included."""
+    from parity_util import compare_rows
+
+    lost = 0
     for k, c in enumerate(load_cases(group)):
-        if not f32_comparable(c):
-            continue
         c32 = dict(c)
-        for key in ("state_in", "goals_in", "params", "safety", "obstacles"):
-            if key in c:
-                c32[key] = c[key].astype(np.float32).astype(np.float64)
+        with np.errstate(over="ignore"):
+            for key in ("state_in", "goals_in", "params", "safety", "obstacles"):
+                if key in c:
+                    c32[key] = c[key].astype(np.float32).astype(np.float64)
         ref, _, _ = _run(c32, np.float64)
         out, _, _ = _run(c32, np.float32)
         n = c["n"]
-        err = np.max(np.abs(out[:n, [0, 1, 3, 4]].astype(np.float64) - ref[:n, [0, 1, 3, 4]]))
-        assert err < F32_TOL_BY_GROUP[group], f"{group} case {k} type {c['type']}: {err}"
+        _, u = compare_rows(out[:n], ref[:n], c32["state_in"][:n, 7], c["dt"], F32_TOL_BY_GROUP[group], c["type"] >= 3,
+                            f"{group} case {k} type {c['type']}")
+        lost += u
+    # rows whose heading float32 cannot hold: none in the synthetic group; the four episode cases in which the reference's own
+    # omega has diverged to 1e11 .. 1e37 (hsfm_new* pushed into walls)
+    assert lost == {"g1_direct": 0, "g1_episode": LOST_HEADING_ROWS_G1_EPISODE}[group], lost
 
 
 def test_block_of_20_substeps_f64():
@@ -70,6 +71,24 @@ def test_block_of_20_substeps_f64():
         err = np.max(np.abs(S - c["out_states"]))
         assert err < 1e-9, f"g2 case {k} {c['kind']} {c['model']}: {err}"
         np.testing.assert_allclose(goals, c["out_goals"], rtol=0, atol=1e-9)
+
+
+def test_blocks_at_baseline_sizes_g13_f64():
+    """The oracle against what the reference produced at the row counts of the BASELINE.json configurations (10, 25 with
+    respawns, 50, 50 + 3 walls + 3 immobile humans), all nine models, 20 substeps: the pin behind the GPU tests of the
+    shape-specialised kernel builds."""
+    kinds = set()
+    for k, c in enumerate(load_cases("g13_block_sizes")):
+        rp = (c["respawn_bounds"] + [0.0]) if c["respawn"] else (0.0, 0.0, 0.0)
+        S, goals, _ = orc.step_block(c["type"], c["in_states"], c["in_goals"], c.get("in_obstacles"),
+                                     c["in_params"], c["dt"], c["n_substeps"], c["in_safety"],
+                                     c["all_params_equal"], respawn=c["respawn"], respawn_par=rp)
+        scale = np.maximum(1.0, np.abs(c["out_states"]))
+        err = np.max(np.abs(S - c["out_states"]) / scale)
+        assert err < 1e-9, f"g13 case {k} {c['kind']} {c['model']}: {err}"
+        np.testing.assert_allclose(goals, c["out_goals"], rtol=0, atol=1e-9)
+        kinds.add((c["kind"], c["n"], c["all_params_equal"]))
+    assert kinds == {("n10", 10, True), ("n25_traffic", 25, True), ("n50", 50, True), ("n50_walls_static", 50, True)}
 
 
 def test_respawn_g7():

@@ -24,7 +24,7 @@ def _worker(rank, world_size, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     first, count = world_shard(rank, world_size, worlds_per_gpu=8)
-    S, goals, P, bounds = sc.hybrid_worlds(count, 5, "hsfm_farina", seed0=shard_seed(first))
+    S, goals, P, bounds = sc.hybrid_worlds(count, 5, "hsfm_farina", seed0=shard_seed(first), first_world=first)
     dist.barrier()
     slowest = max_over_ranks(0.010 * (rank + 1), dist)          # rank 1 is "slower"
     total = sum_over_ranks(float(count), dist)
@@ -54,6 +54,10 @@ def test_two_rank_sharding_and_timing_reduction():
         (f0, c0, d0), (f1, c1, d1) = gathered
         assert (f0, c0) == (0, 8) and (f1, c1) == (8, 8)   # contiguous, disjoint, covering
         assert d0 != d1
+    # a world is a function of (seed, global id): the two shards together are the single-process batch, world for world
+    S_all, _, _, _ = sc.hybrid_worlds(16, 5, "hsfm_farina", seed0=shard_seed(0))
+    (f0, c0, d0), (f1, c1, d1) = res[0][3]
+    assert d0 == float(np.round(S_all[:8, :, 0:2].sum(), 6)) and d1 == float(np.round(S_all[8:, :, 0:2].sum(), 6))
 
 
 def test_strong_scaling_split_is_even_and_covering():

@@ -15,9 +15,8 @@ from social_navigation_pyenvs_amd.csrc import build as hb  # noqa: E402
 
 so = os.path.join(ROOT, "gpurun_out", "libcrowdstep_stamps.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-DCS_STAMPS",
-                       "-I", os.path.join(ROOT, "include"), "-o", so
-                      ] + [os.path.join(hb.CSRC, x) for x in hb.SOURCES])
+subprocess.check_call([hb.hipcc_path()] + hb.FLAGS + ["-shared", "-DCS_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", so
+                      ] + [os.path.join(hb.CSRC, x) for x in hb._sources()])
 _lib.LIB_PATH = so
 _lib._lib = None
 from social_navigation_pyenvs_amd.batched import CrowdWorlds  # noqa: E402
