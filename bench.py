@@ -7,14 +7,26 @@
 A "step" is one pass of the hot path over one batch: ONE Gym step (= `substeps` fused Euler substeps
 of dt = 0.0125 s, social_nav_gym.py:240-245 / env.config:2-4) of every world resident on the GPU,
 i.e. one cs_step launch.  Workload at N=1 = BASELINE.json configs[2] (the config the metric names):
-4096 worlds x 25-agent Headed-SFM (hsfm_farina) hybrid scenario (half circular crossing R=7, half
-14x3 m parallel traffic with respawn), synthetic random-goal crowds, state resident in HBM.
+4096 worlds x 25-agent Headed-SFM (hsfm_farina) hybrid scenario (worlds with an even global id: circular
+crossing R=7; odd: 14x3 m parallel traffic with respawn), synthetic random-goal crowds, state resident in HBM.
 Worlds are independent: each rank owns its own 4096 worlds (weak scaling, no collective on the data
 path); the only collectives are the timing barrier and the MAX over ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (algorithmic
-bytes per launch / average kernel duration measured with HIP events on the launch stream, against
-the 8 TB/s HBM3E peak) and `cpu_baseline` (the C oracle timed on the host cores of this box).
+Timing: the K steps are captured once into a HIP graph (untimed); the timed region -- barrier +
+synchronize, ONE graph launch = exactly K steps, synchronize + barrier -- is repeated R times
+(`timing_repeats`, default 50) and `ms_per_step` is the MEDIAN over the repeats of (MAX over ranks of
+the elapsed time) / K; min and max are reported beside it.  HIP events on the launch stream around
+every replay give the kernel duration.
+
+Prints ONE JSON line on rank 0 with
+  roofline      algorithmic bytes per launch / average kernel duration against the 8 TB/s HBM3E peak (the contract's
+                figure: a NORMALISED ALGORITHMIC THROUGHPUT -- the 20 fused substeps keep the state in registers / LDS,
+                so real HBM traffic is ~3 % of peak), plus `frac_vs_copy` (against a device-copy bandwidth measured in
+                this run), `traffic` / `valu` (rocprofv3 PMC figures of this command, read from profiles/pmc_summary.json
+                and tagged with the profile file they come from; null when that file has no entry)
+  other_configs kernel time and roofline fraction of BASELINE.json configs[1], [3] and [4] (cfg5 = `--total-worlds 65536`
+                x 50 HSFM humans of which 3 immobile + 3 polygon walls, strong-split over the ranks) measured in the same run
+  cpu_baseline  the C oracle timed on the host cores of this box (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -31,20 +43,21 @@ sys.path.insert(0, ROOT)
 
 # algorithmic bytes per agent-substep, f32 (SURVEY.md §8d / BASELINE.md §4)
 ALG_BYTES = {"sfm": 52, "hsfm": 76, "orca": 48}
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
-# HBM-side bytes per agent per LAUNCH from rocprofv3 PMC passes of this very command (profiles/r1i_pmc_traffic.txt (first measured in r1g),
-# method in profiles/r1c_pmc_traffic.md): (FETCH_SIZE 5511.1 KB + WRITE_SIZE 4505.9 KB) / (4096 x 25 agents);
-# independent of the number of fused substeps.  FETCH_SIZE is uncalibrated for 4-byte-per-lane loads on gfx950
-# (reads 0.87x the 64 B/agent the code loads).
-MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH = {("hsfm_farina", "hybrid", False): (5511.07 + 4505.90) * 1024 / (4096 * 25)}
+# flop-equivalents per pair evaluation: Helbing 45, Guo 60, Moussaid 120
+PAIR_FLOPS = {"helbing": 45, "guo": 60, "moussaid": 120}
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32 peak (MI355X_MICROARCH.md)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
+    ap.add_argument("--repeats", type=int, default=50, help="timed replays of the K-step graph (median reported)")
+    ap.add_argument("--worlds", type=int, default=4096, help="worlds per GPU (weak scaling)")
+    ap.add_argument("--total-worlds", type=int, default=None, help="worlds of the whole job, split evenly over the ranks (strong scaling)")
     ap.add_argument("--agents", type=int, default=25)
     ap.add_argument("--model", default="hsfm_farina")
     ap.add_argument("--scenario", default="hybrid", choices=["hybrid", "circle", "traffic"])
@@ -52,48 +65,120 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.0125)
     ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
     ap.add_argument("--walls", action="store_true", help="add 3 shared polygon walls")
+    ap.add_argument("--static", type=int, default=0, help="first N humans immobile (circular_crossing_with_static_obstacles flavour; --scenario circle)")
+    ap.add_argument("--device-generator", action="store_true", help="worlds from cs_generate_worlds (circle crossing R=20, seed 1000 + global id): what the cfg5 entry of other_configs runs")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python (default: one HIP graph of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a one-GPU box")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def build_worlds(args, rank):
+def spec_key(spec) -> str:
+    """key of a configuration in profiles/pmc_summary.json"""
+    W = spec["worlds"]
+    return (f"{spec['model']}_{spec['agents']}_{spec['scenario']}" + ("_walls" if spec["walls"] else "") + ("_static" if spec["static"] else "")
+            + ("" if W in (4096, 8192) else f"_{W}"))
+
+
+def workload_spec(args) -> dict:
+    return dict(name="main", device_generator=bool(args.device_generator), model=args.model, agents=args.agents, scenario=args.scenario, walls=bool(args.walls),
+                static=int(args.static), substeps=args.substeps, dt=args.dt, layout=args.layout,
+                worlds=args.worlds, total_worlds=args.total_worlds)
+
+
+def other_config_specs(args) -> list[dict]:
+    """BASELINE.json configs[1], [3], [4] beside the headline configs[2]."""
+    base = dict(substeps=args.substeps, dt=args.dt, layout=args.layout, walls=False, static=0, total_worlds=None)
+    return [
+        dict(base, name="cfg2", model="sfm_helbing", agents=10, scenario="circle", worlds=4096,
+             title="4096 worlds/GPU x 10-agent SFM (sfm_helbing) circle crossing"),
+        dict(base, name="cfg4", model="orca", agents=25, scenario="circle", worlds=4096,
+             title="4096 worlds/GPU x 25-agent ORCA circle crossing"),
+        dict(base, name="cfg5", model="hsfm_farina", agents=50, scenario="circle", walls=True, static=3, worlds=8192,
+             total_worlds=65536, device_generator=True,
+             title="65536 worlds (whole job, strong split) x 50-agent HSFM circle crossing R=20, 3 immobile humans + 3 polygon walls"),
+    ]
+
+
+def shard_of(spec, rank, world_size):
+    from social_navigation_pyenvs_amd.sharding import world_shard
+
+    return world_shard(rank, world_size, spec["worlds"], spec["total_worlds"])
+
+
+def host_worlds(spec, rank, world_size):
+    """Host arrays of this rank's shard (CPU only: also what tests/test_sharding_gloo.py runs under gloo).  Worlds are functions
+    of (seed, GLOBAL world id): the batch is the same whatever the number of ranks."""
     from social_navigation_pyenvs_amd import scenarios as sc
-    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+    from social_navigation_pyenvs_amd.sharding import shard_seed
 
-    from social_navigation_pyenvs_amd.sharding import shard_seed, world_shard
-
-    W, n = args.worlds, args.agents
-    first, _ = world_shard(rank, int(os.environ.get("WORLD_SIZE", "1")), W)
+    first, W = shard_of(spec, rank, world_size)
+    n, model = spec["agents"], spec["model"]
     seed0 = shard_seed(first)
-    respawn_bounds = None
-    respawn_worlds = None
-    if args.scenario == "hybrid":
-        S, goals, P, respawn_bounds = sc.hybrid_worlds(W, n, "sfm_helbing" if args.model == "orca" else args.model, seed0=seed0)
-        respawn_worlds = (np.arange(W) % 2 == 1).astype(np.int32)
-    elif args.scenario == "circle":
+    hmodel = "sfm_helbing" if model == "orca" else model
+    respawn_bounds = respawn_worlds = None
+    walls = sc.polygon_walls() if spec["walls"] else None
+    if spec["scenario"] == "hybrid":
+        S, goals, P, respawn_bounds = sc.hybrid_worlds(W, n, hmodel, seed0=seed0, first_world=first)
+        respawn_worlds = ((first + np.arange(W)) % 2 == 1).astype(np.int32)
+    elif spec["scenario"] == "circle":
         radius = 7.0 if n <= 30 else 7.0 * n / 25.0
-        pos, yaw, g = sc.circular_crossing(W, n, radius, seed0)
-        S, goals = sc.make_states(pos, yaw, g), g
-        P = None if args.model == "orca" else np.tile(sc.default_params(args.model), (n, 1))
+        if spec["static"] > 0:
+            S, goals, P, _ = sc.static_obstacle_worlds(W, n, hmodel, radius=radius, seed0=seed0, first_world=first, n_static=spec["static"])
+        else:
+            pos, yaw, goals = sc.circular_crossing(W, n, radius, seed0, first_world=first)
+            S, P = sc.make_states(pos, yaw, goals), np.tile(sc.default_params(hmodel), (n, 1))
     else:
-        pos, yaw, g = sc.parallel_traffic(W, n, seed0=seed0)
-        S, goals = sc.make_states(pos, yaw, g), g
-        P = None if args.model == "orca" else np.tile(sc.default_params(args.model), (n, 1))
+        pos, yaw, goals = sc.parallel_traffic(W, n, seed0=seed0, first_world=first)
+        S, P = sc.make_states(pos, yaw, goals), np.tile(sc.default_params(hmodel), (n, 1))
         respawn_bounds = (7.0, 1.5)
-    walls = sc.polygon_walls() if args.walls else None
     margin = None
-    if args.model == "orca":  # cfg4: RVO2 agents, radius + 0.01, preferred velocity in columns 5:7 (unit vector to the goal)
+    if model == "orca":  # cfg4: RVO2 agents, radius + 0.01, preferred velocity in columns 5:7 (unit vector to the goal)
         P = None
         d = goals[:, :, 0] - S[:, :, 0:2]
         S[:, :, 5:7] = d / np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
         margin = np.full(S.shape[:2], 0.01)
-    cw = CrowdWorlds(S, goals, P, margin, walls, type=args.model, all_params_equal=True,
-                     respawn_bounds=respawn_bounds, respawn_worlds=respawn_worlds, layout=args.layout)
-    host = dict(S=S, goals=goals, P=P, walls=walls, respawn_bounds=respawn_bounds, respawn_worlds=respawn_worlds)
-    return cw, host
+    return dict(first=first, W=W, S=S, goals=goals, P=P, walls=walls, margin=margin, respawn_bounds=respawn_bounds,
+                respawn_worlds=respawn_worlds)
+
+
+def build_worlds(spec, rank, world_size):
+    """(CrowdWorlds, host arrays or None, worlds of this rank)"""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    n, model = spec["agents"], spec["model"]
+    if spec.get("device_generator"):
+        # the reference's circular-crossing generator (social_nav_sim.py:200-299, rejection sampling against the placed
+        # humans AND their goals) restated on the device (cs_generate_worlds), seed 1000 + global world id, on R = 20 (50
+        # humans block 100 spots of the circle: R = 7 cannot hold them, SURVEY.md §5); then the first `static` humans are
+        # made immobile as circular_crossing_with_static_obstacles builds them (:381-387, 416-417: desired speed 0, larger
+        # radius, goal = own position, inner circle R - 3) -- that generator itself does not terminate beyond ~10 humans
+        from social_navigation_pyenvs_amd import generators as gen
+
+        first, W = shard_of(spec, rank, world_size)
+        radius = 20.0
+        walls = sc.polygon_walls() if spec["walls"] else None
+        P = np.tile(sc.default_params(model), (n, 1))
+        cw = CrowdWorlds(np.zeros((W, n, 13), np.float32), np.full((W, n, 2, 2), np.nan, np.float32), P, None, walls, type=model,
+                         all_params_equal=True, layout=spec["layout"])
+        gen.generate_worlds(cw, "circle_crossing", 1000 + first + np.arange(W), insert_robot=False, circle_radius=radius)
+        k = spec["static"]
+        if k > 0:
+            S, goals = cw.get_states(), cw.get_goals()
+            ang = 2.0 * np.pi * (np.arange(k) + 0.25) / k
+            p = (radius - 3.0) * np.stack([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
+            S[:, :k, 0:2] = p; S[:, :k, 10:12] = p; S[:, :k, 3:8] = 0.0
+            S[:, :k, 8] = 0.8; S[:, :k, 12] = 0.0
+            goals[:, :k, 0] = p; goals[:, :k, 1] = p
+            cw.set_states(S); cw.set_goals(goals)
+        return cw, None, W
+    h = host_worlds(spec, rank, world_size)
+    cw = CrowdWorlds(h["S"], h["goals"], h["P"], h["margin"], h["walls"], type=model, all_params_equal=True,
+                     respawn_bounds=h["respawn_bounds"], respawn_worlds=h["respawn_worlds"], layout=spec["layout"])
+    return cw, h, h["W"]
 
 
 def effective_cores() -> int:
@@ -149,6 +234,141 @@ def cpu_baseline(args, host, type_id):
                       f"{reps1 * args.substeps} substeps, {el1:.1f} s"}
 
 
+class Runner:
+    """Barrier / timing plumbing shared by the main workload and the other configurations."""
+
+    def __init__(self, torch, dist, stream):
+        self.torch, self.dist, self.stream = torch, dist, stream
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, cw, spec, steps, warmup, repeats, eager=False):
+        """Times `repeats` x (exactly `steps` steps between barrier + synchronize on both sides).  Returns the per-repeat
+        wall times (MAX over ranks) and the HIP-event kernel time per step of every repeat (this rank)."""
+        from social_navigation_pyenvs_amd import _lib
+        from social_navigation_pyenvs_amd.sharding import max_over_ranks
+
+        cw.stream = self.stream
+        dt, n_sub = spec["dt"], spec["substeps"]
+        for _ in range(warmup):
+            cw.step(dt, n_sub)
+        self.barrier()
+        wall, kern = [], []
+        if eager:
+            # one launch per step from Python, a HIP event pair around every launch
+            for _ in range(repeats):
+                starts = [_lib.Event() for _ in range(steps)]
+                stops = [_lib.Event() for _ in range(steps)]
+                self.barrier()
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    starts[k].record(self.stream)
+                    cw.step(dt, n_sub)
+                    stops[k].record(self.stream)
+                _lib.stream_sync(self.stream)
+                self.barrier()
+                wall.append(time.perf_counter() - t0)
+                kern.append(float(np.mean([starts[k].elapsed_ms(stops[k]) for k in range(steps)])))
+        else:
+            # the K steps are captured once into a HIP graph (untimed) and replayed with ONE launch per timed region:
+            # no per-launch host gap; HIP events on the launch stream bracket the K kernels of every replay
+            with _lib.Graph.capture(self.stream) as graph:
+                for k in range(steps):
+                    cw.step(dt, n_sub)
+            graph.launch()                      # one untimed replay (first launch of an instantiated graph uploads it)
+            _lib.stream_sync(self.stream)
+            e0, e1 = _lib.Event(), _lib.Event()
+            for _ in range(repeats):
+                self.barrier()
+                t0 = time.perf_counter()
+                e0.record(self.stream)
+                graph.launch()
+                e1.record(self.stream)
+                _lib.stream_sync(self.stream)
+                self.barrier()
+                wall.append(time.perf_counter() - t0)
+                kern.append(e0.elapsed_ms(e1) / steps)
+        dev = "cuda" if self.dist is not None else None
+        wall = [max_over_ranks(w, self.dist, device=dev) for w in wall]
+        return np.array(wall), np.array(kern)
+
+    def gather(self, value: float) -> list:
+        if self.dist is None or self.dist.get_world_size() == 1:
+            return [float(value)]
+        t = self.torch.tensor([value], dtype=self.torch.float64, device="cuda")
+        out = [self.torch.zeros_like(t) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(out, t)
+        return [float(x.item()) for x in out]
+
+    def copy_bandwidth(self, nbytes=1 << 30, reps=10):
+        """Device-to-device copy bandwidth measured in this run (read + written bytes / time): the practical HBM ceiling
+        (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy) beside the 8 TB/s vendor peak."""
+        import ctypes as C
+
+        from social_navigation_pyenvs_amd import _lib
+
+        a, b = _lib.DeviceBuffer((nbytes // 4,)), _lib.DeviceBuffer((nbytes // 4,))
+        lib = _lib.load()
+        _lib.check(lib.cs_memset(C.c_void_p(a.ptr), C.c_int(1), C.c_size_t(nbytes), C.c_void_p(self.stream)))
+        for _ in range(2):
+            _lib.check(lib.cs_memcpy_d2d(C.c_void_p(b.ptr), C.c_void_p(a.ptr), C.c_size_t(nbytes), C.c_void_p(self.stream)))
+        e0, e1 = _lib.Event(), _lib.Event()
+        best = None
+        for _ in range(reps):
+            e0.record(self.stream)
+            _lib.check(lib.cs_memcpy_d2d(C.c_void_p(b.ptr), C.c_void_p(a.ptr), C.c_size_t(nbytes), C.c_void_p(self.stream)))
+            e1.record(self.stream)
+            ms = e0.elapsed_ms(e1)
+            best = ms if best is None else min(best, ms)
+        a.free(); b.free()
+        return 2.0 * nbytes / (best * 1e-3) / 1e9
+
+
+def family_of(model):
+    return "orca" if model == "orca" else ("hsfm" if model.startswith("hsfm") else "sfm")
+
+
+def pmc_entry(name):
+    """rocprofv3 PMC figures of this configuration from profiles/pmc_summary.json (written from the round's committed
+    counter passes by tools/pmc_summary.py); None when there is no entry."""
+    try:
+        return json.load(open(PMC_SUMMARY)).get(name)
+    except Exception:
+        return None
+
+
+def roofline_block(spec, W, kern_ms, copy_gbs, cw):
+    n, n_sub = spec["agents"], spec["substeps"]
+    fam = family_of(spec["model"])
+    alg = ALG_BYTES[fam] * W * n * n_sub          # walls are shared by all worlds: 0 B per world-substep
+    k_avg = float(np.mean(kern_ms))
+    achieved = alg / (k_avg * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "meaning": "normalised ALGORITHMIC throughput (bytes one substep would move if the state round-tripped HBM every "
+                      "substep) -- the fused launch keeps the state in registers / LDS; see traffic / valu for what the "
+                      "hardware really does",
+           "frac_vs_copy": (achieved / copy_gbs) if copy_gbs else None, "copy_GBs_measured": copy_gbs,
+           "kernel": "k_orca_step" if fam == "orca" else "k_sfm_step", "variant": cw.step_variant(),
+           "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kern_ms)), "kernel_max_ms": float(np.max(kern_ms)),
+           "algorithmic_bytes_per_launch": alg, "bytes_per_agent_substep": ALG_BYTES[fam]}
+    pm = pmc_entry(spec_key(spec)) or {}
+    per_agent = pm.get("hbm_bytes_per_agent_launch")
+    out["traffic"] = per_agent * W * n if per_agent is not None else None
+    out["traffic_source"] = pm.get("traffic_source")
+    out["traffic_GBs"] = (out["traffic"] / (k_avg * 1e-3) / 1e9) if out["traffic"] is not None else None
+    if fam != "orca":
+        soc = "guo" if spec["model"].endswith("guo") else ("moussaid" if spec["model"].endswith("moussaid") else "helbing")
+        pair_flops = PAIR_FLOPS[soc] * W * n * (n - 1) * n_sub   # the reference's count: every ordered pair
+        out["fp32_tflops_equiv"] = pair_flops / (k_avg * 1e-3) / 1e12
+        out["fp32_frac"] = out["fp32_tflops_equiv"] / FP32_PEAK_TFLOPS
+    out["valu"] = pm.get("valu")          # measured VALU issue figures (the true bound of this kernel), tagged with their source
+    return out
+
+
 def main():
     args = parse()
     # stdout carries ONE JSON line and nothing else: native libraries (RCCL prints a version banner from C when NCCL_DEBUG
@@ -179,66 +399,42 @@ def main():
     if args.gpus != world_size and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world_size}", file=sys.stderr)
 
-    cw, host = build_worlds(args, rank)
     stream = _lib.stream_create()
-    cw.stream = stream
-    n_sub = args.substeps
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        cw.step(args.dt, n_sub)
-    barrier()
-    if args.eager:
-        # one launch per step from Python, a HIP event pair around every launch
-        starts = [_lib.Event() for _ in range(args.steps)]
-        stops = [_lib.Event() for _ in range(args.steps)]
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            starts[k].record(stream)
-            cw.step(args.dt, n_sub)
-            stops[k].record(stream)
-        _lib.stream_sync(stream)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = np.array([starts[k].elapsed_ms(stops[k]) for k in range(args.steps)])
-    else:
-        # the K steps are captured once into a HIP graph (untimed) and replayed with ONE launch in the timed region:
-        # no per-launch host gap; HIP events on the launch stream bracket the K kernels
-        with _lib.Graph.capture(stream) as graph:
-            for k in range(args.steps):
-                cw.step(args.dt, n_sub)
-        e0, e1 = _lib.Event(), _lib.Event()
-        barrier()
-        t0 = time.perf_counter()
-        e0.record(stream)
-        graph.launch()
-        e1.record(stream)
-        _lib.stream_sync(stream)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = np.array([e0.elapsed_ms(e1) / args.steps])
-    from social_navigation_pyenvs_amd.sharding import max_over_ranks
-
-    elapsed = max_over_ranks(elapsed, dist, device="cuda")
+    run = Runner(torch, dist, stream)
+    spec = workload_spec(args)
+    cw, host, W = build_worlds(spec, rank, world_size)
+    wall, kern = run.measure(cw, spec, args.steps, args.warmup, args.repeats, eager=args.eager)
+    per_rank_kernel_us = run.gather(float(np.mean(kern)) * 1e3)
+    total_worlds = args.total_worlds if args.total_worlds is not None else world_size * args.worlds
 
     # sanity: the state is finite and moved
     S_end = cw.get_states()
     finite = float(np.mean(np.isfinite(S_end[..., :8])))
 
+    copy_gbs = run.copy_bandwidth() if rank == 0 else None
+    others = []
+    if not args.no_other_configs:
+        for ospec in other_config_specs(args):
+            ocw, _, oW = build_worlds(ospec, rank, world_size)
+            k_o = max(5, min(args.steps, 20 if ospec["model"] == "orca" else 50))
+            owall, okern = run.measure(ocw, ospec, k_o, 3, 7)
+            ous = run.gather(float(np.mean(okern)) * 1e3)
+            if rank == 0:
+                tot = ospec["total_worlds"] if ospec["total_worlds"] is not None else world_size * ospec["worlds"]
+                med = float(np.median(owall))
+                rl = roofline_block(ospec, oW, okern, copy_gbs, ocw)
+                others.append({"name": ospec["name"], "workload": ospec["title"], "scaling": "strong" if ospec["total_worlds"] else "weak",
+                               "worlds_this_rank": oW, "worlds_total": tot, "steps": k_o, "timing_repeats": 7,
+                               "ms_per_step": med / k_o * 1e3,
+                               "value": tot * ospec["agents"] * ospec["substeps"] * k_o / med, "unit": "agent-substeps/s",
+                               "kernel_us": rl["kernel_avg_ms"] * 1e3, "per_rank_kernel_us": ous, "frac": rl["frac"], "roofline": rl})
+            del ocw
+
     if rank == 0:
-        agent_substeps = world_size * args.worlds * args.agents * n_sub * args.steps
-        value = agent_substeps / elapsed
-        family = "orca" if args.model == "orca" else ("hsfm" if args.model.startswith("hsfm") else "sfm")
-        alg_bytes_launch = ALG_BYTES[family] * args.worlds * args.agents * n_sub
-        if args.walls:
-            alg_bytes_launch += 16 * 15 * 0  # walls are shared by all worlds: 0 B per world-substep
-        k_avg = float(np.mean(kernel_ms))
-        achieved = alg_bytes_launch / (k_avg * 1e-3) / 1e9
+        n_sub = args.substeps
+        med, lo, hi = float(np.median(wall)), float(np.min(wall)), float(np.max(wall))
+        agent_substeps = total_worlds * args.agents * n_sub * args.steps
+        value = agent_substeps / med
         g, b, wpb = cw.launch_geometry()
         out = {
             "metric": "env-steps/sec (worlds x agents) for HSFM 25-agent crowd",
@@ -247,34 +443,31 @@ def main():
             "n_gpus": world_size,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": med / args.steps * 1e3,
+            "ms_per_step_min": lo / args.steps * 1e3,
+            "ms_per_step_max": hi / args.steps * 1e3,
+            "timing_repeats": int(len(wall)),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_worlds is not None else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.worlds} worlds/GPU x {args.agents}-agent {args.model} {args.scenario} scenario"
-                            f"{' + 3 polygon walls' if args.walls else ''}, {n_sub} fused substeps of "
-                            f"{args.dt} s per step (one Gym step), state resident in HBM ({args.layout})",
-                "worlds_per_gpu": args.worlds, "agents": args.agents, "substeps_per_step": n_sub,
+                "workload": f"{W} worlds/GPU x {args.agents}-agent {args.model} {args.scenario} scenario"
+                            f"{' + 3 polygon walls' if args.walls else ''}{f' + {args.static} immobile humans' if args.static else ''}, "
+                            f"{n_sub} fused substeps of {args.dt} s per step (one Gym step), state resident in HBM ({args.layout})",
+                "worlds_per_gpu": W, "worlds_total": total_worlds, "agents": args.agents, "substeps_per_step": n_sub,
                 "model": args.model, "scenario": args.scenario, "parallelism": f"worlds sharded x{world_size}, no collective",
                 "launch": {"grid": g, "block": b, "worlds_per_block": wpb},
+                "timed_region": "eager launches, one HIP event pair per launch" if args.eager else
+                                "barrier + sync | ONE replay of a HIP graph holding exactly K cs_step launches | sync + barrier; repeated R times, median reported",
             },
             "world_substeps_per_s": value / args.agents,
             "gym_steps_per_s": value / args.agents / n_sub,
             "finite_fraction": finite,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH[(args.model, args.scenario, args.walls)] * args.worlds * args.agents
-                            if (args.model, args.scenario, args.walls) in MEASURED_TRAFFIC_B_PER_AGENT_LAUNCH else None),
-                "traffic_note": "HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/)",
-                "kernel": "k_orca_step" if args.model == "orca" else "k_sfm_step", "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kernel_ms)),
-                "launch_mode": "eager, one HIP event pair per launch" if args.eager else "HIP graph of K launches, events around the graph",
-                "algorithmic_bytes_per_launch": alg_bytes_launch,
-                "bytes_per_agent_substep": ALG_BYTES[family],
-            },
+            "per_rank_kernel_us": per_rank_kernel_us,
+            "roofline": roofline_block(spec, W, kern, copy_gbs, cw),
+            "other_configs": others,
         }
         if not args.no_cpu_baseline and args.model != "orca" and world_size == 1:  # rank 0, N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))

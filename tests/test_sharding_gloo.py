@@ -74,3 +74,65 @@ def test_strong_scaling_split_is_even_and_covering():
 def test_single_process_is_identity():
     assert max_over_ranks(1.5) == 1.5 and sum_over_ranks(2.0) == 2.0
     assert torch.distributed.is_available()
+
+
+def _bench_worker(rank, world_size, port, q):
+    """bench.py's own argument / shard / seed plumbing under a 2-rank gloo group (everything of main() that needs no GPU)."""
+    import sys
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size), LOCAL_RANK=str(rank))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    args = bench.parse(["--gpus", "2", "--steps", "5", "--warmup", "1", "--worlds", "12", "--agents", "5"])
+    weak = bench.host_worlds(bench.workload_spec(args), rank, world_size)
+    args5 = bench.parse(["--gpus", "2", "--total-worlds", "21", "--agents", "8", "--model", "hsfm_farina", "--scenario", "circle",
+                         "--walls", "--static", "3"])
+    strong = bench.host_worlds(bench.workload_spec(args5), rank, world_size)
+    rec = dict(rank=rank, weak=(weak["first"], weak["W"], float(weak["S"][:, :, 0:2].sum()), weak["respawn_worlds"].tolist()),
+               strong=(strong["first"], strong["W"], float(strong["S"][:, :, 0:2].sum())),
+               scaling=("strong" if args5.total_worlds is not None else "weak", "strong" if args.total_worlds is not None else "weak"),
+               keys=[bench.spec_key(o) for o in bench.other_config_specs(args)],
+               cfg5_shard=bench.shard_of(bench.other_config_specs(args)[2], rank, world_size))
+    out = [None] * world_size
+    dist.all_gather_object(out, rec)
+    slow = max_over_ranks(0.5 + rank, dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out, slow))
+
+
+def test_bench_argument_and_seed_plumbing_two_ranks():
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, recs, slow = res[0]
+    assert slow == 1.5
+    r0, r1 = sorted(recs, key=lambda r: r["rank"])
+    # weak scaling: 12 worlds per rank, contiguous global ids, hybrid parity by GLOBAL id
+    assert r0["weak"][:2] == (0, 12) and r1["weak"][:2] == (12, 12)
+    assert r0["weak"][3] == [i % 2 for i in range(12)] and r1["weak"][3] == [i % 2 for i in range(12, 24)]
+    # strong scaling: 21 worlds split 11 + 10, and the union is the single-process batch world for world
+    assert r0["strong"][:2] == (0, 11) and r1["strong"][:2] == (11, 10)
+    assert r0["scaling"] == ("strong", "weak")
+    one = bench.host_worlds(bench.workload_spec(bench.parse(["--total-worlds", "21", "--agents", "8", "--model", "hsfm_farina",
+                                                             "--scenario", "circle", "--walls", "--static", "3"])), 0, 1)
+    assert abs(float(one["S"][:11, :, 0:2].sum()) - r0["strong"][2]) < 1e-9 and abs(float(one["S"][11:, :, 0:2].sum()) - r1["strong"][2]) < 1e-9
+    # BASELINE configs[4]: 65536 worlds over the ranks, 32768 each at two ranks
+    assert r0["cfg5_shard"] == (0, 32768) and r1["cfg5_shard"] == (32768, 32768)
+    assert r0["keys"] == ["sfm_helbing_10_circle", "orca_25_circle", "hsfm_farina_50_circle_walls_static"]

@@ -1,0 +1,30 @@
+#!/bin/bash
+# usage (GPU box): tools/profile_round2.sh TAG [config ...]
+# Per configuration (BASELINE.json configs[1..4]): rocprofv3 kernel stats of bench.py and three PMC passes (FETCH_SIZE,
+# WRITE_SIZE, SQ issue counters -- separate passes, never combined with a trace domain).  tools/pmc_summary.py turns the
+# counter CSVs into profiles/pmc_summary.json, which bench.py reads back (roofline.traffic / roofline.valu).
+TAG=$1; shift
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd $R
+declare -A CFG
+CFG[cfg3]=""
+CFG[cfg2]="--agents 10 --model sfm_helbing --scenario circle"
+CFG[cfg4]="--model orca --scenario circle"
+CFG[cfg5]="--worlds 8192 --agents 50 --model hsfm_farina --scenario circle --walls --static 3 --device-generator"
+CFG[cfg3x4]="--worlds 16384"
+CFG[moussaid]="--model hsfm_new_moussaid"
+NAMES=${@:-cfg3 cfg2 cfg4 cfg5}
+for name in $NAMES; do
+  A="${CFG[$name]} --no-cpu-baseline --no-other-configs"
+  echo "== $name: $A"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${name}_stats -- python3 bench.py $A --steps 50 --warmup 5 --repeats 4 > $O/${name}_bench.json 2> $O/${name}_stats.log || { echo "stats run failed"; tail -5 $O/${name}_stats.log; exit 1; }
+  cp $(find $O/${name}_stats -name "*kernel_stats.csv" | head -1) $O/${name}_kernel_stats.csv && head -3 $O/${name}_kernel_stats.csv
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+    p=$(echo $pass | cut -d' ' -f1)
+    rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/${name}_pmc_$p -- python3 bench.py $A --steps 10 --warmup 2 --repeats 1 > /dev/null 2> $O/${name}_pmc_$p.log || { echo "pmc $p failed"; tail -5 $O/${name}_pmc_$p.log; exit 1; }
+    cp $(find $O/${name}_pmc_$p -name "*counter_collection.csv" | head -1) $O/${name}_pmc_$p.csv
+    rm -rf $O/${name}_pmc_$p
+  done
+  rm -rf $O/${name}_stats
+done
+python3 tools/pmc_summary.py $O $O/pmc_summary.json && cat $O/pmc_summary.json
