@@ -301,6 +301,12 @@ int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_pe
  * with d_out != d_state, 2 = cs_peek.  buf receives e.g. "k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2". */
 int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen);
 
+/* Diagnostic: the ORCA kernels' correctly rounded divide / square root sequences (csrc/orca.hip ieee_div, ieee_sqrt: the
+ * compiler's FMA sequences without the exponent-range handling) against the compiler's operators on n_pairs random operand
+ * pairs of the linear programmes' range.  h_out[0], h_out[1] = number of quotients / roots that differ in any bit (must be 0),
+ * h_out[2], h_out[3] = bit patterns of the first differing operand pair.  Synchronises. */
+int cs_debug_divsqrt_check(unsigned long long n_pairs, unsigned seed, unsigned long long* h_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

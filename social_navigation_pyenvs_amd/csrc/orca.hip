@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -62,11 +63,42 @@ struct OArgs {
     const float* verts;
     int nv, KO;
     float time_horizon_obst;
+    int lp3_static;        // diagnostic A/B switch: linearProgram3 as the statically unrolled walk (lp3_fast10) instead of lp3_rows
 };
 
 __device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
 // IEEE divide / sqrt are kept on purpose: with v_rcp_f32 / v_sqrt_f32 the kernel ran 1.3x faster but left the
 // 1e-5 band around the C restatement (the LP's branch decisions amplify ulp-level differences).
+//
+// ieee_div / ieee_sqrt: the correctly rounded quotient / root by the very FMA sequences hipcc emits for `a / b` and
+// sqrtf(x) on gfx950 -- v_rcp_f32, one Newton step on the reciprocal, the quotient refined twice (the last refinement is
+// what v_div_fmas_f32 does); v_sqrt_f32 corrected by the two one-ulp residual tests -- WITHOUT the range handling around
+// them (v_div_scale_f32 x2 + v_div_fixup_f32; the 2^32 pre-scale of sqrt), which only acts on operands whose exponents lie
+// outside [-96, 96] or so: the linear programmes work on velocities, unit directions and their determinants (|x| in
+// 1e-30 .. 1e8; quotients of parallel lines, the one place a denominator can vanish, are discarded by a select).  8 VALU
+// instructions instead of 11, 9 instead of 13.  tests/test_gpu_orca.py::test_ieee_div_sqrt_sequences_are_correctly_rounded
+// compares both with the compiler's operators on 2^31 operand pairs drawn from that range, bit for bit.
+__device__ __forceinline__ float ieee_div(float a, float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e0 = fmaf(-b, r, 1.0f);
+    r = fmaf(e0, r, r);
+    float q = a * r;
+    const float e1 = fmaf(-b, q, a);
+    q = fmaf(e1, r, q);
+    const float e2 = fmaf(-b, q, a);
+    return fmaf(e2, r, q);
+}
+__device__ __forceinline__ float ieee_sqrt(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-dn, s, x);
+    const float t = (rd <= 0.0f) ? dn : s;      // (0 >= residual): the root was rounded up, step down
+    const float ru = fmaf(-up, s, x);
+    const float res = (ru > 0.0f) ? up : t;     // the root was rounded down, step up
+    return (x == 0.0f) ? x : res;               // +-0 stay (s - 1 ulp of 0 is not a number to step to)
+}
 
 // per-lane column views into LDS: element i of lane tid lives at base[i * T + tid]
 struct Lines {
@@ -366,13 +398,13 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
                 const float d = det2(li.z, li.w, lj.z, lj.w);
                 const bool par = fabsf(d) <= RVO_EPSILON;
                 const bool same = li.z * lj.z + li.w * lj.w > 0.0f;
-                const float s = det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y) / d;
+                const float s = ieee_div(det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y), d);
                 float4 ln;
                 ln.x = par ? 0.5f * (li.x + lj.x) : li.x + s * li.z;
                 ln.y = par ? 0.5f * (li.y + lj.y) : li.y + s * li.w;
                 const float ex = lj.z - li.z, ey = lj.w - li.w;
-                const float en = sqrtf(ex * ex + ey * ey);
-                const float inv = 1.0f / en;
+                const float en = ieee_sqrt(ex * ex + ey * ey);
+                const float inv = ieee_div(1.0f, en);
                 ln.z = ex * inv; ln.w = ey * inv;
                 Pr[j] = ln;
                 pvalid |= (par && same) ? 0u : (1u << j);
@@ -391,14 +423,14 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
                     const float dot = lk.x * lk.z + lk.y * lk.w;
                     const float disc = dot * dot + vmax * vmax - (lk.x * lk.x + lk.y * lk.y);
                     bool ok = !(disc < 0.0f);
-                    const float sq = sqrtf(fmaxf(disc, 0.0f));
+                    const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
                     float tL = -dot - sq, tR = -dot + sq;
 #pragma unroll
                     for (int m = 0; m < k; ++m) {   // branch-free: the divisions of all m are independent and overlap
                         const float4 lm = Pr[m];
                         const float den = det2(lk.z, lk.w, lm.z, lm.w);
                         const float num = det2(lm.z, lm.w, lk.x - lm.x, lk.y - lm.y);
-                        const float t = num / den;
+                        const float t = ieee_div(num, den);
                         const bool live = ((pvalid >> m) & 1u) != 0;
                         const bool par = fabsf(den) <= RVO_EPSILON;
                         const bool upd = live && !par && ok;             // (after a failure RVO2 has already returned)
@@ -421,6 +453,194 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
     }
 }
 
+// ---- linearProgram3, one 16-lane ROW per (agent, violated line) ----------------------------------------------------------
+// Measured on the restatement in the dense phase of the cfg4 crossing: 35 % of the agents have an infeasible programme in a
+// substep, such an agent walks 1.2 of the ten LP3 levels, projects 7 lines and calls linearProgram1 3.6 times with 7 inner
+// iterations in all -- but a wavefront of 50 agents executes the UNION of its lanes' paths: 7.5 levels, each with every
+// projection and nearly every linearProgram1 of its triangle, for 2.7 active lanes on average (lp3_fast10 above: 6400 of the
+// 9700 vector instructions of a wavefront-substep).  Here the lanes' roles are re-dealt for LP3 only: every agent with a
+// pending level gets a row of 16 lanes (four agents per pass, passes until the wavefront's pending agents are served, rounds
+// until no agent has a further violated line).  Inside a row lane j owns line j: the i projections of a level are ONE step,
+// linearProgram2 over them finds the first violated line with a ballot, and linearProgram1's loop over the earlier lines --
+// a min / max of quotients with an any-fail flag, exact and order-independent -- is one step plus a DPP row reduction.  Every
+// operation on the path RVO2 takes is the same operation on the same operands (the early exits of linearProgram1 become the
+// final tL > tR test: tL only grows, tR only shrinks), so the results stay bit-identical to oracle/orca_oracle.c.
+// Rows talk through LDS inside ONE wavefront (in-order LDS, compiler-only fences): the agents' lines L[10][TL] (stored by the
+// owners), the projected lines P[9][TL], one (result, maxSpeed, distance) record and one ticket per agent.
+#define ORCA_LDS_FENCE() asm volatile("" ::: "memory")
+// P [9][8] projected lines of the eight rows in flight, A [9][8] their chords on the speed circle (tL0, tR0; (+inf, -inf) when
+// the line misses the circle, which fails linearProgram1 through its own tL > tR test), q [T] agent records, sel [T] tickets
+struct RowLds { float4* P; float2* A; float4* q; int* sel; };
+
+// min and max over the 16-lane row of the calling lane, left in every lane of the row: four rotate-and-combine steps
+// (row_ror 8, 4, 2, 1) with the DPP operand fused into v_min_f32 / v_max_f32 -- the two chains alternate, one wait state
+// covers the VALU-write -> DPP-read hazard.  The operands are finite or +-inf, never NaN.
+__device__ __forceinline__ void row_minmax16(float& mn, float& mx)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(mn), "+v"(mx));
+}
+
+// Called by ALL 64 lanes of a wavefront (lanes without an agent pass cnt = failed = 0).  Lr: the caller's ten lines (also
+// stored in L's column L.tid); on return (rx, ry) is linearProgram3's result for lanes with failed < cnt.
+// A pass serves 4 * NC agents (NC contexts per lane, written as arrays so that their chains interleave; NC = 1 is what ships).
+__device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R, int cnt, int failed, float vmax, float& rx, float& ry)
+{
+    constexpr int NC = 1;   // contexts per lane and pass (two were measured: slower -- the row work is issue-bound)
+    const int TL = L.T, me = L.tid;
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    const int row_sh = lane & 48, j = lane & 15, jj = j < 9 ? j : 8;
+    float distance = 0.0f;
+    int next_i = failed;
+#pragma nounroll
+    for (int round = 0; round < 10; ++round) {
+        // owner: my next violated line at or behind next_i, with the current result and distance (RVO2 walks i upwards)
+        int lvl = -1;
+#pragma unroll
+        for (int i = 9; i >= 0; --i) {
+            const float4 li = Lr[i];
+            const bool v = (i >= next_i) && (i < cnt) && (det2(li.z, li.w, li.x - rx, li.y - ry) > distance);
+            lvl = v ? i : lvl;
+        }
+        const bool pending = lvl >= 0;
+        const unsigned long long pm = __builtin_amdgcn_ballot_w64(pending);
+        if (pm == 0) break;
+        const int npend = __builtin_popcountll(pm);
+        if (pending) {
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
+            R.sel[wbase + rank] = me | (lvl << 16);
+            R.q[me] = make_float4(rx, ry, vmax, distance);
+        }
+        ORCA_LDS_FENCE();
+#pragma nounroll
+        for (int p0 = 0; p0 < npend; p0 += 4 * NC) {
+            bool rowvalid[NC], live[NC], done[NC], fail2[NC];
+            int a[NC], lv[NC], k[NC];
+            float4 qa[NC], li[NC], pr[NC];
+            float2 aux[NC];
+            int slot[NC];
+            float qx[NC], qy[NC], ox[NC], oy[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int idx = p0 + 4 * c + (lane >> 4);
+                rowvalid[c] = idx < npend;
+                const int e = rowvalid[c] ? R.sel[wbase + idx] : 0;
+                a[c] = e & 0xFFFF; lv[c] = e >> 16;
+                slot[c] = 4 * c + (lane >> 4);
+            }
+            float4 lj[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                qa[c] = R.q[a[c]];
+                li[c] = L.p[lv[c] * TL + a[c]];
+                lj[c] = L.p[jj * TL + a[c]];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bool task = rowvalid[c] && j < lv[c];
+                // RVO2 linearProgram3: line j projected on line i
+                const float d = det2(li[c].z, li[c].w, lj[c].z, lj[c].w);
+                const bool par = fabsf(d) <= RVO_EPSILON;
+                const bool same = li[c].z * lj[c].z + li[c].w * lj[c].w > 0.0f;
+                const float sp = ieee_div(det2(lj[c].z, lj[c].w, li[c].x - lj[c].x, li[c].y - lj[c].y), d);
+                pr[c].x = par ? 0.5f * (li[c].x + lj[c].x) : li[c].x + sp * li[c].z;
+                pr[c].y = par ? 0.5f * (li[c].y + lj[c].y) : li[c].y + sp * li[c].w;
+                const float ex = lj[c].z - li[c].z, ey = lj[c].w - li[c].w;
+                const float en = ieee_sqrt(ex * ex + ey * ey);
+                const float inv = ieee_div(1.0f, en);
+                pr[c].z = ex * inv; pr[c].w = ey * inv;
+                live[c] = task && !(par && same);   // RVO2 drops a parallel line that points the same way
+                // what linearProgram1 computes from this line alone, should it become the violated one: the circle's chord
+                const float vm = qa[c].z;
+                const float dot = pr[c].x * pr[c].z + pr[c].y * pr[c].w;
+                const float disc = dot * dot + vm * vm - (pr[c].x * pr[c].x + pr[c].y * pr[c].y);
+                const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
+                aux[c] = (disc < 0.0f) ? make_float2(INFINITY, -INFINITY) : make_float2(-dot - sq, -dot + sq);
+                if (task) { R.P[jj * 8 + slot[c]] = pr[c]; R.A[jj * 8 + slot[c]] = aux[c]; }
+                // linearProgram2(projLines, radius, (-dir.y, dir.x), directionOpt = true) starts on the circle
+                ox[c] = -li[c].w; oy[c] = li[c].z;
+                qx[c] = ox[c] * vm; qy[c] = oy[c] * vm;
+                k[c] = -1; fail2[c] = false; done[c] = !rowvalid[c];
+            }
+            ORCA_LDS_FENCE();
+#pragma nounroll
+            for (int it = 0; it < 9; ++it) {
+                unsigned long long vmask[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bool viol = live[c] && !done[c] && (j > k[c]) && (det2(pr[c].z, pr[c].w, pr[c].x - qx[c], pr[c].y - qy[c]) > 0.0f);
+                    vmask[c] = __builtin_amdgcn_ballot_w64(viol);
+                }
+                if ((vmask[0] | vmask[NC - 1]) == 0) break;
+                bool any[NC];
+                int kk[NC];
+                float4 lk[NC];
+                float2 ak[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const unsigned rb = (unsigned)(vmask[c] >> row_sh) & 0xFFFFu;
+                    any[c] = rb != 0;
+                    kk[c] = any[c] ? (int)__builtin_ctz(rb) : 0;    // first violated line of my row
+                    done[c] = done[c] || !any[c];                     // no line violated: linearProgram2 succeeded
+                    lk[c] = R.P[kk[c] * 8 + slot[c]];
+                    ak[c] = R.A[kk[c] * 8 + slot[c]];
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    // linearProgram1(projLines, kk, ...): lane j < kk evaluates line j against line kk
+                    const bool in = live[c] && (j < kk[c]);
+                    const float den = det2(lk[c].z, lk[c].w, pr[c].z, pr[c].w);
+                    const float num = det2(pr[c].z, pr[c].w, lk[c].x - pr[c].x, lk[c].y - pr[c].y);
+                    const float t = ieee_div(num, den);
+                    const bool parl = fabsf(den) <= RVO_EPSILON;
+                    // a parallel earlier line with this line on its wrong side fails linearProgram1 outright: it enters the
+                    // reduction as the empty interval (tR = -inf, tL = +inf), which the tL > tR test below turns into the failure
+                    const bool failp = in && parl && (num < 0.0f);
+                    float rmin = failp ? -INFINITY : ((in && !parl && (den >= 0.0f)) ? t : INFINITY);
+                    float rmax = failp ? INFINITY : ((in && !parl && !(den >= 0.0f)) ? t : -INFINITY);
+                    row_minmax16(rmin, rmax);
+                    const float tR = fminf(ak[c].y, rmin), tL = fmaxf(ak[c].x, rmax);
+                    const bool ok = !(tL > tR);
+                    const float tt = (ox[c] * lk[c].z + oy[c] * lk[c].w > 0.0f) ? tR : tL;
+                    const bool run = any[c] && !done[c];
+                    const bool set = run && ok, bad = run && !ok;
+                    qx[c] = set ? lk[c].x + tt * lk[c].z : qx[c];
+                    qy[c] = set ? lk[c].y + tt * lk[c].w : qy[c];
+                    k[c] = set ? kk[c] : k[c];
+                    fail2[c] = fail2[c] || bad;                       // linearProgram2 failed: LP3 keeps the old result
+                    done[c] = done[c] || bad;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bool take = rowvalid[c] && !fail2[c];
+                const float nrx = take ? qx[c] : qa[c].x, nry = take ? qy[c] : qa[c].y;
+                const float ndist = det2(li[c].z, li[c].w, li[c].x - nrx, li[c].y - nry);
+                if (rowvalid[c] && j == 0) R.q[a[c]] = make_float4(nrx, nry, qa[c].z, ndist);
+            }
+            ORCA_LDS_FENCE();
+        }
+        if (pending) {
+            const float4 qo = R.q[me];
+            rx = qo.x; ry = qo.y; distance = qo.w;
+            next_i = lvl + 1;
+        }
+        ORCA_LDS_FENCE();
+    }
+}
+
 // Register-resident solve for maxNeighbors = 10 (ORCA_DEFAULTS): same arithmetic and the same order of
 // operations as the generic path, organised for the SIMD:
 //  * neighbours: the 10 smallest (distSq, row) pairs in lexicographic order -- what RVO2's insertion with
@@ -430,9 +650,10 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
 //    line) triangle, each line's LP1 skipped wave-uniformly when no lane violates that line;
 //  * linearProgram3 (infeasible programme: about a third of the agents of a circular crossing, every substep) stays in
 //    registers too (lp3_fast10).
-__device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
+//  Called by all 64 lanes of a wavefront (`active` = this lane holds an agent): linearProgram3 re-deals the lanes (lp3_rows).
+__device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
                                      float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
-                                     float time_horizon, float dt, const Lines& L, float& nvx, float& nvy,
+                                     float time_horizon, float dt, const Lines& L, const RowLds& R, float& nvx, float& nvy,
                                      unsigned long long* g_ost, unsigned long long& g_ost_last)
 {
     constexpr int KF = 10;
@@ -446,7 +667,7 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
         const float4 q = pv[b];
         const float ddx = px - q.x, ddy = py - q.y;
         const float dsq = ddx * ddx + ddy * ddy;
-        const bool in = (dsq < range2) && (b != row);
+        const bool in = active && (dsq < range2) && (b != row);
         double x = in ? __hiloint2double((int)__float_as_uint(dsq), b) : sentinel;
 #pragma unroll
         for (int s = 0; s < KF; ++s) {
@@ -487,14 +708,14 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
             const float dot = ln.x * ln.z + ln.y * ln.w;
             const float disc = dot * dot + vmax * vmax - (ln.x * ln.x + ln.y * ln.y);
             bool ok = !(disc < 0.0f);
-            const float sq = sqrtf(fmaxf(disc, 0.0f));
+            const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
             float tL = -dot - sq, tR = -dot + sq;
 #pragma unroll
             for (int j = 0; j < i; ++j) {   // branch-free: the divisions of all j are independent and overlap
                 const float4 lj = Lr[j];
                 const float den = det2(ln.z, ln.w, lj.z, lj.w);
                 const float num = det2(lj.z, lj.w, ln.x - lj.x, ln.y - lj.y);
-                const float t = num / den;
+                const float t = ieee_div(num, den);
                 const bool par = fabsf(den) <= RVO_EPSILON;
                 const bool upd = !par && ok;                     // (after a failure RVO2 has already returned)
                 const float nR = (den >= 0.0f) ? fminf(tR, t) : tR, nL = (den >= 0.0f) ? tL : fmaxf(tL, t);
@@ -512,9 +733,13 @@ __device__ void orca_velocity_fast10(const float4* pv, const float* rr, int rows
     }
     OSTAMP(3);
     if (__builtin_amdgcn_ballot_w64(failed < cnt) != 0) { // some lane's programme is infeasible: linearProgram3
+        if (active) {
 #pragma unroll
-        for (int k = 0; k < KF; ++k) L.set(k, Lr[k]);
-        lp3_fast10(Lr, L, cnt, failed, vmax, rx, ry);
+            for (int k = 0; k < KF; ++k) L.set(k, Lr[k]);
+        }
+        ORCA_LDS_FENCE();
+        if (lp3_static) lp3_fast10(Lr, L, cnt, failed, vmax, rx, ry);   // (A/B switch, CROWDSTEP_ORCA_LP3=static)
+        else lp3_rows(Lr, L, R, cnt, failed, vmax, rx, ry);
     }
     OSTAMP(4);
     nvx = rx; nvy = ry;
@@ -533,10 +758,14 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
     // register-resident build (FAST10) keeps lines, projected lines and neighbour keys in registers and has no columns at all
     const int TL = a.wpb * a.rows;
     const int KN = FAST10 ? 0 : K;
+    const int KLP = FAST10 ? 0 : KL;
     float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [2][T] x, y, vx, vy
     float4* lds_L = lds_pv + 2 * T;                                  // [KL][TL] ORCA lines
     float4* lds_P = lds_L + KLL * TL;                                // [KL][TL] LP3 projection lines
-    float* lds_r = reinterpret_cast<float*>(lds_P + KL * TL);        // [T] radius + margin
+    float4* lds_rowP = lds_P + KLP * TL;                             // lp3_rows (FAST10, one-wavefront blocks): [9][8] projected lines,
+    float2* lds_rowA = reinterpret_cast<float2*>(lds_rowP + ((FAST10 && !a.lp3_static) ? 72 : 0));   // [9][8] their chords,
+    float4* lds_q = reinterpret_cast<float4*>(lds_rowA + ((FAST10 && !a.lp3_static) ? 72 : 0));       // [T] (result, maxSpeed, distance) per agent
+    float* lds_r = reinterpret_cast<float*>(lds_q + (FAST10 ? T : 0)); // [T] radius + margin
     float* lds_nd = lds_r + T;                                       // [KN][TL] neighbour distSq
     int* lds_ni = reinterpret_cast<int*>(lds_nd + KN * TL);          // [KN][TL] neighbour row
     float* lds_rp = reinterpret_cast<float*>(lds_ni + KN * TL);      // [T] plain radius (respawn rule)
@@ -544,6 +773,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);             // [T] respawn scratch
     float* lds_od = reinterpret_cast<float*>(lds_flag + T);          // [KO][TL] obstacle edge distSq
     int* lds_oi = reinterpret_cast<int*>(lds_od + a.KO * TL);        // [KO][TL] obstacle edge (first vertex)
+    int* lds_sel = lds_oi + a.KO * TL;                               // [T] lp3_rows tickets (FAST10)
 
     const int tid = threadIdx.x;
     const int rows = a.rows, n = a.n;
@@ -586,6 +816,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
     __syncthreads();
 
     const Lines L{lds_L, TL, tid}, P{lds_P, TL, tid};
+    const RowLds RL{lds_rowP, lds_rowA, lds_q, lds_sel};
     unsigned long long ost_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long* g_ost = nullptr;
     unsigned long long g_ost_last = 0;
@@ -599,14 +830,17 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
         if (valid && robot_moves && (is_robot || (!robot_row && row == 0))) { // robot.step(action, dt) (holonomic)
             rbx += ax * dt; rby += ay * dt; rbvx = ax; rbvy = ay;
         }
+        float nvx = 0.0f, nvy = 0.0f;
+        if constexpr (FAST10) {
+            // every lane of the wavefront takes part (linearProgram3 re-deals the lanes); lanes without a human carry no lines
+            const int hb = human ? base : 0, hr = human ? row : 0;
+            orca_velocity_fast10(human, a.lp3_static != 0, lds_pv + cur * T + hb, lds_r + hb, rows, hr, px, py, vx, vy, r + margin, vmax, pvx, pvy,
+                                 a.neighbor_dist, a.time_horizon, dt, L, RL, nvx, nvy, g_ost, g_ost_last);
+        }
         if (human) {
             const float4* pv = lds_pv + cur * T + base;
             const float* rr = lds_r + base;
-            float nvx, nvy;
-            if constexpr (FAST10) {
-                orca_velocity_fast10(pv, rr, rows, row, px, py, vx, vy, r + margin, vmax, pvx, pvy, a.neighbor_dist,
-                                     a.time_horizon, dt, L, nvx, nvy, g_ost, g_ost_last);
-            } else {
+            if constexpr (!FAST10) {
                 // ---- Agent::computeNeighbors / insertAgentNeighbor (index order; strict <, ties keep order)
                 int cnt = 0;
                 float rangeSq = a.neighbor_dist * a.neighbor_dist;
@@ -828,6 +1062,10 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
     float4* lds_pv = reinterpret_cast<float4*>(smem_raw);            // [wpb][ent] x, y, vx, vy
     float* lds_rr = reinterpret_cast<float*>(lds_pv + a.wpb * ent);  // [wpb][ent] radius + margin
     float4* lds_ln = reinterpret_cast<float4*>(lds_rr + ((a.wpb * ent + 3) & ~3));   // [10][64] the lanes' ORCA lines for LP3
+    float4* lds_pr = lds_ln + 10 * 64;                               // [9][8] projected lines of the rows in flight (lp3_rows)
+    float2* lds_pa = reinterpret_cast<float2*>(lds_pr + 72);         // [9][8] their chords
+    float4* lds_q = reinterpret_cast<float4*>(lds_pa + 72);          // [64]
+    int* lds_sel = reinterpret_cast<int*>(lds_q + 64);               // [64]
     const int w0 = blockIdx.x * a.wpb;
     for (int k = tid; k < a.wpb * a.n; k += 64) {
         const int wl = k / a.n, b = k - wl * a.n, w = w0 + wl;
@@ -848,7 +1086,6 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
         lds_rr[tid * ent + a.n] = r;
     }
     __syncthreads();
-    if (!mine) return;
     float pvx, pvy;
     {
         const float ddx = gx - px, ddy = gy - py;
@@ -858,8 +1095,11 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
     float nvx, nvy;
     unsigned long long ost_last = 0;
     const Lines L{lds_ln, 64, tid};
-    orca_velocity_fast10(lds_pv + tid * ent, lds_rr + tid * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
-                         a.time_horizon, a.dt, L, nvx, nvy, nullptr, ost_last);
+    const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
+    const int mt = mine ? tid : 0;                                    // all 64 lanes take part (lp3_rows re-deals them)
+    orca_velocity_fast10(mine, false, lds_pv + mt * ent, lds_rr + mt * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
+                         a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
+    if (!mine) return;
     vx = nvx; vy = nvy;
     px += vx * a.dt; py += vy * a.dt;
     rb[0] = px; rb[1] = py; rb[3] = vx; rb[4] = vy;
@@ -867,6 +1107,39 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
         float* s = a.S + ((long)w * a.rows + a.n) * a.as;
         s[0] = px; s[a.fs] = py; s[3 * a.fs] = vx; s[4 * a.fs] = vy;
     }
+}
+
+// ---- diagnostic: ieee_div / ieee_sqrt against the compiler's operators, bit for bit, on random operands of the range the
+// linear programmes work in (exponents 2^-60 .. 2^40, both signs, every mantissa pattern equally likely)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float rand_operand(unsigned u)
+{
+    const unsigned expo = 67u + ((u >> 23) & 0xFFu) % 101u;          // biased exponent 67 .. 167  = 2^-60 .. 2^40
+    return __uint_as_float((u & 0x80000000u) | (expo << 23) | (u & 0x007FFFFFu));
+}
+__global__ void k_divsqrt_check(unsigned long long per_thread, unsigned seed, unsigned long long* out)
+{
+    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad_div = 0, bad_sqrt = 0;
+    for (unsigned long long k = 0; k < per_thread; ++k) {
+        const unsigned long long h = mix64((gid * per_thread + k) ^ ((unsigned long long)seed << 40));
+        const float a = rand_operand((unsigned)h), b = rand_operand((unsigned)(h >> 32));
+        const float q0 = a / b, q1 = ieee_div(a, b);
+        const float x = fabsf(a), s0 = sqrtf(x), s1 = ieee_sqrt(x);
+        const float z = (k & 1023) == 0 ? 0.0f : a;                  // exact zeros: numerators and discriminants can be 0
+        const float q2 = z / b, q3 = ieee_div(z, b);
+        if (__float_as_uint(q0) != __float_as_uint(q1) || __float_as_uint(q2) != __float_as_uint(q3)) {
+            if (bad_div == 0) { out[2] = __float_as_uint(a); out[3] = __float_as_uint(b); }
+            ++bad_div;
+        }
+        if (__float_as_uint(s0) != __float_as_uint(s1) || __float_as_uint(sqrtf(0.0f * x)) != __float_as_uint(ieee_sqrt(0.0f * x))) ++bad_sqrt;
+    }
+    if (bad_div) atomicAdd(&out[0], bad_div);
+    if (bad_sqrt) atomicAdd(&out[1], bad_sqrt);
 }
 
 } // namespace
@@ -907,8 +1180,13 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     const int grid = (w->W + a.wpb - 1) / a.wpb;
     const bool fast10 = a.K == 10 && a.nv == 0; // the register-resident solve has no obstacle lines
     const int TL = a.wpb * rows;                // lanes that hold an agent: the width of the per-lane LDS columns
+    // linearProgram3 of the register-resident build: one 16-lane row per (agent, violated line) (lp3_rows) in one-wavefront blocks;
+    // worlds of more than 64 rows keep the statically unrolled walk (their blocks have no LDS left for the projected lines)
+    const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
+    a.lp3_static = (T > 64 || (lp3_env && std::strcmp(lp3_env, "static") == 0)) ? 1 : 0;
     const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
-                         (fast10 ? (size_t)10 * TL * sizeof(float4) : (size_t)(a.K + a.KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
+                         (fast10 ? (size_t)10 * TL * sizeof(float4) + (a.lp3_static ? 0 : 72 * (sizeof(float4) + sizeof(float2))) + (size_t)T * (sizeof(float4) + sizeof(int))
+                                 : (size_t)(a.K + a.KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
     if (shmem > 160 * 1024) return fail(CS_ERR_ARG, "ORCA worlds of this many rows need max_neighbors = 10 and no static obstacles "
                                                     "(the per-agent line columns do not fit the LDS)");
     auto launch = [&](auto kernel) -> int {
@@ -960,7 +1238,8 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
     // 1.18 ms per 20-substep imitation step at 4096 worlds), so the packing only has to reach every CU
     a.wpb = 16;
     if (a.K == 10 && a.nv == 0 && a.n + 1 <= 128) {   // the reference's defaults, no walls: register-resident solve
-        const size_t sh = (size_t)a.wpb * (a.n + 1) * sizeof(float4) + (size_t)(((a.wpb * (a.n + 1)) + 3) & ~3) * sizeof(float) + 10 * 64 * sizeof(float4);
+        const size_t sh = (size_t)a.wpb * (a.n + 1) * sizeof(float4) + (size_t)(((a.wpb * (a.n + 1)) + 3) & ~3) * sizeof(float) +
+                          (10 + 1) * 64 * sizeof(float4) + 72 * (sizeof(float4) + sizeof(float2)) + 64 * sizeof(int);
         hipLaunchKernelGGL(k_orca_robot_step_fast, dim3((w->W + a.wpb - 1) / a.wpb), dim3(64), sh, stream, a);
         HIP_TRY(hipGetLastError());
         return CS_OK;
@@ -971,3 +1250,19 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
 }
 
 } // namespace csimpl
+
+extern "C" int cs_debug_divsqrt_check(unsigned long long n_pairs, unsigned seed, unsigned long long* h_out, void* stream)
+{
+    if (!h_out) return csimpl::fail(CS_ERR_ARG, "null output");
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), (hipStream_t)stream));
+    const int block = 256, grid = 4096;
+    const unsigned long long per_thread = (n_pairs + (unsigned long long)block * grid - 1) / ((unsigned long long)block * grid);
+    hipLaunchKernelGGL(k_divsqrt_check, dim3(grid), dim3(block), 0, (hipStream_t)stream, per_thread, seed, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_out, d, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipFree(d));
+    return CS_OK;
+}

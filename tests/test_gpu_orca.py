@@ -370,3 +370,46 @@ def test_orca_cfg4_full_size():
     cols = [0, 1, 3, 4, 5, 6, 10, 11]
     np.testing.assert_array_equal(full[sample][..., cols], ref[..., cols])
     np.testing.assert_array_equal(gfull[sample], rg)
+
+
+def test_ieee_div_sqrt_sequences_are_correctly_rounded():
+    """The ORCA kernels' 8-instruction divide and 9-instruction square root (the compiler's FMA sequences without their
+    exponent-range handling) give the compiler's (IEEE, correctly rounded) results bit for bit on 2^31 random operand pairs of
+    the range the linear programmes work in -- exact zeros included."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd import _lib
+
+    lib = _lib.load()
+    out = (C.c_ulonglong * 4)()
+    _lib.check(lib.cs_debug_divsqrt_check(C.c_ulonglong(1 << 31), C.c_uint(12345), out, C.c_void_p(None)))
+    assert out[0] == 0 and out[1] == 0, (out[0], out[1], hex(out[2]), hex(out[3]))
+
+
+def test_lp3_rows_equals_the_static_walk_bitwise():
+    """linearProgram3 as one 16-lane row per (agent, violated line) (lp3_rows, the default) and as the statically unrolled
+    per-lane walk (lp3_fast10, CROWDSTEP_ORCA_LP3=static) are the same arithmetic in two lane assignments: identical bits
+    over 200 substeps of a dense 25-agent crossing, and of 10- and 40-agent worlds (3 and 1 worlds per wavefront)."""
+    import os
+
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    for n, R in ((25, 5.0), (10, 2.5), (40, 7.0)):
+        W = 37
+        pos, yaw, g = sc.circular_crossing(W, n, R, 99 + n)
+        S = sc.make_states(pos, yaw, g).astype(np.float32)
+        d = g[:, :, 0] - S[:, :, 0:2]
+        S[:, :, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+        margin = np.full((W, n), 0.01, np.float32)
+        res = {}
+        for mode in ("rows", "static"):
+            os.environ["CROWDSTEP_ORCA_LP3"] = mode
+            try:
+                cw = CrowdWorlds(S, g, None, margin, None, type="orca")
+                for _ in range(10):
+                    cw.step(0.0125, 20)
+                res[mode] = cw.get_states()
+            finally:
+                os.environ.pop("CROWDSTEP_ORCA_LP3", None)
+        np.testing.assert_array_equal(res["rows"], res["static"])

@@ -32,7 +32,7 @@ if model == "orca":
     gg, b, wpb = cw.launch_geometry() if False else ((W + (64 // n) - 1) // (64 // n), 64, 64 // n)
     buf = _lib.DeviceBuffer((gg, 8), np.uint64)
     _lib.load().cs_debug_set_stamp_buffer(C.c_void_p(buf.ptr))
-    for _ in range(3):
+    for _ in range(int(os.environ.get("STAMP_STEPS", "3"))):   # 24: the dense phase of the crossing
         cw.step(0.0125, 20)
     cw.sync()
     st = buf.download().astype(np.float64)
