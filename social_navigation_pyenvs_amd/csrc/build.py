@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(PKG, "libcrowdstep.so")
 MANIFEST_PATH = LIB_PATH + ".manifest.json"
 OBJ_DIR = os.path.join(CSRC, ".build")
 SOURCES = ["crowdstep.hip", "orca.hip", "lookahead.hip", "generate.hip", "laser.hip", "social_momentum.hip", "robot_model.hip",
-           "rk45.hip", "gymstep.hip", "bigworld.hip"]
+           "rk45.hip", "rowstep.hip", "gymstep.hip", "bigworld.hip"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: v_pk_*_f32 has no throughput advantage over two scalar ops on gfx950 (measured,
 # tools/valu_microbench.hip) and packing costs ~2 v_mov per partner in the pair loop

@@ -6,6 +6,8 @@
 
 #include "crowdstep.h"
 
+namespace cstep { struct KArgs; }
+
 namespace csimpl {
 
 extern thread_local std::string g_err;
@@ -26,6 +28,9 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
 int orca_variant(const cs_worlds* w, char* buf, size_t buflen);
 // the robot's own ORCA model, one doStep of the robot per world (orca.hip; cs_robot_model_step with CS_ORCA)
 int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream);
+// small worlds, one per 16-lane DPP row (rowstep.hip)
+bool row16_supports(int rows);
+int row16_launch(const cstep::KArgs& a, hipStream_t stream);
 // social-momentum branch (social_momentum.hip)
 int social_momentum_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);
 

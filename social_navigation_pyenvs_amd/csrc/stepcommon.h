@@ -1,0 +1,222 @@
+// stepcommon.h -- what the SFM / HSFM step kernels share (crowdstep.hip: the LDS pair-once / all-partners kernel;
+// rowstep.hip: the DPP-row kernel for small worlds): kernel arguments, launch modes, single-instruction math, the pair
+// force parameters.  Device code for gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "common.h"
+
+namespace cstep {
+
+// ------------------------------------------------------------------------------------------
+// kernel arguments
+// ------------------------------------------------------------------------------------------
+enum : int {
+    M_COMMIT_GOALS = 1,   // write rotated goals back to d_goals
+    M_MUTATE_INPUT = 2,   // reproduce the in-place writes on the input rows (out != in)
+    M_PEEK = 4,           // write [n][8] observable rows to peek_out, nothing else
+    M_ROBOT_FROM_ARRAY = 8 // robot row comes from d_robot (mmm.py:359), not from the state array
+};
+
+struct KArgs {
+    int W, n, rows, G, O, Smax;
+    int type, flags, mode;
+    int nsub, wpb;
+    int seg_tab;           // wall segments staged in LDS per block (0: read them from global memory in every substep)
+    int ws;                // LDS rows between the doubled row blocks of consecutive worlds of a block (>= 2 * rows)
+    float dt;
+    float* Sin;            // mutated only with M_MUTATE_INPUT
+    float* Sout;
+    long in_as, in_fs, out_as, out_fs;
+    float* goals;
+    const float* params;
+    const float* safety;
+    const float* obstacles;
+    float* robot;
+    const float* action;
+    float* peek_out;
+    const int* world_flags;
+    float bx, by;
+    unsigned long long* stamps; // diagnostic build only
+};
+
+// ---- math: gfx950 single-instruction transcendentals (1 ulp each) ---------------------------
+// The parity bar is 1e-5 absolute on positions/velocities against the f64 reference; v_rsq_f32 /
+// v_rcp_f32 / v_sqrt_f32 / v_exp_f32 (<= 1 ulp) stay two orders of magnitude inside it, while the
+// IEEE-exact divide / sqrt / libm exp sequences cost 10-15 VALU slots each in an O(N^2) loop.
+// Diagnostic build only (-DCS_STAMPS): per-section cycle shares via s_memtime, written to a debug
+// buffer that nothing else reads (cdna_hip_programming.md §7 "In-kernel stamps").
+#if defined(CS_STAMPS) && !defined(STAMP)
+#define STAMP(k)                                                                             \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long t__;                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");          \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        st_acc[k] += t__ - st_last;                                                          \
+        st_last = t__;                                                                       \
+    } while (0)
+#elif !defined(STAMP)
+#define STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int PADR = 8;  // partner rows are read in groups of 8: readable (finite) padding behind each buffer
+
+__device__ __forceinline__ float norm2(float x, float y) { return sqrt_fast(fmaf(x, x, y * y)); }
+
+// sin and cos together: Cody-Waite reduction by pi/2 + degree-7/8 minimax polynomials; abs error
+// < 1e-7 for |x| < 50 (theta is kept in [-pi, pi] by bound_angle)
+__device__ __forceinline__ void sincos_fast(float x, float& s, float& c)
+{
+    const float k = rintf(x * 0.6366197723675814f);
+    const int q = (int)k;
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.371139000186241e-08f, r);
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    sp = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const bool odd = (q & 1) != 0;
+    const float ss = odd ? cp : sp;
+    const float cc = odd ? sp : cp;
+    s = __uint_as_float(__float_as_uint(ss) ^ ((unsigned)(q & 2) << 30));        // quadrants 2,3: -sin
+    c = __uint_as_float(__float_as_uint(cc) ^ ((unsigned)((q + 1) & 2) << 30));  // quadrants 1,2: -cos
+}
+
+// social_gym/src/utils.py:7-13 (Python % == fmod for the operand signs reaching each branch)
+__device__ __forceinline__ float bound_angle(float a)
+{
+    const float two_pi = 6.283185307179586f;
+    const float pi = 3.141592653589793f;
+    if (a >= two_pi) a = fmodf(a, two_pi);
+    if (a <= -two_pi) a = fmodf(a, two_pi);
+    if (a > pi) a -= two_pi;
+    if (a < -pi) a += two_pi;
+    return a;
+}
+
+// bound_angle for the heading update, branch-free: a - 2 pi rint(a / 2 pi) with a two-term (Cody-Waite) 2 pi, which
+// is what the reference's branches give for any |a| (fmod by 2 pi, then one fold into [-pi, pi]); ties at exactly
+// +-pi stay, as in the reference.  A data-dependent branch costs ~55 cycles of wave latency on this SIMD
+// (tools/valu_microbench.hip), the four instructions below ~12.
+__device__ __forceinline__ float wrap_angle(float a)
+{
+    const float k = rintf(a * 0.15915494309189535f);
+    a = fmaf(k, -6.2831854820251465f, a);      // float(2 pi)
+    return fmaf(k, 1.7484556000744883e-07f, a); // float(2 pi) - 2 pi
+}
+
+// atan2 with |error| < 2e-7 rad (degree-7 minimax in a^2 on [0,1], a = min/max); atan2(0, 0) = 0
+__device__ __forceinline__ float atan2_fast(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-30f), mn = fminf(ax, ay);
+    const float a = mn * rcp_fast(mx);
+    const float s = a * a;
+    float r = -0.004054529592394829f;
+    r = fmaf(r, s, 0.021862812340259552f);
+    r = fmaf(r, s, -0.05591210350394249f);
+    r = fmaf(r, s, 0.09642179310321808f);
+    r = fmaf(r, s, -0.13908621668815613f);
+    r = fmaf(r, s, 0.19946563243865967f);
+    r = fmaf(r, s, -0.33329859375953674f);
+    r = fmaf(r, s, 0.9999993443489075f);
+    r *= a;
+    if (ay > ax) r = 1.5707963267948966f - r;
+    if (x < 0.0f) r = 3.141592653589793f - r;
+    return copysignf(r, y);
+}
+
+// Social-force parameters used inside the pair loop (subset of the 20-vector, agent.py:268-388),
+// with the exponent scales pre-multiplied: exp(x / B) = exp2(x * (log2(e) / B))
+struct SocP {
+    float Ai, cB, Ci, cD, Ei, k1, k2, lam, gam, ns, ns1;
+    float lA, sA, lC, sC; // A * exp(x/B) = sA * exp2(x * cB + lA),  lA = log2|A|  (A = 0 -> exp2(-inf) = 0)
+    float sAC;            // sA * sC
+};
+
+__device__ __forceinline__ SocP load_socp(const float* P)
+{
+    SocP s;
+    s.Ai = P[1]; s.cB = LOG2E / P[3]; s.Ci = P[5]; s.cD = LOG2E / P[7]; s.Ei = P[9];
+    s.k1 = P[10]; s.k2 = P[11]; s.lam = P[12]; s.gam = P[13]; s.ns = P[14]; s.ns1 = P[15];
+    s.lA = log2f(fabsf(s.Ai)); s.sA = copysignf(1.0f, s.Ai);
+    s.lC = log2f(fabsf(s.Ci)); s.sC = copysignf(1.0f, s.Ci);
+    s.sAC = s.sA * s.sC;
+    return s;
+}
+
+// forces_parallel.py:120-130 / :72-83 -- Moussaid force on (pi, vi) from (pj, vj); `skip` marks the
+// lane's own row / padding.  rij = r_i + r_j + safety_i + safety_j.
+__device__ __forceinline__ void pair_force_moussaid(const SocP& p, float pix, float piy, float vix, float viy,
+                                                    float pjx, float pjy, float vjx, float vjy, float rij,
+                                                    bool skip, float& fx, float& fy)
+{
+    const float dx = pix - pjx, dy = piy - pjy;
+    const float d2 = skip ? 1.0f : fmaf(dx, dx, dy * dy);
+    const float inv = rsq_fast(d2);
+    const float dist = d2 * inv;
+    const float nx = dx * inv, ny = dy * inv;
+    const float rd = rij - dist;
+    const float m0 = fmaxf(0.0f, rd);
+    const float vdx = vix - vjx, vdy = viy - vjy;
+    const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);
+    const float i2 = fmaxf(fmaf(ivx, ivx, ivy * ivy), 1e-30f);
+    const float iinv = rsq_fast(i2);
+    const float inorm = i2 * iinv;
+    const float ix = ivx * iinv, iy = ivy * iinv;
+    // theta_ij = wrap(angle(n) - angle(i) + pi) is the signed angle from i to -n (:124): one atan2 of (cross, dot)
+    const float th = atan2_fast(iy * nx - ix * ny, -(ix * nx + iy * ny));
+    const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
+    const float hx = -iy, hy = ix;
+    const float F = p.gam * inorm;
+    const float dv = -(vdx * hx + vdy * hy);
+    const float e0 = p.Ei * exp2_fast(-dist * rcp_fast(F) * LOG2E);
+    const float a1 = p.ns1 * F * th, a2 = p.ns * F * th;
+    const float e1 = exp2_fast(-(a1 * a1) * LOG2E), e2 = exp2_fast(-(a2 * a2) * LOG2E);
+    const float sel = skip ? 0.0f : 1.0f;
+    const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
+    fx -= sel * (e0 * (e1 * ix + k * e2 * hx) + kk * ix + kt * hx);
+    fy -= sel * (e0 * (e1 * iy + k * e2 * hy) + kk * iy + kt * hy);
+}
+
+// Same force, returned instead of accumulated (no own-row / padding slot): used by the pair-once loop, which
+// also hands -f to the partner (the reference's all_params_equal path does exactly that, :100-104).
+__device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx, float dy, float vdx, float vdy,
+                                                         float rij, float& fx, float& fy)
+{
+    const float d2 = fmaf(dx, dx, dy * dy);
+    const float inv = rsq_fast(d2);
+    const float dist = d2 * inv;
+    const float nx = dx * inv, ny = dy * inv;
+    const float m0 = fmaxf(0.0f, rij - dist);
+    const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);
+    const float i2 = fmaxf(fmaf(ivx, ivx, ivy * ivy), 1e-30f);
+    const float iinv = rsq_fast(i2);
+    const float inorm = i2 * iinv;
+    const float ix = ivx * iinv, iy = ivy * iinv;
+    const float th = atan2_fast(iy * nx - ix * ny, -(ix * nx + iy * ny));
+    const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
+    const float hx = -iy, hy = ix;
+    const float F = p.gam * inorm;
+    const float dv = -(vdx * hx + vdy * hy);
+    const float e0 = p.Ei * exp2_fast(-dist * rcp_fast(F) * LOG2E);
+    const float a1 = p.ns1 * F * th, a2 = p.ns * F * th;
+    const float e1 = exp2_fast(-(a1 * a1) * LOG2E), e2 = exp2_fast(-(a2 * a2) * LOG2E);
+    const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
+    fx = -(e0 * (e1 * ix + k * e2 * hx) + kk * ix + kt * hx);
+    fy = -(e0 * (e1 * iy + k * e2 * hy) + kk * iy + kt * hy);
+}
+
+
+} // namespace cstep

@@ -29,7 +29,7 @@ def _worlds(cfg):
 
 # the kernel build behind each published number (crowdstep.hip select_variant); asserted so that a dispatch change cannot
 # silently un-test a build
-VARIANT = {"cfg2": "MAXT=64,OCC=4,ROWS_CT=10,LEAN=1", "cfg3": "MAXT=64,OCC=1,ROWS_CT=25,LEAN=1",
+VARIANT = {"cfg2": "k_sfm_step_row16<SOC=0,HEADED=0,ROWS=10>", "cfg3": "MAXT=64,OCC=1,ROWS_CT=25,LEAN=1",
            "cfg3x4": "MAXT=64,OCC=4,ROWS_CT=25,LEAN=1", "cfg5shard": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=2"}
 
 

@@ -147,7 +147,7 @@ def _block_worlds(c):
 
 
 # the kernel build cs_step must pick for each G13 kind (crowdstep.hip select_variant): the builds the published numbers come from
-G13_VARIANT = {"n10": "MAXT=64,OCC=4,ROWS_CT=10,LEAN=1", "n25_traffic": "MAXT=64,OCC=1,ROWS_CT=25,LEAN=1",
+G13_VARIANT = {"n10": "k_sfm_step_row16<SOC=%d,HEADED=%d,ROWS=10>", "n25_traffic": "MAXT=64,OCC=1,ROWS_CT=25,LEAN=1",
                "n50": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=1", "n50_walls_static": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=2"}
 
 
@@ -162,7 +162,9 @@ def test_block_of_20_substeps(group):
         headed = c["type"] >= 3
         cw = _block_worlds(c)
         if group == "g13_block_sizes":
-            assert G13_VARIANT[c["kind"]] in cw.step_variant(), (c["kind"], cw.step_variant())
+            want = G13_VARIANT[c["kind"]]
+            want = want % (c["type"] % 3, c["type"] // 3) if "%d" in want else want
+            assert want in cw.step_variant(), (c["kind"], cw.step_variant())
         ref, ref_goals, _ = _block_reference(c, c["n_substeps"])
         om_in = f32(c["in_states"])[:, 7].astype(np.float64)
         wild = max(np.max(np.abs(ref[:, 7])), np.max(np.abs(c["out_states"][:, 7])), np.max(np.abs(om_in))) >= 1e3
@@ -270,7 +272,7 @@ def test_bad_type_raises_value_error():
         CrowdWorlds(f32(c["state_in"]), f32(c["goals_in"]), f32(c["params"]), type=11)  # 0..8 SFM/HSFM, 9 ORCA, 10 social momentum
 
 
-@pytest.mark.parametrize("rows_case", [(1, False), (2, False), (1, True), (3, False), (4, True), (7, False), (10, False), (16, False),
+@pytest.mark.parametrize("rows_case", [(1, False), (2, False), (1, True), (3, False), (4, True), (5, False), (7, False), (10, False), (16, False),
                                        (21, True), (25, False), (31, True), (32, False), (33, False), (50, False), (63, True), (64, False)])
 def test_pair_once_loop_world_sizes(rows_case):
     """Edge sizes of the pair-once loop (ring distance (rows-1)/2, antipodal partner for even rows, several worlds per
@@ -314,3 +316,29 @@ def test_pair_once_loop_world_sizes(rows_case):
                                    0.0125, 3, safety, True, robot_visible=robot_row)
         err = np.max(np.abs(got[:, :n][..., PV] - ref[:, :n][..., PV]), axis=(1, 2))
         assert np.all(err < (3e-4 if t % 3 == 2 else 5e-5)), f"{model} rows={rows}: worst world {int(np.argmax(err))}: {err.max()}"
+
+
+def test_small_worlds_on_the_lds_kernel_too():
+    """10- and 5-human plain worlds run on the DPP-row kernel (rowstep.hip) by default; CROWDSTEP_ROW16=0 keeps them on the
+    LDS pair-once kernel (its compile-time 10-row build).  Both against the f64 oracle on the golden n10 blocks, and against
+    each other within float32 rounding of 20 substeps."""
+    import os
+
+    cases = [c for c in load_cases("g13_block_sizes") if c["kind"] == "n10"]
+    for c in cases:
+        ref, _, _ = _block_reference(c, c["n_substeps"])
+        got = {}
+        for env in ("1", "0"):
+            os.environ["CROWDSTEP_ROW16"] = env
+            try:
+                cw = _block_worlds(c)
+                assert ("row16" in cw.step_variant()) == (env == "1"), cw.step_variant()
+                if env == "0":
+                    assert "MAXT=64,OCC=4,ROWS_CT=10,LEAN=1" in cw.step_variant()
+                cw.step(c["dt"], c["n_substeps"])
+                got[env] = cw.get_states()[0]
+            finally:
+                os.environ.pop("CROWDSTEP_ROW16", None)
+            tol = 5e-5 if c["type"] % 3 != 2 else 2e-3
+            assert np.max(np.abs(got[env][:, PV] - ref[:, PV])) < tol, (c["model"], env)
+        assert np.max(np.abs(got["1"][:, PV] - got["0"][:, PV])) < (1e-5 if c["type"] % 3 != 2 else 2e-3)
