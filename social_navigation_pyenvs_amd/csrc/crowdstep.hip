@@ -90,7 +90,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);           // [T] respawn scratch
     float2* lds_acc = reinterpret_cast<float2*>(lds_flag + T);     // [UA][2T] reaction accumulators (N3L only)
     float4* lds_seg = reinterpret_cast<float4*>(lds_acc + (N3L ? UA * ACC_PITCH : 0)); // [seg_tab] x1, y1, ex, ey
-    float* lds_sinv = reinterpret_cast<float*>(lds_seg + a.seg_tab);                   // [seg_tab] 1 / |e|^2, -1 = NaN slot
+    float* lds_sinv = reinterpret_cast<float*>(lds_seg + a.seg_tab);                   // [seg_tab] 1 / |e|^2, 0 = NaN slot
+    float4* lds_poly = reinterpret_cast<float4*>(lds_sinv + ((a.seg_tab + 3) & ~3));   // [seg_tab / Smax] bounding circle cx, cy, R of every polygon
 
     const int tid = threadIdx.x;
     static_assert(!LEAN || (PEQ && MAXT == 64), "the lean build is a pair-once build");
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     // parameters: my own row of P for the single-agent forces; P[0] of my world for the pair loop
     // when all_params_equal (forces_parallel.py:220), else my own row (:261)
     float m_tau = 0, Aw = 0, cBw = 0, Cw = 0, cDw = 0, k1 = 0, k2 = 0, ko = 0, kd = 0, alpha = 1, klam = 0;
-    float dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0;
+    float dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0, wall_cut = 0;
     SocP sp = {};
     float g0x = gx, g0y = gy, g1x = 0, g1y = 0;
     int gk = 0;          // length of the non-NaN prefix of my goal list
@@ -142,6 +143,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         const float* P = a.params + pw + (long)row * 20;
         m_tau = m / P[0];                       // m / relax_t              (:39)
         Aw = P[2]; cBw = LOG2E / P[4]; Cw = P[6]; cDw = LOG2E / P[8]; k1 = P[10]; k2 = P[11];
+        // beyond this distance a wall's force on me is below |A| e^-36 = 5e-13 N (its contact terms are exact zeros there):
+        // a polygon that every agent of the wavefront is that far from is skipped in the substep loop
+        wall_cut = r + safety + a.wall_efolds * fmaxf(P[4], obs_type == 1 ? P[8] : 0.0f);
         ko = P[16]; kd = P[17]; alpha = P[18]; klam = P[19];
         dt_m = a.dt / m;                        // (F / m) * dt             (:277,:282)
         inv_alpha = 1.0f / alpha;
@@ -166,8 +170,10 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     for (int i = tid; i < (LEAN == 1 ? 0 : a.seg_tab); i += T) {
         const int lwi = i / (nseg > 0 ? nseg : 1);
         const long wi = (long)blockIdx.x * a.wpb + lwi;
-        float4 e = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float inv = -1.0f;
+        // a NaN slot becomes a degenerate segment 1e18 m away: squared distance 2e36, never the polygon's minimum (the reference
+        // stores the largest int64 as that slot's distance, forces_parallel.py:247) -- no per-slot test in the substep loop
+        float4 e = make_float4(1.0e18f, 1.0e18f, 0.0f, 0.0f);
+        float inv = 0.0f;
         if ((a.flags & CS_OBSTACLES_SHARED) || wi < a.W) {
             const float* src = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? (long)i * 4 : (wi * nseg + (i - lwi * nseg)) * 4);
             const float4 seg = *reinterpret_cast<const float4*>(src);
@@ -210,6 +216,25 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         lds_v[i] = make_float2(0.0f, 0.0f);
     }
     __syncthreads();
+    // bounding circle of every staged polygon (centre = mean of its segments' midpoints, radius = farthest endpoint)
+    for (int q = tid; q < (LEAN == 1 || a.Smax <= 0 ? 0 : a.seg_tab / a.Smax); q += T) {
+        float cx = 0.0f, cy = 0.0f, cnt = 0.0f;
+        for (int sg = 0; sg < a.Smax; ++sg) {
+            const float4 e = lds_seg[q * a.Smax + sg];
+            if (lds_sinv[q * a.Smax + sg] > 0.0f) { cx += e.x + 0.5f * e.z; cy += e.y + 0.5f * e.w; cnt += 1.0f; }
+        }
+        const float ic = cnt > 0.0f ? 1.0f / cnt : 0.0f;
+        cx *= ic; cy *= ic;
+        float r2 = 0.0f;
+        for (int sg = 0; sg < a.Smax; ++sg) {
+            const float4 e = lds_seg[q * a.Smax + sg];
+            if (lds_sinv[q * a.Smax + sg] > 0.0f) {
+                const float ax0 = e.x - cx, ay0 = e.y - cy, bx0 = ax0 + e.z, by0 = ay0 + e.w;
+                r2 = fmaxf(r2, fmaxf(fmaf(ax0, ax0, ay0 * ay0), fmaf(bx0, bx0, by0 * by0)));
+            }
+        }
+        lds_poly[q] = make_float4(cx, cy, cnt > 0.0f ? sqrtf(r2) : -1.0e30f, 0.0f);   // an empty polygon is never near
+    }
     // radius + safety space never changes during a launch: it is stored once in both buffers, a substep only rewrites
     // (x, y) -- two 8-byte LDS stores instead of two 16-byte ones
     auto publish = [&](int buf) {      // my position, both copies
@@ -353,9 +378,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     // first argmin over the polygon's segments, on squared distances (same order)
                     float best = INFINITY, bdx = 0.0f, bdy = 0.0f;   // the first slot always beats +inf: a first argmin
                     if (a.seg_tab > 0) {
+                        {   // nobody of this wavefront within reach of the polygon: its force is < 5e-13 N on everyone, skip it
+                            const float4 pc = lds_poly[(sbase / a.Smax) + o];
+                            const float dxc = px - pc.x, dyc = py - pc.y, lim = pc.z + wall_cut;
+                            if (__builtin_amdgcn_ballot_w64(fmaf(dxc, dxc, dyc * dyc) < lim * lim) == 0) continue;
+                        }
                         // branch-free, four slots per trip (then two, then one): the LDS reads of a trip (uniform addresses,
-                        // broadcasts) are issued before its arithmetic; a NaN slot (zeros in the table, 1/|e|^2 = -1) gets the
-                        // reference's huge distance
+                        // broadcasts) are issued before its arithmetic; a NaN slot is a far-away degenerate segment in the table
                         const float4* sgp = lds_seg + sbase + o * a.Smax;
                         const float* sip = lds_sinv + sbase + o * a.Smax;
                         auto trip = [&](int s0, auto width) {
@@ -366,10 +395,11 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             for (int j = 0; j < NW; ++j) { e[j] = sgp[s0 + j]; iv[j] = sip[s0 + j]; }
 #pragma unroll
                             for (int j = 0; j < NW; ++j) {
-                                const float t = ((px - e[j].x) * e[j].z + (py - e[j].y) * e[j].w) * iv[j];
+                                const float qx = px - e[j].x, qy = py - e[j].y;
+                                const float t = fmaf(qx, e[j].z, qy * e[j].w) * iv[j];
                                 const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
-                                const float ddx = px - fmaf(ts, e[j].z, e[j].x), ddy = py - fmaf(ts, e[j].w, e[j].y);
-                                const float d = (iv[j] < 0.0f) ? 3.0e38f : fmaf(ddx, ddx, ddy * ddy);
+                                const float ddx = fmaf(-ts, e[j].z, qx), ddy = fmaf(-ts, e[j].w, qy);   // p - (a + ts e)
+                                const float d = fmaf(ddx, ddx, ddy * ddy);
                                 const bool better = d < best;
                                 best = better ? d : best;
                                 bdx = better ? ddx : bdx;
@@ -1132,6 +1162,10 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.robot = w->d_robot; a.action = d_action; a.peek_out = d_peek;
     a.bx = w->respawn_bound_x; a.by = w->respawn_bound_y;
     a.world_flags = w->d_world_flags;
+    {   // |A| e^-36 = 5e-13 N: far below float32 resolution of any force sum (diagnostic override: CROWDSTEP_WALL_EFOLDS)
+        const char* e = std::getenv("CROWDSTEP_WALL_EFOLDS");
+        a.wall_efolds = e ? (float)std::atof(e) : 36.0f;
+    }
 #ifdef CS_STAMPS
     a.stamps = g_stamp_buf;
 #endif
@@ -1148,7 +1182,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     // wall segment table (x1, y1, e, 1/|e|^2), shared or one per world of the block, when it is small enough
     const long seg_tab = (long)w->O * w->Smax * ((w->flags & CS_OBSTACLES_SHARED) ? 1 : g.wpb);
     a.seg_tab = (seg_tab > 0 && seg_tab * 20 <= 16 * 1024) ? (int)seg_tab : 0;
-    shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float));
+    shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float)) + 16 + (size_t)(a.seg_tab > 0 ? a.seg_tab / w->Smax : 0) * sizeof(float4);
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(fn, dim3(g.grid), dim3(g.block), shmem, stream, a);

@@ -39,6 +39,7 @@ struct KArgs {
     float* peek_out;
     const int* world_flags;
     float bx, by;
+    float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     unsigned long long* stamps; // diagnostic build only
 };
 
