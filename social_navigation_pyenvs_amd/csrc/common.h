@@ -28,6 +28,10 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
 int orca_variant(const cs_worlds* w, char* buf, size_t buflen);
 // the robot's own ORCA model, one doStep of the robot per world (orca.hip; cs_robot_model_step with CS_ORCA)
 int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream);
+// library-owned device scratch (grow-only, one slot per use, per host thread): the double-buffered state and the neighbour grid of
+// worlds beyond one block.  Returns nullptr (and sets the error) when hipMalloc fails.
+void* scratch(size_t bytes, int slot);
+int big_world_min_rows(int dflt);
 // small worlds, one per 16-lane DPP row (rowstep.hip)
 bool row16_supports(int rows);
 int row16_launch(const cstep::KArgs& a, hipStream_t stream);

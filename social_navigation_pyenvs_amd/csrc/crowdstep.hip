@@ -29,6 +29,21 @@
 
 namespace csimpl {
 thread_local std::string g_err;
+
+void* scratch(size_t bytes, int slot)
+{
+    struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; };
+    static thread_local Slot slots[4];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { g_err = "hipGetDevice failed"; return nullptr; }
+    Slot& s = slots[slot & 3];
+    if (s.p && s.dev == dev && s.cap >= bytes) return s.p;
+    if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }     // (hipFree synchronises: earlier users of the old block are done)
+    const hipError_t e = hipMalloc(&s.p, bytes);
+    if (e != hipSuccess) { g_err = std::string("hipMalloc of crowdstep scratch: ") + hipGetErrorString(e); s.p = nullptr; return nullptr; }
+    s.cap = bytes; s.dev = dev;
+    return s.p;
+}
 #ifdef CS_STAMPS
 unsigned long long* g_stamp_buf = nullptr;
 #endif

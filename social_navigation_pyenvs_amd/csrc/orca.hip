@@ -650,32 +650,26 @@ __device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R
 //    line) triangle, each line's LP1 skipped wave-uniformly when no lane violates that line;
 //  * linearProgram3 (infeasible programme: about a third of the agents of a circular crossing, every substep) stays in
 //    registers too (lp3_fast10).
-//  Called by all 64 lanes of a wavefront (`active` = this lane holds an agent): linearProgram3 re-deals the lanes (lp3_rows).
-__device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
-                                     float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
-                                     float time_horizon, float dt, const Lines& L, const RowLds& R, float& nvx, float& nvy,
-                                     unsigned long long* g_ost, unsigned long long& g_ost_last)
+// insertion of one candidate into the ten sorted (distSq, row) keys
+__device__ __forceinline__ void key_insert10(double (&key)[10], double x)
+{
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+        const double lo = fmin(key[s], x);
+        x = fmax(key[s], x);
+        key[s] = lo;
+    }
+}
+__device__ __forceinline__ double key_sentinel() { return __hiloint2double(0x7F7FFFFF, (int)0xFFFFFFFFu); }
+
+// From the ten neighbour keys on: ORCA lines, linearProgram2, linearProgram3.  fetch(b, q, rad): (x, y, vx, vy) and radius +
+// margin of row b (LDS rows of the world in the crowd kernel, global rows found through the grid in the big-world kernel).
+template <class Fetch>
+__device__ void orca_solve_fast10(bool active, bool lp3_static, const double (&key)[10], int row, Fetch&& fetch, float px, float py, float vx,
+                                  float vy, float my_r, float vmax, float pvx, float pvy, float time_horizon, float dt, const Lines& L,
+                                  const RowLds& R, float& nvx, float& nvy, unsigned long long* g_ost, unsigned long long& g_ost_last)
 {
     constexpr int KF = 10;
-    OSTAMP(0);
-    const double sentinel = __hiloint2double(0x7F7FFFFF, (int)0xFFFFFFFFu);
-    double key[KF];
-#pragma unroll
-    for (int s = 0; s < KF; ++s) key[s] = sentinel;
-    const float range2 = neighbor_dist * neighbor_dist;
-    for (int b = 0; b < rows; ++b) {
-        const float4 q = pv[b];
-        const float ddx = px - q.x, ddy = py - q.y;
-        const float dsq = ddx * ddx + ddy * ddy;
-        const bool in = active && (dsq < range2) && (b != row);
-        double x = in ? __hiloint2double((int)__float_as_uint(dsq), b) : sentinel;
-#pragma unroll
-        for (int s = 0; s < KF; ++s) {
-            const double lo = fmin(key[s], x);
-            x = fmax(key[s], x);
-            key[s] = lo;
-        }
-    }
     int cnt = 0;
 #pragma unroll
     for (int s = 0; s < KF; ++s) cnt += (__double2hiint(key[s]) != 0x7F7FFFFF) ? 1 : 0;
@@ -687,7 +681,10 @@ __device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4*
 #pragma unroll
     for (int k = 0; k < KF; ++k) {
         const int b = (k < cnt) ? __double2loint(key[k]) : row; // unused slots read my own row (finite, never used)
-        Lr[k] = orca_line(px, py, vx, vy, pv[b], my_r + rr[b], invT, invDt);
+        float4 q;
+        float rad;
+        fetch(b, q, rad);
+        Lr[k] = orca_line(px, py, vx, vy, q, my_r + rad, invT, invDt);
     }
 
     OSTAMP(2);
@@ -743,6 +740,29 @@ __device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4*
     }
     OSTAMP(4);
     nvx = rx; nvy = ry;
+}
+
+//  The crowd kernel's form: the world's rows in LDS, brute-force walk in index order.
+//  Called by all 64 lanes of a wavefront (`active` = this lane holds an agent): linearProgram3 re-deals the lanes (lp3_rows).
+__device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
+                                     float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
+                                     float time_horizon, float dt, const Lines& L, const RowLds& R, float& nvx, float& nvy,
+                                     unsigned long long* g_ost, unsigned long long& g_ost_last)
+{
+    OSTAMP(0);
+    double key[10];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
+    const float range2 = neighbor_dist * neighbor_dist;
+    for (int b = 0; b < rows; ++b) {
+        const float4 q = pv[b];
+        const float ddx = px - q.x, ddy = py - q.y;
+        const float dsq = ddx * ddx + ddy * ddy;
+        const bool in = active && (dsq < range2) && (b != row);
+        key_insert10(key, in ? __hiloint2double((int)__float_as_uint(dsq), b) : key_sentinel());
+    }
+    orca_solve_fast10(active, lp3_static, key, row, [&](int b, float4& q, float& rad) { q = pv[b]; rad = rr[b]; }, px, py, vx, vy, my_r, vmax,
+                      pvx, pvy, time_horizon, dt, L, R, nvx, nvy, g_ost, g_ost_last);
 }
 
 // MAXT = 64: floor(64 / rows) worlds per one-wavefront block; MAXT = 256 / 512: one world of up to MAXT rows per block
@@ -1109,6 +1129,144 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
     }
 }
 
+// ---- worlds beyond one block (second half): neighbour search through a uniform grid ---------------------
+// RVO2 finds an agent's neighbours with a kd-tree (Agent::computeNeighbors -> KdTree::queryAgentTreeRecursive); what the
+// tree returns is the set of the maxNeighbors nearest agents inside neighborDist, ordered by (distSq, insertion order).  The
+// crowd kernel above gets the same list by a brute-force walk over the world's rows in LDS; a world of thousands of agents
+// spans many blocks, so here the agents are binned into square cells of edge neighborDist (a hashed table of buckets in HBM,
+// counting sort per substep) and an agent walks the 3 x 3 cells around its own: every agent inside neighborDist is in one of
+// them.  The ten smallest (distSq, row) keys are order-independent, so the visiting order of the grid does not matter: the
+// neighbour list, the ORCA lines and the solve are bit-identical to the restatement's index-order walk.  State is double-buffered
+// in HBM (every agent reads the old rows, RVO2's doStep is a Jacobi update), one launch per substep.
+struct BigArgs {
+    int W, n, G, NB;
+    float dt, neighbor_dist, time_horizon, inv_cell;
+    const float* Sin; float* Sout; long as, fs;
+    float* goals; const float* margin;
+    int2* cellxy; int* count; int* start; int* fill; int* sorted;
+    int lp3_static;
+};
+
+__device__ __forceinline__ int cell_bucket(int cx, int cy, int NB) { return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u)) & (NB - 1); }
+
+__global__ void k_bw_bin(const BigArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= a.n) return;
+    const float* s = a.Sin + ((long)w * a.n + i) * a.as;
+    const int cx = (int)floorf(s[0] * a.inv_cell), cy = (int)floorf(s[a.fs] * a.inv_cell);
+    a.cellxy[(long)w * a.n + i] = make_int2(cx, cy);
+    atomicAdd(&a.count[(long)w * a.NB + cell_bucket(cx, cy, a.NB)], 1);
+}
+
+__global__ __launch_bounds__(1024) void k_bw_scan(const BigArgs a)   // exclusive scan of a world's bucket counts (one block per world)
+{
+    __shared__ int part[1024];
+    const int w = blockIdx.x, t = threadIdx.x, per = (a.NB + 1023) / 1024;
+    const int* c = a.count + (long)w * a.NB;
+    int* st = a.start + (long)w * (a.NB + 1);
+    int sum = 0;
+    for (int k = 0; k < per; ++k) { const int idx = t * per + k; if (idx < a.NB) sum += c[idx]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int k = 0; k < per; ++k) { const int idx = t * per + k; if (idx < a.NB) { st[idx] = run; run += c[idx]; } }
+    if (t == 1023) st[a.NB] = part[1023];
+}
+
+__global__ void k_bw_scatter(const BigArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= a.n) return;
+    const int2 c = a.cellxy[(long)w * a.n + i];
+    const int b = cell_bucket(c.x, c.y, a.NB);
+    const int pos = a.start[(long)w * (a.NB + 1) + b] + atomicAdd(&a.fill[(long)w * a.NB + b], 1);
+    a.sorted[(long)w * a.n + pos] = i;
+}
+
+__global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
+{
+    __shared__ float4 lds_ln[10 * 64];
+    __shared__ float4 lds_pr[72];
+    __shared__ float2 lds_pa[72];
+    __shared__ float4 lds_q[64];
+    __shared__ int lds_sel[64];
+    const int tid = threadIdx.x, i = blockIdx.x * 64 + tid, w = blockIdx.y, n = a.n;
+    const bool human = i < n;
+    const float* Sw = a.Sin + (long)w * n * a.as;
+    const long fs = a.fs;
+    float px = 0, py = 0, vx = 0, vy = 0, pvx = 0, pvy = 0, r = 0, vmax = 0, margin = 0;
+    const float* srow = Sw + (long)(human ? i : 0) * a.as;
+    if (human) {
+        px = srow[0]; py = srow[fs]; vx = srow[3 * fs]; vy = srow[4 * fs];
+        pvx = srow[5 * fs]; pvy = srow[6 * fs]; r = srow[8 * fs]; vmax = srow[12 * fs];
+        margin = a.margin[(long)w * n + i];
+    }
+    // Agent::computeNeighbors through the grid: the 3 x 3 cells around mine hold every agent closer than neighborDist
+    double key[10];
+#pragma unroll
+    for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
+    if (human) {
+        const float range2 = a.neighbor_dist * a.neighbor_dist;
+        const int2 mc = a.cellxy[(long)w * n + i];
+        const int* st = a.start + (long)w * (a.NB + 1);
+        const int* so = a.sorted + (long)w * n;
+        const int2* cxy = a.cellxy + (long)w * n;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int cx = mc.x + dx, cy = mc.y + dy;
+                const int bk = cell_bucket(cx, cy, a.NB);
+                for (int p = st[bk]; p < st[bk + 1]; ++p) {
+                    const int b = so[p];
+                    const int2 cb = cxy[b];
+                    if (cb.x != cx || cb.y != cy || b == i) continue;      // another cell hashed into this bucket, or myself
+                    const float* sb = Sw + (long)b * a.as;
+                    const float ddx = px - sb[0], ddy = py - sb[fs];
+                    const float dsq = ddx * ddx + ddy * ddy;
+                    if (dsq < range2) key_insert10(key, __hiloint2double((int)__float_as_uint(dsq), b));
+                }
+            }
+    }
+    float nvx = 0.0f, nvy = 0.0f;
+    unsigned long long ost_last = 0;
+    const Lines L{lds_ln, 64, tid};
+    const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
+    const float* mg = a.margin + (long)w * n;
+    orca_solve_fast10(human, a.lp3_static != 0, key, human ? i : 0,
+                      [&](int b, float4& q, float& rad) {
+                          const float* sb = Sw + (long)b * a.as;
+                          q = make_float4(sb[0], sb[fs], sb[3 * fs], sb[4 * fs]);
+                          rad = sb[8 * fs] + mg[b];
+                      },
+                      px, py, vx, vy, r + margin, vmax, pvx, pvy, a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
+    if (!human) return;
+    // Agent::update, then the reference's read-back + update_goals_orca (motion_model_manager.py:390-394, :125-133)
+    vx = nvx; vy = nvy;
+    px += vx * a.dt; py += vy * a.dt;
+    float* gi = a.goals + ((long)w * n + i) * a.G * 2;
+    float g0x = gi[0], g0y = gi[1];
+    float ddx = g0x - px, ddy = g0y - py;
+    if (sqrtf(ddx * ddx + ddy * ddy) < r) { // update_goals: strict <  (:66-70)
+        int k = a.G;
+        for (int g = 0; g < a.G; ++g) if (isnan(gi[2 * g])) { k = g; break; }
+        const float r0 = gi[0], r1 = gi[1];
+        for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
+        if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
+        g0x = gi[0]; g0y = gi[1];
+        ddx = g0x - px; ddy = g0y - py;
+    }
+    const float nrm = sqrtf(ddx * ddx + ddy * ddy);
+    if (nrm > vmax) { pvx = ddx / nrm; pvy = ddy / nrm; } else { pvx = ddx; pvy = ddy; }
+    float* o = a.Sout + ((long)w * n + i) * a.as;
+    o[0] = px; o[fs] = py; o[3 * fs] = vx; o[4 * fs] = vy; o[5 * fs] = pvx; o[6 * fs] = pvy; o[10 * fs] = g0x; o[11 * fs] = g0y;
+}
+
 // ---- diagnostic: ieee_div / ieee_sqrt against the compiler's operators, bit for bit, on random operands of the range the
 // linear programmes work in (exponents 2^-60 .. 2^40, both signs, every mantissa pattern equally likely)
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
@@ -1146,6 +1304,63 @@ __global__ void k_divsqrt_check(unsigned long long per_thread, unsigned seed, un
 
 namespace csimpl {
 
+// worlds of more than `dflt` rows take the grid path; CROWDSTEP_BIGWORLD_MIN_ROWS lowers the threshold (tests run the grid path
+// on worlds small enough for the restatement to check quickly)
+int big_world_min_rows(int dflt)
+{
+    const char* e = std::getenv("CROWDSTEP_BIGWORLD_MIN_ROWS");
+    const int v = e ? std::atoi(e) : dflt;
+    return v < dflt ? (v < 1 ? 1 : v) : dflt;
+}
+
+static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream)
+{
+    if (w->flags & CS_ROBOT_ROW) return fail(CS_ERR_ARG, "ORCA worlds beyond one block (grid neighbour search) have no robot row");
+    if (d_action) return fail(CS_ERR_ARG, "ORCA worlds beyond one block take no robot action");
+    if (d_peek) return fail(CS_ERR_ARG, "cs_peek is not built for ORCA worlds beyond one block");
+    if (w->flags & CS_RESPAWN) return fail(CS_ERR_ARG, "the respawn rule is not built for ORCA worlds beyond one block");
+    if (w->orca_max_neighbors != 10 || w->orca_n_vertices != 0)
+        return fail(CS_ERR_ARG, "ORCA worlds beyond one block need max_neighbors = 10 and no static obstacles");
+    const int n = w->n, W = w->W;
+    int NB = 1024;
+    while (NB < 2 * n && NB < (1 << 20)) NB <<= 1;
+    const size_t state_bytes = (size_t)W * n * 13 * sizeof(float);
+    const size_t ints = (size_t)W * n * 2 /*cellxy*/ + (size_t)W * NB * 2 /*count, fill*/ + (size_t)W * (NB + 1) /*start*/ + (size_t)W * n /*sorted*/;
+    char* base = (char*)scratch(state_bytes + ints * sizeof(int) + 256, 0);
+    if (!base) return CS_ERR_HIP;
+    BigArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = W; a.n = n; a.G = w->G; a.NB = NB; a.dt = dt; a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
+    // cell edge = neighborDist (a floor keeps a degenerate neighborDist = 0 from dividing by zero: nobody is a neighbour then)
+    a.inv_cell = 1.0f / (w->orca_neighbor_dist > 1e-3f ? w->orca_neighbor_dist : 1e-3f);
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)W * n; }
+    a.goals = w->d_goals; a.margin = w->d_safety;
+    float* S2 = (float*)base;
+    int* ip = (int*)(base + ((state_bytes + 255) & ~(size_t)255));
+    a.cellxy = (int2*)ip; ip += (size_t)W * n * 2;
+    a.count = ip; ip += (size_t)W * NB;
+    a.fill = ip; ip += (size_t)W * NB;
+    a.start = ip; ip += (size_t)W * (NB + 1);
+    a.sorted = ip;
+    const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
+    a.lp3_static = (lp3_env && std::strcmp(lp3_env, "static") == 0) ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(S2, w->d_state, state_bytes, hipMemcpyDeviceToDevice, stream));   // the columns a step does not write
+    const float* cur = w->d_state;
+    float* nxt = S2;
+    for (int sub = 0; sub < n_substeps; ++sub) {
+        a.Sin = cur; a.Sout = nxt;
+        HIP_TRY(hipMemsetAsync(a.count, 0, (size_t)W * NB * 2 * sizeof(int), stream));
+        hipLaunchKernelGGL(k_bw_bin, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_bw_scan, dim3(W), dim3(1024), 0, stream, a);
+        hipLaunchKernelGGL(k_bw_scatter, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_bw_orca_step, dim3((n + 63) / 64, W), dim3(64), 0, stream, a);
+        const float* t = cur; cur = nxt; nxt = const_cast<float*>(t);
+    }
+    HIP_TRY(hipGetLastError());
+    if (cur != w->d_state) HIP_TRY(hipMemcpyAsync(w->d_state, cur, state_bytes, hipMemcpyDeviceToDevice, stream));
+    return CS_OK;
+}
+
 int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream)
 {
     if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
@@ -1157,7 +1372,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (w->orca_n_vertices > 0 && !(w->orca_time_horizon_obst > 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
     if (w->flags & CS_ROBOT_UNICYCLE) return fail(CS_ERR_ARG, "ORCA step supports holonomic robot actions only");
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
-    if (rows > 512) return fail(CS_ERR_ARG, "ORCA step supports up to 512 rows per world");
+    if (rows > big_world_min_rows(512)) return orca_big_launch(w, dt, n_substeps, d_action, d_peek, stream);
     if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
     if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
     OArgs a;

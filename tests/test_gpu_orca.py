@@ -144,8 +144,11 @@ def test_orca_large_world_limits():
     S[0, :, 8] = 0.3
     S[0, :, 12] = 1.0
     g = np.zeros((1, 513, 1, 2), np.float32)
-    with pytest.raises(ValueError, match="512"):
-        CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca").step(0.0125, 1)
+    # beyond 512 rows a world takes the grid path (test_orca_world_of_4096_agents_through_the_grid); what that path does not build
+    # is refused loudly: static obstacles, a robot row, the respawn rule
+    CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca").step(0.0125, 1)
+    with pytest.raises(ValueError, match="beyond one block"):
+        CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca", respawn_bounds=(7.0, 1.5)).step(0.0125, 1)
     # the generic variant keeps (K + obstacle lines) x 40 B per agent in the LDS: 300 agents with a square of walls do not fit
     verts = orc.process_obstacles([[[-50, -50], [50, -50], [50, 50], [-50, 50]]])
     with pytest.raises(ValueError, match="LDS"):
@@ -413,3 +416,71 @@ def test_lp3_rows_equals_the_static_walk_bitwise():
             finally:
                 os.environ.pop("CROWDSTEP_ORCA_LP3", None)
         np.testing.assert_array_equal(res["rows"], res["static"])
+
+
+def _lattice_world(W, rows, rng, spacing=0.9):
+    S = np.zeros((W, rows, 13), np.float32)
+    goals = np.full((W, rows, 2, 2), np.nan, np.float32)
+    side = int(np.ceil(np.sqrt(rows)))
+    for w in range(W):   # a jittered lattice walking towards the mirrored position: dense, every agent has 10 neighbours
+        gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+        pos = (np.stack([gx.ravel(), gy.ravel()], -1)[:rows] - side / 2) * spacing + rng.uniform(-0.1, 0.1, (rows, 2))
+        S[w, :, 0:2] = pos
+        S[w, :, 3:5] = rng.normal(0, 0.3, (rows, 2))
+        S[w, :, 8] = rng.uniform(0.25, 0.35, rows)
+        S[w, :, 12] = rng.uniform(0.8, 1.2, rows)
+        goals[w, :, 0] = -pos
+        goals[w, :, 1] = pos
+        d = goals[w, :, 0] - pos
+        nrm = np.linalg.norm(d, axis=1, keepdims=True)
+        S[w, :, 5:7] = np.where(nrm > S[w, :, 12:13], d / nrm, d)
+        S[w, :, 10:12] = goals[w, :, 0]
+    return S, goals
+
+
+def test_orca_world_of_4096_agents_through_the_grid():
+    """a world far beyond one block.  The agents are binned into cells of edge neighborDist (hashed buckets,
+    counting sort per substep) and every agent walks the 3 x 3 cells around its own; the ten smallest (distSq, row) keys do not
+    depend on the visiting order, so the world stays bit-identical to the restatement's index-order walk over all 4096 rows."""
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rows = 4096
+    rng = np.random.default_rng(4096)
+    S, goals = _lattice_world(1, rows, rng)
+    margin = np.full((1, rows), 0.01, np.float32)
+    cw = CrowdWorlds(S, goals, None, margin, None, type="orca")
+    cw.step(0.0125, 6)
+    ref, rgoals, _ = orc.orca_step_block(S, goals, margin, 0.0125, 6)
+    cols = [0, 1, 3, 4, 5, 6, 10, 11]
+    np.testing.assert_array_equal(cw.get_states()[..., cols], ref[..., cols])
+    np.testing.assert_array_equal(cw.get_goals(), rgoals)
+    assert np.max(np.abs(ref[..., 0:2] - S[..., 0:2])) > 0.01          # they did move
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+def test_orca_grid_path_on_small_worlds_equals_the_restatement(layout):
+    """The grid path forced onto several small worlds at once (CROWDSTEP_BIGWORLD_MIN_ROWS): negative cell coordinates, buckets
+    shared by several cells, agents that change cell between substeps, goal rotation -- bit-identical over 40 substeps."""
+    import os
+
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rng = np.random.default_rng(7)
+    W, rows = 5, 150
+    S, goals = _lattice_world(W, rows, rng, spacing=3.5)               # 43 m across: several cells of edge 10 m
+    S[:, ::11, 0:2] *= 0.05                                             # some agents start next to their goal: goal rotation
+    goals[:, ::11, 0] = S[:, ::11, 0:2] + 0.2
+    S[:, :, 10:12] = goals[:, :, 0]
+    margin = np.full((W, rows), 0.01, np.float32)
+    os.environ["CROWDSTEP_BIGWORLD_MIN_ROWS"] = "1"
+    try:
+        cw = CrowdWorlds(S, goals, None, margin, None, type="orca", layout=layout)
+        for _ in range(2):
+            cw.step(0.0125, 20)
+        got, ggoals = cw.get_states(), cw.get_goals()
+    finally:
+        os.environ.pop("CROWDSTEP_BIGWORLD_MIN_ROWS", None)
+    ref, rgoals, _ = orc.orca_step_block(S, goals, margin, 0.0125, 40)
+    cols = [0, 1, 3, 4, 5, 6, 10, 11]
+    np.testing.assert_array_equal(got[..., cols], ref[..., cols])
+    np.testing.assert_array_equal(ggoals, rgoals)
