@@ -1,0 +1,390 @@
+// bigworld.hip -- the SFM / HSFM step for worlds beyond one block (more than 1024 rows; SURVEY.md §8 row f3, second half).
+//
+// Same reference path as crowdstep.hip (update_humans_parallel, /root/reference/social_gym/src/forces_parallel.py:185-284; the
+// per-agent social force :43-84, all pairs :87-133), re-laid for thousands of agents in ONE world: a world no longer fits a
+// block's LDS, so the rows stay in HBM (double-buffered: every agent reads the incoming rows, as the reference evaluates all
+// forces from the incoming state), lane = agent across as many blocks as the world needs, and the partners of an agent are found
+// through a uniform grid instead of a walk over all rows: cells whose edge is the force's reach (the distance beyond which a
+// partner's force is below |A| e^-36 ~ 5e-13 N: radii + 36 e-folding lengths, from the parameters and radii of the world
+// itself), hashed into buckets, counting-sorted per substep; an agent walks the 3 x 3 cells around its own.  In a world small
+// against the reach (Moussaid's exp(-d / F) reaches tens of metres) the walk degenerates to all rows, still exact.
+// Every ordered pair is evaluated by its own lane (no hand-over between blocks); the contact terms are part of the pair formula.
+//
+// Supported: all nine types, all_params_equal or per-agent parameters, polygon walls, goal lists of any length, the robot as the
+// last row of the state array (a source, never updated), cs_step / cs_update_humans_parallel (in or out of place).
+// Not built for these worlds (refused loudly): the respawn rule, a robot driven through cs_worlds.d_robot, cs_peek.
+//
+// gfx950 only: no portability macros, no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>   // stable device radix sort (ROCm toolchain header) for the cell lists
+
+#include "common.h"
+#include "crowdstep.h"
+#include "stepcommon.h"
+
+namespace {
+
+using namespace cstep;
+using csimpl::fail;
+
+struct GArgs {
+    int W, n, rows, G, O, Smax, NB, type, flags, mutate;
+    float dt;
+    const float* Sin; float* Sout; float* Smut; long as, fs;
+    float* goals; const float* params; const float* safety; const float* obstacles;
+    const int2* cellxy; const int* start; const int* sorted;   // the grid (csimpl::grid_build)
+    float* inv_cell;   // [W] device scalars: 1 / cell edge of every world
+    float2* in_v;      // [W][rows] refreshed linear velocity of the incoming rows (out-of-place update: written back afterwards)
+};
+
+// reach of the pair force in every world: max over rows of (r + safety) twice, plus 36 e-folding lengths of the slowest-decaying
+// exponential any row's parameters describe (Helbing B; Guo also D; Moussaid F <= gamma (lambda (vd_i + vd_j) + 1))
+__global__ __launch_bounds__(256) void k_bw_reach(const GArgs a)
+{
+    __shared__ float red[3][256];
+    const int w = blockIdx.x, t = threadIdx.x;
+    float rs = 0.0f, len = 0.0f, vd = 0.0f;
+    for (int i = t; i < a.rows; i += 256) {
+        const float* s = a.Sin + ((long)w * a.rows + i) * a.as;
+        rs = fmaxf(rs, s[8 * a.fs] + a.safety[(long)w * a.rows + i]);
+        vd = fmaxf(vd, fmaxf(s[12 * a.fs], sqrtf(s[3 * a.fs] * s[3 * a.fs] + s[4 * a.fs] * s[4 * a.fs])));
+    }
+    const int soc = a.type % 3;
+    for (int i = t; i < a.n; i += 256) {
+        const float* P = a.params + ((a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * a.n * 20) + (long)i * 20;
+        float l = fabsf(P[3]);
+        if (soc == 1) l = fmaxf(l, fabsf(P[7]));
+        if (soc == 2) l = fabsf(P[13]);                    // gamma; completed below with the speeds
+        len = fmaxf(len, l);
+    }
+    red[0][t] = rs; red[1][t] = len; red[2][t] = vd;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) for (int k = 0; k < 3; ++k) red[k][t] = fmaxf(red[k][t], red[k][t + off]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        float l = red[1][0];
+        if (soc == 2) {
+            float lam = 0.0f;
+            for (int i = 0; i < a.n; ++i) lam = fmaxf(lam, fabsf(a.params[((a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * a.n * 20) + (long)i * 20 + 12]));
+            l = l * (lam * 2.0f * red[2][0] + 1.0f);
+        }
+        const float reach = 2.0f * red[0][0] + 36.0f * l;
+        a.inv_cell[w] = 1.0f / fmaxf(reach, 0.5f);
+    }
+}
+
+// ---- the uniform grid (shared with the ORCA grid path, orca.hip) -------------------------------------------------------
+// key of row i of world w = w * NB + bucket(cell of i); a STABLE radix sort of (key, i) gives every bucket's rows in index
+// order, so the walk over a cell -- and with it the floating-point order of the force sums -- is the same in every run (a
+// scatter through atomics would not be: fused substeps and repeated launches must agree bit for bit).
+__global__ void k_grid_keys(csimpl::GridView g, const float* S, long as, long fs, const float* d_inv_cell, float inv_cell)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= g.rows) return;
+    const float* s = S + ((long)w * g.rows + i) * as;
+    const float ic = d_inv_cell ? d_inv_cell[w] : inv_cell;
+    const int cx = (int)floorf(s[0] * ic), cy = (int)floorf(s[fs] * ic);
+    const long k = (long)w * g.rows + i;
+    g.cellxy[k] = make_int2(cx, cy);
+    g.keys[k] = (unsigned)(w * g.NB + csimpl::cell_bucket(cx, cy, g.NB));
+    g.idx[k] = i;
+}
+
+// start[b] = first position of key b in the sorted list, for every b in 0 .. W * NB (a key that owns nothing points at the next one)
+__global__ void k_grid_mark(csimpl::GridView g, int total)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > total) return;
+    const int kcur = p < total ? (int)g.keys_sorted[p] : g.W * g.NB;
+    const int kprev = p > 0 ? (int)g.keys_sorted[p - 1] : -1;
+    for (int b = kprev + 1; b <= kcur; ++b) g.start[b] = p;
+}
+
+template <int SOC, int HEADED, bool PEQ>
+__global__ __launch_bounds__(256) void k_bw_sfm_step(const GArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, w = blockIdx.y, rows = a.rows, n = a.n;
+    if (i >= rows) return;
+    const long fs = a.fs;
+    const float* Sw = a.Sin + (long)w * rows * a.as;
+    const float* s = Sw + (long)i * a.as;
+    float px = s[0], py = s[fs], th = s[2 * fs], vx = s[3 * fs], vy = s[4 * fs], bvx = s[5 * fs], bvy = s[6 * fs], om = s[7 * fs];
+    const float r = s[8 * fs], m = s[9 * fs], vd = s[12 * fs];
+    float gx = s[10 * fs], gy = s[11 * fs];
+    float* o = a.Sout + ((long)w * rows + i) * a.as;
+    if (i >= n) {   // the robot row: a source of force, never updated (forces_parallel.py:212-213)
+        for (int f = 0; f < 13; ++f) o[f * fs] = s[f * fs];
+        return;
+    }
+    const float safety = a.safety[(long)w * rows + i];
+    const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20;
+    const float* P = a.params + pw + (long)i * 20;
+    const SocP sp = load_socp(PEQ ? a.params + pw : P);
+    const float m_tau = m / P[0], Aw = P[2], cBw = LOG2E / P[4], Cw = P[6], cDw = LOG2E / P[8], k1 = P[10], k2 = P[11];
+    const float ko = P[16], kd = P[17], alpha = P[18], klam = P[19];
+    const float dt = a.dt, dt_m = dt / m, inertia = 0.5f * m * r * r, dt_inertia = dt / inertia;
+    const int obs_type = (a.type == 1 || a.type == 4 || a.type == 7) ? 1 : 0;
+
+    // -- goal switch, forces_parallel.py:226-234 (on the incoming position; the list rotates in place)
+    float* gi = a.goals + ((long)w * n + i) * a.G * 2;
+    {
+        const float gdx = gi[0] - px, gdy = gi[1] - py;
+        if (fmaf(gdx, gdx, gdy * gdy) <= r * r) {
+            int k = a.G;
+            for (int g = a.G - 1; g >= 0; --g)
+                if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) k = g;
+            const float r0 = gi[0], r1 = gi[1];
+            for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
+            if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
+            gx = gi[0]; gy = gi[1];
+        }
+    }
+    float cs = 1.0f, sn = 0.0f, cvx = vx, cvy = vy;
+    if constexpr (HEADED > 0) {
+        sincos_fast(th, sn, cs);
+        cvx = cs * bvx + (-sn) * bvy;
+        cvy = sn * bvx + cs * bvy;
+    }
+    // -- social force: my partners through the grid
+    const float my_rs = r + safety;
+    const float vix = PEQ ? vx : cvx, viy = PEQ ? vy : cvy;   // (all_params_equal: every row's stored velocity, :220; else :256 then :261)
+    float fsx = 0.0f, fsy = 0.0f;
+    {
+        const int2 mc = a.cellxy[(long)w * rows + i];
+        const int* st = a.start + (long)w * a.NB;     // positions in the job-wide sorted list
+        const int* so = a.sorted;
+        const int2* cxy = a.cellxy + (long)w * rows;
+        const float* saf = a.safety + (long)w * rows;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int cx = mc.x + dx, cy = mc.y + dy;
+                const int bk = csimpl::cell_bucket(cx, cy, a.NB);
+                for (int p = st[bk]; p < st[bk + 1]; ++p) {
+                    const int j = so[p];
+                    const int2 cb = cxy[j];
+                    if (cb.x != cx || cb.y != cy || j == i) continue;
+                    const float* q = Sw + (long)j * a.as;
+                    const float qx = q[0], qy = q[fs];
+                    float vjx = q[3 * fs], vjy = q[4 * fs];
+                    if constexpr (!PEQ && HEADED > 0) {
+                        if (j < i && j < n) {   // rows before mine have had their linear velocity refreshed in place (:256, range order)
+                            float sj, cj;
+                            sincos_fast(q[2 * fs], sj, cj);
+                            const float bx = q[5 * fs], by = q[6 * fs];
+                            vjx = cj * bx - sj * by; vjy = sj * bx + cj * by;
+                        }
+                    }
+                    const float rij = my_rs + q[8 * fs] + saf[j];
+                    if constexpr (SOC == 2) {
+                        pair_force_moussaid(sp, px, py, vix, viy, qx, qy, vjx, vjy, rij, false, fsx, fsy);
+                    } else {
+                        const float ddx = px - qx, ddy = py - qy;
+                        const float d2 = fmaxf(fmaf(ddx, ddx, ddy * ddy), 1e-30f);
+                        const float inv = rsq_fast(d2);
+                        const float rd = fmaf(-d2, inv, rij);
+                        const float m0 = fmaxf(0.0f, rd);
+                        const float nx = ddx * inv, ny = ddy * inv;
+                        const float dv = (vjy - viy) * nx - (vjx - vix) * ny;                 // (v_j - v_i) . t
+                        const float fn = fmaf(sp.sA, exp2_fast(fmaf(rd, sp.cB, sp.lA)), sp.k1 * m0);
+                        float ft = (sp.k2 * m0) * dv;
+                        if constexpr (SOC == 1) ft = fmaf(sp.sC, exp2_fast(fmaf(rd, sp.cD, sp.lC)), ft);
+                        fsx += fn * nx - ft * ny;
+                        fsy += fn * ny + ft * nx;
+                    }
+                }
+            }
+    }
+    // -- desired force, :23-40
+    float fdx, fdy;
+    {
+        const float dx = gx - px, dy = gy - py;
+        const float d2 = fmaf(dx, dx, dy * dy);
+        const float inv = rsq_fast(fmaxf(d2, 1e-30f));
+        const bool far_ = d2 * inv > r;
+        fdx = far_ ? m_tau * (dx * inv * vd - cvx) : 0.0f;
+        fdy = far_ ? m_tau * (dy * inv * vd - cvy) : 0.0f;
+    }
+    // -- obstacle force: closest point per polygon :236-252, then :136-162
+    float fox = 0.0f, foy = 0.0f;
+    if (a.O > 0) {
+        const float* obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
+        for (int ob = 0; ob < a.O; ++ob) {
+            float best = INFINITY, bdx = 0.0f, bdy = 0.0f;
+            for (int sg = 0; sg < a.Smax; ++sg) {
+                const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)ob * a.Smax + sg) * 4);
+                float d = 3.0e38f, ddx = 0.0f, ddy = 0.0f;
+                if (!isnan(seg.x)) {
+                    const float ex = seg.z - seg.x, ey = seg.w - seg.y;
+                    const float t = ((px - seg.x) * ex + (py - seg.y) * ey) * rcp_fast(fmaf(ex, ex, ey * ey));
+                    const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                    ddx = px - fmaf(ts, ex, seg.x); ddy = py - fmaf(ts, ey, seg.y);
+                    d = fmaf(ddx, ddx, ddy * ddy);
+                }
+                if (d < best) { best = d; bdx = ddx; bdy = ddy; }
+            }
+            const float inv = rsq_fast(fmaxf(best, 1e-30f));
+            const float dist = best * inv;
+            const float nx = bdx * inv, ny = bdy * inv;
+            const float dv = -(cvy * nx - cvx * ny);
+            const float rd = r - dist + safety;
+            const float m0 = fmaxf(0.0f, rd);
+            const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
+            const float ft = obs_type == 0 ? -(k2 * m0) * dv : (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
+            fox += fn * nx - ft * ny;
+            foy += fn * ny + ft * nx;
+        }
+        const float inv_O = 1.0f / (float)a.O;
+        fox *= inv_O; foy *= inv_O;
+    }
+    // -- total force, body frame, torque, explicit Euler  :262-283
+    const float fix = fdx + fox + fsx, fiy = fdy + foy + fsy;
+    const float in_vx = cvx, in_vy = cvy;
+    px += vx * dt; py += vy * dt;            // the velocity stored in the incoming row
+    if constexpr (HEADED > 0) {
+        const float tfx = HEADED == 1 ? fdx : fix, tfy = HEADED == 1 ? fdy : fiy;
+        const float kf = klam * norm2(tfx, tfy);
+        const float k_theta = inertia * kf;
+        const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf / alpha);
+        const float delta = atan2_fast(sn * tfx - cs * tfy, cs * tfx + sn * tfy);
+        const float torque = -k_theta * delta - k_omega * om;
+        const float gfx = fix * cs + fiy * sn;
+        const float gfy = ko * ((fox + fsx) * (-sn) + (foy + fsy) * cs) - kd * bvy;
+        th = wrap_angle(fmaf(om, dt, th));
+        bvx = fmaf(gfx, dt_m, bvx); bvy = fmaf(gfy, dt_m, bvy);
+        const float nb2 = fmaf(bvx, bvx, bvy * bvy);
+        const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
+        if (nb2 * ninv > vd) { const float sc = vd * ninv; bvx *= sc; bvy *= sc; }
+        om = fmaf(torque, dt_inertia, om);
+        float s2, c2;
+        sincos_fast(th, s2, c2);
+        vx = c2 * bvx + (-s2) * bvy;
+        vy = s2 * bvx + c2 * bvy;
+    } else {
+        vx = fmaf(fix, dt_m, vx); vy = fmaf(fiy, dt_m, vy);
+        const float nb2 = fmaf(vx, vx, vy * vy);
+        const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
+        if (nb2 * ninv > vd) { const float sc = vd * ninv; vx *= sc; vy *= sc; }
+    }
+    o[0] = px; o[fs] = py; o[2 * fs] = th; o[3 * fs] = vx; o[4 * fs] = vy; o[5 * fs] = bvx; o[6 * fs] = bvy; o[7 * fs] = om;
+    o[8 * fs] = r; o[9 * fs] = m; o[10 * fs] = gx; o[11 * fs] = gy; o[12 * fs] = vd;
+    if (a.mutate) a.in_v[(long)w * rows + i] = make_float2(in_vx, in_vy);
+}
+
+// the reference's in-place writes on the INPUT rows of an out-of-place update (refreshed linear velocity of headed models :256,
+// goal columns :231-234), applied after the step: other lanes were still reading those rows during it
+__global__ void k_bw_mutate(const GArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= a.n) return;
+    float* si = a.Smut + ((long)w * a.rows + i) * a.as;
+    const float* so = a.Sout + ((long)w * a.rows + i) * a.as;
+    if (a.type >= 3) { const float2 v = a.in_v[(long)w * a.rows + i]; si[3 * a.fs] = v.x; si[4 * a.fs] = v.y; }
+    si[10 * a.fs] = so[10 * a.fs]; si[11 * a.fs] = so[11 * a.fs];
+}
+
+using gfn = void (*)(const GArgs);
+
+template <bool PEQ>
+gfn pick_big(int type)
+{
+    switch (type) {
+        case 0: return (gfn)k_bw_sfm_step<0, 0, PEQ>; case 1: return (gfn)k_bw_sfm_step<1, 0, PEQ>; case 2: return (gfn)k_bw_sfm_step<2, 0, PEQ>;
+        case 3: return (gfn)k_bw_sfm_step<0, 1, PEQ>; case 4: return (gfn)k_bw_sfm_step<1, 1, PEQ>; case 5: return (gfn)k_bw_sfm_step<2, 1, PEQ>;
+        case 6: return (gfn)k_bw_sfm_step<0, 2, PEQ>; case 7: return (gfn)k_bw_sfm_step<1, 2, PEQ>; case 8: return (gfn)k_bw_sfm_step<2, 2, PEQ>;
+    }
+    return nullptr;
+}
+
+} // namespace
+
+namespace csimpl {
+
+size_t grid_bytes(int W, int rows, int NB)
+{
+    const size_t total = (size_t)W * rows;
+    size_t temp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, temp, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, total, 0, 32, (hipStream_t)0);
+    return total * (sizeof(int2) + 2 * sizeof(unsigned) + 2 * sizeof(int)) + ((size_t)W * NB + 2) * sizeof(int) + temp + 1024;
+}
+
+int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const float* d_inv_cell, float inv_cell, void* mem, GridView& g, hipStream_t stream)
+{
+    const size_t total = (size_t)W * rows;
+    char* p = (char*)mem;
+    auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
+    g.W = W; g.rows = rows; g.NB = NB;
+    g.cellxy = (int2*)take(total * sizeof(int2));
+    g.keys = (unsigned*)take(total * sizeof(unsigned));
+    g.keys_sorted = (unsigned*)take(total * sizeof(unsigned));
+    g.idx = (int*)take(total * sizeof(int));
+    g.sorted = (int*)take(total * sizeof(int));
+    g.start = (int*)take(((size_t)W * NB + 2) * sizeof(int));
+    size_t temp = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp, g.keys, g.keys_sorted, g.idx, g.sorted, total, 0, 32, stream));
+    void* tmp = take(temp);
+    int bits = 1;
+    while ((1ll << bits) < (long long)W * NB) ++bits;
+    hipLaunchKernelGGL(k_grid_keys, dim3((rows + 255) / 256, W), dim3(256), 0, stream, g, S, as, fs, d_inv_cell, inv_cell);
+    HIP_TRY(rocprim::radix_sort_pairs(tmp, temp, g.keys, g.keys_sorted, g.idx, g.sorted, total, 0, (unsigned)bits, stream));
+    hipLaunchKernelGGL(k_grid_mark, dim3((unsigned)((total + 256) / 256)), dim3(256), 0, stream, g, (int)total);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+// n_substeps Euler substeps of worlds beyond one block.  d_out: where the result goes (w->d_state for cs_step / the in-place
+// update); mutate_input: reproduce the reference's in-place writes on w->d_state (out-of-place cs_update_humans_parallel).
+int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, int mutate_input, bool robot_from_array, const float* d_action,
+                   float* d_peek, hipStream_t stream)
+{
+    if (d_peek) return fail(CS_ERR_ARG, "cs_peek is not built for worlds beyond one block");
+    if (w->flags & CS_RESPAWN) return fail(CS_ERR_ARG, "the respawn rule is not built for worlds beyond one block");
+    if (robot_from_array || d_action) return fail(CS_ERR_ARG, "worlds beyond one block take the robot as the last state row (no cs_worlds.d_robot, no action)");
+    const int W = w->W, n = w->n, rows = n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    int NB = 1024;
+    while (NB < 2 * rows && NB < (1 << 20)) NB <<= 1;
+    const size_t state_bytes = ((size_t)W * rows * 13 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t misc = (((size_t)W * sizeof(float) + 255) & ~(size_t)255) + (size_t)W * rows * sizeof(float2) + 256;
+    char* base = (char*)scratch(2 * state_bytes + misc + grid_bytes(W, rows, NB), 1);
+    if (!base) return CS_ERR_HIP;
+    GArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = W; a.n = n; a.rows = rows; a.G = w->G; a.O = w->O; a.Smax = w->Smax; a.NB = NB; a.type = w->type; a.flags = w->flags; a.dt = dt;
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)W * rows; }
+    a.goals = w->d_goals; a.params = w->d_params; a.safety = w->d_safety; a.obstacles = w->d_obstacles;
+    float* SA = (float*)base;
+    float* SB = (float*)(base + state_bytes);
+    a.inv_cell = (float*)(base + 2 * state_bytes);
+    a.in_v = (float2*)(base + 2 * state_bytes + (((size_t)W * sizeof(float) + 255) & ~(size_t)255));
+    void* grid_mem = base + 2 * state_bytes + misc;
+    const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
+    const gfn step = peq ? pick_big<true>(w->type) : pick_big<false>(w->type);
+    if (!step) return fail(CS_ERR_TYPE, "Type " + std::to_string(w->type) + " does not exist for this implementation");
+    const float* cur = w->d_state;
+    for (int sub = 0; sub < n_substeps; ++sub) {
+        const bool last = sub + 1 == n_substeps;
+        float* nxt = last ? d_out : ((sub & 1) ? SB : SA);
+        if (nxt == cur) nxt = (cur == SA) ? SB : SA;      // (in-place single substep: through a scratch buffer, copied back below)
+        a.Sin = cur; a.Sout = nxt;
+        a.mutate = (mutate_input && sub == 0) ? 1 : 0;
+        a.Smut = w->d_state;
+        if (sub == 0) hipLaunchKernelGGL(k_bw_reach, dim3(W), dim3(256), 0, stream, a);   // radii, parameters and speed limits hold for the launch
+        GridView g;
+        int rcg = grid_build(cur, a.as, a.fs, W, rows, NB, a.inv_cell, 0.0f, grid_mem, g, stream);
+        if (rcg) return rcg;
+        a.cellxy = g.cellxy; a.start = g.start; a.sorted = g.sorted;
+        hipLaunchKernelGGL(step, dim3((rows + 255) / 256, W), dim3(256), 0, stream, a);
+        if (a.mutate) hipLaunchKernelGGL(k_bw_mutate, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
+        cur = nxt;
+    }
+    HIP_TRY(hipGetLastError());
+    if (cur != d_out) HIP_TRY(hipMemcpyAsync(d_out, cur, (size_t)W * rows * 13 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    return CS_OK;
+}
+
+} // namespace csimpl

@@ -32,6 +32,15 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
 // worlds beyond one block.  Returns nullptr (and sets the error) when hipMalloc fails.
 void* scratch(size_t bytes, int slot);
 int big_world_min_rows(int dflt);
+// the uniform grid of worlds beyond one block (bigworld.hip): rows binned into hashed buckets of square cells, every bucket's rows in
+// index order (stable radix sort); start[w * NB + b] .. start[w * NB + b + 1] = bucket b of world w in `sorted` (row indices)
+struct GridView { int W, rows, NB; int2* cellxy; unsigned* keys; unsigned* keys_sorted; int* idx; int* sorted; int* start; };
+__host__ __device__ inline int cell_bucket(int cx, int cy, int NB) { return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u)) & (NB - 1); }
+size_t grid_bytes(int W, int rows, int NB);
+int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const float* d_inv_cell, float inv_cell, void* mem, GridView& g, hipStream_t stream);
+// SFM / HSFM worlds beyond one block (bigworld.hip)
+int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, int mutate_input, bool robot_from_array, const float* d_action,
+                   float* d_peek, hipStream_t stream);
 // small worlds, one per 16-lane DPP row (rowstep.hip)
 bool row16_supports(int rows);
 int row16_launch(const cstep::KArgs& a, hipStream_t stream);

@@ -1081,7 +1081,8 @@ struct Geometry { int grid, block, wpb, ws; };
 int geometry(const cs_worlds* w, Geometry& g)
 {
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
-    if (rows <= 0 || rows > 1024) return fail(CS_ERR_ARG, "rows per world must be in 1..1024");
+    if (rows <= 0) return fail(CS_ERR_ARG, "rows per world must be positive");
+    if (rows > csimpl::big_world_min_rows(1024)) { g.block = 256; g.wpb = 1; g.ws = 0; g.grid = ((rows + 255) / 256) * w->W; return CS_OK; }   // grid path (bigworld.hip)
     if (rows <= 64) { g.block = 64; g.wpb = 64 / rows; }
     else { g.block = ((rows + 63) / 64) * 64; g.wpb = 1; }
     // world pitch in the doubled LDS buffers: 2 * rows, padded so that row index == lane (mod 32) in every world of the
@@ -1166,6 +1167,9 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     rc = geometry(w, g);
     if (rc) return rc;
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    if (rows > csimpl::big_world_min_rows(1024))   // worlds beyond one block: partners through a uniform grid in HBM (bigworld.hip)
+        return csimpl::sfm_big_launch(w, dt, nsub, d_out ? d_out : w->d_state, (mode & M_MUTATE_INPUT) ? 1 : 0,
+                                      (mode & M_ROBOT_FROM_ARRAY) != 0, d_action, (mode & M_PEEK) ? d_peek : nullptr, stream);
     KArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = w->W; a.n = w->n; a.rows = rows; a.G = w->G; a.O = w->O; a.Smax = w->Smax;
@@ -1358,6 +1362,11 @@ int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)
     int mode = entry == 2 ? (int)M_PEEK : (int)M_COMMIT_GOALS;
     if (entry == 1) mode |= M_MUTATE_INPUT;
     if (entry != 1 && (w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
+    if (w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0) > csimpl::big_world_min_rows(1024)) {
+        std::snprintf(buf, buflen, "k_bw_sfm_step<SOC=%d,HEADED=%d,PEQ=%d> grid=%d block=256 (uniform grid in HBM)", w->type % 3, w->type / 3,
+                      (w->flags & CS_ALL_PARAMS_EQUAL) ? 1 : 0, g.grid);
+        return CS_OK;
+    }
     const Variant v = select_variant(w, mode, g);
     if (v.maxt == 16) {
         std::snprintf(buf, buflen, "k_sfm_step_row16<SOC=%d,HEADED=%d,ROWS=%d> grid=%d block=64 wpb=4", w->type % 3, w->type / 3, v.rows_ct, (w->W + 3) / 4);

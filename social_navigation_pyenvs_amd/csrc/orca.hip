@@ -1143,52 +1143,9 @@ struct BigArgs {
     float dt, neighbor_dist, time_horizon, inv_cell;
     const float* Sin; float* Sout; long as, fs;
     float* goals; const float* margin;
-    int2* cellxy; int* count; int* start; int* fill; int* sorted;
+    const int2* cellxy; const int* start; const int* sorted;   // the grid (csimpl::grid_build, bigworld.hip)
     int lp3_static;
 };
-
-__device__ __forceinline__ int cell_bucket(int cx, int cy, int NB) { return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u)) & (NB - 1); }
-
-__global__ void k_bw_bin(const BigArgs a)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
-    if (i >= a.n) return;
-    const float* s = a.Sin + ((long)w * a.n + i) * a.as;
-    const int cx = (int)floorf(s[0] * a.inv_cell), cy = (int)floorf(s[a.fs] * a.inv_cell);
-    a.cellxy[(long)w * a.n + i] = make_int2(cx, cy);
-    atomicAdd(&a.count[(long)w * a.NB + cell_bucket(cx, cy, a.NB)], 1);
-}
-
-__global__ __launch_bounds__(1024) void k_bw_scan(const BigArgs a)   // exclusive scan of a world's bucket counts (one block per world)
-{
-    __shared__ int part[1024];
-    const int w = blockIdx.x, t = threadIdx.x, per = (a.NB + 1023) / 1024;
-    const int* c = a.count + (long)w * a.NB;
-    int* st = a.start + (long)w * (a.NB + 1);
-    int sum = 0;
-    for (int k = 0; k < per; ++k) { const int idx = t * per + k; if (idx < a.NB) sum += c[idx]; }
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int run = part[t] - sum;
-    for (int k = 0; k < per; ++k) { const int idx = t * per + k; if (idx < a.NB) { st[idx] = run; run += c[idx]; } }
-    if (t == 1023) st[a.NB] = part[1023];
-}
-
-__global__ void k_bw_scatter(const BigArgs a)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
-    if (i >= a.n) return;
-    const int2 c = a.cellxy[(long)w * a.n + i];
-    const int b = cell_bucket(c.x, c.y, a.NB);
-    const int pos = a.start[(long)w * (a.NB + 1) + b] + atomicAdd(&a.fill[(long)w * a.NB + b], 1);
-    a.sorted[(long)w * a.n + pos] = i;
-}
 
 __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
 {
@@ -1215,13 +1172,13 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
     if (human) {
         const float range2 = a.neighbor_dist * a.neighbor_dist;
         const int2 mc = a.cellxy[(long)w * n + i];
-        const int* st = a.start + (long)w * (a.NB + 1);
-        const int* so = a.sorted + (long)w * n;
+        const int* st = a.start + (long)w * a.NB;      // positions in the job-wide sorted list
+        const int* so = a.sorted;
         const int2* cxy = a.cellxy + (long)w * n;
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int cx = mc.x + dx, cy = mc.y + dy;
-                const int bk = cell_bucket(cx, cy, a.NB);
+                const int bk = csimpl::cell_bucket(cx, cy, a.NB);
                 for (int p = st[bk]; p < st[bk + 1]; ++p) {
                     const int b = so[p];
                     const int2 cb = cxy[b];
@@ -1325,8 +1282,8 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     int NB = 1024;
     while (NB < 2 * n && NB < (1 << 20)) NB <<= 1;
     const size_t state_bytes = (size_t)W * n * 13 * sizeof(float);
-    const size_t ints = (size_t)W * n * 2 /*cellxy*/ + (size_t)W * NB * 2 /*count, fill*/ + (size_t)W * (NB + 1) /*start*/ + (size_t)W * n /*sorted*/;
-    char* base = (char*)scratch(state_bytes + ints * sizeof(int) + 256, 0);
+    const size_t state_pad = (state_bytes + 255) & ~(size_t)255;
+    char* base = (char*)scratch(state_pad + grid_bytes(W, n, NB), 0);
     if (!base) return CS_ERR_HIP;
     BigArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -1336,12 +1293,7 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)W * n; }
     a.goals = w->d_goals; a.margin = w->d_safety;
     float* S2 = (float*)base;
-    int* ip = (int*)(base + ((state_bytes + 255) & ~(size_t)255));
-    a.cellxy = (int2*)ip; ip += (size_t)W * n * 2;
-    a.count = ip; ip += (size_t)W * NB;
-    a.fill = ip; ip += (size_t)W * NB;
-    a.start = ip; ip += (size_t)W * (NB + 1);
-    a.sorted = ip;
+    void* grid_mem = base + state_pad;
     const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
     a.lp3_static = (lp3_env && std::strcmp(lp3_env, "static") == 0) ? 1 : 0;
     HIP_TRY(hipMemcpyAsync(S2, w->d_state, state_bytes, hipMemcpyDeviceToDevice, stream));   // the columns a step does not write
@@ -1349,10 +1301,10 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     float* nxt = S2;
     for (int sub = 0; sub < n_substeps; ++sub) {
         a.Sin = cur; a.Sout = nxt;
-        HIP_TRY(hipMemsetAsync(a.count, 0, (size_t)W * NB * 2 * sizeof(int), stream));
-        hipLaunchKernelGGL(k_bw_bin, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(k_bw_scan, dim3(W), dim3(1024), 0, stream, a);
-        hipLaunchKernelGGL(k_bw_scatter, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
+        GridView g;
+        const int rcg = grid_build(cur, a.as, a.fs, W, n, NB, nullptr, a.inv_cell, grid_mem, g, stream);
+        if (rcg) return rcg;
+        a.cellxy = g.cellxy; a.start = g.start; a.sorted = g.sorted;
         hipLaunchKernelGGL(k_bw_orca_step, dim3((n + 63) / 64, W), dim3(64), 0, stream, a);
         const float* t = cur; cur = nxt; nxt = const_cast<float*>(t);
     }

@@ -194,3 +194,105 @@ def test_long_rollout_soak(model):
                                       P.astype(np.float64), 0.0125, np.zeros(n), True, False)
         err = np.max(np.abs(out[w][:, [0, 1, 3, 4]] - ref[:, [0, 1, 3, 4]]))
         assert err < tol, (model, int(w), err)
+
+
+def _big_world(rows, n, model, rng, spacing=0.8):
+    from social_navigation_pyenvs_amd import scenarios as sc
+
+    side = int(np.ceil(np.sqrt(rows)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    pos = (np.stack([gx.ravel(), gy.ravel()], -1)[:rows] - side / 2) * spacing + rng.uniform(-0.12, 0.12, (rows, 2))
+    S = np.zeros((1, rows, 13))
+    S[0, :, 0:2] = pos
+    S[0, :, 2] = rng.uniform(-np.pi, np.pi, rows)
+    S[0, :, 5:7] = rng.normal(0, 0.4, (rows, 2))
+    c, s = np.cos(S[0, :, 2]), np.sin(S[0, :, 2])
+    S[0, :, 3] = c * S[0, :, 5] - s * S[0, :, 6]; S[0, :, 4] = s * S[0, :, 5] + c * S[0, :, 6]
+    if not model.startswith("hsfm"):
+        S[0, :, 3:5] = rng.normal(0, 0.4, (rows, 2)); S[0, :, 5:8] = 0
+    else:
+        S[0, :, 7] = rng.normal(0, 0.3, rows)
+    S[0, :, 8] = rng.uniform(0.25, 0.35, rows); S[0, :, 9] = rng.uniform(60, 90, rows); S[0, :, 12] = rng.uniform(0.8, 1.3, rows)
+    goals = np.full((1, n, 3, 2), np.nan)
+    goals[0, :, 0] = -pos[:n] + rng.normal(0, 0.5, (n, 2)); goals[0, :, 1] = pos[:n]
+    goals[0, ::17, 0] = pos[:n][::17] + 0.1                       # some humans stand on their goal: the list rotates
+    S[0, :n, 10:12] = goals[0, :, 0]
+    return S.astype(np.float32), goals.astype(np.float32), np.tile(sc.default_params(model), (n, 1)).astype(np.float32)
+
+
+@pytest.mark.parametrize("model,peq,robot,walls", [("sfm_helbing", True, False, False), ("hsfm_farina", True, True, True),
+                                                   ("hsfm_new_guo", False, False, True), ("sfm_moussaid", True, False, False)])
+def test_world_of_4096_rows_through_the_grid(model, peq, robot, walls):
+    """a world far beyond one block (4096 rows; the LDS kernel ends at 1024).  Rows stay in HBM, partners come
+    from the 3 x 3 cells of a uniform grid whose edge is the force's reach; one substep through the array seam (in place and out of
+    place, with the reference's in-place side effects) and a fused block of substeps, against the f64 oracle on all 4096 rows."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    rows = 4096
+    n = rows - int(robot)
+    rng = np.random.default_rng(rows + len(model))
+    S, goals, P = _big_world(rows, n, model, rng)
+    if not peq:
+        P = (P * rng.uniform(0.9, 1.1, P.shape)).astype(np.float32)
+    W = sc.polygon_walls().astype(np.float32) if walls else None
+    t = SFMS.index(model)
+    cw = CrowdWorlds(S, goals, P, None, W, type=model, all_params_equal=peq, robot_row=robot)
+    assert "k_bw_sfm_step" in cw.step_variant("update"), cw.step_variant("update")
+    out = cw.get_states(cw.update_humans_parallel(0.0125, in_place=False))[0]
+    ref, s_after, g_after = orc.update_humans(t, S[0].astype(np.float64), goals[0].astype(np.float64), None if W is None else W.astype(np.float64),
+                                              P.astype(np.float64), 0.0125, np.zeros(rows), peq, robot)
+    # a dense lattice with ~200 body contacts: the class of deliberately extreme synthetic states (g1_direct: 5e-5; the float32
+    # instantiation of the oracle itself is 2.5e-5 off on the hsfm_new_guo world); Moussaid: sign(theta ~ 0) (SURVEY.md App. F.9)
+    tol = 5e-5 if not model.endswith("moussaid") else 3e-4
+    err = np.max(np.abs(out[:n][:, [0, 1, 3, 4]] - ref[:n][:, [0, 1, 3, 4]]))
+    assert err < tol, (model, err)
+    record(f"4096-row world through the grid, {model} (GPU vs f64 oracle)", err)
+    np.testing.assert_array_equal(cw.get_goals()[0], g_after.astype(np.float32))                  # rotated goal lists, exact
+    s_in = cw.get_states()[0]
+    np.testing.assert_array_equal(s_in[:n, 10:12], s_after[:n, 10:12].astype(np.float32))        # goal columns written back
+    if model.startswith("hsfm"):
+        assert np.max(np.abs(s_in[:n, 3:5] - s_after[:n, 3:5])) < 1e-5                            # refreshed linear velocity
+    if robot:
+        np.testing.assert_array_equal(out[n], S[0, n])
+    # a fused block (double-buffered in HBM, the grid rebuilt every substep) == repeated single substeps, bitwise
+    a = CrowdWorlds(S, goals, P, None, W, type=model, all_params_equal=peq, robot_row=robot)
+    b = CrowdWorlds(S, goals, P, None, W, type=model, all_params_equal=peq, robot_row=robot)
+    a.step(0.0125, 3)
+    for _ in range(3):
+        b.step(0.0125, 1)
+    np.testing.assert_array_equal(a.get_states(), b.get_states())
+    ref3, _, _ = orc.step_block(t, S[0].astype(np.float64), goals[0].astype(np.float64), None if W is None else W.astype(np.float64),
+                                P.astype(np.float64), 0.0125, 3, np.zeros(rows), peq, robot_visible=robot)
+    err3 = np.max(np.abs(a.get_states()[0][:n][:, [0, 1, 3, 4]] - ref3[:n][:, [0, 1, 3, 4]]))
+    # the lattice holds ~200 body contacts (k1 = 1.2e5 N/m): three stiff substeps amplify float32 rounding to 1e-4 in the float32
+    # instantiation of the oracle itself
+    assert err3 < max(3e-4, 5 * tol), (model, err3)
+
+
+def test_grid_path_on_small_worlds_equals_the_lds_kernel():
+    """The grid path forced onto small worlds (CROWDSTEP_BIGWORLD_MIN_ROWS=1): several worlds per launch, SoA layout, per-world
+    parameters -- within float32 rounding of the LDS kernel's result and of the oracle."""
+    import os
+
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    rng = np.random.default_rng(3)
+    W, n = 7, 90
+    parts = [_big_world(n, n, "hsfm_guo", rng, spacing=0.9) for _ in range(W)]
+    S = np.concatenate([p[0] for p in parts]); goals = np.concatenate([p[1] for p in parts]); P = parts[0][2]
+    res = {}
+    for mode in ("grid", "lds"):
+        if mode == "grid":
+            os.environ["CROWDSTEP_BIGWORLD_MIN_ROWS"] = "1"
+        try:
+            cw = CrowdWorlds(S, goals, P, None, None, type="hsfm_guo", all_params_equal=True, layout="soa")
+            assert ("k_bw_sfm_step" in cw.step_variant()) == (mode == "grid")
+            cw.step(0.0125, 4)
+            res[mode] = cw.get_states()
+        finally:
+            os.environ.pop("CROWDSTEP_BIGWORLD_MIN_ROWS", None)
+    assert np.max(np.abs(res["grid"][..., [0, 1, 3, 4]] - res["lds"][..., [0, 1, 3, 4]])) < 2e-5
+    ref, _, _ = orc.step_block(SFMS.index("hsfm_guo"), S.astype(np.float64), goals.astype(np.float64), None, P.astype(np.float64), 0.0125, 4,
+                               np.zeros((W, n)), True)
+    assert np.max(np.abs(res["grid"][..., [0, 1, 3, 4]] - ref[..., [0, 1, 3, 4]])) < 2e-5
