@@ -289,6 +289,19 @@ int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* 
                        const float* d_clock, int clock_len, int auto_reset, float* d_reward, uint8_t* d_terminated,
                        uint8_t* d_truncated, int32_t* d_info, void* stream);
 
+/*
+ * cs_gym_observe  replaces SocialNavGym.compute_humans_observable_state (social_nav_gym.py:100-105: the list of
+ *   human.get_observable_state() / get_observable_state_headed(), agent.py:247-253) for W worlds: d_obs [W][n][5] rows
+ *   px, py, vx, vy, radius, or [W][n][7] with theta, omega appended when theta_and_omega_visible.
+ * cs_copy_worlds_masked  the second half of a masked auto-reset: the worlds with d_mask[w] != 0 are copied from `src` (a staging
+ *   batch cs_generate_worlds filled, possibly on another stream beside cs_step) over those of `dst`: state rows, goal lists,
+ *   robot rows, world flags.  Both descriptors have the same shape and layout.
+ * With cs_collision_reward, cs_gym_bookkeeping, cs_step and cs_generate_worlds these make a whole vectorised Gym step a
+ * sequence of library launches with fixed arguments: capture it once (cs_graph_begin_capture), replay it per step.
+ */
+int cs_gym_observe(const cs_worlds* w, int theta_and_omega_visible, float* d_obs, void* stream);
+int cs_copy_worlds_masked(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

@@ -284,12 +284,28 @@ class CrowdWorlds:
                                               C.c_void_p(_ptr(self.d_human_margin)), C.c_void_p(_ptr(self.d_robot_memory)),
                                               C.c_float(dt), C.c_void_p(self.stream)))
 
-    def imitation_block(self, dt: float, n_substeps: int) -> None:
+    def imitation_block(self, dt: float, n_substeps: int, graph: bool = True) -> None:
         """The substep loop of SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263):
-        n_substeps x { update_robot(t, dt) ; update_humans(t, dt) }, launches only, no host copy."""
-        for _ in range(int(n_substeps)):
-            self.robot_model_step(dt)
-            self.step(dt, 1, None)
+        n_substeps x { update_robot(t, dt) ; update_humans(t, dt) }, launches only, no host copy.  The 2 x n_substeps launches
+        (two different integrators that the reference strictly alternates) are captured into ONE HIP graph the first time and
+        replayed afterwards: a launch-bound loop without its host gaps."""
+        if not graph:
+            for _ in range(int(n_substeps)):
+                self.robot_model_step(dt)
+                self.step(dt, 1, None)
+            return
+        if self.stream is None:
+            self.stream = _lib.stream_create()      # graph capture needs a stream of its own
+        key = ("imitation_graph", float(dt), int(n_substeps), self.robot_model, self.robot_margin)
+        g = self._scratch.get(key)
+        if g is None:
+            _lib.stream_sync(self.stream)
+            with _lib.Graph.capture(self.stream) as g:
+                for _ in range(int(n_substeps)):
+                    self.robot_model_step(dt)
+                    self.step(dt, 1, None)
+            self._scratch[key] = g
+        g.launch()
 
     def actual_collision_reward(self, T: float, global_time, reward_cfg=(50.0, 1.0, -0.25, 0.2, 0.5)) -> np.ndarray:
         """[W, 7] like collision_reward, from the distances of the current state (social_nav_gym.py:107-118)."""
@@ -352,3 +368,17 @@ class CrowdWorlds:
         buf = C.create_string_buffer(256)
         check(_lib.load().cs_step_variant(C.byref(d), C.c_int({"step": 0, "update": 1, "peek": 2}[entry]), buf, C.c_size_t(256)))
         return buf.value.decode()
+
+    def staging_copy(self):
+        """A second batch of the same shape whose world-dependent buffers (state, goals, robot rows, world flags) are separate
+        allocations and everything else (parameters, margins, walls) is shared: the target of a masked cs_generate_worlds that
+        runs beside cs_step; cs_copy_worlds_masked moves the regenerated worlds over afterwards."""
+        import copy
+
+        st = copy.copy(self)
+        st._scratch = {}
+        st.d_state = DeviceBuffer(self.d_state.shape)
+        st.d_goals = DeviceBuffer(self.d_goals.shape)
+        st.d_robot = None if self.d_robot is None else DeviceBuffer(self.d_robot.shape)
+        st.d_world_flags = None if self.d_world_flags is None else DeviceBuffer(self.d_world_flags.shape, np.int32)
+        return st

@@ -407,6 +407,20 @@ class BatchedSocialNavGym:
                   state=self.cw.d_state.torch().view(W, self.cw.rows, 13),
                   gen=gen.make_generator(self.cw, self._gen_scenario, **self._gen_kw),
                   cols=torch.as_tensor([0, 1, 3, 4, 8] + ([2, 7] if self.headed_obs else []), device="cuda"))
+        # the step graph: a torch side stream carries it (ordered against the caller's stream with wait_stream), a library stream
+        # carries the concurrent regeneration; persistent action / observation tensors; a staging batch for regenerated worlds
+        dl["stream"] = torch.cuda.Stream()
+        dl["stream_b"] = _lib.stream_create()
+        dl["fork"], dl["join"] = _lib.Event(), _lib.Event()
+        dl["act"] = torch.zeros((W, 2), dtype=torch.float32, device="cuda")
+        dl["obs"] = torch.zeros((W, self.n, 7 if self.headed_obs else 5), dtype=torch.float32, device="cuda")
+        dl["staging"] = self.cw.staging_copy()
+        dl["staging"].stream = dl["stream_b"]
+        import ctypes as C
+        nbytes = int(_lib.load().cs_generate_scratch_bytes(C.c_int(W)))      # (no hipMalloc inside the graph capture)
+        dl["staging"]._buffer("gen_mt19937", (nbytes // 4,), np.uint32)
+        self.cw.stream = dl["stream"].cuda_stream
+        torch.cuda.synchronize()
         self._dl = dl
         return dl
 
@@ -415,44 +429,79 @@ class BatchedSocialNavGym:
         dl = self._device_loop_state()
         return dl["state"][:, :self.n].index_select(2, dl["cols"])
 
-    def step_device(self, actions, auto_reset=True):
-        """``step`` without leaving the GPU: ``actions`` is a float32 torch CUDA tensor [W, 2] (holonomic vx, vy).
-        Returns torch CUDA tensors (obs [W, N, 5|7], reward [W], terminated [W], truncated [W], info_code [W]).
-        With ``auto_reset`` the worlds whose episode ended are regenerated on the device (``cs_generate_worlds`` with a
-        mask) from the next unused seeds before the observation is taken, as vectorised Gym environments do."""
-        import ctypes as C
+    def _step_graph(self, dl, parity, auto_reset):
+        r"""One vectorised Gym step as ONE HIP graph of library launches (captured once per result set):
 
-        import torch
+            stream A:  cs_collision_reward -> cs_gym_bookkeeping --fork--> cs_step --------join--> cs_copy_worlds_masked -> cs_gym_observe
+            stream B:                                              \--> masked cs_generate_worlds (into a staging batch) --/
+
+        Which worlds end is known from the reward of the state BEFORE the substeps (social_nav_gym.py:229-233), so their
+        regeneration (one wavefront per world, latency-bound: ~100 us for the slowest of the ~1 % that end per step) runs
+        beside the 20 fused substeps instead of behind them."""
+        import ctypes as C
 
         from .. import generators as gen
 
-        dl = self._device_loop_state()
-        cw = self.cw
-        a = actions
-        if a.dtype != torch.float32 or not a.is_cuda or not a.is_contiguous():
-            a = a.to(device="cuda", dtype=torch.float32).contiguous()
+        key = ("graph", parity, bool(auto_reset))
+        if key in dl:
+            return dl[key]
+        cw, lib = self.cw, _lib.load()
+        A, B = dl["stream"].cuda_stream, dl["stream_b"]
         d = cw.descriptor()
         cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
-        lib = _lib.load()
-        _lib.check(lib.cs_collision_reward(C.byref(d), C.c_void_p(a.data_ptr()), C.c_float(self.robot_time_step),
-                                           C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()),
-                                           C.c_void_p(cw.stream)))
-        _lib.check(lib.cs_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(a.data_ptr()),
-                               C.c_void_p(cw.stream)))
-        # typed results of this step (two sets, alternating: the tensors of the previous step stay valid for one more call),
-        # step counter, float32 clock, reset mask and next seeds in ONE small launch instead of a dozen element-wise torch ops
-        res = dl["results"][dl["parity"]]
+        reward, terminated, truncated, info = dl["results"][parity]
+        act = dl["act"]
+        with _lib.Graph.capture(A) as graph:
+            _lib.check(lib.cs_collision_reward(C.byref(d), C.c_void_p(act.data_ptr()), C.c_float(self.robot_time_step),
+                                               C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()), C.c_void_p(A)))
+            # typed results of this step, step counter, float32 clock, reset mask and next seeds: one small launch
+            _lib.check(lib.cs_gym_bookkeeping(C.c_int(self.W), C.c_void_p(dl["out"].data_ptr()), C.c_void_p(dl["counter"].data_ptr()),
+                                              C.c_void_p(dl["seeds"].data_ptr()), C.c_void_p(dl["mask"].data_ptr()),
+                                              C.c_void_p(dl["gtime"].data_ptr()), C.c_void_p(dl["clock"].data_ptr()),
+                                              C.c_int(dl["clock"].numel()), C.c_int(int(bool(auto_reset))),
+                                              C.c_void_p(reward.data_ptr()), C.c_void_p(terminated.data_ptr()),
+                                              C.c_void_p(truncated.data_ptr()), C.c_void_p(info.data_ptr()), C.c_void_p(A)))
+            if auto_reset:
+                dl["fork"].record(A)
+                dl["fork"].wait(B)
+                gen.generate_worlds_device(dl["staging"], dl["gen"], dl["seeds"], dl["mask"])   # (the staging batch launches on stream B)
+            _lib.check(lib.cs_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
+                                   C.c_void_p(A)))
+            if auto_reset:
+                dl["join"].record(B)
+                dl["join"].wait(A)
+                ds = dl["staging"].descriptor()
+                _lib.check(lib.cs_copy_worlds_masked(C.byref(ds), C.byref(d), C.c_void_p(dl["mask"].data_ptr()), C.c_void_p(A)))
+            _lib.check(lib.cs_gym_observe(C.byref(d), C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
+        dl[key] = graph
+        return graph
+
+    def step_device(self, actions, auto_reset=True):
+        """``step`` without leaving the GPU: ``actions`` is a float32 torch CUDA tensor [W, 2] (holonomic vx, vy) -- or
+        ``env.action_buffer()`` itself, filled in place (no copy).  Returns torch CUDA tensors (obs [W, N, 5|7], reward [W],
+        terminated [W], truncated [W], info_code [W]); obs is a persistent buffer rewritten by the next call, the other four
+        alternate between two sets (those of the previous step stay valid for one more call).
+        With ``auto_reset`` the worlds whose episode ended are regenerated on the device from the next unused seeds before the
+        observation is taken, as vectorised Gym environments do.  The whole step is one replay of a HIP graph (``_step_graph``)."""
+        import torch
+
+        dl = self._device_loop_state()
+        parity = dl["parity"]
         dl["parity"] ^= 1
-        reward, terminated, truncated, info = res
-        _lib.check(lib.cs_gym_bookkeeping(C.c_int(self.W), C.c_void_p(dl["out"].data_ptr()), C.c_void_p(dl["counter"].data_ptr()),
-                                          C.c_void_p(dl["seeds"].data_ptr()), C.c_void_p(dl["mask"].data_ptr()),
-                                          C.c_void_p(dl["gtime"].data_ptr()), C.c_void_p(dl["clock"].data_ptr()),
-                                          C.c_int(dl["clock"].numel()), C.c_int(int(bool(auto_reset))),
-                                          C.c_void_p(reward.data_ptr()), C.c_void_p(terminated.data_ptr()),
-                                          C.c_void_p(truncated.data_ptr()), C.c_void_p(info.data_ptr()), C.c_void_p(cw.stream)))
-        if auto_reset:
-            gen.generate_worlds_device(cw, dl["gen"], dl["seeds"], dl["mask"])
-        return self.observe_device(), reward, terminated, truncated, info
+        graph = self._step_graph(dl, parity, auto_reset)
+        side, cur = dl["stream"], torch.cuda.current_stream()
+        side.wait_stream(cur)                      # device-side ordering with whatever produced the actions
+        if actions is not dl["act"]:
+            with torch.cuda.stream(side):
+                dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
+        graph.launch()
+        cur.wait_stream(side)                      # ... and with whoever reads the results
+        reward, terminated, truncated, info = dl["results"][parity]
+        return dl["obs"], reward, terminated, truncated, info
+
+    def action_buffer(self):
+        """The persistent [W, 2] action tensor the step graph reads: write actions into it and pass it to ``step_device``."""
+        return self._device_loop_state()["act"]
 
     def lookahead_device(self, action_space):
         """The per-decision array work of CADRL / SARL for every world, on the device: one-step look-ahead of the humans
@@ -465,6 +514,18 @@ class BatchedSocialNavGym:
         import torch
 
         dl = self._device_loop_state()
+        side, cur_stream = dl["stream"], torch.cuda.current_stream()
+        side.wait_stream(cur_stream)
+        with torch.cuda.stream(side):               # the library launches on this stream (cw.stream); the torch ops between them follow
+            out = self._lookahead_on_side_stream(dl, action_space)
+        cur_stream.wait_stream(side)
+        return out
+
+    def _lookahead_on_side_stream(self, dl, action_space):
+        import ctypes as C
+
+        import torch
+
         cw, W, n = self.cw, self.W, self.n
         if cw.d_robot is None:
             raise ValueError("lookahead_device needs the robot rows")

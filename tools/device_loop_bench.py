@@ -41,3 +41,25 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(f"{K} Gym steps of {W} worlds x {n} humans: {el / K * 1e6:.1f} us per batched step, {W * K / el:.3e} Gym steps/s, "
       f"{W * K * n * 20 / el:.3e} agent-substeps/s, {int(ended)} episodes ended and were regenerated on the device")
+
+# the loop alone: actions written into the persistent buffer once, nothing else launched per step
+buf = env.action_buffer()
+buf.copy_(torch.randn(W, 2, device="cuda") * 0.5)
+for _ in range(20):
+    env.step_device(buf)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K):
+    env.step_device(buf)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(f"graph replay only (actions in place, no per-step torch ops): {el / K * 1e6:.1f} us per batched step, {W * K / el:.3e} Gym steps/s")
+for _ in range(20):
+    env.step_device(buf, auto_reset=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K):
+    env.step_device(buf, auto_reset=False)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(f"graph replay without the auto-reset branch: {el / K * 1e6:.1f} us per batched step")

@@ -39,7 +39,7 @@ for rmodel in (sys.argv[3:] or ["sfm_helbing", "hsfm_new_guo", "orca"]):
     eager = (time.perf_counter() - t0) / K
     with _lib.Graph.capture(stream) as graph:
         for _ in range(K):
-            cw.imitation_block(0.0125, 20)
+            cw.imitation_block(0.0125, 20, graph=False)
     e0, e1 = _lib.Event(), _lib.Event()
     e0.record(stream)
     graph.launch()
