@@ -256,6 +256,18 @@ int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* rob
                         const float* d_human_margin, float* d_robot_memory, float dt, void* stream);
 
 /*
+ * cs_imitation_block  replaces the substep loop of SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263):
+ *   n_substeps x { motion_model_manager.update_robot(t, dt) ; motion_model_manager.update_humans(t, dt) }, arguments as
+ *   cs_robot_model_step.  With an invisible robot (no CS_ROBOT_ROW: the crowd does not see it) and SFM / HSFM models on both sides
+ *   this is TWO launches: the crowd's n fused substeps, which also record what the robot's integrator sees of the humans at the
+ *   start of every substep (positions and linear velocities, library-owned scratch), and the robot's n substeps against those
+ *   records -- bit-identical to the alternating launches.  Otherwise (visible robot, ORCA on either side) the 2 n launches are
+ *   issued in the reference's order.
+ */
+int cs_imitation_block(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
+                       const float* d_human_margin, float* d_robot_memory, float dt, int n_substeps, void* stream);
+
+/*
  * cs_actual_collision_reward  replaces SocialNavGym.check_actual_collisions_and_goal (social_nav_gym.py:107-118) +
  *   compute_reward_and_infos (social_nav_sim.py:986-1029) for W worlds: distances of the CURRENT state (no swept test;
  *   collision when the smallest distance is <= 0).  Same reward_cfg and d_out layout as cs_collision_reward.

@@ -286,26 +286,21 @@ class CrowdWorlds:
 
     def imitation_block(self, dt: float, n_substeps: int, graph: bool = True) -> None:
         """The substep loop of SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263):
-        n_substeps x { update_robot(t, dt) ; update_humans(t, dt) }, launches only, no host copy.  The 2 x n_substeps launches
-        (two different integrators that the reference strictly alternates) are captured into ONE HIP graph the first time and
-        replayed afterwards: a launch-bound loop without its host gaps."""
+        n_substeps x { update_robot(t, dt) ; update_humans(t, dt) } = cs_imitation_block: two launches when the robot is invisible
+        to the crowd (the crowd's fused substeps record what the robot sees, the robot integrates behind them), the reference's
+        strict alternation of 2 x n_substeps launches otherwise.  ``graph=False``: always the alternating launches."""
+        if getattr(self, "robot_model", None) is None:
+            raise ValueError("no robot motion model set")
         if not graph:
             for _ in range(int(n_substeps)):
                 self.robot_model_step(dt)
                 self.step(dt, 1, None)
             return
-        if self.stream is None:
-            self.stream = _lib.stream_create()      # graph capture needs a stream of its own
-        key = ("imitation_graph", float(dt), int(n_substeps), self.robot_model, self.robot_margin)
-        g = self._scratch.get(key)
-        if g is None:
-            _lib.stream_sync(self.stream)
-            with _lib.Graph.capture(self.stream) as g:
-                for _ in range(int(n_substeps)):
-                    self.robot_model_step(dt)
-                    self.step(dt, 1, None)
-            self._scratch[key] = g
-        g.launch()
+        d = self.descriptor()
+        pr = (C.c_float * 20)(*[float(x) for x in self.robot_params])
+        check(_lib.load().cs_imitation_block(C.byref(d), C.c_int(self.robot_model), pr, C.c_float(self.robot_margin),
+                                             C.c_void_p(_ptr(self.d_human_margin)), C.c_void_p(_ptr(self.d_robot_memory)),
+                                             C.c_float(dt), C.c_int(int(n_substeps)), C.c_void_p(self.stream)))
 
     def actual_collision_reward(self, T: float, global_time, reward_cfg=(50.0, 1.0, -0.25, 0.2, 0.5)) -> np.ndarray:
         """[W, 7] like collision_reward, from the distances of the current state (social_nav_gym.py:107-118)."""

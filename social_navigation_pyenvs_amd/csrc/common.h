@@ -44,6 +44,9 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
 // small worlds, one per 16-lane DPP row (rowstep.hip)
 bool row16_supports(int rows);
 int row16_launch(const cstep::KArgs& a, hipStream_t stream);
+// the robot's n substeps against the crowd snapshots of an imitation block (robot_model.hip)
+int robot_block_launch(const cs_worlds* w, int robot_type, const float* robot_params, float robot_margin, const float* d_human_margin,
+                       float* d_robot_memory, float dt, int n_substeps, const float4* d_snap, hipStream_t stream);
 // social-momentum branch (social_momentum.hip)
 int social_momentum_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);
 

@@ -297,6 +297,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
         STAMP(7);
+        // imitation block: what the robot's own integrator sees of the crowd at this substep (it runs before update_humans)
+        if (a.snap != nullptr && human) a.snap[((long)sub * a.W + w) * n + row] = make_float4(px, py, vx, vy);
         const int Hf = (rows - 1) >> 1;
         const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
         const float2* rv = lds_v + cur * TP + pbase + row + 1;
@@ -1117,7 +1119,7 @@ void strides(const cs_worlds* w, int rows, long& as, long& fs)
 // diagnostic entry the parity tests use to assert that every benched build is the one they compared with the oracle).
 struct Variant { int maxt, occ, rows_ct, lean; bool peq; };
 
-Variant select_variant(const cs_worlds* w, int mode, const Geometry& g)
+Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool need_snap = false)
 {
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
@@ -1132,7 +1134,7 @@ Variant select_variant(const cs_worlds* w, int mode, const Geometry& g)
     // DPP row, partners exchanged with row shifts instead of LDS (rowstep.hip).  CROWDSTEP_ROW16=0 keeps them on the LDS kernel.
     const char* row16_env = std::getenv("CROWDSTEP_ROW16");
     const bool row16_on = !(row16_env && row16_env[0] == '0');
-    if (lean && row16_on && csimpl::row16_supports(rows)) return Variant{16, 2, rows, 1, true};
+    if (lean && row16_on && !need_snap && csimpl::row16_supports(rows)) return Variant{16, 2, rows, 1, true};
     // compile-time row counts of the BASELINE.json configurations with 25, 10 and 50 humans (50 rows unrolled spill 30-47 VGPRs
     // at the 4-wave budget: they are built for three waves per SIMD); 10 rows fit 128 VGPRs without spills in every model
     if (lean && rows == 25) return Variant{64, crowded ? 4 : 1, 25, 1, true};
@@ -1159,7 +1161,7 @@ kfn variant_kernel(const Variant& v, int type)
 }
 
 int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, const float* d_action,
-                float* d_peek, hipStream_t stream)
+                float* d_peek, hipStream_t stream, float4* d_snap = nullptr)
 {
     int rc = check_worlds(w);
     if (rc) return rc;
@@ -1188,7 +1190,8 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
 #ifdef CS_STAMPS
     a.stamps = g_stamp_buf;
 #endif
-    const Variant v = select_variant(w, mode, g);
+    a.snap = d_snap;
+    const Variant v = select_variant(w, mode, g, d_snap != nullptr);
     const bool peq = v.peq;
     if (v.maxt == 16) return csimpl::row16_launch(a, stream);
     const kfn fn = variant_kernel(v, w->type);
@@ -1347,6 +1350,33 @@ int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void*
 #ifdef CS_STAMPS
 int cs_debug_set_stamp_buffer(void* d_buf) { g_stamp_buf = (unsigned long long*)d_buf; return CS_OK; }
 #endif
+
+int cs_imitation_block(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin, const float* d_human_margin,
+                       float* d_robot_memory, float dt, int n_substeps, void* stream)
+{
+    if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
+    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    // An invisible robot does not act on the crowd: the crowd's n substeps fuse into ONE launch that leaves what the robot's integrator
+    // sees of it at every substep in a snapshot, and the robot's n substeps are ONE launch behind it -- 2 launches instead of 2 n.
+    const bool fusable = !(w->flags & CS_ROBOT_ROW) && w->type >= 0 && w->type <= 8 && robot_type >= 0 && robot_type <= 8 &&
+                         rows <= 64 && w->d_robot != nullptr;
+    if (fusable) {
+        float4* snap = (float4*)csimpl::scratch((size_t)n_substeps * w->W * w->n * sizeof(float4), 2);
+        if (!snap) return CS_ERR_HIP;
+        int rc = launch_step(w, dt, n_substeps, M_COMMIT_GOALS, nullptr, nullptr, nullptr, (hipStream_t)stream, snap);
+        if (rc) return rc;
+        return csimpl::robot_block_launch(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, n_substeps, snap,
+                                          (hipStream_t)stream);
+    }
+    for (int k = 0; k < n_substeps; ++k) {   // a visible robot and the crowd act on each other: the reference's strict alternation
+        int rc = cs_robot_model_step(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, stream);
+        if (rc) return rc;
+        rc = cs_step(w, dt, 1, nullptr, stream);
+        if (rc) return rc;
+    }
+    return CS_OK;
+}
 
 int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)
 {

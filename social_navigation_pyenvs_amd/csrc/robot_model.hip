@@ -42,6 +42,8 @@ struct RArgs {
     float* robot;            // [W][13]
     float* memory;           // [W][2] desired force of the previous substep
     const float* obstacles;
+    const float4* snap;      // imitation block: [nsub][W][n] (x, y, vx, vy) of the humans at the start of every substep (else nullptr)
+    int nsub;
 };
 
 constexpr float PI_F = 3.14159265358979323846f;
@@ -70,23 +72,30 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
     const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= a.W) return;
     float* rb = a.robot + (long)w * 13;
-    const float px = rb[0], py = rb[1], yaw = rb[2], bvx = rb[5], bvy = rb[6], om = rb[7];
+    float px = rb[0], py = rb[1], yaw = rb[2], bvx = rb[5], bvy = rb[6], om = rb[7];
     const float radius = rb[8], mass = rb[9], gx = rb[10], gy = rb[11], vd = rb[12];
     const bool headed = a.type >= CS_HSFM_FARINA;
     const int soc = a.type % 3;                 // 0 Helbing, 1 Guo, 2 Moussaid
     const bool torque_new = a.type >= CS_HSFM_NEW;
-    float sn, cs;
-    sincosf(yaw, &sn, &cs);
     float vx = rb[3], vy = rb[4];
-    if (headed) { vx = cs * bvx - sn * bvy; vy = sn * bvx + cs * bvy; }   // headed_agent_update_linear_velocity (:143-145)
     const float* P = a.P;
     const float rme = radius + a.robot_margin;
+    float* mem = a.memory + (long)w * 2;
+    float fdx = mem[0], fdy = mem[1];
+    // one substep (cs_robot_model_step), or all substeps of an imitation block against the crowd's snapshots: every lane carries
+    // the robot's state and integrates it identically (same inputs, same operations), lane 0 writes it back at the end
+    for (int sub = 0; sub < a.nsub; ++sub) {
+    float sn, cs;
+    sincosf(yaw, &sn, &cs);
+    if (headed) { vx = cs * bvx - sn * bvy; vy = sn * bvx + cs * bvy; }   // headed_agent_update_linear_velocity (:143-145)
 
     // ---- social force: humans in strides of 64, then a butterfly sum
     float fsx = 0.0f, fsy = 0.0f;
     for (int j = lane; j < a.n; j += 64) {
         const float* s = a.S + ((long)w * a.rows + j) * a.as;
-        const float hx = s[0], hy = s[a.fs], hvx = s[3 * a.fs], hvy = s[4 * a.fs];
+        float hx, hy, hvx, hvy;
+        if (a.snap != nullptr) { const float4 q = a.snap[((long)sub * a.W + w) * a.n + j]; hx = q.x; hy = q.y; hvx = q.z; hvy = q.w; }
+        else { hx = s[0]; hy = s[a.fs]; hvx = s[3 * a.fs]; hvy = s[4 * a.fs]; }
         const float rij = rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + j];
         const float dx = px - hx, dy = py - hy;
         const float dn = sqrtf(dx * dx + dy * dy);
@@ -119,11 +128,8 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
     }
     fsx = wave_sum(fsx);
     fsy = wave_sum(fsy);
-    if (lane != 0) return;
 
     // ---- desired force (forces.py:9-16); within one radius of the goal the previous one is kept
-    float* mem = a.memory + (long)w * 2;
-    float fdx = mem[0], fdy = mem[1];
     {
         const float ddx = gx - px, ddy = gy - py;
         const float dist = sqrtf(ddx * ddx + ddy * ddy);
@@ -193,6 +199,10 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         sincosf(nyaw, &s2, &c2);
         nvx = c2 * nbx - s2 * nby; nvy = s2 * nbx + c2 * nby;
     }
+    px = npx; py = npy; yaw = nyaw; vx = nvx; vy = nvy; bvx = nbx; bvy = nby; om = nom;
+    }   // substeps
+    if (lane != 0) return;
+    const float npx = px, npy = py, nyaw = yaw, nvx = vx, nvy = vy, nbx = bvx, nby = bvy, nom = om;
     rb[0] = npx; rb[1] = npy; rb[2] = nyaw; rb[3] = nvx; rb[4] = nvy; rb[5] = nbx; rb[6] = nby; rb[7] = nom;
     mem[0] = fdx; mem[1] = fdy;
     if (a.write_row) {
@@ -283,6 +293,7 @@ int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* rob
     a.S = w->d_state;
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * a.rows; }
     a.hmargin = hm; a.robot = w->d_robot; a.memory = d_robot_memory; a.obstacles = w->d_obstacles;
+    a.snap = nullptr; a.nsub = 1;
     const int wpb = 4;
     hipLaunchKernelGGL(k_robot_model_step, dim3((w->W + wpb - 1) / wpb), dim3(64 * wpb), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
@@ -323,3 +334,25 @@ int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* 
 }
 
 } // extern "C"
+
+int csimpl::robot_block_launch(const cs_worlds* w, int robot_type, const float* robot_params, float robot_margin, const float* d_human_margin,
+                               float* d_robot_memory, float dt, int n_substeps, const float4* d_snap, hipStream_t stream)
+{
+    const float* hm = d_human_margin ? d_human_margin : w->d_safety;
+    if (!hm || !robot_params || !d_robot_memory || !d_snap) return fail(CS_ERR_ARG, "null argument");
+    if (w->O < 0 || (w->O > 0 && (!w->d_obstacles || w->Smax <= 0))) return fail(CS_ERR_ARG, "bad obstacle description");
+    RArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = w->W; a.n = w->n; a.robot_row = 0; a.rows = w->n; a.write_row = 0;
+    a.O = w->O; a.Smax = w->Smax; a.type = robot_type; a.obstacles_shared = (w->flags & CS_OBSTACLES_SHARED) ? 1 : 0;
+    a.dt = dt; a.robot_margin = robot_margin;
+    std::memcpy(a.P, robot_params, sizeof(a.P));
+    a.S = w->d_state;
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * a.rows; }
+    a.hmargin = hm; a.robot = w->d_robot; a.memory = d_robot_memory; a.obstacles = w->d_obstacles;
+    a.snap = d_snap; a.nsub = n_substeps;
+    const int wpb = 4;
+    hipLaunchKernelGGL(k_robot_model_step, dim3((w->W + wpb - 1) / wpb), dim3(64 * wpb), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}

@@ -39,6 +39,7 @@ struct KArgs {
     float* peek_out;
     const int* world_flags;
     float bx, by;
+    float4* snap;          // optional [nsub][W][n] (x, y, vx, vy) of every human at the START of every substep (imitation block)
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     unsigned long long* stamps; // diagnostic build only
 };

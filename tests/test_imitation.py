@@ -294,3 +294,31 @@ def test_robot_model_kernel_edge_sizes_against_the_oracle(n, rmodel):
     got = cw.get_robot()[0]
     tol = 1e-3 if rmodel.endswith("moussaid") else 2e-6
     assert np.max(np.abs(got[:8] - ref[:8])) < tol * max(1.0, np.max(np.abs(ref[:8]))), (got[:8], ref[:8])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hmodel,rmodel,n", [("hsfm_farina", "sfm_helbing", 25), ("sfm_guo", "hsfm_new_guo", 10), ("hsfm_new_moussaid", "hsfm_moussaid", 7)])
+def test_imitation_block_two_launches_equal_the_alternating_launches(hmodel, rmodel, n):
+    """cs_imitation_block with an invisible robot: the crowd's 20 fused substeps (recording what the robot sees at every substep)
+    followed by the robot's 20 substeps == 20 x { cs_robot_model_step ; cs_step(1) } bit for bit, robot rows and crowd alike."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W = 37
+    S, goals, P, rb = sc.hybrid_worlds(W, n, hmodel, seed0=5)
+    rng = np.random.default_rng(n)
+    robot = np.zeros((W, 13), np.float32)
+    robot[:, 0:2] = rng.uniform(-3, 3, (W, 2)); robot[:, 8] = 0.3; robot[:, 9] = 80; robot[:, 10:12] = -robot[:, 0:2]; robot[:, 12] = 1.0
+    walls = sc.polygon_walls()
+    res = []
+    for fused in (True, False):
+        cw = CrowdWorlds(S, goals, P, None, walls, type=hmodel, all_params_equal=True, respawn_bounds=rb,
+                         respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), robot=robot)
+        cw.set_robot_model(rmodel, sc.default_params(rmodel), 0.0, np.zeros((W, n), np.float32))
+        for _ in range(3):
+            cw.imitation_block(0.0125, 20, graph=fused)
+        res.append((cw.get_states(), cw.get_robot(), cw.get_goals()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    assert np.max(np.abs(res[0][1][:, 0:2] - robot[:, 0:2])) > 0.1
