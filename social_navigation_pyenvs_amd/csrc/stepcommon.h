@@ -145,6 +145,7 @@ struct SocP {
     float Ai, cB, Ci, cD, Ei, k1, k2, lam, gam, ns, ns1;
     float lA, sA, lC, sC; // A * exp(x/B) = sA * exp2(x * cB + lA),  lA = log2|A|  (A = 0 -> exp2(-inf) = 0)
     float sAC;            // sA * sC
+    float cg, c1, c2;     // Moussaid: log2(e) / gamma, -ns1^2 log2(e), -ns^2 log2(e)
 };
 
 __device__ __forceinline__ SocP load_socp(const float* P)
@@ -155,6 +156,7 @@ __device__ __forceinline__ SocP load_socp(const float* P)
     s.lA = log2f(fabsf(s.Ai)); s.sA = copysignf(1.0f, s.Ai);
     s.lC = log2f(fabsf(s.Ci)); s.sC = copysignf(1.0f, s.Ci);
     s.sAC = s.sA * s.sC;
+    s.cg = LOG2E / s.gam; s.c1 = -(s.ns1 * s.ns1) * LOG2E; s.c2 = -(s.ns * s.ns) * LOG2E;
     return s;
 }
 
@@ -204,20 +206,19 @@ __device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx
     const float m0 = fmaxf(0.0f, rij - dist);
     const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);
     const float i2 = fmaxf(fmaf(ivx, ivx, ivy * ivy), 1e-30f);
-    const float iinv = rsq_fast(i2);
+    const float iinv = rsq_fast(i2);            // 1 / |w|: also 1 / F up to gamma (F = gamma |w|), no reciprocal of its own
     const float inorm = i2 * iinv;
     const float ix = ivx * iinv, iy = ivy * iinv;
     const float th = atan2_fast(iy * nx - ix * ny, -(ix * nx + iy * ny));
-    const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
     const float hx = -iy, hy = ix;
-    const float F = p.gam * inorm;
     const float dv = -(vdx * hx + vdy * hy);
-    const float e0 = p.Ei * exp2_fast(-dist * rcp_fast(F) * LOG2E);
-    const float a1 = p.ns1 * F * th, a2 = p.ns * F * th;
-    const float e1 = exp2_fast(-(a1 * a1) * LOG2E), e2 = exp2_fast(-(a2 * a2) * LOG2E);
+    const float e0 = p.Ei * exp2_fast(-dist * iinv * p.cg);                   // Ei e^{-dist / F}
+    const float u = p.gam * inorm * th, u2 = u * u;                            // (F theta)^2 shared by the two Gaussians
+    const float e1 = exp2_fast(u2 * p.c1), e2 = exp2_fast(u2 * p.c2);           // e^{-(ns1 F theta)^2}, e^{-(ns F theta)^2}
+    const float e2s = (th == 0.0f) ? 0.0f : copysignf(e2, th);                  // sign(theta) e2
     const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
-    fx = -(e0 * (e1 * ix + k * e2 * hx) + kk * ix + kt * hx);
-    fy = -(e0 * (e1 * iy + k * e2 * hy) + kk * iy + kt * hy);
+    fx = -(e0 * (e1 * ix + e2s * hx) + kk * ix + kt * hx);
+    fy = -(e0 * (e1 * iy + e2s * hy) + kk * iy + kt * hy);
 }
 
 
