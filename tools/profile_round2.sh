@@ -14,6 +14,10 @@ CFG[cfg5]="--worlds 8192 --agents 50 --model hsfm_farina --scenario circle --wal
 CFG[cfg3x4]="--worlds 16384"
 CFG[moussaid]="--model hsfm_new_moussaid"
 NAMES=${@:-cfg3 cfg2 cfg4 cfg5}
+# the default bench command itself under the kernel trace: its k_sfm_step<..., 25, 1> row is the kernel behind `value`
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/main_stats -- python3 bench.py > $O/main_bench.json 2> $O/main_stats.log || { echo "main stats run failed"; tail -5 $O/main_stats.log; exit 1; }
+cp $(find $O/main_stats -name "*kernel_stats.csv" | head -1) $O/main_kernel_stats.csv && head -4 $O/main_kernel_stats.csv | cut -c1-160
+rm -rf $O/main_stats
 for name in $NAMES; do
   A="${CFG[$name]} --no-cpu-baseline --no-other-configs"
   echo "== $name: $A"
