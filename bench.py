@@ -72,6 +72,8 @@ def parse(argv=None):
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a one-GPU box")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --same-device: rehearse the N > 1 path with several ranks on ONE GPU")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (rehearsal on a one-GPU box; never for measurements)")
     return ap.parse_args(argv)
 
 
@@ -237,8 +239,8 @@ def cpu_baseline(args, host, type_id):
 class Runner:
     """Barrier / timing plumbing shared by the main workload and the other configurations."""
 
-    def __init__(self, torch, dist, stream):
-        self.torch, self.dist, self.stream = torch, dist, stream
+    def __init__(self, torch, dist, stream, reduce_device="cuda"):
+        self.torch, self.dist, self.stream, self.reduce_device = torch, dist, stream, reduce_device
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -292,14 +294,14 @@ class Runner:
                 self.barrier()
                 wall.append(time.perf_counter() - t0)
                 kern.append(e0.elapsed_ms(e1) / steps)
-        dev = "cuda" if self.dist is not None else None
+        dev = self.reduce_device if self.dist is not None else None
         wall = [max_over_ranks(w, self.dist, device=dev) for w in wall]
         return np.array(wall), np.array(kern)
 
     def gather(self, value: float) -> list:
         if self.dist is None or self.dist.get_world_size() == 1:
             return [float(value)]
-        t = self.torch.tensor([value], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.reduce_device or "cpu")
         out = [self.torch.zeros_like(t) for _ in range(self.dist.get_world_size())]
         self.dist.all_gather(out, t)
         return [float(x.item()) for x in out]
@@ -385,8 +387,9 @@ def main():
     from social_navigation_pyenvs_amd.batched import HUMAN_MODELS as SFMS
 
     _lib.require_gpu()
-    torch.cuda.set_device(local_rank)
-    _lib.set_device(local_rank)
+    dev_index = 0 if args.same_device else local_rank
+    torch.cuda.set_device(dev_index)
+    _lib.set_device(dev_index)
     dist = None
     if world_size > 1 or args.force_dist:
         import torch.distributed as dist
@@ -395,12 +398,15 @@ def main():
         if args.force_dist and world_size == 1:   # rehearsal of the RCCL barrier path without a launcher
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
                 os.environ.setdefault(k, v)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world_size and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world_size}", file=sys.stderr)
 
     stream = _lib.stream_create()
-    run = Runner(torch, dist, stream)
+    run = Runner(torch, dist, stream, reduce_device="cuda" if args.dist_backend == "nccl" else None)
     spec = workload_spec(args)
     cw, host, W = build_worlds(spec, rank, world_size)
     wall, kern = run.measure(cw, spec, args.steps, args.warmup, args.repeats, eager=args.eager)
