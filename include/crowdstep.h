@@ -314,6 +314,17 @@ int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* 
 int cs_gym_observe(const cs_worlds* w, int theta_and_omega_visible, float* d_obs, void* stream);
 int cs_copy_worlds_masked(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, void* stream);
 
+/*
+ * cs_gym_bookkeeping_next_step  cs_gym_bookkeeping for Gymnasium's NEXT_STEP autoreset mode: a world whose episode ended in the
+ *   previous step (d_prev_mask[w] != 0) spends this step being reset -- its results are those of a reset step (reward 0, not
+ *   terminated, not truncated, Nothing), its step counter and clock restart -- and a world that ends now is flagged in d_mask
+ *   and moves to the next seed of its sequence; its replacement can then be generated BESIDE the next step (cs_generate_worlds
+ *   into a staging batch on another stream) and copied in at that step's end (cs_copy_worlds_masked), off the critical path.
+ */
+int cs_gym_bookkeeping_next_step(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, const int32_t* d_prev_mask,
+                                 float* d_global_time, const float* d_clock, int clock_len, float* d_reward, uint8_t* d_terminated,
+                                 uint8_t* d_truncated, int32_t* d_info, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

@@ -266,9 +266,49 @@ __global__ void k_gym_bookkeeping(int W, const float* out7, int* counter, unsign
     gtime[w] = clock[c];
 }
 
+// The same for Gymnasium's NEXT_STEP autoreset mode: a world whose episode ended in the previous step (prev != 0) is being reset during
+// this step -- its results are the reset step's (reward 0, not terminated, not truncated, Nothing), its clock restarts -- and a world
+// that ends now is only flagged (mask) and takes the next seed of its sequence; its replacement is generated beside the next step.
+__global__ void k_gym_bookkeeping_next_step(int W, const float* out7, int* counter, unsigned* seeds, int* mask, const int* prev, float* gtime,
+                                            const float* clock, int clock_len, float* reward, unsigned char* terminated,
+                                            unsigned char* truncated, int* info)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    if (prev[w]) {
+        reward[w] = 0.0f; terminated[w] = 0; truncated[w] = 0; info[w] = 0;
+        mask[w] = 0; counter[w] = 0; gtime[w] = clock[0];
+        return;
+    }
+    const float* o = out7 + (long)w * 7;
+    const bool term = o[4] > 0.0f, trunc = o[5] > 0.0f;
+    reward[w] = o[3]; terminated[w] = term ? 1 : 0; truncated[w] = trunc ? 1 : 0; info[w] = (int)o[6];
+    const bool done = term || trunc;
+    mask[w] = done ? 1 : 0;
+    if (done) seeds[w] += (unsigned)W;
+    int c = counter[w] + 1;
+    c = c < clock_len - 1 ? c : clock_len - 1;
+    counter[w] = c;
+    gtime[w] = clock[c];
+}
+
 } // namespace
 
 extern "C" {
+
+int cs_gym_bookkeeping_next_step(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, const int32_t* d_prev_mask,
+                                 float* d_global_time, const float* d_clock, int clock_len, float* d_reward, uint8_t* d_terminated,
+                                 uint8_t* d_truncated, int32_t* d_info, void* stream)
+{
+    if (W <= 0 || clock_len <= 0) return fail(CS_ERR_ARG, "W and clock_len must be positive");
+    if (!d_out || !d_counter || !d_seeds || !d_mask || !d_prev_mask || !d_global_time || !d_clock || !d_reward || !d_terminated || !d_truncated || !d_info)
+        return fail(CS_ERR_ARG, "null argument");
+    const int block = 64;
+    hipLaunchKernelGGL(k_gym_bookkeeping_next_step, dim3((W + block - 1) / block), dim3(block), 0, (hipStream_t)stream, W, d_out, d_counter,
+                       d_seeds, d_mask, d_prev_mask, d_global_time, d_clock, clock_len, d_reward, d_terminated, d_truncated, d_info);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
 
 int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
                         const float* d_human_margin, float* d_robot_memory, float dt, void* stream)

@@ -476,16 +476,100 @@ class BatchedSocialNavGym:
         dl[key] = graph
         return graph
 
+    def _next_step_pieces(self, dl, parity):
+        """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's launches with every ctypes argument bound once
+        (six direct launches cost less host time than three graph replays with event calls between them).
+        head = cs_collision_reward, cs_gym_bookkeeping_next_step(mask_p, prev = mask_{1-p});  gen = masked cs_generate_worlds into
+        staging_p on stream B_p;  body = cs_step;  tail = cs_copy_worlds_masked(staging_{1-p} -> live, mask_{1-p}), cs_gym_observe"""
+        import ctypes as C
+
+        key = ("ns", parity)
+        if key in dl:
+            return dl[key]
+        cw, lib = self.cw, _lib.load()
+        A = C.c_void_p(dl["stream"].cuda_stream)
+        d = cw.descriptor()
+        dref = C.byref(d)
+        cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
+        reward, terminated, truncated, info = dl["results"][parity]
+        act, masks = dl["act"], dl["ns_masks"]
+        P = lambda t: C.c_void_p(t.data_ptr())
+        a_rew = (dref, P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg, P(dl["out"]), A)
+        a_bk = (C.c_int(self.W), P(dl["out"]), P(dl["counter"]), P(dl["seeds"]), P(masks[parity]), P(masks[parity ^ 1]), P(dl["gtime"]),
+                P(dl["clock"]), C.c_int(dl["clock"].numel()), P(reward), P(terminated), P(truncated), P(info), A)
+        a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), A)
+        st = dl["ns_staging"][parity]
+        dg = st.descriptor()
+        nbytes = int(lib.cs_generate_scratch_bytes(C.c_int(self.W)))
+        scratch = st._buffer("gen_mt19937", (nbytes // 4,), np.uint32)
+        a_gen = (C.byref(dl["gen"]), C.byref(dg), P(dl["seeds"]), P(masks[parity]), C.c_void_p(None), C.c_void_p(None), C.c_void_p(scratch.ptr),
+                 C.c_void_p(dl["ns_streams"][parity]))
+        ds = dl["ns_staging"][parity ^ 1].descriptor()
+        a_copy = (C.byref(ds), dref, P(masks[parity ^ 1]), A)
+        a_obs = (dref, C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
+        keep = (d, dg, ds, cfg)                    # the structs the byref arguments point into
+        dl[key] = dict(rew=a_rew, bk=a_bk, step=a_step, gen=a_gen, copy=a_copy, obs=a_obs, keep=keep)
+        return dl[key]
+
+    def _step_device_next_step(self, dl, actions):
+        """One step in NEXT_STEP autoreset mode.  A world that ended at step t returns its terminal observation at t, is regenerated
+        BESIDE step t + 1 (stream B_p, into staging batch p) and returns the new episode's first observation -- with reward 0 and no
+        termination -- at t + 1: the regeneration (one wavefront per world, ~120 us for the slowest) never sits on the critical path."""
+        import torch
+
+        if "ns_masks" not in dl:
+            W = self.W
+            dl["ns_masks"] = [torch.zeros(W, dtype=torch.int32, device="cuda") for _ in range(2)]
+            dl["ns_staging"] = [dl["staging"], self.cw.staging_copy()]
+            dl["ns_streams"] = [dl["stream_b"], _lib.stream_create()]
+            for st, sb in zip(dl["ns_staging"], dl["ns_streams"]):
+                st.stream = sb
+            dl["ns_mask_ev"] = [_lib.Event(), _lib.Event()]
+            dl["ns_gen_ev"] = [_lib.Event(), _lib.Event()]
+            for e, sb in zip(dl["ns_gen_ev"], dl["ns_streams"]):
+                e.record(sb)                      # "nothing pending" for the very first tail
+            for p in (0, 1):
+                self._next_step_pieces(dl, p)     # (allocates the generators' scratch once)
+            torch.cuda.synchronize()
+        parity = dl["parity"]
+        dl["parity"] ^= 1
+        c = self._next_step_pieces(dl, parity)
+        lib, chk = _lib.load(), _lib.check
+        side, cur = dl["stream"], torch.cuda.current_stream()
+        A = side.cuda_stream
+        side.wait_stream(cur)
+        if actions is not dl["act"]:
+            with torch.cuda.stream(side):
+                dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
+        chk(lib.cs_collision_reward(*c["rew"]))                     # reward of the state before the substeps ...
+        chk(lib.cs_gym_bookkeeping_next_step(*c["bk"]))              # ... who ends now, who is being reset
+        dl["ns_mask_ev"][parity].record(A)
+        B = dl["ns_streams"][parity]
+        dl["ns_mask_ev"][parity].wait(B)
+        chk(lib.cs_generate_worlds(*c["gen"]))                       # beside this step's substeps and the next step
+        dl["ns_gen_ev"][parity].record(B)
+        chk(lib.cs_step(*c["step"]))                                 # the 20 fused substeps
+        dl["ns_gen_ev"][parity ^ 1].wait(A)                          # the worlds that ended in the PREVIOUS step are ready by now
+        chk(lib.cs_copy_worlds_masked(*c["copy"]))                   # ... copied in
+        chk(lib.cs_gym_observe(*c["obs"]))
+        cur.wait_stream(side)
+        reward, terminated, truncated, info = dl["results"][parity]
+        return dl["obs"], reward, terminated, truncated, info
+
     def step_device(self, actions, auto_reset=True):
         """``step`` without leaving the GPU: ``actions`` is a float32 torch CUDA tensor [W, 2] (holonomic vx, vy) -- or
         ``env.action_buffer()`` itself, filled in place (no copy).  Returns torch CUDA tensors (obs [W, N, 5|7], reward [W],
         terminated [W], truncated [W], info_code [W]); obs is a persistent buffer rewritten by the next call, the other four
         alternate between two sets (those of the previous step stay valid for one more call).
-        With ``auto_reset`` the worlds whose episode ended are regenerated on the device from the next unused seeds before the
-        observation is taken, as vectorised Gym environments do.  The whole step is one replay of a HIP graph (``_step_graph``)."""
+        With ``auto_reset=True`` the worlds whose episode ended are regenerated on the device from the next unused seeds before the
+        observation is taken (same-step autoreset); the whole step is one replay of a HIP graph (``_step_graph``).
+        ``auto_reset="next_step"`` is Gymnasium's NEXT_STEP mode: a finished world returns its terminal observation, spends the next
+        step being reset (reward 0, not terminated) and its regeneration runs beside that step instead of on the critical path."""
         import torch
 
         dl = self._device_loop_state()
+        if auto_reset == "next_step":
+            return self._step_device_next_step(dl, actions)
         parity = dl["parity"]
         dl["parity"] ^= 1
         graph = self._step_graph(dl, parity, auto_reset)

@@ -251,6 +251,55 @@ def test_device_resident_step_equals_host_step_and_auto_resets():
     assert np.all(dev._dl["gtime"].cpu().numpy()[fresh] == 0)
 
 
+def test_device_step_next_step_autoreset_mode():
+    """step_device(auto_reset="next_step") (Gymnasium's NEXT_STEP mode; the regeneration runs beside the following step): until a
+    world's first termination it is bit-identical to the same-step mode; a world that ends at step t returns at t + 1 reward 0, not
+    terminated, Nothing, a restarted clock, and the first observation of the world its next seed generates."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W = 64
+    cfg = _config("circle_crossing", human_num=6)
+    same = BatchedSocialNavGym(cfg, W); same.reset(phase="test", first_case=3, device=True)
+    nxt = BatchedSocialNavGym(cfg, W); nxt.reset(phase="test", first_case=3, device=True)
+    alive = np.ones(W, bool)                      # worlds that have not terminated yet (in either environment: same inputs)
+    prev_done = np.zeros(W, bool)
+    seeds_prev = nxt._device_loop_state()["seeds"].cpu().numpy().copy()
+    checked = 0
+    for k in range(60):
+        rb = nxt.cw.d_robot.torch()
+        to_goal = rb[:, 10:12] - rb[:, 0:2]
+        a = (to_goal / to_goal.norm(dim=1, keepdim=True).clamp(min=1e-6)).contiguous().clone()
+        a[::3] *= 0.3                              # a third of the robots dawdle: terminations spread over many steps
+        o1, r1, t1, u1, i1 = same.step_device(a)
+        o2, r2, t2, u2, i2 = nxt.step_device(a, auto_reset="next_step")
+        o1, o2 = o1.cpu().numpy(), o2.cpu().numpy()
+        done2 = (t2 | u2).cpu().numpy()
+        done1 = (t1 | u1).cpu().numpy()
+        # (a) before its first termination a world is the same in both modes (the terminal step included, except the observation,
+        #     which same-step mode has already replaced by the new episode's)
+        np.testing.assert_array_equal(r1.cpu().numpy()[alive], r2.cpu().numpy()[alive])
+        np.testing.assert_array_equal(done1[alive], done2[alive])
+        still = alive & ~done2
+        np.testing.assert_array_equal(o1[still], o2[still])
+        # (b) the step after a termination is the reset step
+        if prev_done.any():
+            assert np.all(r2.cpu().numpy()[prev_done] == 0) and not done2[prev_done].any() and np.all(i2.cpu().numpy()[prev_done] == 0)
+            assert np.all(nxt._dl["gtime"].cpu().numpy()[prev_done] == 0)
+            seeds_now = nxt._dl["seeds"].cpu().numpy()
+            assert np.all(seeds_now[prev_done] == seeds_prev[prev_done] + W)     # (advanced when the episode ended)
+            check = BatchedSocialNavGym(cfg, W); check.reset(phase="test", first_case=3, device=True)
+            generate_worlds(check.cw, "circle_crossing", seeds_now.astype(np.uint32), insert_robot=True)
+            np.testing.assert_array_equal(nxt.cw.get_states()[prev_done], check.cw.get_states()[prev_done])
+            np.testing.assert_array_equal(o2[prev_done], check.observe()[prev_done])
+            checked += int(prev_done.sum())
+        seeds_prev = np.where(prev_done, nxt._dl["seeds"].cpu().numpy(), seeds_prev)
+        alive &= ~done2
+        prev_done = done2
+    assert checked >= W // 2, checked
+
+
 def test_device_resident_lookahead_feeds_one_batched_value_network_call():
     """BatchedSocialNavGym.lookahead_device (cs_peek + cs_lookahead on resident tensors) == the host path of
     crowd_nav.policy.cadrl.compute_rotated_states_and_reward on downloaded arrays; then a greedy decision loop entirely on the

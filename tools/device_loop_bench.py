@@ -63,3 +63,25 @@ for _ in range(K):
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(f"graph replay without the auto-reset branch: {el / K * 1e6:.1f} us per batched step")
+
+env2 = BatchedSocialNavGym(cfg, W)
+env2.reset(phase="train", first_case=0, device=True)
+buf2 = env2.action_buffer()
+buf2.copy_(torch.randn(W, 2, device="cuda") * 0.5)
+for _ in range(20):
+    env2.step_device(buf2, auto_reset="next_step")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+ended2 = torch.zeros((), dtype=torch.int64, device="cuda")
+for _ in range(K):
+    ob, rew, term, trunc, info = env2.step_device(buf2, auto_reset="next_step")
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(f"NEXT_STEP autoreset (regeneration beside the following step): {el / K * 1e6:.1f} us per batched step, {W * K / el:.3e} Gym steps/s")
+t0 = time.perf_counter()
+for _ in range(K):
+    env2.step_device(buf2, auto_reset="next_step")
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(f"   of which host-side launch time {t_host / K * 1e6:.1f} us per step (total {el / K * 1e6:.1f})")
