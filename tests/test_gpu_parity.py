@@ -342,3 +342,41 @@ def test_small_worlds_on_the_lds_kernel_too():
             tol = 5e-5 if c["type"] % 3 != 2 else 2e-3
             assert np.max(np.abs(got[env][:, PV] - ref[:, PV])) < tol, (c["model"], env)
         assert np.max(np.abs(got["1"][:, PV] - got["0"][:, PV])) < (1e-5 if c["type"] % 3 != 2 else 2e-3)
+
+
+@pytest.mark.parametrize("n,model", [(10, "hsfm_farina"), (10, "sfm_guo"), (5, "sfm_helbing"), (5, "hsfm_new_guo")])
+def test_row16_kernel_respawn_rule_and_goal_switch(n, model):
+    """The DPP-row kernel's own respawn rule (row max by rotations, rank among the flagged lanes of the row) and goal switch:
+    parallel-traffic worlds with several humans inside the 3 m respawn zone (two of them in the same substep), crossings with humans
+    standing on their goal, both kinds in one batch; 20 fused substeps against the f64 oracle, goals and respawned rows included."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    W = 41
+    S, goals, P, rb = sc.hybrid_worlds(W, n, model, seed0=77 + n)
+    rw = (np.arange(W) % 2 == 1).astype(np.int32)
+    rng = np.random.default_rng(n)
+    for w in range(1, W, 2):                               # traffic worlds: push three humans to the edge of the respawn zone
+        for k, i in enumerate(rng.choice(n, 3, replace=False)):
+            S[w, i, 0] = goals[w, i, 0, 0] + 3.0 + (0.004 if k < 2 else 0.05) * (k + 1)
+            S[w, i, 3] = -0.9; S[w, i, 5] = 0.9 if model.startswith("hsfm") else 0.0   # walking towards the goal (yaw = -pi)
+    for w in range(0, W, 2):                               # crossing worlds: two humans stand on their first goal
+        for i in rng.choice(n, 2, replace=False):
+            S[w, i, 0:2] = goals[w, i, 0] + 0.05
+    S32, g32, P32 = f32(S), f32(goals), f32(P)
+    cw = CrowdWorlds(S32, g32, P32, None, None, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw)
+    assert "k_sfm_step_row16" in cw.step_variant(), cw.step_variant()
+    cw.step(0.0125, 20)
+    got, ggoals = cw.get_states(), cw.get_goals()
+    t = SFMS.index(model)
+    moved_any = False
+    for w in range(W):
+        ref, rgoals, _ = orc.step_block(t, S32[w].astype(np.float64), g32[w].astype(np.float64), None, P32.astype(np.float64), 0.0125, 20,
+                                        np.zeros(n), True, respawn=bool(rw[w]), respawn_par=(rb[0], rb[1], 0.0))
+        tol = 2e-3 if t % 3 == 2 else 3e-4
+        assert np.max(np.abs(got[w][:, PV] - ref[:, PV])) < tol, (model, w)
+        assert np.max(np.abs(np.nan_to_num(ggoals[w]) - np.nan_to_num(rgoals))) < 1e-4, (model, w)
+        moved = np.abs(ref[:, 0] - S32[w][:, 0]) > 1.0
+        assert np.array_equal(moved, np.abs(got[w][:, 0] - S32[w][:, 0]) > 1.0)
+        moved_any |= bool(moved.any())
+    assert moved_any
