@@ -47,5 +47,5 @@ for rmodel in (sys.argv[3:] or ["sfm_helbing", "hsfm_new_guo", "orca"]):
     _lib.stream_sync(stream)
     g = e0.elapsed_ms(e1) / K
     rbx = cw.get_robot()
-    print(f"W={W} humans={hmodel} robot={rmodel}: imitation step eager {eager * 1e6:.0f} us, HIP graph {g * 1e3:.0f} us "
+    print(f"W={W} humans={hmodel} robot={rmodel}: imitation step cs_imitation_block {eager * 1e6:.0f} us, the 40 alternating launches replayed from a HIP graph {g * 1e3:.0f} us "
           f"({W / (g * 1e-3):.3g} Gym steps/s); robots moved {np.mean(np.linalg.norm(rbx[:, 0:2] - robot[:, 0:2], axis=1)):.2f} m", flush=True)
