@@ -59,11 +59,20 @@ __device__ __forceinline__ float bound_angle(float a)
     return a;
 }
 
+// sum over the 64 lanes, left in every lane: four DPP rotate-and-add steps inside each 16-lane row, then the four row sums through
+// scalar registers (v_readlane) -- a few dozen cycles instead of six dependent LDS-crossbar shuffles (~120 cycles each)
+template <int N> __device__ __forceinline__ float row_ror_add(float x)
+{
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + N, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = row_ror_add<8>(v); v = row_ror_add<4>(v); v = row_ror_add<2>(v); v = row_ror_add<1>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
@@ -84,7 +93,14 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
     float fdx = mem[0], fdy = mem[1];
     // one substep (cs_robot_model_step), or all substeps of an imitation block against the crowd's snapshots: every lane carries
     // the robot's state and integrates it identically (same inputs, same operations), lane 0 writes it back at the end
+    // imitation block: the humans' records of the NEXT substep are requested while this one is integrated (a substep is a few hundred
+    // instructions, a dependent global load about as long)
+    const bool pre = a.snap != nullptr && a.n <= 64;
+    float4 qpre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (pre && lane < a.n) qpre = a.snap[(long)w * a.n + lane];
     for (int sub = 0; sub < a.nsub; ++sub) {
+    float4 qnext = qpre;
+    if (pre && lane < a.n && sub + 1 < a.nsub) qnext = a.snap[((long)(sub + 1) * a.W + w) * a.n + lane];
     float sn, cs;
     sincosf(yaw, &sn, &cs);
     if (headed) { vx = cs * bvx - sn * bvy; vy = sn * bvx + cs * bvy; }   // headed_agent_update_linear_velocity (:143-145)
@@ -94,12 +110,16 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
     for (int j = lane; j < a.n; j += 64) {
         const float* s = a.S + ((long)w * a.rows + j) * a.as;
         float hx, hy, hvx, hvy;
-        if (a.snap != nullptr) { const float4 q = a.snap[((long)sub * a.W + w) * a.n + j]; hx = q.x; hy = q.y; hvx = q.z; hvy = q.w; }
+        if (pre) { hx = qpre.x; hy = qpre.y; hvx = qpre.z; hvy = qpre.w; }
+        else if (a.snap != nullptr) { const float4 q = a.snap[((long)sub * a.W + w) * a.n + j]; hx = q.x; hy = q.y; hvx = q.z; hvy = q.w; }
         else { hx = s[0]; hy = s[a.fs]; hvx = s[3 * a.fs]; hvy = s[4 * a.fs]; }
         const float rij = rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + j];
+        // (single-instruction rsq / exp as in the crowd kernel: <= 1 ulp each, two orders of magnitude inside the parity bar)
         const float dx = px - hx, dy = py - hy;
-        const float dn = sqrtf(dx * dx + dy * dy);
-        const float nx = dx / dn, ny = dy / dn;
+        const float d2h = dx * dx + dy * dy;
+        const float dinv = __builtin_amdgcn_rsqf(d2h);
+        const float dn = d2h * dinv;
+        const float nx = dx * dinv, ny = dy * dinv;
         const float rd = rij - dn;
         const float comp = fmaxf(0.0f, rd);
         if (soc == 2) {
@@ -119,9 +139,9 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         } else {
             const float tx = -ny, ty = nx;
             const float dv = (hvx - vx) * tx + (hvy - vy) * ty;
-            const float fn = P[1] * expf(rd / P[3]) + P[10] * comp;
+            const float fn = P[1] * __expf(rd / P[3]) + P[10] * comp;
             float ft = P[11] * comp * dv;
-            if (soc == 1) ft += P[5] * expf(rd / P[7]);
+            if (soc == 1) ft += P[5] * __expf(rd / P[7]);
             fsx += fn * nx + ft * tx;
             fsy += fn * ny + ft * ty;
         }
@@ -200,6 +220,7 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         nvx = c2 * nbx - s2 * nby; nvy = s2 * nbx + c2 * nby;
     }
     px = npx; py = npy; yaw = nyaw; vx = nvx; vy = nvy; bvx = nbx; bvy = nby; om = nom;
+    qpre = qnext;
     }   // substeps
     if (lane != 0) return;
     const float npx = px, npy = py, nyaw = yaw, nvx = vx, nvy = vy, nbx = bvx, nby = bvy, nom = om;
