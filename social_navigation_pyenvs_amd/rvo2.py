@@ -11,7 +11,7 @@ The reference reaches RVO2 through the ``rvo2.PyRVOSimulator`` object API (SURVE
 programmes and ``position += velocity * timeStep`` (RVO2 ``Agent::computeNeighbors / computeNewVelocity / update``,
 restated in csrc/orca.hip; parity with the third-party library itself is unpinned).
 
-Supported: any number of agents up to 512 (10 neighbours and no obstacles above 64), per-agent radius / maxSpeed / position / velocity / preferred velocity;
+Supported: any number of agents (10 neighbours and no obstacles above 64; above 512 the neighbours come from a uniform grid in HBM), per-agent radius / maxSpeed / position / velocity / preferred velocity;
 ``neighborDist``, ``maxNeighbors``, ``timeHorizon`` must be the same for every agent (the reference never varies
 them: ORCA_DEFAULTS, motion_model_manager.py:14).  Static obstacles: ``addObstacle(vertices)`` (counter-clockwise
 polygons, or two vertices for a one-sided wall) + ``processObstacles()`` build RVO2's vertex records (point, unit direction
@@ -87,8 +87,7 @@ class PyRVOSimulator:
         for name, val in (("neighborDist", neighborDist), ("maxNeighbors", maxNeighbors), ("timeHorizon", timeHorizon)):
             if val is not None and float(val) != float(d[name]):
                 raise NotImplementedError(f"per-agent {name} is not supported (the reference uses ORCA_DEFAULTS for every agent)")
-        if len(self._pos) >= 512:
-            raise NotImplementedError("the ORCA step supports up to 512 agents per simulator")
+        # (any number of agents: worlds of more than 512 take the grid neighbour search of the kernel, csrc/orca.hip)
         self._pos.append([float(pos[0]), float(pos[1])])
         v = d["velocity"] if velocity is None else velocity
         self._vel.append([float(v[0]), float(v[1])])

@@ -484,3 +484,26 @@ def test_orca_grid_path_on_small_worlds_equals_the_restatement(layout):
     cols = [0, 1, 3, 4, 5, 6, 10, 11]
     np.testing.assert_array_equal(got[..., cols], ref[..., cols])
     np.testing.assert_array_equal(ggoals, rgoals)
+
+
+def test_rvo2_module_with_a_thousand_agents():
+    """The PyRVOSimulator facade beyond one block: 1000 agents (the kernel's grid neighbour search), one doStep against the
+    restatement's index-order walk, bit for bit."""
+    from social_navigation_pyenvs_amd import rvo2
+
+    rng = np.random.default_rng(1000)
+    n = 1000
+    S, goals = _lattice_world(1, n, rng)
+    pos, vel, rad, vmax = S[0, :, 0:2], S[0, :, 3:5], S[0, :, 8], S[0, :, 12]
+    pref = S[0, :, 5:7]
+    sim = rvo2.PyRVOSimulator(1 / 60, 10, 10, 5, 5, 0.3, 1)
+    for i in range(n):
+        sim.addAgent((float(pos[i, 0]), float(pos[i, 1])), 10, 10, 5, 5, float(rad[i]) + 0.01, float(vmax[i]), (float(vel[i, 0]), float(vel[i, 1])))
+        sim.setAgentPrefVelocity(i, (float(pref[i, 0]), float(pref[i, 1])))
+    sim.setTimeStep(0.0125)
+    sim.doStep()
+    nv = orc.orca_new_velocities(pos, vel, pref, (rad + np.float32(0.01)).astype(np.float32), vmax, 10.0, 10, 5.0, 0.0125)
+    got_v = np.array([sim.getAgentVelocity(i) for i in range(n)], dtype=np.float32)
+    got_p = np.array([sim.getAgentPosition(i) for i in range(n)], dtype=np.float32)
+    np.testing.assert_array_equal(got_v, nv)
+    np.testing.assert_array_equal(got_p, pos + nv * np.float32(0.0125))
