@@ -256,6 +256,15 @@ int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* rob
                         const float* d_human_margin, float* d_robot_memory, float dt, void* stream);
 
 /*
+ * cs_robot_model_velocities  replaces MotionModelManager.update_robot(t, dt, just_velocities=True) (motion_model_manager.py:615-629
+ *   with euler_*_single_agent_update(..., just_velocities=True), :72-85): the robot's velocities (linear or body + angular) are
+ *   integrated by its SFM / HSFM model, its position and yaw stay (SocialNavSim moves the pose at its own rate with
+ *   update_robot_pose, :655-659).  Arguments as cs_robot_model_step; robot_type 0..8.
+ */
+int cs_robot_model_velocities(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
+                              const float* d_human_margin, float* d_robot_memory, float dt, void* stream);
+
+/*
  * cs_imitation_block  replaces the substep loop of SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263):
  *   n_substeps x { motion_model_manager.update_robot(t, dt) ; motion_model_manager.update_humans(t, dt) }, arguments as
  *   cs_robot_model_step.  With an invisible robot (no CS_ROBOT_ROW: the crowd does not see it) and SFM / HSFM models on both sides

@@ -508,7 +508,7 @@ def closest_points(walls, p):
     return out
 
 
-def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls, dt):
+def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls, dt, just_velocities=False):
     """One update_robot(t, dt) of an SFM / HSFM robot.  row = [x, y, yaw, vx, vy, bvx, bvy, omega, radius, mass, gx, gy,
     desired_speed, safety_space, desired_force_x, desired_force_y] (copied); returns the new row."""
     r = np.array(row, dtype=np.float64)
@@ -570,7 +570,8 @@ def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety,
                 fs += (P[1] * np.exp(rd / P[3]) + P[10] * max(0, rd)) * n_ij + P[11] * max(0, rd) * dv * t_ij
     if not headed:
         gf = fd + fo + fs
-        pos = pos + vel * dt
+        if not just_velocities:                      # motion_model_manager.py:73
+            pos = pos + vel * dt
         vel = vel + gf / mass * dt
         sp = np.linalg.norm(vel)
         if sp > vd:
@@ -582,8 +583,9 @@ def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety,
         k_omega = inertia * (1 + P[18]) * np.sqrt(P[19] * tn / P[18])
         torque = -k_theta * _bound_angle(yaw - np.arctan2(tot[1], tot[0])) - k_omega * om
         gf = np.array([np.dot(fd + fo + fs, R[:, 0]), P[16] * np.dot(fo + fs, R[:, 1]) - P[17] * bvel[1]])
-        pos = pos + vel * dt
-        yaw = _bound_angle(yaw + om * dt)
+        if not just_velocities:                      # motion_model_manager.py:79-81
+            pos = pos + vel * dt
+            yaw = _bound_angle(yaw + om * dt)
         bvel = bvel + gf / mass * dt
         om = om + torque / inertia * dt
         sp = np.linalg.norm(bvel)

@@ -274,13 +274,14 @@ class CrowdWorlds:
             ov = np.ascontiguousarray(orca_vertices, dtype=np.float32).reshape(-1, 8)
             self.d_orca_vertices, self.orca_n_vertices = DeviceBuffer.from_numpy(ov), len(ov)
 
-    def robot_model_step(self, dt: float) -> None:
-        """update_robot(t, dt) of every world (motion_model_manager.py:615-653), in place on the robot rows."""
+    def robot_model_step(self, dt: float, just_velocities: bool = False) -> None:
+        """update_robot(t, dt, just_velocities) of every world (motion_model_manager.py:615-653), in place on the robot rows."""
         if getattr(self, "robot_model", None) is None:
             raise ValueError("no robot motion model set")
         d = self.descriptor()
         pr = (C.c_float * 20)(*[float(x) for x in self.robot_params])
-        check(_lib.load().cs_robot_model_step(C.byref(d), C.c_int(self.robot_model), pr, C.c_float(self.robot_margin),
+        fn = _lib.load().cs_robot_model_velocities if just_velocities else _lib.load().cs_robot_model_step
+        check(fn(C.byref(d), C.c_int(self.robot_model), pr, C.c_float(self.robot_margin),
                                               C.c_void_p(_ptr(self.d_human_margin)), C.c_void_p(_ptr(self.d_robot_memory)),
                                               C.c_float(dt), C.c_void_p(self.stream)))
 

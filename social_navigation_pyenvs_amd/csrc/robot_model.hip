@@ -42,6 +42,7 @@ struct RArgs {
     float* robot;            // [W][13]
     float* memory;           // [W][2] desired force of the previous substep
     const float* obstacles;
+    int just_velocities;     // update_robot(just_velocities=True): velocities integrate, position and yaw stay (:72-85)
     const float4* snap;      // imitation block: [nsub][W][n] (x, y, vx, vy) of the humans at the start of every substep (else nullptr)
     int nsub;
 };
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
     float npx, npy, nyaw = yaw, nvx, nvy, nbx = bvx, nby = bvy, nom = om;
     if (!headed) {
         const float gfx = fdx + fox + fsx, gfy = fdy + foy + fsy;
-        npx = px + vx * a.dt; npy = py + vy * a.dt;
+        npx = a.just_velocities ? px : px + vx * a.dt; npy = a.just_velocities ? py : py + vy * a.dt;
         nvx = vx + gfx / mass * a.dt; nvy = vy + gfy / mass * a.dt;
         const float sp = sqrtf(nvx * nvx + nvy * nvy);
         if (sp > vd) { nvx = nvx / sp * vd; nvy = nvy / sp * vd; }
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         // global_force = [ (fd + fo + fs) . R[:,0] ,  ko * (fo + fs) . R[:,1] - kd * body_velocity[1] ]
         const float g0 = (fdx + fox + fsx) * cs + (fdy + foy + fsy) * sn;
         const float g1 = P[16] * ((fox + fsx) * -sn + (foy + fsy) * cs) - P[17] * bvy;
-        npx = px + vx * a.dt; npy = py + vy * a.dt;
-        nyaw = bound_angle(yaw + om * a.dt);
+        npx = a.just_velocities ? px : px + vx * a.dt; npy = a.just_velocities ? py : py + vy * a.dt;
+        nyaw = a.just_velocities ? yaw : bound_angle(yaw + om * a.dt);
         nbx = bvx + g0 / mass * a.dt; nby = bvy + g1 / mass * a.dt;
         nom = om + torque / inertia * a.dt;
         const float sp = sqrtf(nbx * nbx + nby * nby);
@@ -331,8 +332,24 @@ int cs_gym_bookkeeping_next_step(int W, const float* d_out, int32_t* d_counter, 
     return CS_OK;
 }
 
+static int robot_step_impl(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
+                           const float* d_human_margin, float* d_robot_memory, float dt, int just_velocities, void* stream);
+
 int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
                         const float* d_human_margin, float* d_robot_memory, float dt, void* stream)
+{
+    return robot_step_impl(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, 0, stream);
+}
+
+int cs_robot_model_velocities(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
+                              const float* d_human_margin, float* d_robot_memory, float dt, void* stream)
+{
+    if (robot_type == CS_ORCA) return fail(CS_ERR_ARG, "just_velocities is built for the SFM / HSFM robot models, not for the ORCA robot");
+    return robot_step_impl(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, 1, stream);
+}
+
+static int robot_step_impl(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
+                           const float* d_human_margin, float* d_robot_memory, float dt, int just_velocities, void* stream)
 {
     if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
     if (w->W <= 0 || w->n <= 0 || !w->d_state || !w->d_robot) return fail(CS_ERR_ARG, "bad cs_worlds (a robot needs d_robot)");
@@ -354,7 +371,7 @@ int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* rob
     a.S = w->d_state;
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * a.rows; }
     a.hmargin = hm; a.robot = w->d_robot; a.memory = d_robot_memory; a.obstacles = w->d_obstacles;
-    a.snap = nullptr; a.nsub = 1;
+    a.snap = nullptr; a.nsub = 1; a.just_velocities = just_velocities;
     const int wpb = 4;
     hipLaunchKernelGGL(k_robot_model_step, dim3((w->W + wpb - 1) / wpb), dim3(64 * wpb), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

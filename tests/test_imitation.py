@@ -292,8 +292,21 @@ def test_robot_model_kernel_edge_sizes_against_the_oracle(n, rmodel):
     ref = orc.robot_model_substep(row, P.astype(np.float32).astype(np.float64), rmodel, S[0, :, 0:2].astype(np.float64),
                                   S[0, :, 3:5].astype(np.float64), S[0, :, 8].astype(np.float64), hs.astype(np.float64), None, DT)
     got = cw.get_robot()[0]
-    tol = 1e-3 if rmodel.endswith("moussaid") else 2e-6
+    # (2e-6 with IEEE divide / libm exp; the per-human loop now uses the crowd kernel's single-instruction rsq / exp: 1 ulp each)
+    tol = 1e-3 if rmodel.endswith("moussaid") else 1e-5
     assert np.max(np.abs(got[:8] - ref[:8])) < tol * max(1.0, np.max(np.abs(ref[:8]))), (got[:8], ref[:8])
+    # update_robot(t, dt, just_velocities=True) (motion_model_manager.py:72-85, 615-629): velocities integrate, the pose stays
+    cw2 = CrowdWorlds(S, goals, None, np.zeros((1, n), np.float32), None, type="orca", robot=_robot13(row))
+    cw2.set_robot_model(rmodel, P, 0.02, hs[None])
+    cw2.robot_model_step(DT, just_velocities=True)
+    refv = orc.robot_model_substep(row, P.astype(np.float32).astype(np.float64), rmodel, S[0, :, 0:2].astype(np.float64),
+                                   S[0, :, 3:5].astype(np.float64), S[0, :, 8].astype(np.float64), hs.astype(np.float64), None, DT,
+                                   just_velocities=True)
+    gv = cw2.get_robot()[0]
+    np.testing.assert_array_equal(gv[0:3], _robot13(row)[0:3])                                   # x, y, yaw untouched
+    assert np.max(np.abs(gv[:8] - refv[:8])) < tol * max(1.0, np.max(np.abs(refv[:8]))), (gv[:8], refv[:8])
+    if rmodel.startswith("hsfm"):
+        np.testing.assert_array_equal(gv[5:8], got[5:8])                                         # body / angular velocity: same update
 
 
 @pytest.mark.gpu
