@@ -150,6 +150,16 @@ int cs_update_humans_parallel(const cs_worlds* w, float dt, float* d_out, void* 
 int cs_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action, void* stream);
 
 /*
+ * cs_step_trace  cs_step (same kernel build, same arithmetic, same in-place update -- the launch differs only in one non-NULL
+ *   kernel argument) that also records every human's row AFTER every fused substep, so that a test can check each substep of a
+ *   fused launch on its own against the reference's single-substep function (forces_parallel.py:185-284 + the respawn rule,
+ *   motion_model_manager.py:407-422) restarted from the previous record.
+ *   d_trace [n_substeps][W][n][12] = px, py, theta, vx, vy, bvx, bvy, omega, gx, gy (state columns 10:12), goals[0].x, goals[0].y.
+ *   Types 0..8, worlds of up to 1024 rows; other worlds -> CS_ERR_ARG.
+ */
+int cs_step_trace(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_trace, void* stream);
+
+/*
  * cs_peek  replaces MotionModelManager.get_next_human_observable_states(dt, theta_and_omega_visible)
  *   (motion_model_manager.py:691-709): one Euler step of size dt WITHOUT committing it.
  *   d_next: [W][n][8] rows  x, y, yaw, Vx, Vy, Omega, Gx, Gy  (get_human_states(include_goal=True,

@@ -299,6 +299,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         STAMP(7);
         // imitation block: what the robot's own integrator sees of the crowd at this substep (it runs before update_humans)
         if (a.snap != nullptr && human) a.snap[((long)sub * a.W + w) * n + row] = make_float4(px, py, vx, vy);
+        // cs_step_trace: my row as the previous substep left it (the last one is written behind the loop)
+        if (a.trace != nullptr && human && sub > 0)
+            write_trace(a.trace + (((long)(sub - 1) * a.W + w) * n + row) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
         const int Hf = (rows - 1) >> 1;
         const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
         const float2* rv = lds_v + cur * TP + pbase + row + 1;
@@ -901,6 +904,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     }
 #endif
 
+    if (a.trace != nullptr && human && a.nsub > 0)
+        write_trace(a.trace + (((long)(a.nsub - 1) * a.W + w) * n + row) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
+
     // ---- epilogue ---------------------------------------------------------------------------
     if (kmode & M_PEEK) {
         if (human) {
@@ -1161,7 +1167,7 @@ kfn variant_kernel(const Variant& v, int type)
 }
 
 int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, const float* d_action,
-                float* d_peek, hipStream_t stream, float4* d_snap = nullptr)
+                float* d_peek, hipStream_t stream, float4* d_snap = nullptr, float* d_trace = nullptr)
 {
     int rc = check_worlds(w);
     if (rc) return rc;
@@ -1169,6 +1175,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     rc = geometry(w, g);
     if (rc) return rc;
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    if (rows > csimpl::big_world_min_rows(1024) && d_trace) return fail(CS_ERR_ARG, "cs_step_trace is not built for worlds beyond one block");
     if (rows > csimpl::big_world_min_rows(1024))   // worlds beyond one block: partners through a uniform grid in HBM (bigworld.hip)
         return csimpl::sfm_big_launch(w, dt, nsub, d_out ? d_out : w->d_state, (mode & M_MUTATE_INPUT) ? 1 : 0,
                                       (mode & M_ROBOT_FROM_ARRAY) != 0, d_action, (mode & M_PEEK) ? d_peek : nullptr, stream);
@@ -1191,6 +1198,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.stamps = g_stamp_buf;
 #endif
     a.snap = d_snap;
+    a.trace = d_trace;
     const Variant v = select_variant(w, mode, g, d_snap != nullptr);
     const bool peq = v.peq;
     if (v.maxt == 16) return csimpl::row16_launch(a, stream);
@@ -1285,6 +1293,17 @@ int cs_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action,
     int mode = M_COMMIT_GOALS;
     if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
     return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream);
+}
+
+int cs_step_trace(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_trace, void* stream)
+{
+    if (!w || !d_trace) return fail(CS_ERR_ARG, "null argument");
+    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
+    if (d_action && !w->d_robot) return fail(CS_ERR_ARG, "robot action given but cs_worlds.d_robot is null");
+    if (w->type < 0 || w->type > 8) return fail(CS_ERR_ARG, "cs_step_trace covers the SFM / HSFM models (types 0..8)");
+    int mode = M_COMMIT_GOALS;
+    if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
+    return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream, nullptr, d_trace);
 }
 
 int cs_peek(const cs_worlds* w, float dt, float* d_next, void* stream)

@@ -122,6 +122,9 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
     if (HEADED > 0 && human) sincos_fast(th, sn, cs);
 
     for (int sub = 0; sub < a.nsub; ++sub) {
+        // cs_step_trace: my row as the previous substep left it (the last one is written behind the loop)
+        if (a.trace != nullptr && human && sub > 0)
+            write_trace(a.trace + (((long)(sub - 1) * a.W + w) * ROWS + r) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
         // -- goal switch, forces_parallel.py:226-234, predicated: lists of <= 2 goals rotate in registers
         {
             const float gdx = g0x - px, gdy = g0y - py;
@@ -261,6 +264,9 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
             }
         }
     }
+
+    if (a.trace != nullptr && human && a.nsub > 0)
+        write_trace(a.trace + (((long)(a.nsub - 1) * a.W + w) * ROWS + r) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
 
     // ---- epilogue ---------------------------------------------------------------------------
     if (human && gdirty) { gi[0] = g0x; gi[1] = g0y; gi[2] = g1x; gi[3] = g1y; }

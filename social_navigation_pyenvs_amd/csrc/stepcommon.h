@@ -40,6 +40,8 @@ struct KArgs {
     const int* world_flags;
     float bx, by;
     float4* snap;          // optional [nsub][W][n] (x, y, vx, vy) of every human at the START of every substep (imitation block)
+    float* trace;          // optional [nsub][W][n][12] px, py, theta, vx, vy, bvx, bvy, omega, gx, gy, goals[0].x, goals[0].y of every
+                           // human AFTER every substep (respawn included): cs_step_trace, the per-substep parity tests
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     unsigned long long* stamps; // diagnostic build only
 };
@@ -72,6 +74,16 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int PADR = 8;  // partner rows are read in groups of 8: readable (finite) padding behind each buffer
 
 __device__ __forceinline__ float norm2(float x, float y) { return sqrt_fast(fmaf(x, x, y * y)); }
+
+// one human's record of cs_step_trace (three 16-byte stores; the record stride is 48 bytes)
+__device__ __forceinline__ void write_trace(float* o, float px, float py, float th, float vx, float vy, float bvx, float bvy, float om,
+                                            float gx, float gy, float g0x, float g0y)
+{
+    float4* q = reinterpret_cast<float4*>(o);
+    q[0] = make_float4(px, py, th, vx);
+    q[1] = make_float4(vy, bvx, bvy, om);
+    q[2] = make_float4(gx, gy, g0x, g0y);
+}
 
 // sin and cos together: Cody-Waite reduction by pi/2 + degree-7/8 minimax polynomials; abs error
 // < 1e-7 for |x| < 50 (theta is kept in [-pi, pi] by bound_angle)

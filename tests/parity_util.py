@@ -81,3 +81,114 @@ def write_report(root: str) -> None:
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_report.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Per-substep parity INSIDE a fused launch (cs_step_trace): substep k + 1 of the GPU against the oracle's single substep
+# restarted from the GPU's own substep-k rows.  The bar is north_star's 1e-5 on every substep; a substep on which the
+# float32 instantiation of the oracle itself is farther than that from its float64 instantiation (a body contact at
+# 25 kN/m after a respawn, Moussaid's sign(theta ~ 0)) is ill-conditioned in float32 whoever computes it: there the GPU
+# must stay within twice the float32 oracle's own error, and the case is counted as outside 1e-5 in the report.
+# ---------------------------------------------------------------------------------------------------------------------
+def row_errors(got, ref, omega_in, dt, headed):
+    """Vectorised column rules of this module for rows [..., >= 8]: returns (err [...], omega_rel [...], lost [...] bool):
+    err = worst of |d px|, |d py| (+ |d bvx|, |d bvy|, and theta / vx / vy minus what float32 holds of theta + omega_in dt when
+    headed); omega_rel = relative omega error; lost = rows whose heading float32 cannot hold at all."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        d = np.abs(got[..., :8] - ref[..., :8])
+        e = np.maximum(d[..., 0], d[..., 1])
+        zero = np.zeros(e.shape)
+        if not headed:
+            return np.maximum(e, np.maximum(d[..., 3], d[..., 4])), zero, np.zeros(e.shape, bool)
+        e = np.maximum(e, np.maximum(d[..., 5], d[..., 6]))
+        swing = np.abs(np.asarray(omega_in, dtype=np.float64)) * abs(dt)
+        lost = ~(swing <= 1e4)
+        allow = 4.0 * EPS32 * np.where(lost, 0.0, swing)
+        dth = np.minimum(d[..., 2], np.abs(d[..., 2] - 2.0 * np.pi))
+        hv = np.maximum(np.maximum(d[..., 3], d[..., 4]), dth) - allow
+        e = np.where(lost, e, np.maximum(e, hv))
+        small = (np.abs(ref[..., 7]) < 1e30) & (np.abs(np.asarray(omega_in, dtype=np.float64)) < 1e30)
+        rel = np.where(small, d[..., 7] / np.maximum(1.0, np.abs(ref[..., 7])), 0.0)
+    e = np.where(np.isfinite(e), e, np.inf)
+    return e, rel, lost
+
+
+def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, nsub, peq, *, respawn=None, respawn_bounds=None,
+                             robot_row=False, worlds=None, group=None, what="", bar=1e-5, omega_rtol=2e-4):
+    """Run cw.step_trace(dt, nsub) (cs_step's kernel build, state updated in place) and check EVERY substep of the fused
+    launch: record k + 1 against orc.step_block(1 substep, respawn rule included) from the GPU's record k (float32 rows
+    read as float64).  S0 [W, rows, 13], goals0 [W, n, G, 2] = what the batch was created from; `worlds` = the worlds to
+    check (default all).  Returns a dict of figures; asserts the bar described above on every substep of every checked world."""
+    from oracle import crowd_oracle as orc
+
+    trace = cw.step_trace(dt, nsub)                                     # [K, W, n, 12]
+    S0 = np.asarray(S0, dtype=np.float32); goals0 = np.asarray(goals0, dtype=np.float32)
+    if S0.ndim == 2:
+        S0, goals0 = S0[None], goals0[None]
+    W, rows = S0.shape[0], S0.shape[1]
+    n = rows - int(robot_row)
+    sel = np.arange(W) if worlds is None else np.asarray(worlds)
+    S = S0[sel].astype(np.float64)
+    goals = goals0[sel].astype(np.float64).reshape(len(sel), n, -1, 2)
+    G = goals.shape[2]
+    P64 = np.asarray(P, dtype=np.float32).astype(np.float64)
+    Psel = P64 if P64.ndim == 2 else P64[sel]
+    saf = np.ascontiguousarray(np.broadcast_to(np.asarray(0.0 if safety is None else safety, dtype=np.float32), (W, rows)))[sel].astype(np.float64)
+    obs = None if obstacles is None else np.asarray(obstacles, dtype=np.float32).astype(np.float64)
+    rsp = np.zeros(len(sel), bool) if respawn is None else np.broadcast_to(np.asarray(respawn).astype(bool), (W,))[sel]
+    headed = type_ >= 3
+    out = {"substeps": 0, "within": 0, "worst": 0.0, "worst_f32_oracle": 0.0, "ill_conditioned": 0, "goal_flips": 0, "lost_heading_rows": 0}
+    for k in range(nsub):
+        ref = np.empty_like(S); ref32 = np.empty_like(S); gnext = np.empty_like(goals)
+        for flag in (False, True):
+            m = rsp == flag
+            if not m.any():
+                continue
+            rp = (respawn_bounds[0], respawn_bounds[1], 0.0) if flag else (0.0, 0.0, 0.0)
+            o = obs if (obs is None or obs.ndim == 4) else obs[sel][m]
+            args = (type_, S[m], goals[m], o, Psel if Psel.ndim == 2 else Psel[m], dt, 1, saf[m], peq)
+            r64, g64, _ = orc.step_block(*args, robot_visible=robot_row, respawn=flag, respawn_par=rp)
+            with np.errstate(over="ignore", invalid="ignore"):
+                r32, _, _ = orc.step_block(*args, robot_visible=robot_row, respawn=flag, respawn_par=rp, dtype=np.float32)
+            ref[m], ref32[m], gnext[m] = r64, r32, g64.reshape(-1, n, G, 2)
+        got = trace[k][sel].astype(np.float64)                           # [w, n, 12]
+        om_in = S[:, :n, 7]
+        e_gpu, rel, lost = row_errors(got, ref[:, :n], om_in, dt, headed)
+        e_f32, _, _ = row_errors(ref32[:, :n], ref[:, :n], om_in, dt, headed)
+        wg, wf = e_gpu.max(axis=1), e_f32.max(axis=1)                     # per world
+        allowed = np.maximum(bar, 2.0 * wf)
+        bad = ~(wg < allowed)
+        assert not bad.any(), (f"{what}: substep {k + 1} of the fused launch, world {int(sel[np.argmax(bad)])}: GPU {wg[bad].max():.3e} vs f64 oracle "
+                               f"(float32 oracle {wf[bad].max():.3e}, bar {bar:.0e})")
+        if headed:
+            relw = np.where(lost, 0.0, rel).max(axis=1)
+            assert np.all(relw < np.maximum(omega_rtol, 1e3 * wf)), f"{what}: substep {k + 1}: omega relative error {relw.max():.3e}"
+        # exact / control-flow columns: the state's goal columns, the head of the goal list
+        gcol = np.abs(got[..., 8:10] - ref[:, :n, 10:12]).max(axis=-1)
+        head = np.abs(np.nan_to_num(got[..., 10:12]) - np.nan_to_num(gnext[:, :, 0])).max(axis=-1)
+        flip = (head > 1e-5) | (gcol > 1e-5)
+        if flip.any():                                                    # a goal-switch / respawn decision on a float32 rounding edge
+            fw, fi = np.nonzero(flip)
+            for a_, b_ in zip(fw, fi):
+                p_in, r_in = S[a_, b_, 0:2], S[a_, b_, 8]
+                edge = abs(np.linalg.norm(goals[a_, b_, 0] - p_in) - r_in) < 1e-5 or abs(np.linalg.norm(p_in - goals[a_, b_, 0]) - 3.0) < 1e-4
+                assert edge, f"{what}: substep {k + 1} world {int(sel[a_])} human {b_}: goal columns differ away from a decision edge"
+                if G >= 2 and np.allclose(got[a_, b_, 10:12], gnext[a_, b_, 1], atol=1e-5):
+                    gnext[a_, b_, [0, 1]] = gnext[a_, b_, [1, 0]]
+            out["goal_flips"] += int(flip.sum())
+        out["substeps"] += len(sel); out["within"] += int(np.sum(wg < bar)); out["ill_conditioned"] += int(np.sum(wf >= bar))
+        out["worst"] = max(out["worst"], float(wg.max())); out["worst_f32_oracle"] = max(out["worst_f32_oracle"], float(wf.max()))
+        out["lost_heading_rows"] += int(lost.sum())
+        if group:
+            for x, y in zip(wg, wf):
+                record(group, float(x), bar)
+                REPORT[group]["worst_f32_oracle"] = max(REPORT[group].get("worst_f32_oracle", 0.0), float(y))
+        # the next substep starts from the GPU's rows; goal lists follow the oracle's rotation with the GPU's (float32) head
+        S[:, :n, 0:8] = got[..., 0:8]
+        S[:, :n, 10:12] = got[..., 8:10]
+        goals = gnext
+        keep = ~np.isnan(goals[:, :, 0, 0])
+        goals[:, :, 0][keep] = got[..., 10:12][keep]
+    return out

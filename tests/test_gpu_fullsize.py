@@ -106,6 +106,40 @@ def test_full_size_properties(cfg):
         record(f"full size {cfg} 20 substeps from the evolved state (GPU vs f64 oracle)", err)
 
 
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg3x4", "cfg5shard"])
+def test_full_size_every_substep_of_the_fused_launch(cfg):
+    """north_star's 1e-5 per SUBSTEP inside the fused 20-substep launch at BASELINE.json's full sizes, for the very kernel
+    builds the published numbers come from: cs_step_trace records every row after every fused substep of ALL worlds; 48 sampled
+    worlds are checked substep by substep against the oracle's single substep (respawn rule included) restarted from the GPU's
+    own previous rows -- from the initial state and from the evolved one (three Gym steps in: contacts, goal switches, respawns)."""
+    from parity_util import fused_substeps_vs_oracle
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    W, n, model, S, goals, P, rb, rw, walls = _worlds(cfg)
+    t = SFMS.index(model)
+    rng = np.random.default_rng(11)
+
+    def make(S_, g_):
+        return CrowdWorlds(S_, g_, P, None, walls, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw, layout="soa")
+
+    cw = make(S, goals)
+    assert VARIANT[cfg] in cw.step_variant(), cw.step_variant()
+    S_k, g_k = S, goals
+    for phase in ("initial state", "evolved state"):
+        sample = rng.choice(W, 48, replace=False)
+        res = fused_substeps_vs_oracle(cw, t, S_k, g_k, P, None, walls, 0.0125, 20, True, respawn=rw, respawn_bounds=rb, worlds=sample,
+                                       group=f"full size {cfg} per substep inside the fused launch, {phase}", what=f"{cfg} {phase}")
+        assert res["within"] >= res["substeps"] - res["ill_conditioned"], (cfg, phase, res)
+        if phase == "initial state":
+            # the traced launch is cs_step's launch: same rows as an untraced batch, bit for bit
+            ref = make(S, goals)
+            ref.step(0.0125, 20)
+            np.testing.assert_array_equal(cw.get_states(), ref.get_states())
+            for _ in range(3):
+                cw.step(0.0125, 20)
+            S_k, g_k = cw.get_states(), cw.get_goals()
+
+
 def test_fused_block_equals_repeated_single_substeps_bitwise():
     """n fused substeps == n launches of one substep (same arithmetic, state round-trips through HBM)."""
     from social_navigation_pyenvs_amd.batched import CrowdWorlds

@@ -15,7 +15,7 @@ import pytest
 
 from golden_io import load_cases
 from oracle import crowd_oracle as orc
-from parity_util import compare_rows, f32, record
+from parity_util import compare_rows, f32, fused_substeps_vs_oracle, record, row_errors
 
 pytestmark = pytest.mark.gpu
 
@@ -61,10 +61,19 @@ def test_single_substep_vs_golden_and_oracle(group):
         with np.errstate(over="ignore"):
             om_in = f32(c["state_in"])[:n, 7].astype(np.float64)
         ref64, s_after, goals_after = oracle_from_f32(c)
-        # every dynamic column against the f64 oracle run from the same f32-rounded inputs
-        err_o, u = compare_rows(got[:n], ref64[:n], om_in, c["dt"], TOL[group], headed, f"{group} case {k} type {c['type']} vs oracle")
+        # every dynamic column against the f64 oracle run from the same f32-rounded inputs.  The bar is 1e-5; a synthetic extreme
+        # state on which the float32 instantiation of the oracle is itself farther than that from the float64 one (overlaps, forces
+        # of 1e7 N) may be as far as twice the float32 oracle's own error -- measured per case, no blanket tolerance
+        with np.errstate(over="ignore", invalid="ignore"):
+            ref32, _, _ = oracle_from_f32(c, dtype=np.float32)
+        e32 = float(row_errors(ref32[:n], ref64[:n], om_in, c["dt"], headed)[0].max())
+        tol_k = max(1e-5, 2.0 * e32)
+        assert tol_k <= TOL[group], (group, k, e32)
+        err_o, u = compare_rows(got[:n], ref64[:n], om_in, c["dt"], tol_k, headed, f"{group} case {k} type {c['type']} vs oracle (f32 oracle {e32:.2e})")
         lost += u
         record(f"{group} (GPU vs f64 oracle, same f32 inputs)", err_o, unrepresentable_rows=u)
+        if e32 >= 1e-5:
+            record(f"{group} cases whose float32 ORACLE is beyond 1e-5 (GPU error / float32 oracle error)", err_o / e32, bar=2.0)
         if c["type"] % 3 != 2:  # continuous models: straight against what the reference returned
             err_g, _ = compare_rows(got[:n], c["state_out"][:n], om_in, c["dt"], TOL[group], headed,
                                     f"{group} case {k} type {c['type']} vs golden")
@@ -197,6 +206,39 @@ def test_block_of_20_substeps(group):
             moved = np.abs(c["out_states"][:, 0] - c["in_states"][:, 0]) > 1.0
             assert np.array_equal(moved, np.abs(got[:, 0] - f32(c["in_states"])[:, 0]) > 1.0)
     assert first_only <= {"g2_block": 1, "g13_block_sizes": 2}[group], first_only
+
+
+@pytest.mark.parametrize("group", ["g2_block", "g13_block_sizes"])
+def test_every_substep_inside_the_fused_block(group):
+    """north_star's 1e-5 PER SUBSTEP inside the fused launch, for every golden block and every kernel build they select
+    (row16, ROWS_CT = 25 / 50, LEAN = 1 / 2, the generic build): cs_step_trace records every human's row after every one
+    of the 20 fused substeps (respawn substeps included); substep k + 1 is compared with the oracle's single substep
+    (forces_parallel.py:185-284 + motion_model_manager.py:407-422) restarted from the GPU's own substep-k rows.  No
+    tolerance is widened for accumulated chaos: the 20-substep end state (test_block_of_20_substeps) is the secondary bound.
+    Where the float32 instantiation of the oracle is itself farther than 1e-5 from the float64 one (a respawned human placed
+    at exact contact distance, Moussaid's sign(theta ~ 0)) the GPU must stay within twice that."""
+    strict_cases = strict_ok = 0
+    for k, c in enumerate(load_cases(group)):
+        cw = _block_worlds(c)
+        if group == "g13_block_sizes":
+            want = G13_VARIANT[c["kind"]]
+            want = want % (c["type"] % 3, c["type"] // 3) if "%d" in want else want
+            assert want in cw.step_variant(), (c["kind"], cw.step_variant())
+        fam = "Moussaid" if c["type"] % 3 == 2 else "Helbing / Guo"
+        res = fused_substeps_vs_oracle(cw, c["type"], c["in_states"], c["in_goals"], c["in_params"], c["in_safety"], c.get("in_obstacles"),
+                                       c["dt"], c["n_substeps"], c["all_params_equal"], respawn=c["respawn"],
+                                       respawn_bounds=c["respawn_bounds"] if c["respawn"] else None,
+                                       group=f"{group} per substep inside fused block ({fam})", what=f"{group} case {k} {c['kind']} {c['model']}")
+        if c["type"] % 3 != 2:
+            strict_cases += res["substeps"] - res["ill_conditioned"]
+            strict_ok += res["within"]
+            assert res["within"] >= res["substeps"] - res["ill_conditioned"], (k, res)
+        # the traced launch IS cs_step: same end state, bit for bit
+        ref = _block_worlds(c)
+        ref.step(c["dt"], c["n_substeps"])
+        np.testing.assert_array_equal(cw.get_states(), ref.get_states())
+        np.testing.assert_array_equal(cw.get_goals(), ref.get_goals())
+    assert strict_cases > 0 and strict_ok >= strict_cases
 
 
 def test_respawn_g7_with_and_without_robot():
