@@ -279,12 +279,24 @@ int cs_robot_model_velocities(const cs_worlds* w, int32_t robot_type, const floa
  *   n_substeps x { motion_model_manager.update_robot(t, dt) ; motion_model_manager.update_humans(t, dt) }, arguments as
  *   cs_robot_model_step.  With an invisible robot (no CS_ROBOT_ROW: the crowd does not see it) and SFM / HSFM models on both sides
  *   this is TWO launches: the crowd's n fused substeps, which also record what the robot's integrator sees of the humans at the
- *   start of every substep (positions and linear velocities, library-owned scratch), and the robot's n substeps against those
+ *   start of every substep (positions and linear velocities, library-owned scratch: see cs_reserve_scratch), and the robot's n substeps against those
  *   records -- bit-identical to the alternating launches.  Otherwise (visible robot, ORCA on either side) the 2 n launches are
  *   issued in the reference's order.
  */
 int cs_imitation_block(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
                        const float* d_human_margin, float* d_robot_memory, float dt, int n_substeps, void* stream);
+
+/*
+ * Library-owned scratch.  Three entry points keep device scratch of their own: cs_imitation_block's fused form (what the robot sees
+ * of the crowd, [n_substeps][W][n] x 16 B) and cs_step / cs_update_humans_parallel for worlds beyond one block (double-buffered
+ * rows + the neighbour grid).  The block belongs to (device, stream, use): batches driven on different streams never share one.
+ * Nothing is allocated, grown or freed while `stream` is capturing: an entry point that would have to returns CS_ERR_ARG
+ * -- call cs_reserve_scratch(w, n_substeps, stream) (or the entry point itself once) before cs_graph_begin_capture.  A block
+ * handed out during a capture is never freed behind a graph's back (growing it later retires the old block); cs_release_scratch
+ * synchronises the device and frees every block -- only when no captured graph that used them will be replayed again.
+ */
+int cs_reserve_scratch(const cs_worlds* w, int n_substeps, void* stream);
+int cs_release_scratch(void);
 
 /*
  * cs_actual_collision_reward  replaces SocialNavGym.check_actual_collisions_and_goal (social_nav_gym.py:107-118) +

@@ -315,6 +315,12 @@ class CrowdWorlds:
                                              C.c_void_p(_ptr(self.d_human_margin)), C.c_void_p(_ptr(self.d_robot_memory)),
                                              C.c_float(dt), C.c_int(int(n_substeps)), C.c_void_p(self.stream)))
 
+    def reserve_scratch(self, n_substeps: int = 20) -> None:
+        """cs_reserve_scratch: allocate, outside any stream capture, the library-owned scratch that imitation_block (fused form) or
+        step (worlds beyond one block) need for this batch on its stream -- required before the first such call is CAPTURED."""
+        d = self.descriptor()
+        check(_lib.load().cs_reserve_scratch(C.byref(d), C.c_int(int(n_substeps)), C.c_void_p(self.stream)))
+
     def actual_collision_reward(self, T: float, global_time, reward_cfg=(50.0, 1.0, -0.25, 0.2, 0.5)) -> np.ndarray:
         """[W, 7] like collision_reward, from the distances of the current state (social_nav_gym.py:107-118)."""
         if self.d_robot is None:

@@ -316,6 +316,7 @@ size_t grid_bytes(int W, int rows, int NB)
 int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const float* d_inv_cell, float inv_cell, void* mem, GridView& g, hipStream_t stream)
 {
     const size_t total = (size_t)W * rows;
+    if ((long long)W * NB >= (1ll << 31) || total >= (1ull << 31)) return fail(CS_ERR_ARG, "worlds beyond one block: W x buckets (or W x rows) does not fit the 32-bit grid keys");
     char* p = (char*)mem;
     auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
     g.W = W; g.rows = rows; g.NB = NB;
@@ -337,6 +338,21 @@ int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const 
     return CS_OK;
 }
 
+int big_world_buckets(int rows)
+{
+    int NB = 1024;
+    while (NB < 2 * rows && NB < (1 << 20)) NB <<= 1;
+    return NB;
+}
+
+size_t sfm_big_scratch_bytes(const cs_worlds* w)
+{
+    const int W = w->W, rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    const size_t state_bytes = ((size_t)W * rows * 13 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t misc = (((size_t)W * sizeof(float) + 255) & ~(size_t)255) + (size_t)W * rows * sizeof(float2) + 256;
+    return 2 * state_bytes + misc + grid_bytes(W, rows, big_world_buckets(rows));
+}
+
 // n_substeps Euler substeps of worlds beyond one block.  d_out: where the result goes (w->d_state for cs_step / the in-place
 // update); mutate_input: reproduce the reference's in-place writes on w->d_state (out-of-place cs_update_humans_parallel).
 int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, int mutate_input, bool robot_from_array, const float* d_action,
@@ -346,12 +362,14 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
     if (w->flags & CS_RESPAWN) return fail(CS_ERR_ARG, "the respawn rule is not built for worlds beyond one block");
     if (robot_from_array || d_action) return fail(CS_ERR_ARG, "worlds beyond one block take the robot as the last state row (no cs_worlds.d_robot, no action)");
     const int W = w->W, n = w->n, rows = n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
-    int NB = 1024;
-    while (NB < 2 * rows && NB < (1 << 20)) NB <<= 1;
+    const int NB = big_world_buckets(rows);
     const size_t state_bytes = ((size_t)W * rows * 13 * sizeof(float) + 255) & ~(size_t)255;
     const size_t misc = (((size_t)W * sizeof(float) + 255) & ~(size_t)255) + (size_t)W * rows * sizeof(float2) + 256;
-    char* base = (char*)scratch(2 * state_bytes + misc + grid_bytes(W, rows, NB), 1);
-    if (!base) return CS_ERR_HIP;
+    char* base = nullptr;
+    {
+        const int rcs = scratch((void**)&base, sfm_big_scratch_bytes(w), SCRATCH_SFM_BIG, stream);
+        if (rcs) return rcs;
+    }
     GArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = W; a.n = n; a.rows = rows; a.G = w->G; a.O = w->O; a.Smax = w->Smax; a.NB = NB; a.type = w->type; a.flags = w->flags; a.dt = dt;

@@ -28,15 +28,21 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
 int orca_variant(const cs_worlds* w, char* buf, size_t buflen);
 // the robot's own ORCA model, one doStep of the robot per world (orca.hip; cs_robot_model_step with CS_ORCA)
 int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream);
-// library-owned device scratch (grow-only, one slot per use, per host thread): the double-buffered state and the neighbour grid of
-// worlds beyond one block.  Returns nullptr (and sets the error) when hipMalloc fails.
-void* scratch(size_t bytes, int slot);
+// library-owned device scratch, one block per (device, stream, use); never allocated, grown or freed while `stream` is capturing
+// (CS_ERR_ARG then -- cs_reserve_scratch first), a block handed out during a capture is never freed before cs_release_scratch
+enum { SCRATCH_ORCA_BIG = 0, SCRATCH_SFM_BIG = 1, SCRATCH_IMITATION = 2 };
+int scratch(void** out, size_t bytes, int slot, hipStream_t stream);
+int scratch_release_all();
+inline size_t imitation_scratch_bytes(const cs_worlds* w, int n_substeps) { return (size_t)n_substeps * w->W * w->n * 4 * sizeof(float); }
+size_t sfm_big_scratch_bytes(const cs_worlds* w);
+size_t orca_big_scratch_bytes(const cs_worlds* w);
 int big_world_min_rows(int dflt);
 // the uniform grid of worlds beyond one block (bigworld.hip): rows binned into hashed buckets of square cells, every bucket's rows in
 // index order (stable radix sort); start[w * NB + b] .. start[w * NB + b + 1] = bucket b of world w in `sorted` (row indices)
 struct GridView { int W, rows, NB; int2* cellxy; unsigned* keys; unsigned* keys_sorted; int* idx; int* sorted; int* start; };
 __host__ __device__ inline int cell_bucket(int cx, int cy, int NB) { return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u)) & (NB - 1); }
 size_t grid_bytes(int W, int rows, int NB);
+int big_world_buckets(int rows);   // hashed buckets of a world's grid: the power of two >= 2 * rows (1024 .. 2^20)
 int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const float* d_inv_cell, float inv_cell, void* mem, GridView& g, hipStream_t stream);
 // SFM / HSFM worlds beyond one block (bigworld.hip)
 int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, int mutate_input, bool robot_from_array, const float* d_action,

@@ -19,7 +19,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
+#include <vector>
 #include <type_traits>
 #include <utility>
 
@@ -30,19 +34,56 @@
 namespace csimpl {
 thread_local std::string g_err;
 
-void* scratch(size_t bytes, int slot)
+// Library-owned device scratch, keyed by (device, stream, use): two batches on different streams never share a block
+// (work on ONE stream is ordered, so reuse there is safe).  Capture rules: nothing is allocated or freed while `stream` is
+// capturing -- a block that would have to be allocated or grown then is refused with CS_ERR_ARG (reserve it first:
+// cs_reserve_scratch, or one call of the entry point outside the capture); a block handed out during a capture is PINNED:
+// a graph holds its address, so growing it later retires the old block instead of freeing it (cs_release_scratch frees all).
+namespace {
+struct ScratchBlock { void* p = nullptr; size_t cap = 0; bool pinned = false; };
+std::mutex g_scratch_mu;
+std::map<std::tuple<int, hipStream_t, int>, ScratchBlock> g_scratch;
+std::vector<std::pair<int, void*>> g_retired;
+}
+
+int scratch(void** out, size_t bytes, int slot, hipStream_t stream)
 {
-    struct Slot { void* p = nullptr; size_t cap = 0; int dev = -1; };
-    static thread_local Slot slots[4];
+    *out = nullptr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { g_err = "hipGetDevice failed"; return nullptr; }
-    Slot& s = slots[slot & 3];
-    if (s.p && s.dev == dev && s.cap >= bytes) return s.p;
-    if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }     // (hipFree synchronises: earlier users of the old block are done)
-    const hipError_t e = hipMalloc(&s.p, bytes);
-    if (e != hipSuccess) { g_err = std::string("hipMalloc of crowdstep scratch: ") + hipGetErrorString(e); s.p = nullptr; return nullptr; }
-    s.cap = bytes; s.dev = dev;
-    return s.p;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(CS_ERR_HIP, "hipGetDevice failed");
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (stream != nullptr && hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusNone; }
+    const bool capturing = st == hipStreamCaptureStatusActive;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    ScratchBlock& b = g_scratch[std::make_tuple(dev, stream, slot)];
+    if (b.p && b.cap >= bytes) { b.pinned = b.pinned || capturing; *out = b.p; return CS_OK; }
+    if (capturing)
+        return fail(CS_ERR_ARG, "crowdstep needs " + std::to_string(bytes) + " bytes of library scratch on this stream, which cannot be allocated while "
+                                "the stream is capturing: call cs_reserve_scratch (or this entry point once) on the stream before the capture");
+    if (b.p) {
+        if (b.pinned) g_retired.emplace_back(dev, b.p);     // a captured graph may still replay into it
+        else (void)hipFree(b.p);                            // (hipFree synchronises: earlier users of the old block are done)
+        b = ScratchBlock{};
+    }
+    const hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { b = ScratchBlock{}; return fail(CS_ERR_HIP, std::string("hipMalloc of crowdstep scratch: ") + hipGetErrorString(e)); }
+    b.cap = bytes;
+    *out = b.p;
+    return CS_OK;
+}
+
+int scratch_release_all()
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    int dev0 = 0;
+    (void)hipGetDevice(&dev0);
+    for (auto& kv : g_scratch)
+        if (kv.second.p) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(kv.second.p); }
+    g_scratch.clear();
+    for (auto& r : g_retired) { (void)hipSetDevice(r.first); (void)hipFree(r.second); }
+    g_retired.clear();
+    (void)hipSetDevice(dev0);
+    return CS_OK;
 }
 #ifdef CS_STAMPS
 unsigned long long* g_stamp_buf = nullptr;
@@ -1381,9 +1422,10 @@ int cs_imitation_block(const cs_worlds* w, int32_t robot_type, const float* robo
     const bool fusable = !(w->flags & CS_ROBOT_ROW) && w->type >= 0 && w->type <= 8 && robot_type >= 0 && robot_type <= 8 &&
                          rows <= 64 && w->d_robot != nullptr;
     if (fusable) {
-        float4* snap = (float4*)csimpl::scratch((size_t)n_substeps * w->W * w->n * sizeof(float4), 2);
-        if (!snap) return CS_ERR_HIP;
-        int rc = launch_step(w, dt, n_substeps, M_COMMIT_GOALS, nullptr, nullptr, nullptr, (hipStream_t)stream, snap);
+        float4* snap = nullptr;
+        int rc = csimpl::scratch((void**)&snap, csimpl::imitation_scratch_bytes(w, n_substeps), csimpl::SCRATCH_IMITATION, (hipStream_t)stream);
+        if (rc) return rc;
+        rc = launch_step(w, dt, n_substeps, M_COMMIT_GOALS, nullptr, nullptr, nullptr, (hipStream_t)stream, snap);
         if (rc) return rc;
         return csimpl::robot_block_launch(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, n_substeps, snap,
                                           (hipStream_t)stream);
@@ -1395,6 +1437,30 @@ int cs_imitation_block(const cs_worlds* w, int32_t robot_type, const float* robo
         if (rc) return rc;
     }
     return CS_OK;
+}
+
+int cs_reserve_scratch(const cs_worlds* w, int n_substeps, void* stream)
+{
+    if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
+    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    void* p = nullptr;
+    int rc = CS_OK;
+    if (w->type == CS_ORCA) {
+        if (rows > csimpl::big_world_min_rows(512)) rc = csimpl::scratch(&p, csimpl::orca_big_scratch_bytes(w), csimpl::SCRATCH_ORCA_BIG, (hipStream_t)stream);
+        return rc;
+    }
+    if (w->type < 0 || w->type > 8) return CS_OK;   // (social momentum keeps no library scratch)
+    if (rows > csimpl::big_world_min_rows(1024)) return csimpl::scratch(&p, csimpl::sfm_big_scratch_bytes(w), csimpl::SCRATCH_SFM_BIG, (hipStream_t)stream);
+    if (!(w->flags & CS_ROBOT_ROW) && rows <= 64 && w->d_robot != nullptr)   // what cs_imitation_block's fused form records
+        rc = csimpl::scratch(&p, csimpl::imitation_scratch_bytes(w, n_substeps), csimpl::SCRATCH_IMITATION, (hipStream_t)stream);
+    return rc;
+}
+
+int cs_release_scratch(void)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    return csimpl::scratch_release_all();
 }
 
 int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)

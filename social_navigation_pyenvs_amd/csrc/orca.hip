@@ -1270,6 +1270,12 @@ int big_world_min_rows(int dflt)
     return v < dflt ? (v < 1 ? 1 : v) : dflt;
 }
 
+size_t orca_big_scratch_bytes(const cs_worlds* w)
+{
+    const size_t state_bytes = (size_t)w->W * w->n * 13 * sizeof(float);
+    return ((state_bytes + 255) & ~(size_t)255) + grid_bytes(w->W, w->n, big_world_buckets(w->n));
+}
+
 static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream)
 {
     if (w->flags & CS_ROBOT_ROW) return fail(CS_ERR_ARG, "ORCA worlds beyond one block (grid neighbour search) have no robot row");
@@ -1279,12 +1285,14 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     if (w->orca_max_neighbors != 10 || w->orca_n_vertices != 0)
         return fail(CS_ERR_ARG, "ORCA worlds beyond one block need max_neighbors = 10 and no static obstacles");
     const int n = w->n, W = w->W;
-    int NB = 1024;
-    while (NB < 2 * n && NB < (1 << 20)) NB <<= 1;
+    const int NB = big_world_buckets(n);
     const size_t state_bytes = (size_t)W * n * 13 * sizeof(float);
     const size_t state_pad = (state_bytes + 255) & ~(size_t)255;
-    char* base = (char*)scratch(state_pad + grid_bytes(W, n, NB), 0);
-    if (!base) return CS_ERR_HIP;
+    char* base = nullptr;
+    {
+        const int rcs = scratch((void**)&base, orca_big_scratch_bytes(w), SCRATCH_ORCA_BIG, stream);
+        if (rcs) return rcs;
+    }
     BigArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = W; a.n = n; a.G = w->G; a.NB = NB; a.dt = dt; a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
@@ -1324,9 +1332,9 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (w->orca_n_vertices > 0 && !(w->orca_time_horizon_obst > 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
     if (w->flags & CS_ROBOT_UNICYCLE) return fail(CS_ERR_ARG, "ORCA step supports holonomic robot actions only");
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
-    if (rows > big_world_min_rows(512)) return orca_big_launch(w, dt, n_substeps, d_action, d_peek, stream);
     if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
     if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
+    if (rows > big_world_min_rows(512)) return orca_big_launch(w, dt, n_substeps, d_action, d_peek, stream);
     OArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = w->W; a.n = w->n; a.rows = rows; a.G = w->G; a.flags = w->flags; a.nsub = n_substeps;

@@ -108,3 +108,32 @@ def generate_worlds(cw, scenario, seeds, *, mask=None, insert_robot=True, random
             raise ValueError("Number of humans specified is too big for desided traffic height and length")
         raise RuntimeError(f"world {bad} (seed {int(seeds[bad])}): could not place all humans within {max_tries} tries")
     return status, scn
+
+
+def static_obstacle_crossing(W, n, model="hsfm_farina", *, first_world=0, radius=14.0, n_static=3, walls=True, layout="soa",
+                             stream=None):
+    """BASELINE.json configs[4] as bench.py measures it and tests/test_gpu_fullsize.py checks it (ONE function, so both step the
+    same worlds): the reference's circular-crossing generator (social_nav_sim.py:200-299: rejection sampling against the placed
+    humans AND their goals) run on the device by cs_generate_worlds with seed 1000 + GLOBAL world id (a world does not depend on
+    the shard it is generated in), on a circle of `radius`; then the first `n_static` humans are made immobile the way
+    circular_crossing_with_static_obstacles builds them (:381-387, 416-417: desired speed 0, radius 0.8, both goals = own
+    position, standing on the inner circle radius - 3) -- that generator itself does not terminate beyond ~10 humans -- and
+    three shared polygon walls are added (scenarios.polygon_walls()).  Returns the CrowdWorlds batch."""
+    from . import scenarios as sc
+    from .batched import CrowdWorlds
+
+    obstacles = sc.polygon_walls() if walls else None
+    P = np.tile(sc.default_params(model), (n, 1))
+    cw = CrowdWorlds(np.zeros((W, n, 13), np.float32), np.full((W, n, 2, 2), np.nan, np.float32), P, None, obstacles, type=model,
+                     all_params_equal=True, layout=layout, stream=stream)
+    generate_worlds(cw, "circle_crossing", 1000 + int(first_world) + np.arange(W), insert_robot=False, circle_radius=radius)
+    k = int(n_static)
+    if k > 0:
+        S, goals = cw.get_states(), cw.get_goals()
+        ang = 2.0 * np.pi * (np.arange(k) + 0.25) / k
+        p = (radius - 3.0) * np.stack([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
+        S[:, :k, 0:2] = p; S[:, :k, 10:12] = p; S[:, :k, 3:8] = 0.0
+        S[:, :k, 8] = 0.8; S[:, :k, 12] = 0.0
+        goals[:, :k, 0] = p; goals[:, :k, 1] = p
+        cw.set_states(S); cw.set_goals(goals)
+    return cw

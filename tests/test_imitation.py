@@ -335,3 +335,54 @@ def test_imitation_block_two_launches_equal_the_alternating_launches(hmodel, rmo
     np.testing.assert_array_equal(res[0][1], res[1][1])
     np.testing.assert_array_equal(res[0][2], res[1][2])
     assert np.max(np.abs(res[0][1][:, 0:2] - robot[:, 0:2])) > 0.1
+
+
+@pytest.mark.gpu
+def test_first_ever_imitation_block_captured_into_a_graph():
+    """Library scratch and stream capture (include/crowdstep.h, cs_reserve_scratch): the very first cs_imitation_block of a
+    process-new (stream, size) may not allocate inside a capture -- it is refused with CS_ERR_ARG and the capture stays usable;
+    after cs_reserve_scratch the same first-ever call is captured, and replaying the graph equals the eager calls bit for bit.
+    Two batches on two streams keep separate scratch blocks: interleaved replays do not disturb each other."""
+    from social_navigation_pyenvs_amd import _lib
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n = 53, 19                      # a (W, n, n_substeps) no other test uses: the scratch really is new
+    S, goals, P, rb = sc.hybrid_worlds(W, n, "hsfm_farina", seed0=9)
+    rng = np.random.default_rng(3)
+    robot = np.zeros((W, 13), np.float32)
+    robot[:, 0:2] = rng.uniform(-3, 3, (W, 2)); robot[:, 8] = 0.3; robot[:, 9] = 80; robot[:, 10:12] = -robot[:, 0:2]; robot[:, 12] = 1.0
+
+    def make(stream):
+        cw = CrowdWorlds(S, goals, P, None, None, type="hsfm_farina", all_params_equal=True, respawn_bounds=rb,
+                         respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), robot=robot, stream=stream)
+        cw.set_robot_model("sfm_guo", sc.default_params("sfm_guo"), 0.0, np.zeros((W, n), np.float32))
+        return cw
+
+    eager = make(None)
+    for _ in range(4):
+        eager.imitation_block(0.0125, 23)
+    s1, s2 = _lib.stream_create(), _lib.stream_create()
+    a, b = make(s1), make(s2)
+    # (1) unreserved: refused inside the capture, nothing allocated, the capture itself survives (it records nothing)
+    with pytest.raises(ValueError, match="cs_reserve_scratch"):
+        with _lib.Graph.capture(s1):
+            a.imitation_block(0.0125, 23)
+    # (2) reserved: the first-ever call is captured
+    a.reserve_scratch(23)
+    b.reserve_scratch(23)
+    with _lib.Graph.capture(s1) as ga:
+        a.imitation_block(0.0125, 23)
+    with _lib.Graph.capture(s2) as gb:
+        b.imitation_block(0.0125, 23)
+    for _ in range(4):                  # interleaved replays on two streams: separate scratch blocks
+        ga.launch(); gb.launch()
+    _lib.stream_sync(s1); _lib.stream_sync(s2)
+    for cw in (a, b):
+        np.testing.assert_array_equal(cw.get_states(), eager.get_states())
+        np.testing.assert_array_equal(cw.get_robot(), eager.get_robot())
+    # (3) a larger block on the same stream after the capture: the pinned block is retired, not freed -- the old graph still replays
+    a.imitation_block(0.0125, 40)
+    ga.launch()
+    _lib.stream_sync(s1)
+    assert np.all(np.isfinite(a.get_states()[..., :8]))
