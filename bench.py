@@ -12,25 +12,32 @@ crossing R=7; odd: 14x3 m parallel traffic with respawn), synthetic random-goal 
 Worlds are independent: each rank owns its own 4096 worlds (weak scaling, no collective on the data
 path); the only collectives are the timing barrier and the MAX over ranks.
 
-Timing: the K steps are captured once into a HIP graph (untimed); the timed region -- barrier +
-synchronize, ONE graph launch = exactly K steps, synchronize + barrier -- is repeated R times
-(`timing_repeats`, default 50) and `ms_per_step` is the MEDIAN over the repeats of (MAX over ranks of
-the elapsed time) / K; min and max are reported beside it.  HIP events on the launch stream around
-every replay give the kernel duration.
+Timing -- STATIONARY: after the W warm-up steps the worlds (state rows, goal lists, robot rows) are snapshotted; the K
+steps are captured once into a HIP graph (untimed); the timed region -- [untimed: restore the snapshot] barrier +
+synchronize | ONE graph launch = exactly K steps | synchronize + barrier -- is repeated R times (`timing_repeats`,
+default 50), so every repeat times the SAME trajectory segment (Gym steps W .. W+K of the episode that starts at the
+reset: with W = 20, K = 200 that is the span of a whole reference episode, time_limit 50 s = 200 Gym steps).
+`ms_per_step` is the MEDIAN over the repeats of (MAX over ranks of the elapsed wall time) / K; HIP events on the launch
+stream around every replay give the kernel duration of the same samples (mean and median reported; kernel <= wall).
 
 Prints ONE JSON line on rank 0 with
   roofline      algorithmic bytes per launch / average kernel duration against the 8 TB/s HBM3E peak (the contract's
                 figure: a NORMALISED ALGORITHMIC THROUGHPUT -- the 20 fused substeps keep the state in registers / LDS,
                 so real HBM traffic is ~3 % of peak), plus `frac_vs_copy` (against a device-copy bandwidth measured in
-                this run), `traffic` / `valu` (rocprofv3 PMC figures of this command, read from profiles/pmc_summary.json
-                and tagged with the profile file they come from; null when that file has no entry)
-  other_configs kernel time and roofline fraction of BASELINE.json configs[1], [3] and [4] (cfg5 = `--total-worlds 65536`
-                x 50 HSFM humans of which 3 immobile + 3 polygon walls, strong-split over the ranks) measured in the same run
+                this run), `traffic` / `valu` (rocprofv3 PMC figures of this command from profiles/pmc_summary.json, tagged
+                with their source files and with `pmc_build_matches`: whether they were measured on the library build that is
+                running now), `valu_frac` (PMC VALU instructions per launch x 4 issue cycles / (1024 SIMDs x kernel cycles at
+                2.4 GHz): the bound that really holds for these kernels)
+  other_configs kernel time and roofline fraction of BASELINE.json configs[1], [3] (two named phases of the crossing) and [4]
+                (cfg5 = `--total-worlds 65536` x 50 HSFM humans of which 3 immobile + 3 polygon walls, strong-split over the
+                ranks), and of the shapes beside the benchmark's own (visible robot, 30 humans, per-agent parameters,
+                hsfm_new_guo), measured in the same run with the same protocol
   cpu_baseline  the C oracle timed on the host cores of this box (rank 0, N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -47,6 +54,7 @@ ALG_BYTES = {"sfm": 52, "hsfm": 76, "orca": 48}
 PAIR_FLOPS = {"helbing": 45, "guo": 60, "moussaid": 120}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32 peak (MI355X_MICROARCH.md)
+SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 256 * 4, 2.4e9, 4.0   # one wave64 VALU instruction holds its SIMD's issue for 4 cycles
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 
 
@@ -66,7 +74,10 @@ def parse(argv=None):
     ap.add_argument("--layout", default="soa", choices=["aos", "soa"])
     ap.add_argument("--walls", action="store_true", help="add 3 shared polygon walls")
     ap.add_argument("--static", type=int, default=0, help="first N humans immobile (circular_crossing_with_static_obstacles flavour; --scenario circle)")
-    ap.add_argument("--device-generator", action="store_true", help="worlds from cs_generate_worlds (circle crossing R=20, seed 1000 + global id): what the cfg5 entry of other_configs runs")
+    ap.add_argument("--device-generator", action="store_true", help="worlds from cs_generate_worlds (generators.static_obstacle_crossing: circle crossing R=14, seed 1000 + global id): what the cfg5 entry of other_configs runs")
+    ap.add_argument("--robot", action="store_true", help="a visible robot as the last state row of every world (rows = agents + 1), driven by a constant action")
+    ap.add_argument("--per-agent-params", action="store_true", help="every human its own (jittered) parameter row: all_params_equal = False")
+    ap.add_argument("--no-restore", action="store_true", help="let the worlds evolve from replay to replay (the round-2 protocol) instead of restoring the snapshot")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python (default: one HIP graph of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -81,26 +92,35 @@ def spec_key(spec) -> str:
     """key of a configuration in profiles/pmc_summary.json"""
     W = spec["worlds"]
     return (f"{spec['model']}_{spec['agents']}_{spec['scenario']}" + ("_walls" if spec["walls"] else "") + ("_static" if spec["static"] else "")
-            + ("" if W in (4096, 8192) else f"_{W}"))
+            + ("_robot" if spec.get("robot") else "") + ("_peragent" if spec.get("per_agent") else "")
+            + (f"_{spec['phase_key']}" if spec.get("phase_key") else "") + ("" if W in (4096, 8192) else f"_{W}"))
 
 
 def workload_spec(args) -> dict:
     return dict(name="main", device_generator=bool(args.device_generator), model=args.model, agents=args.agents, scenario=args.scenario, walls=bool(args.walls),
-                static=int(args.static), substeps=args.substeps, dt=args.dt, layout=args.layout,
-                worlds=args.worlds, total_worlds=args.total_worlds)
+                static=int(args.static), substeps=args.substeps, dt=args.dt, layout=args.layout, robot=bool(args.robot),
+                per_agent=bool(args.per_agent_params), worlds=args.worlds, total_worlds=args.total_worlds)
 
 
 def other_config_specs(args) -> list[dict]:
-    """BASELINE.json configs[1], [3], [4] beside the headline configs[2]."""
-    base = dict(substeps=args.substeps, dt=args.dt, layout=args.layout, walls=False, static=0, total_worlds=None)
+    """BASELINE.json configs[1], [3], [4] beside the headline configs[2], and the shapes around the benchmark's own."""
+    base = dict(substeps=args.substeps, dt=args.dt, layout=args.layout, walls=False, static=0, total_worlds=None, robot=False, per_agent=False,
+                scenario="hybrid", model="hsfm_farina", agents=25, worlds=4096, warmup=20, steps=50)
     return [
-        dict(base, name="cfg2", model="sfm_helbing", agents=10, scenario="circle", worlds=4096,
+        dict(base, name="cfg2", model="sfm_helbing", agents=10, scenario="circle",
              title="4096 worlds/GPU x 10-agent SFM (sfm_helbing) circle crossing"),
-        dict(base, name="cfg4", model="orca", agents=25, scenario="circle", worlds=4096,
-             title="4096 worlds/GPU x 25-agent ORCA circle crossing"),
-        dict(base, name="cfg5", model="hsfm_farina", agents=50, scenario="circle", walls=True, static=3, worlds=8192,
-             total_worlds=65536, device_generator=True,
-             title="65536 worlds (whole job, strong split) x 50-agent HSFM circle crossing R=20, 3 immobile humans + 3 polygon walls"),
+        # ORCA's cost follows the crossing (how many agents have an infeasible linear programme): two named, restored phases
+        dict(base, name="cfg4_first20", model="orca", scenario="circle", warmup=0, steps=20, phase_key="first20",
+             title="4096 worlds/GPU x 25-agent ORCA circle crossing, Gym steps 0-20 from the reset (agents still near the rim)"),
+        dict(base, name="cfg4_dense", model="orca", scenario="circle", warmup=25, steps=20, phase_key="dense",
+             title="4096 worlds/GPU x 25-agent ORCA circle crossing, Gym steps 25-45 (the crowd meets at the centre: the dense phase)"),
+        dict(base, name="cfg5", agents=50, scenario="circle", walls=True, static=3, worlds=8192, total_worlds=65536, device_generator=True,
+             title="65536 worlds (whole job, strong split) x 50-agent HSFM circle crossing R=14 (generators.static_obstacle_crossing: "
+                   "the worlds tests/test_gpu_fullsize.py checks), 3 immobile humans + 3 polygon walls"),
+        dict(base, name="cfg3_new_guo", model="hsfm_new_guo", title="4096 worlds/GPU x 25-agent hsfm_new_guo hybrid scenario (SURVEY.md §8d cfg3's second model)"),
+        dict(base, name="robot26", robot=True, title="4096 worlds/GPU x 25-agent hsfm_farina hybrid scenario + a VISIBLE robot (26 rows per world), constant action"),
+        dict(base, name="n30", agents=30, title="4096 worlds/GPU x 30-agent hsfm_farina hybrid scenario"),
+        dict(base, name="peragent", per_agent=True, title="4096 worlds/GPU x 25-agent hsfm_farina hybrid scenario, per-agent parameters (all_params_equal = False)"),
     ]
 
 
@@ -142,58 +162,42 @@ def host_worlds(spec, rank, world_size):
         d = goals[:, :, 0] - S[:, :, 0:2]
         S[:, :, 5:7] = d / np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
         margin = np.full(S.shape[:2], 0.01)
+    if spec.get("per_agent"):   # every human its own parameters (+-5 %, a function of the global world id): the all-partners loop
+        from social_navigation_pyenvs_amd.scenarios import _u01
+
+        wid = np.arange(first, first + W, dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            jit = np.stack([np.stack([_u01(seed0 + 11, wid, i, k, 0) for k in range(20)], -1) for i in range(n)], 1)   # [W, n, 20]
+        P = np.asarray(P)[None] * (0.95 + 0.1 * jit)
+    robot = action = None
+    if spec.get("robot"):       # a visible robot crossing the scene on the y axis (last state row of every world, moved by its action)
+        robot = np.zeros((W, 13))
+        robot[:, 0:2] = (0.0, -4.0); robot[:, 2] = np.pi / 2; robot[:, 8] = 0.3; robot[:, 9] = 80.0; robot[:, 10:12] = (0.0, 4.0); robot[:, 12] = 1.0
+        S = np.concatenate([S, robot[:, None, :]], axis=1)
+        action = np.tile(np.array([0.0, 0.4]), (W, 1))
     return dict(first=first, W=W, S=S, goals=goals, P=P, walls=walls, margin=margin, respawn_bounds=respawn_bounds,
-                respawn_worlds=respawn_worlds)
+                respawn_worlds=respawn_worlds, robot=robot, action=action, all_params_equal=not spec.get("per_agent"))
 
 
 def build_worlds(spec, rank, world_size):
     """(CrowdWorlds, host arrays or None, worlds of this rank)"""
-    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd._lib import DeviceBuffer
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
     n, model = spec["agents"], spec["model"]
     if spec.get("device_generator"):
-        # the reference's circular-crossing generator (social_nav_sim.py:200-299, rejection sampling against the placed
-        # humans AND their goals) restated on the device (cs_generate_worlds), seed 1000 + global world id, on R = 20 (50
-        # humans block 100 spots of the circle: R = 7 cannot hold them, SURVEY.md §5); then the first `static` humans are
-        # made immobile as circular_crossing_with_static_obstacles builds them (:381-387, 416-417: desired speed 0, larger
-        # radius, goal = own position, inner circle R - 3) -- that generator itself does not terminate beyond ~10 humans
         from social_navigation_pyenvs_amd import generators as gen
 
         first, W = shard_of(spec, rank, world_size)
-        radius = 20.0
-        walls = sc.polygon_walls() if spec["walls"] else None
-        P = np.tile(sc.default_params(model), (n, 1))
-        cw = CrowdWorlds(np.zeros((W, n, 13), np.float32), np.full((W, n, 2, 2), np.nan, np.float32), P, None, walls, type=model,
-                         all_params_equal=True, layout=spec["layout"])
-        gen.generate_worlds(cw, "circle_crossing", 1000 + first + np.arange(W), insert_robot=False, circle_radius=radius)
-        k = spec["static"]
-        if k > 0:
-            S, goals = cw.get_states(), cw.get_goals()
-            ang = 2.0 * np.pi * (np.arange(k) + 0.25) / k
-            p = (radius - 3.0) * np.stack([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
-            S[:, :k, 0:2] = p; S[:, :k, 10:12] = p; S[:, :k, 3:8] = 0.0
-            S[:, :k, 8] = 0.8; S[:, :k, 12] = 0.0
-            goals[:, :k, 0] = p; goals[:, :k, 1] = p
-            cw.set_states(S); cw.set_goals(goals)
+        cw = gen.static_obstacle_crossing(W, n, model, first_world=first, radius=14.0, n_static=spec["static"], walls=spec["walls"], layout=spec["layout"])
+        cw.bench_action = None
         return cw, None, W
     h = host_worlds(spec, rank, world_size)
-    cw = CrowdWorlds(h["S"], h["goals"], h["P"], h["margin"], h["walls"], type=model, all_params_equal=True,
-                     respawn_bounds=h["respawn_bounds"], respawn_worlds=h["respawn_worlds"], layout=spec["layout"])
+    cw = CrowdWorlds(h["S"], h["goals"], h["P"], h["margin"], h["walls"], type=model, all_params_equal=h["all_params_equal"],
+                     respawn_bounds=h["respawn_bounds"], respawn_worlds=h["respawn_worlds"], layout=spec["layout"],
+                     robot_row=h["robot"] is not None, robot=h["robot"])
+    cw.bench_action = None if h["action"] is None else DeviceBuffer.from_numpy(h["action"])
     return cw, h, h["W"]
-
-
-def effective_cores() -> int:
-    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
-    logical CPUs but grants 16 through cpu.max; more OpenMP threads than that only get throttled)."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
 
 
 def cpu_baseline(args, host, type_id):
@@ -203,7 +207,7 @@ def cpu_baseline(args, host, type_id):
     from oracle import crowd_oracle as orc
 
     orc.build()
-    cores = min(orc.num_threads(), effective_cores())
+    cores = min(orc.num_threads(), orc.effective_cores())
     respawn = host["respawn_bounds"] is not None
     rp = (host["respawn_bounds"][0], host["respawn_bounds"][1], 0.0) if respawn else (0.0, 0.0, 0.0)
 
@@ -236,6 +240,33 @@ def cpu_baseline(args, host, type_id):
                       f"{reps1 * args.substeps} substeps, {el1:.1f} s"}
 
 
+class Snapshot:
+    """The mutable buffers of a batch (state rows, goal lists, robot rows) as they stand after the warm-up; restore() copies them
+    back on the launch stream (device to device, outside the timed region) so that every timed replay steps the same trajectory."""
+
+    def __init__(self, cw, stream):
+        from social_navigation_pyenvs_amd import _lib
+
+        self.lib, self.stream, self.pairs = _lib.load(), stream, []
+        for buf in (cw.d_state, cw.d_goals, cw.d_robot):
+            if buf is None:
+                continue
+            keep = _lib.DeviceBuffer((max(buf.nbytes // 4, 1),))
+            self.pairs.append((buf, keep))
+            _lib.check(self.lib.cs_memcpy_d2d(C.c_void_p(keep.ptr), C.c_void_p(buf.ptr), C.c_size_t(buf.nbytes), C.c_void_p(stream)))
+        _lib.stream_sync(stream)
+
+    def restore(self):
+        from social_navigation_pyenvs_amd import _lib
+
+        for buf, keep in self.pairs:
+            _lib.check(self.lib.cs_memcpy_d2d(C.c_void_p(buf.ptr), C.c_void_p(keep.ptr), C.c_size_t(buf.nbytes), C.c_void_p(self.stream)))
+
+    def free(self):
+        for _, keep in self.pairs:
+            keep.free()
+
+
 class Runner:
     """Barrier / timing plumbing shared by the main workload and the other configurations."""
 
@@ -248,28 +279,33 @@ class Runner:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def measure(self, cw, spec, steps, warmup, repeats, eager=False):
-        """Times `repeats` x (exactly `steps` steps between barrier + synchronize on both sides).  Returns the per-repeat
-        wall times (MAX over ranks) and the HIP-event kernel time per step of every repeat (this rank)."""
+    def measure(self, cw, spec, steps, warmup, repeats, eager=False, restore=True):
+        """Times `repeats` x (exactly `steps` steps between barrier + synchronize on both sides), every repeat from the state the
+        `warmup` steps left (restored outside the timed region).  Returns the per-repeat wall times (MAX over ranks) and the
+        HIP-event kernel time per step of every repeat (this rank) -- the same samples."""
         from social_navigation_pyenvs_amd import _lib
         from social_navigation_pyenvs_amd.sharding import max_over_ranks
 
         cw.stream = self.stream
         dt, n_sub = spec["dt"], spec["substeps"]
+        action = getattr(cw, "bench_action", None)
         for _ in range(warmup):
-            cw.step(dt, n_sub)
+            cw.step(dt, n_sub, action)
         self.barrier()
+        snap = Snapshot(cw, self.stream) if restore else None
         wall, kern = [], []
         if eager:
             # one launch per step from Python, a HIP event pair around every launch
             for _ in range(repeats):
                 starts = [_lib.Event() for _ in range(steps)]
                 stops = [_lib.Event() for _ in range(steps)]
+                if snap:
+                    snap.restore()
                 self.barrier()
                 t0 = time.perf_counter()
                 for k in range(steps):
                     starts[k].record(self.stream)
-                    cw.step(dt, n_sub)
+                    cw.step(dt, n_sub, action)
                     stops[k].record(self.stream)
                 _lib.stream_sync(self.stream)
                 self.barrier()
@@ -280,11 +316,13 @@ class Runner:
             # no per-launch host gap; HIP events on the launch stream bracket the K kernels of every replay
             with _lib.Graph.capture(self.stream) as graph:
                 for k in range(steps):
-                    cw.step(dt, n_sub)
+                    cw.step(dt, n_sub, action)
             graph.launch()                      # one untimed replay (first launch of an instantiated graph uploads it)
             _lib.stream_sync(self.stream)
             e0, e1 = _lib.Event(), _lib.Event()
             for _ in range(repeats):
+                if snap:
+                    snap.restore()              # untimed: the replay below starts from the post-warm-up worlds every time
                 self.barrier()
                 t0 = time.perf_counter()
                 e0.record(self.stream)
@@ -294,6 +332,8 @@ class Runner:
                 self.barrier()
                 wall.append(time.perf_counter() - t0)
                 kern.append(e0.elapsed_ms(e1) / steps)
+        if snap:
+            snap.free()
         dev = self.reduce_device if self.dist is not None else None
         wall = [max_over_ranks(w, self.dist, device=dev) for w in wall]
         return np.array(wall), np.array(kern)
@@ -309,8 +349,6 @@ class Runner:
     def copy_bandwidth(self, nbytes=1 << 30, reps=10):
         """Device-to-device copy bandwidth measured in this run (read + written bytes / time): the practical HBM ceiling
         (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy) beside the 8 TB/s vendor peak."""
-        import ctypes as C
-
         from social_navigation_pyenvs_amd import _lib
 
         a, b = _lib.DeviceBuffer((nbytes // 4,)), _lib.DeviceBuffer((nbytes // 4,))
@@ -334,13 +372,19 @@ def family_of(model):
     return "orca" if model == "orca" else ("hsfm" if model.startswith("hsfm") else "sfm")
 
 
-def pmc_entry(name):
-    """rocprofv3 PMC figures of this configuration from profiles/pmc_summary.json (written from the round's committed
-    counter passes by tools/pmc_summary.py); None when there is no entry."""
+def build_id() -> str:
+    from social_navigation_pyenvs_amd import _lib
+
+    lib = _lib.load()
+    lib.cs_build_id.restype = C.c_char_p
+    return lib.cs_build_id().decode()
+
+
+def pmc_summary() -> dict:
     try:
-        return json.load(open(PMC_SUMMARY)).get(name)
+        return json.load(open(PMC_SUMMARY))
     except Exception:
-        return None
+        return {}
 
 
 def roofline_block(spec, W, kern_ms, copy_gbs, cw):
@@ -351,23 +395,33 @@ def roofline_block(spec, W, kern_ms, copy_gbs, cw):
     achieved = alg / (k_avg * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "meaning": "normalised ALGORITHMIC throughput (bytes one substep would move if the state round-tripped HBM every "
-                      "substep) -- the fused launch keeps the state in registers / LDS; see traffic / valu for what the "
+                      "substep) -- the fused launch keeps the state in registers / LDS; see traffic / valu_frac for what the "
                       "hardware really does",
            "frac_vs_copy": (achieved / copy_gbs) if copy_gbs else None, "copy_GBs_measured": copy_gbs,
            "kernel": "k_orca_step" if fam == "orca" else "k_sfm_step", "variant": cw.step_variant(),
-           "kernel_avg_ms": k_avg, "kernel_min_ms": float(np.min(kern_ms)), "kernel_max_ms": float(np.max(kern_ms)),
-           "algorithmic_bytes_per_launch": alg, "bytes_per_agent_substep": ALG_BYTES[fam]}
-    pm = pmc_entry(spec_key(spec)) or {}
+           "kernel_avg_ms": k_avg, "kernel_median_ms": float(np.median(kern_ms)), "kernel_min_ms": float(np.min(kern_ms)),
+           "kernel_max_ms": float(np.max(kern_ms)), "algorithmic_bytes_per_launch": alg, "bytes_per_agent_substep": ALG_BYTES[fam]}
+    summary = pmc_summary()
+    pm = summary.get(spec_key(spec)) or {}
     per_agent = pm.get("hbm_bytes_per_agent_launch")
     out["traffic"] = per_agent * W * n if per_agent is not None else None
     out["traffic_source"] = pm.get("traffic_source")
     out["traffic_GBs"] = (out["traffic"] / (k_avg * 1e-3) / 1e9) if out["traffic"] is not None else None
+    # the PMC figures are read back from the round's committed counter passes: say whether those ran on THIS library build
+    out["pmc_build_id"] = pm.get("build_id", summary.get("_build_id"))
+    out["pmc_build_matches"] = (out["pmc_build_id"] == build_id()) if pm else None
     if fam != "orca":
         soc = "guo" if spec["model"].endswith("guo") else ("moussaid" if spec["model"].endswith("moussaid") else "helbing")
         pair_flops = PAIR_FLOPS[soc] * W * n * (n - 1) * n_sub   # the reference's count: every ordered pair
         out["fp32_tflops_equiv"] = pair_flops / (k_avg * 1e-3) / 1e12
         out["fp32_frac"] = out["fp32_tflops_equiv"] / FP32_PEAK_TFLOPS
     out["valu"] = pm.get("valu")          # measured VALU issue figures (the true bound of this kernel), tagged with their source
+    out["valu_frac"] = None
+    if out["valu"] and out["valu"].get("valu_insts_per_wave_substep"):
+        insts = out["valu"]["valu_insts_per_wave_substep"] * out["valu"]["waves_per_launch"] * n_sub * (W / float(pm.get("worlds", W)))
+        out["valu_frac"] = insts * VALU_ISSUE_CYCLES / (SIMDS * k_avg * 1e-3 * CLOCK_HZ)
+        out["valu_frac_meaning"] = ("VALU instructions per launch (PMC SQ_INSTS_VALU) x 4 issue cycles / (1024 SIMDs x kernel time x 2.4 GHz): "
+                                    "share of the chip's VALU issue slots the kernel fills -- the bound that holds for this kernel")
     return out
 
 
@@ -409,7 +463,7 @@ def main():
     run = Runner(torch, dist, stream, reduce_device="cuda" if args.dist_backend == "nccl" else None)
     spec = workload_spec(args)
     cw, host, W = build_worlds(spec, rank, world_size)
-    wall, kern = run.measure(cw, spec, args.steps, args.warmup, args.repeats, eager=args.eager)
+    wall, kern = run.measure(cw, spec, args.steps, args.warmup, args.repeats, eager=args.eager, restore=not args.no_restore)
     per_rank_kernel_us = run.gather(float(np.mean(kern)) * 1e3)
     total_worlds = args.total_worlds if args.total_worlds is not None else world_size * args.worlds
 
@@ -422,18 +476,21 @@ def main():
     if not args.no_other_configs:
         for ospec in other_config_specs(args):
             ocw, _, oW = build_worlds(ospec, rank, world_size)
-            k_o = max(5, min(args.steps, 20 if ospec["model"] == "orca" else 50))
-            owall, okern = run.measure(ocw, ospec, k_o, 3, 7)
+            k_o = max(5, min(args.steps, ospec["steps"]))
+            r_o = 7
+            owall, okern = run.measure(ocw, ospec, k_o, ospec["warmup"], r_o, restore=not args.no_restore)
             ous = run.gather(float(np.mean(okern)) * 1e3)
             if rank == 0:
                 tot = ospec["total_worlds"] if ospec["total_worlds"] is not None else world_size * ospec["worlds"]
                 med = float(np.median(owall))
                 rl = roofline_block(ospec, oW, okern, copy_gbs, ocw)
                 others.append({"name": ospec["name"], "workload": ospec["title"], "scaling": "strong" if ospec["total_worlds"] else "weak",
-                               "worlds_this_rank": oW, "worlds_total": tot, "steps": k_o, "timing_repeats": 7,
+                               "worlds_this_rank": oW, "worlds_total": tot, "warmup": ospec["warmup"], "steps": k_o, "timing_repeats": r_o,
                                "ms_per_step": med / k_o * 1e3,
                                "value": tot * ospec["agents"] * ospec["substeps"] * k_o / med, "unit": "agent-substeps/s",
-                               "kernel_us": rl["kernel_avg_ms"] * 1e3, "per_rank_kernel_us": ous, "frac": rl["frac"], "roofline": rl})
+                               "kernel_us": rl["kernel_avg_ms"] * 1e3, "kernel_us_median": rl["kernel_median_ms"] * 1e3,
+                               "kernel_le_wall": bool(rl["kernel_median_ms"] <= med / k_o * 1e3),
+                               "per_rank_kernel_us": ous, "frac": rl["frac"], "valu_frac": rl["valu_frac"], "roofline": rl})
             del ocw
 
     if rank == 0:
@@ -442,6 +499,7 @@ def main():
         agent_substeps = total_worlds * args.agents * n_sub * args.steps
         value = agent_substeps / med
         g, b, wpb = cw.launch_geometry()
+        rl = roofline_block(spec, W, kern, copy_gbs, cw)
         out = {
             "metric": "env-steps/sec (worlds x agents) for HSFM 25-agent crowd",
             "value": value,
@@ -458,25 +516,32 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "build_id": build_id(),
             "config": {
                 "workload": f"{W} worlds/GPU x {args.agents}-agent {args.model} {args.scenario} scenario"
-                            f"{' + 3 polygon walls' if args.walls else ''}{f' + {args.static} immobile humans' if args.static else ''}, "
+                            f"{' + 3 polygon walls' if args.walls else ''}{f' + {args.static} immobile humans' if args.static else ''}"
+                            f"{' + a visible robot' if args.robot else ''}{', per-agent parameters' if args.per_agent_params else ''}, "
                             f"{n_sub} fused substeps of {args.dt} s per step (one Gym step), state resident in HBM ({args.layout})",
                 "worlds_per_gpu": W, "worlds_total": total_worlds, "agents": args.agents, "substeps_per_step": n_sub,
                 "model": args.model, "scenario": args.scenario, "parallelism": f"worlds sharded x{world_size}, no collective",
                 "launch": {"grid": g, "block": b, "worlds_per_block": wpb},
                 "timed_region": "eager launches, one HIP event pair per launch" if args.eager else
-                                "barrier + sync | ONE replay of a HIP graph holding exactly K cs_step launches | sync + barrier; repeated R times, median reported",
+                                "[untimed: worlds restored to the post-warm-up snapshot] barrier + sync | ONE replay of a HIP graph holding exactly K "
+                                "cs_step launches | sync + barrier; repeated R times on the SAME trajectory segment (Gym steps W .. W+K), median reported",
+                "stationary": not args.no_restore,
             },
             "world_substeps_per_s": value / args.agents,
             "gym_steps_per_s": value / args.agents / n_sub,
             "finite_fraction": finite,
+            "kernel_us": rl["kernel_avg_ms"] * 1e3,
+            "kernel_us_median": rl["kernel_median_ms"] * 1e3,
+            "kernel_le_wall": bool(rl["kernel_median_ms"] <= med / args.steps * 1e3),
             "per_rank_kernel_us": per_rank_kernel_us,
-            "roofline": roofline_block(spec, W, kern, copy_gbs, cw),
+            "roofline": rl,
             "other_configs": others,
         }
-        if not args.no_cpu_baseline and args.model != "orca" and world_size == 1:  # rank 0, N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))
+        if not args.no_cpu_baseline and args.model != "orca" and world_size == 1 and host is not None and not args.robot and not args.per_agent_params:
+            out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))   # rank 0, N = 1 only
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

@@ -154,7 +154,9 @@ int cs_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action,
  *   kernel argument) that also records every human's row AFTER every fused substep, so that a test can check each substep of a
  *   fused launch on its own against the reference's single-substep function (forces_parallel.py:185-284 + the respawn rule,
  *   motion_model_manager.py:407-422) restarted from the previous record.
- *   d_trace [n_substeps][W][n][12] = px, py, theta, vx, vy, bvx, bvy, omega, gx, gy (state columns 10:12), goals[0].x, goals[0].y.
+ *   d_trace [n_substeps][W][rows][12] = px, py, theta, vx, vy, bvx, bvy, omega, gx, gy (state columns 10:12), goals[0].x, goals[0].y
+ *   (rows = n + 1 with CS_ROBOT_ROW: the robot's record k is the robot as substep k + 1 sees it -- it moves before the humans,
+ *   social_nav_gym.py:240-243 -- and as it stands at the end for the last record).
  *   Types 0..8, worlds of up to 1024 rows; other worlds -> CS_ERR_ARG.
  */
 int cs_step_trace(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_trace, void* stream);

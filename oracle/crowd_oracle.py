@@ -105,6 +105,8 @@ def step_block(type_, S, goals, obstacles, P, dt, n_substeps, safety, all_params
     if action is not None:
         action = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=dtype), (W, 2)))
     rp = np.asarray(respawn_par, dtype=dtype)
+    if threads <= 0:   # one OpenMP thread per world, at most what the cgroup grants
+        threads = max(1, min(W, effective_cores()))
     fn = getattr(lib(), f"orc_step_block_batched_{sfx}")
     fn.restype = C.c_int
     rc = fn(C.c_int(W), C.c_int(type_), _ptr(S, ct), _ptr(goals, ct), C.c_int(G), _ptr(obstacles, ct),
@@ -304,6 +306,19 @@ def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot
     if single:
         return S[0], goals[0], (robot[0] if robot is not None else None)
     return S, goals, robot
+
+
+def effective_cores() -> int:
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows 256 logical CPUs
+    and grants 16 through cpu.max: an OpenMP team of 256 only gets throttled, and costs ~0.1 s to spin up per call)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def num_threads() -> int:

@@ -186,12 +186,14 @@ class CrowdWorlds:
 
     def step_trace(self, dt: float, n_substeps: int = 1, action=None) -> np.ndarray:
         """step() through cs_step_trace: the same kernel build and arithmetic, and every human's row after every fused substep:
-        [n_substeps, W, n, 12] = px, py, theta, vx, vy, bvx, bvy, omega, gx, gy, goals[0].x, goals[0].y."""
+        [n_substeps, W, rows, 12] = px, py, theta, vx, vy, bvx, bvy, omega, gx, gy, goals[0].x, goals[0].y (the robot row, if any,
+        as the following substep sees it)."""
         d = self.descriptor()
         a_ptr = None
-        if action is not None:
+        if isinstance(action, (np.ndarray, list, tuple)):
             a_ptr = self._upload("action", np.broadcast_to(np.asarray(action, dtype=np.float32), (self.W, 2))).ptr
-        out = self._buffer("trace", (int(n_substeps), self.W, self.n, 12))
+        a_ptr = a_ptr if (action is None or isinstance(action, (np.ndarray, list, tuple))) else _ptr(action)
+        out = self._buffer("trace", (int(n_substeps), self.W, self.rows, 12))
         check(_lib.load().cs_step_trace(C.byref(d), C.c_float(dt), C.c_int(n_substeps), C.c_void_p(a_ptr), C.c_void_p(out.ptr),
                                         C.c_void_p(self.stream)))
         return out.download(self.stream)

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_bw_sfm_step(const GArgs a)
                         const float d2 = fmaxf(fmaf(ddx, ddx, ddy * ddy), 1e-30f);
                         const float inv = rsq_fast(d2);
                         const float rd = fmaf(-d2, inv, rij);
-                        const float m0 = fmaxf(0.0f, rd);
+                        const float m0 = fmaxf(0.0f, rij - dist_refined(d2, inv));
                         const float nx = ddx * inv, ny = ddy * inv;
                         const float dv = (vjy - viy) * nx - (vjx - vix) * ny;                 // (v_j - v_i) . t
                         const float fn = fmaf(sp.sA, exp2_fast(fmaf(rd, sp.cB, sp.lA)), sp.k1 * m0);
@@ -228,12 +228,13 @@ __global__ __launch_bounds__(256) void k_bw_sfm_step(const GArgs a)
                 }
                 if (d < best) { best = d; bdx = ddx; bdy = ddy; }
             }
-            const float inv = rsq_fast(fmaxf(best, 1e-30f));
+            const float bcl = fmaxf(best, 1e-30f);
+            const float inv = rsq_fast(bcl);
             const float dist = best * inv;
             const float nx = bdx * inv, ny = bdy * inv;
             const float dv = -(cvy * nx - cvx * ny);
             const float rd = r - dist + safety;
-            const float m0 = fmaxf(0.0f, rd);
+            const float m0 = fmaxf(0.0f, r - dist_refined(bcl, inv) + safety);
             const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
             const float ft = obs_type == 0 ? -(k2 * m0) * dv : (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
             fox += fn * nx - ft * ny;

@@ -37,6 +37,7 @@ inline size_t imitation_scratch_bytes(const cs_worlds* w, int n_substeps) { retu
 size_t sfm_big_scratch_bytes(const cs_worlds* w);
 size_t orca_big_scratch_bytes(const cs_worlds* w);
 int big_world_min_rows(int dflt);
+int device_simds();   // CUs x 4 of the current device
 // the uniform grid of worlds beyond one block (bigworld.hip): rows binned into hashed buckets of square cells, every bucket's rows in
 // index order (stable radix sort); start[w * NB + b] .. start[w * NB + b + 1] = bucket b of world w in `sorted` (row indices)
 struct GridView { int W, rows, NB; int2* cellxy; unsigned* keys; unsigned* keys_sorted; int* idx; int* sorted; int* start; };

@@ -117,12 +117,13 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         const float rij = rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + j];
         // (single-instruction rsq / exp as in the crowd kernel: <= 1 ulp each, two orders of magnitude inside the parity bar)
         const float dx = px - hx, dy = py - hy;
-        const float d2h = dx * dx + dy * dy;
+        const float d2h = fmaxf(dx * dx + dy * dy, 1e-30f);    // (coincident robot and human: finite, as in the crowd kernel)
         const float dinv = __builtin_amdgcn_rsqf(d2h);
         const float dn = d2h * dinv;
         const float nx = dx * dinv, ny = dy * dinv;
         const float rd = rij - dn;
-        const float comp = fmaxf(0.0f, rd);
+        // body-contact overlap from a Newton-refined distance: one ulp of dist is 1.4e-5 of the k1 / k2 force (stepcommon.h dist_refined)
+        const float comp = fmaxf(0.0f, rij - fmaf(fmaf(-dn, dn, d2h), 0.5f * dinv, dn));
         if (soc == 2) {
             const float ivx = P[12] * (vx - hvx) - nx, ivy = P[12] * (vy - hvy) - ny;
             const float inorm = sqrtf(ivx * ivx + ivy * ivy);

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
                     const float dx = px - qx, dy = py - qy;
                     const float d2 = fmaxf(fmaf(dx, dx, dy * dy), 1e-30f);
                     const float inv = rsq_fast(d2);
-                    const float m0 = fmaxf(0.0f, fmaf(-d2, inv, my_rs + qrs));
+                    const float m0 = fmaxf(0.0f, (my_rs + qrs) - dist_refined(d2, inv));
                     const float nx = dx * inv, ny = dy * inv;
                     const float dv = (qvy - vy) * nx - (qvx - vx) * ny;     // (v_j - v_i) . t
                     const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;

@@ -1,0 +1,954 @@
+// sfmstep_kernel.h -- the fused SFM / HSFM step kernel template (k_sfm_step) of libcrowdstep.so, shared by the translation units that
+// instantiate its builds (sfmstep_*.hip: one group of builds each, compiled in parallel) and by crowdstep.hip, which picks the build.
+//
+// Hot path: the reference's per-substep pedestrian update
+//   update_humans_parallel            /root/reference/social_gym/src/forces_parallel.py:185-284
+//   MotionModelManager.update_humans  /root/reference/social_gym/src/motion_model_manager.py:354-422
+//   SocialNavGym.step substep loop    /root/reference/social_gym/social_nav_gym.py:240-245
+// Design notes: DESIGN.md §4.1.  gfx950 only: no portability macros, no CPU fallback.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "crowdstep.h"
+#include "stepcommon.h"
+
+namespace cstep {
+
+// ------------------------------------------------------------------------------------------
+// the fused SFM / HSFM step kernel
+//   SOC    = type % 3  (0 Helbing, 1 Guo, 2 Moussaid)          forces_parallel.py:215
+//   HEADED = type / 3  (0 SFM, 1 HSFM torque on desired force, 2 on total force)   :217
+//   PEQ    = all_params_equal
+//   MAXT   = 64 (one wavefront, floor(64/rows) worlds) or 1024 (one world per block)
+// ------------------------------------------------------------------------------------------
+template <class F, int... I>
+__device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// The pair-once loop hands values from lane to lane through LDS inside ONE wavefront.  The hardware executes a wave's LDS
+// operations in order, so no s_barrier / s_waitcnt is needed -- but the compiler does not know that another lane's store
+// feeds this lane's load, and with compile-time offsets it can prove "no alias" for the lane's own addresses and hoist the
+// load above the store.  This compiler-only fence pins the program order of the LDS accesses around it.
+#define LDS_ORDER_FENCE() asm volatile("" ::: "memory")
+
+constexpr int UA = 4; // reaction accumulator rows of the pair-once loop (independent LDS read-modify-write chains)
+constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one wavefront: 2 x 64 doubled rows)
+
+//   OCC    = waves per SIMD the register allocation must allow: 4 (<= 128 VGPRs, a few spills) when the grid holds more
+//            than two wavefronts per SIMD, 1 (unconstrained, ~150 VGPRs, no spills) otherwise -- at 4096 x 25 there
+//            are exactly two waves per SIMD and the spill-free build is 6 % faster; at 16384 x 25 the 4-wave build is 7 % faster
+//   ROWS_CT = rows per world known at compile time (0: read from the arguments): the partner-group loop unrolls and
+//            its ~9 scalar branches per substep (~24 cycles of wave latency each) disappear
+//   LEAN   = 1 / 2 / 3: pair-once build for the plain crowd batch: no walls (1), walls kept (2), or no walls + a robot as the last
+//            row (3: what a Gym with a VISIBLE robot steps; rows = humans + 1), goal lists of <= 2 entries, state committed in
+//            place -- the wall / robot / goal-list-in-memory code and their branches are compiled out wherever the build
+//            does not need them and the goal switch is predicated
+template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, int LEAN>
+__global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    // all_params_equal, whole worlds inside one wavefront: every unordered pair is evaluated ONCE (as the reference
+    // does, forces_parallel.py:100-131: F[i,j] = f, F[j,i] = -f) and the reaction handed over through LDS.
+    constexpr bool N3L = PEQ && MAXT == 64;
+    const int T = blockDim.x;
+    // Every world's rows are stored TWICE, back to back ([w][2][rows]): lane i then reads its partners
+    // i+1 .. i+rows-1 at constant offsets from one base address -- no own-row slot, no modulo, no
+    // per-partner compare (v_cmp + v_cndmask costs as much as a transcendental on this SIMD).
+    const int TP = 2 * T + PADR;                                   // rows per position buffer (+ finite padding)
+    float4* lds_p = reinterpret_cast<float4*>(smem_raw);           // [2][TP] x, y, radius+safety, -
+    float2* lds_v = reinterpret_cast<float2*>(lds_p + 2 * TP);     // [2][TP] stored linear velocity (doubled rows like lds_p)
+    float2* lds_vr = lds_v + 2 * TP;                               // [2][T] velocity as refreshed in-place
+    float* lds_g0x = reinterpret_cast<float*>(lds_vr + 2 * T);     // [T] respawn scratch
+    int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);           // [T] respawn scratch
+    float2* lds_acc = reinterpret_cast<float2*>(lds_flag + T);     // [UA][2T] reaction accumulators (N3L only)
+    float4* lds_seg = reinterpret_cast<float4*>(lds_acc + (N3L ? UA * ACC_PITCH : 0)); // [seg_tab] x1, y1, ex, ey
+    float* lds_sinv = reinterpret_cast<float*>(lds_seg + a.seg_tab);                   // [seg_tab] 1 / |e|^2, 0 = NaN slot
+    float4* lds_poly = reinterpret_cast<float4*>(lds_sinv + ((a.seg_tab + 3) & ~3));   // [seg_tab / Smax] bounding circle cx, cy, R of every polygon
+
+    const int tid = threadIdx.x;
+    static_assert(!LEAN || (PEQ && MAXT == 64), "the lean build is a pair-once build");
+    constexpr bool NO_WALLS = LEAN == 1 || LEAN == 3;      // wall code compiled out
+    const int rows = ROWS_CT > 0 ? ROWS_CT : a.rows;
+    const int n = LEAN == 3 ? rows - 1 : (LEAN ? rows : a.n);
+    const int kmode = LEAN == 3 ? ((int)M_COMMIT_GOALS | (a.mode & (int)M_ROBOT_FROM_ARRAY)) : (LEAN ? (int)M_COMMIT_GOALS : a.mode);
+    const int lw = tid / rows;
+    const int row = tid - lw * rows;
+    const int w = blockIdx.x * a.wpb + lw;
+    const bool valid = (lw < a.wpb) && (w < a.W);
+    const bool robot_row = LEAN == 3 ? true : (LEAN ? false : (a.flags & CS_ROBOT_ROW) != 0);
+    const bool human = valid && row < n;
+    const bool is_robot = valid && robot_row && row == n;
+    const int base = lw * rows;        // first row of my world in the per-row arrays (lds_v, lds_vr, ...)
+    const int pbase = lw * a.ws;       // first row of my world in the doubled position buffers
+    const float dt = a.dt;
+    const int obs_type = (a.type == 1 || a.type == 4 || a.type == 7) ? 1 : 0;
+
+    // ---- load my row ------------------------------------------------------------------
+    float px = 0, py = 0, th = 0, vx = 0, vy = 0, bvx = 0, bvy = 0, om = 0, r = 0, m = 1, gx = 0, gy = 0, vd = 0;
+    float safety = 0;
+    const long sidx = (long)w * rows + row;
+    if (valid) {
+        const float* s = a.Sin + sidx * a.in_as;
+        if (is_robot && (kmode & M_ROBOT_FROM_ARRAY)) {
+            const float* rb = a.robot + (long)w * 13;
+            px = rb[0]; py = rb[1]; th = rb[2]; vx = rb[3]; vy = rb[4]; bvx = rb[5]; bvy = rb[6]; om = rb[7];
+            r = rb[8]; m = rb[9]; gx = rb[10]; gy = rb[11]; vd = rb[12];
+        } else {
+            const long fs = a.in_fs;
+            px = s[0]; py = s[fs]; th = s[2 * fs]; vx = s[3 * fs]; vy = s[4 * fs]; bvx = s[5 * fs];
+            bvy = s[6 * fs]; om = s[7 * fs]; r = s[8 * fs]; m = s[9 * fs]; gx = s[10 * fs]; gy = s[11 * fs];
+            vd = s[12 * fs];
+        }
+        safety = a.safety[sidx];
+    }
+    // parameters: my own row of P for the single-agent forces; P[0] of my world for the pair loop
+    // when all_params_equal (forces_parallel.py:220), else my own row (:261)
+    float m_tau = 0, Aw = 0, cBw = 0, Cw = 0, cDw = 0, k1 = 0, k2 = 0, ko = 0, kd = 0, alpha = 1, klam = 0;
+    float dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0, wall_cut = 0;
+    SocP sp = {};
+    float g0x = gx, g0y = gy, g1x = 0, g1y = 0;
+    int gk = 0;          // length of the non-NaN prefix of my goal list
+    bool gdirty = false; // a two-goal list rotated in registers, to be written back in the epilogue
+    float* gi = nullptr;
+    if (N3L && valid) sp = load_socp(a.params + ((a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20));
+    if (human) {
+        const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20;
+        const float* P = a.params + pw + (long)row * 20;
+        m_tau = m / P[0];                       // m / relax_t              (:39)
+        Aw = P[2]; cBw = LOG2E / P[4]; Cw = P[6]; cDw = LOG2E / P[8]; k1 = P[10]; k2 = P[11];
+        // beyond this distance a wall's force on me is below |A| e^-36 = 5e-13 N (its contact terms are exact zeros there):
+        // a polygon that every agent of the wavefront is that far from is skipped in the substep loop
+        wall_cut = r + safety + a.wall_efolds * fmaxf(P[4], obs_type == 1 ? P[8] : 0.0f);
+        ko = P[16]; kd = P[17]; alpha = P[18]; klam = P[19];
+        dt_m = a.dt / m;                        // (F / m) * dt             (:277,:282)
+        inv_alpha = 1.0f / alpha;
+        inertia = 0.5f * m * r * r;             // :265
+        dt_inertia = a.dt / inertia;            // (torque / I) * dt        (:279)
+        if constexpr (!N3L) sp = load_socp(PEQ ? (a.params + pw) : P);
+        gi = a.goals + ((long)w * n + row) * a.G * 2;
+        g0x = gi[0]; g0y = gi[1];
+        // goal lists of <= 2 entries (every Gym scenario) rotate in registers; longer ones go through memory
+        gk = a.G;
+        for (int g = a.G - 1; g >= 0; --g)
+            if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) gk = g;
+        if (gk == 2) { g1x = gi[2]; g1y = gi[3]; }
+    }
+    const float inv_O = a.O > 0 ? 1.0f / (float)a.O : 0.0f;
+    const float* obst = nullptr;
+    if (!NO_WALLS && a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
+    // wall segments are constant over the launch: stage (x1, y1, e, 1/|e|^2) in LDS once instead of re-loading and
+    // re-deriving them in every substep (3 polygons x 5 segments cost as much as the whole 50-agent pair loop otherwise)
+    const int nseg = NO_WALLS ? 0 : a.O * a.Smax;
+    const int sbase = (a.flags & CS_OBSTACLES_SHARED) ? 0 : lw * nseg;
+    for (int i = tid; i < (NO_WALLS ? 0 : a.seg_tab); i += T) {
+        const int lwi = i / (nseg > 0 ? nseg : 1);
+        const long wi = (long)blockIdx.x * a.wpb + lwi;
+        // a NaN slot becomes a degenerate segment 1e18 m away: squared distance 2e36, never the polygon's minimum (the reference
+        // stores the largest int64 as that slot's distance, forces_parallel.py:247) -- no per-slot test in the substep loop
+        float4 e = make_float4(1.0e18f, 1.0e18f, 0.0f, 0.0f);
+        float inv = 0.0f;
+        if ((a.flags & CS_OBSTACLES_SHARED) || wi < a.W) {
+            const float* src = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? (long)i * 4 : (wi * nseg + (i - lwi * nseg)) * 4);
+            const float4 seg = *reinterpret_cast<const float4*>(src);
+            if (!isnan(seg.x)) {
+                e = make_float4(seg.x, seg.y, seg.z - seg.x, seg.w - seg.y);
+                inv = rcp_fast(fmaf(e.z, e.z, e.w * e.w));
+            }
+        }
+        lds_seg[i] = e;
+        lds_sinv[i] = inv;
+    }
+
+    const bool respawn_here = valid && (a.world_flags == nullptr || (a.world_flags[w] & 1));
+
+    // robot action (held for the whole block, social_nav_gym.py:240-243)
+    const bool robot_moves = a.action != nullptr; // (lean build: only the invisible robot of the epilogue)
+    float ax = 0, ay = 0;
+    if (valid && robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
+    auto robot_step = [&]() { // robot_agent.py:114-136
+        if (a.flags & CS_ROBOT_UNICYCLE) {
+            float c, s;
+            sincos_fast(th + ay, s, c);
+            px += c * ax * dt; py += s * ax * dt;
+            th = fmodf(th + ay, 6.283185307179586f);
+            if (th < 0) th += 6.283185307179586f;
+            sincos_fast(th, s, c);
+            vx = c * ax; vy = s * ax;
+        } else {
+            px += ax * dt; py += ay * dt; vx = ax; vy = ay;
+        }
+    };
+
+    float cs = 1.0f, sn = 0.0f; // cos / sin of my theta, carried from one substep to the next
+
+    // ---- prologue: publish substep-0 rows ----------------------------------------------
+    if (is_robot && robot_moves) robot_step();
+    const float my_rs = r + safety;
+    for (int i = tid; i < 2 * TP; i += T) { // padding stays finite
+        lds_p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        lds_v[i] = make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+    // bounding circle of every staged polygon (centre = mean of its segments' midpoints, radius = farthest endpoint)
+    for (int q = tid; q < (NO_WALLS || a.Smax <= 0 ? 0 : a.seg_tab / a.Smax); q += T) {
+        float cx = 0.0f, cy = 0.0f, cnt = 0.0f;
+        for (int sg = 0; sg < a.Smax; ++sg) {
+            const float4 e = lds_seg[q * a.Smax + sg];
+            if (lds_sinv[q * a.Smax + sg] > 0.0f) { cx += e.x + 0.5f * e.z; cy += e.y + 0.5f * e.w; cnt += 1.0f; }
+        }
+        const float ic = cnt > 0.0f ? 1.0f / cnt : 0.0f;
+        cx *= ic; cy *= ic;
+        float r2 = 0.0f;
+        for (int sg = 0; sg < a.Smax; ++sg) {
+            const float4 e = lds_seg[q * a.Smax + sg];
+            if (lds_sinv[q * a.Smax + sg] > 0.0f) {
+                const float ax0 = e.x - cx, ay0 = e.y - cy, bx0 = ax0 + e.z, by0 = ay0 + e.w;
+                r2 = fmaxf(r2, fmaxf(fmaf(ax0, ax0, ay0 * ay0), fmaf(bx0, bx0, by0 * by0)));
+            }
+        }
+        lds_poly[q] = make_float4(cx, cy, cnt > 0.0f ? sqrtf(r2) : -1.0e30f, 0.0f);   // an empty polygon is never near
+    }
+    // radius + safety space never changes during a launch: it is stored once in both buffers, a substep only rewrites
+    // (x, y) -- two 8-byte LDS stores instead of two 16-byte ones
+    auto publish = [&](int buf) {      // my position, both copies
+        const float2 me = make_float2(px, py);
+        *reinterpret_cast<float2*>(&lds_p[buf * TP + pbase + row]) = me;
+        *reinterpret_cast<float2*>(&lds_p[buf * TP + pbase + rows + row]) = me;
+    };
+    // Helbing / Guo pair-once builds read partner velocities only in the (rare) contact pass, which publishes them itself
+    constexpr bool VEL_ON_DEMAND = N3L && SOC != 2;
+    auto publish_v = [&](int buf) {    // stored linear velocity; second copy only where the rotated loop reads it
+        if constexpr (!VEL_ON_DEMAND) {
+            lds_v[buf * TP + pbase + row] = make_float2(vx, vy);
+            if constexpr (N3L && SOC == 2) lds_v[buf * TP + pbase + rows + row] = make_float2(vx, vy);
+        }
+    };
+    if (valid) {
+        const float4 me = make_float4(px, py, my_rs, 0.0f);
+        for (int buf = 0; buf < 2; ++buf) {
+            lds_p[buf * TP + pbase + row] = me;
+            lds_p[buf * TP + pbase + rows + row] = me;
+        }
+        publish_v(0);
+        float rvx = vx, rvy = vy;
+        if (HEADED > 0 && human) {
+            sincos_fast(th, sn, cs);
+            rvx = cs * bvx + (-sn) * bvy;
+            rvy = sn * bvx + cs * bvy;
+        }
+        lds_vr[tid] = make_float2(rvx, rvy);
+    }
+    __syncthreads();
+
+    if constexpr (N3L) {
+        float4* z = reinterpret_cast<float4*>(lds_acc);
+#pragma unroll
+        for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        LDS_ORDER_FENCE();
+    }
+#ifdef CS_STAMPS
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+    int cur = 0;
+    for (int sub = 0; sub < a.nsub; ++sub) {
+        const int nxt = cur ^ 1;
+        STAMP(7);
+        // imitation block: what the robot's own integrator sees of the crowd at this substep (it runs before update_humans)
+        if (a.snap != nullptr && human) a.snap[((long)sub * a.W + w) * n + row] = make_float4(px, py, vx, vy);
+        // cs_step_trace: my row as the previous substep left it (the last one is written behind the loop)
+        if (a.trace != nullptr && (human || is_robot) && sub > 0)
+            write_trace(a.trace + (((long)(sub - 1) * a.W + w) * rows + row) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
+        const int Hf = (rows - 1) >> 1;
+        const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
+        const float2* rv = lds_v + cur * TP + pbase + row + 1;
+        float4 qa[UA];
+        float2 va[UA];
+        auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                q[u] = rp[kk + u];
+                if constexpr (N3L && SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
+            }
+        };
+        // lean build: request the first group's partner rows first thing; the goal test and part A below run while they
+        // are in flight (with walls the rows would be held in registers across the segment loops: fetched at the head of
+        // the group loop instead)
+        if constexpr (LEAN) { if (valid && Hf >= UA) fetch(qa, va, 0); }
+        // even row counts: the antipodal partner (evaluated by both ends, no hand-over) is requested up front as well
+        float4 qz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float2 vz = make_float2(0.0f, 0.0f);
+        if constexpr (LEAN) {
+            if (valid && (rows & 1) == 0) {
+                qz = rp[Hf];
+                if constexpr (SOC == 2) vz = rv[Hf];
+            }
+        }
+        if constexpr (LEAN) {
+            // -- goal switch, forces_parallel.py:226-234, predicated: lists of <= 2 goals rotate in registers
+            const float gdx = g0x - px, gdy = g0y - py;
+            const bool hit = human && fmaf(gdx, gdx, gdy * gdy) <= r * r;
+            const bool sw = hit && gk == 2;
+            const float t0 = g0x, t1 = g0y;
+            g0x = sw ? g1x : g0x; g0y = sw ? g1y : g0y;
+            g1x = sw ? t0 : g1x; g1y = sw ? t1 : g1y;
+            gdirty = gdirty || sw;
+            gx = hit ? g0x : gx; gy = hit ? g0y : gy;
+        } else if (human) {
+            // -- goal switch, forces_parallel.py:226-234 (on the incoming position)
+            const float gdx = g0x - px, gdy = g0y - py;
+            if (fmaf(gdx, gdx, gdy * gdy) <= r * r) { // |goals[i][0] - p| <= r ; rare, divergent
+                const int k = gk;
+                if (k <= 2) {                       // rotation of a list of 0, 1 or 2 goals: registers only
+                    if (k == 2) {
+                        const float t0 = g0x, t1 = g0y;
+                        g0x = g1x; g0y = g1y; g1x = t0; g1y = t1;
+                        gdirty = true;
+                    }
+                } else if (kmode & M_COMMIT_GOALS) {
+                    const float r0 = gi[0], r1 = gi[1];
+                    for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
+                    if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
+                    g0x = gi[0]; g0y = gi[1];
+                } else if (k > 1) {
+                    g0x = gi[2]; g0y = gi[3];
+                }
+                gx = g0x; gy = g0y;
+            }
+        }
+        STAMP(0);
+        // -- social force, pair-once form (:87-133).  Lane i evaluates its partners at ring distance 1 .. (rows-1)/2
+        //    inside its world (rows even: plus the antipodal one, evaluated by both ends).  The partner's share -f
+        //    is added to accumulator slot [k mod UA][i + distance] of UA LDS rows: plain read-modify-write, no
+        //    atomics -- one wavefront executes its LDS operations in order, so each of the UA chains is race-free.
+        //    Index i + distance runs past the world's rows without a modulo: receiver j sums slots j and j + rows.
+        //    Order of a substep: the first group's partner rows are requested from LDS, then everything that does not
+        //    depend on this substep's social force is computed while they are in flight (rotation, desired and wall
+        //    forces, the Farina torque, the new heading and its sine / cosine), then the partner groups, and only the
+        //    short force-dependent tail (body-frame projection, Euler step, publish) follows the reaction sum.
+        float fsx = 0.0f, fsy = 0.0f;
+        // (the reaction accumulators were zeroed behind the previous substep's reaction sum, off the critical path)
+        STAMP(8);
+        // -- part A of the per-agent update: everything that does not need this substep's social force
+        const float c = cs, s = sn;          // rotation matrix of the incoming heading, :254-256
+        float cvx = vx, cvy = vy;            // refreshed linear velocity
+        float fdx = 0.0f, fdy = 0.0f, fox = 0.0f, foy = 0.0f;
+        float th_n = th, sn_n = sn, cs_n = cs, torque_a = 0.0f;
+        if (human) {
+            if constexpr (HEADED > 0) {
+                cvx = c * bvx + (-s) * bvy;
+                cvy = s * bvx + c * bvy;
+            }
+            // -- desired force, :23-40
+            {
+                const float dx = gx - px, dy = gy - py;
+                const float d2 = fmaf(dx, dx, dy * dy);
+                const float inv = rsq_fast(fmaxf(d2, 1e-30f));
+                const float wx = m_tau * (dx * inv * vd - cvx), wy = m_tau * (dy * inv * vd - cvy);
+                const bool far_ = d2 * inv > r;   // selects, not a branch: a data-dependent branch costs ~55 cycles of latency
+                fdx = far_ ? wx : 0.0f;
+                fdy = far_ ? wy : 0.0f;
+            }
+            // -- obstacle force: closest point per polygon :236-252, then :136-162
+            if (obst != nullptr) {
+                for (int o = 0; o < a.O; ++o) {
+                    // first argmin over the polygon's segments, on squared distances (same order)
+                    float best = INFINITY, bdx = 0.0f, bdy = 0.0f;   // the first slot always beats +inf: a first argmin
+                    if (a.seg_tab > 0) {
+                        {   // nobody of this wavefront within reach of the polygon: its force is < 5e-13 N on everyone, skip it
+                            const float4 pc = lds_poly[(sbase / a.Smax) + o];
+                            const float dxc = px - pc.x, dyc = py - pc.y, lim = pc.z + wall_cut;
+                            if (__builtin_amdgcn_ballot_w64(fmaf(dxc, dxc, dyc * dyc) < lim * lim) == 0) continue;
+                        }
+                        // branch-free, four slots per trip (then two, then one): the LDS reads of a trip (uniform addresses,
+                        // broadcasts) are issued before its arithmetic; a NaN slot is a far-away degenerate segment in the table
+                        const float4* sgp = lds_seg + sbase + o * a.Smax;
+                        const float* sip = lds_sinv + sbase + o * a.Smax;
+                        auto trip = [&](int s0, auto width) {
+                            constexpr int NW = decltype(width)::value;
+                            float4 e[NW];
+                            float iv[NW];
+#pragma unroll
+                            for (int j = 0; j < NW; ++j) { e[j] = sgp[s0 + j]; iv[j] = sip[s0 + j]; }
+#pragma unroll
+                            for (int j = 0; j < NW; ++j) {
+                                const float qx = px - e[j].x, qy = py - e[j].y;
+                                const float t = fmaf(qx, e[j].z, qy * e[j].w) * iv[j];
+                                const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                                const float ddx = fmaf(-ts, e[j].z, qx), ddy = fmaf(-ts, e[j].w, qy);   // p - (a + ts e)
+                                const float d = fmaf(ddx, ddx, ddy * ddy);
+                                const bool better = d < best;
+                                best = better ? d : best;
+                                bdx = better ? ddx : bdx;
+                                bdy = better ? ddy : bdy;
+                            }
+                        };
+                        int s0 = 0;
+                        // polygons of up to six slots (triangles to hexagons) in ONE trip: all their LDS reads are in flight together
+                        if (a.Smax == 5) { trip(0, std::integral_constant<int, 5>{}); s0 = 5; }
+                        else if (a.Smax == 6) { trip(0, std::integral_constant<int, 6>{}); s0 = 6; }
+                        else if (a.Smax == 3) { trip(0, std::integral_constant<int, 3>{}); s0 = 3; }
+                        for (; s0 + 4 <= a.Smax; s0 += 4) trip(s0, std::integral_constant<int, 4>{});
+                        if (s0 + 2 <= a.Smax) { trip(s0, std::integral_constant<int, 2>{}); s0 += 2; }
+                        if (s0 < a.Smax) trip(s0, std::integral_constant<int, 1>{});
+                    } else {
+                        for (int sg = 0; sg < a.Smax; ++sg) {
+                            const float4 seg = *reinterpret_cast<const float4*>(obst + ((long)o * a.Smax + sg) * 4);
+                            const float x1 = seg.x, y1 = seg.y, ex = seg.z - seg.x, ey = seg.w - seg.y;
+                            float d, ddx = 0.0f, ddy = 0.0f;
+                            if (isnan(seg.x)) {
+                                d = 3.0e38f; // NaN slot: the reference stores iinfo(int64).max as the distance (:247)
+                            } else {
+                                const float t = ((px - x1) * ex + (py - y1) * ey) * rcp_fast(fmaf(ex, ex, ey * ey));
+                                const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                                ddx = px - fmaf(ts, ex, x1); ddy = py - fmaf(ts, ey, y1);
+                                d = fmaf(ddx, ddx, ddy * ddy);
+                            }
+                            if (d < best) { best = d; bdx = ddx; bdy = ddy; }
+                        }
+                    }
+                    const float bcl = fmaxf(best, 1e-30f);
+                    const float inv = rsq_fast(bcl);
+                    const float dist = best * inv;
+                    const float nx = bdx * inv, ny = bdy * inv;
+                    const float dv = -(cvy * nx - cvx * ny);                 // -(v . t), t = (-ny, nx)
+                    const float rd = r - dist + safety;
+                    const float m0 = fmaxf(0.0f, r - dist_refined(bcl, inv) + safety);
+                    const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
+                    float ft;                                                 // coefficient of t
+                    if (obs_type == 0) ft = -(k2 * m0) * dv;
+                    else ft = (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
+                    fox += fn * nx - ft * ny;
+                    foy += fn * ny + ft * nx;
+                }
+                fox *= inv_O; foy *= inv_O;
+            }
+            if constexpr (HEADED > 0) {
+                th_n = wrap_angle(fmaf(om, dt, th));   // :278; the new heading needs omega of the incoming row only
+                sincos_fast(th_n, sn_n, cs_n);
+            }
+            if constexpr (HEADED == 1) {               // Farina: the torque follows the desired force alone, :165-182
+                const float kf = klam * norm2(fdx, fdy);
+                const float k_theta = inertia * kf;
+                const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf * inv_alpha);
+                const float delta = atan2_fast(s * fdx - c * fdy, c * fdx + s * fdy);
+                torque_a = -k_theta * delta - k_omega * om;
+            }
+        }
+        STAMP(1);
+        if constexpr (N3L) {
+            if (valid) {
+                float2* acc = lds_acc + pbase + row + 1;                 // acc[u * 2T + k]: that partner's slot in row u
+                float ex = 0.0f, ey = 0.0f, rdmax = -1.0f;
+                if constexpr (!LEAN) { if (Hf >= UA) fetch(qa, va, 0); }
+                auto pair_once = [&](const float4 q, const float2 vq, float& fx, float& fy) {
+                    const float dx = px - q.x, dy = py - q.y;
+                    if constexpr (SOC == 2) {
+                        pair_force_moussaid_once(sp, dx, dy, vx - vq.x, vy - vq.y, my_rs + q.z, fx, fy);
+                    } else {
+                        // [A e^{rd/B}] n + [C e^{rd/D}] t, in units of sign(A); the k1 / k2 contact parts are exact
+                        // zeros unless rd > 0 and are added by the contact pass below
+                        const float d2 = fmaf(dx, dx, dy * dy);
+                        const float inv = rsq_fast(d2);
+                        const float rd = fmaf(-d2, inv, my_rs + q.z);             // rij - dist
+                        const float ga = exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv; // |A| e^{rd/B} / dist
+                        fx = ga * dx; fy = ga * dy;
+                        if constexpr (SOC == 1) {
+                            const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * (inv * sp.sAC); // +-|C| e^{rd/D} / dist
+                            fx = fmaf(-gc, dy, fx); fy = fmaf(gc, dx, fy);                       // along t = (-ny, nx)
+                        }
+                        rdmax = fmaxf(rdmax, rd);
+                    }
+                };
+                // groups of UA partners; the partner rows of the NEXT group are fetched while the current group is
+                // evaluated (two register sets, a compiler memory barrier pins the prefetch), and the accumulator
+                // slots are read before the evaluation and written after it
+                // accumulator row pitch: 2 KiB, out of reach of the ds_read2_b64 / ds_write2_b64 offset fields on purpose:
+                // the paired forms take 8 / 13 LDS cycles, two single b64 accesses 4 / 12 (MI355X_MICROARCH.md, LDS table)
+                constexpr int AR = ACC_PITCH;
+                auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], float2 (&ac)[UA], int kk) {
+                    if constexpr (SOC == 2) {
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            float fx, fy;
+                            pair_once(q[u], vq[u], fx, fy);
+                            ex += fx; ey += fy;
+                            ac[u].x += fx; ac[u].y += fy;
+                        }
+                    } else {
+                        // Helbing / Guo: the UA partners advance stage by stage (scheduling barriers between the
+                        // stages), so the UA v_rsq_f32 and the UA v_exp_f32 issue back to back and each result is
+                        // consumed ~UA instructions later instead of right behind its transcendental
+                        float dx[UA], dy[UA], d2[UA], inv[UA], rd[UA], ea[UA], ec[UA];
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            dx[u] = px - q[u].x; dy[u] = py - q[u].y;
+                            d2[u] = fmaf(dx[u], dx[u], dy[u] * dy[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) inv[u] = rsq_fast(d2[u]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            rd[u] = fmaf(-d2[u], inv[u], my_rs + q[u].z);
+                            ea[u] = fmaf(rd[u], sp.cB, sp.lA);
+                            if constexpr (SOC == 1) ec[u] = fmaf(rd[u], sp.cD, sp.lC);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            ea[u] = exp2_fast(ea[u]);
+                            if constexpr (SOC == 1) ec[u] = exp2_fast(ec[u]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) {
+                            const float ga = ea[u] * inv[u];
+                            float fx = ga * dx[u], fy = ga * dy[u];
+                            if constexpr (SOC == 1) {
+                                const float gc = ec[u] * (inv[u] * sp.sAC);
+                                fx = fmaf(-gc, dy[u], fx); fy = fmaf(gc, dx[u], fy);
+                            }
+                            ex += fx; ey += fy;
+                            ac[u].x += fx; ac[u].y += fy;
+                        }
+#pragma unroll
+                        for (int u = 0; u < UA; u += 2) rdmax = fmaxf(fmaxf(rdmax, rd[u]), rd[u + 1]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) acc[u * AR + kk + u] = ac[u];
+                    LDS_ORDER_FENCE(); // the next group's slots were written by other lanes in this group
+                };
+                int k0 = 0;
+                if constexpr (ROWS_CT > 0) {
+                    // rows known at compile time: the groups are laid out one after the other, no loop, no scalar branches
+                    constexpr int NG = ((ROWS_CT - 1) / 2) / UA;
+                    float4 qb[UA];
+                    float2 vb[UA], ac[UA];
+                    for_each_index([&](auto gtag) {
+                        constexpr int g = decltype(gtag)::value;
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + g * UA + u];
+                        if constexpr (g + 1 < NG) {
+                            if constexpr (g & 1) fetch(qa, va, (g + 1) * UA); else fetch(qb, vb, (g + 1) * UA);
+                        }
+                        asm volatile("" ::: "memory");
+                        if constexpr (g & 1) group(qb, vb, ac, g * UA); else group(qa, va, ac, g * UA);
+                    }, std::make_integer_sequence<int, NG>{});
+                    k0 = NG * UA;
+                } else if (Hf >= UA) {
+                    float4 qb[UA];
+                    float2 vb[UA], ac[UA];
+                    for (;;) {
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + k0 + u];
+                        const bool more_b = k0 + 2 * UA <= Hf;
+                        if (more_b) fetch(qb, vb, k0 + UA);
+                        asm volatile("" ::: "memory");
+                        group(qa, va, ac, k0);
+                        k0 += UA;
+                        if (!more_b) break;
+#pragma unroll
+                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + k0 + u];
+                        const bool more_a = k0 + 2 * UA <= Hf;
+                        if (more_a) fetch(qa, va, k0 + UA);
+                        asm volatile("" ::: "memory");
+                        group(qb, vb, ac, k0);
+                        k0 += UA;
+                        if (!more_a) break;
+                    }
+                }
+                for (int k = k0; k < Hf; ++k) {
+                    float fx, fy;
+                    float2 vq = make_float2(0.0f, 0.0f);
+                    if constexpr (SOC == 2) vq = rv[k];
+                    pair_once(rp[k], vq, fx, fy);
+                    ex += fx; ey += fy;
+                    float2 ac = acc[k];
+                    ac.x += fx; ac.y += fy;
+                    acc[k] = ac;
+                    LDS_ORDER_FENCE();
+                }
+                if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself (lean build: row fetched at the top)
+                    float fx, fy;
+                    if constexpr (!LEAN) {
+                        qz = rp[Hf];
+                        if constexpr (SOC == 2) vz = rv[Hf];
+                    }
+                    pair_once(qz, vz, fx, fy);
+                    ex += fx; ey += fy;
+                }
+                STAMP(9);
+                LDS_ORDER_FENCE(); // the reaction slots of this lane were written by its partners
+                float rx = 0.0f, ry = 0.0f;
+                const float2* rr = lds_acc + pbase + row;
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    const float2 lo = rr[u * AR], hi = rr[u * AR + rows];
+                    rx += lo.x + hi.x; ry += lo.y + hi.y;
+                }
+                fsx = ex - rx; fsy = ey - ry;
+                STAMP(10);
+                if constexpr (SOC != 2) {
+                    fsx *= sp.sA; fsy *= sp.sA;
+                    if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
+                        const float4* pp = lds_p + cur * TP + pbase;
+                        float2* pvel = lds_v + cur * TP + pbase;
+                        pvel[row] = make_float2(vx, vy); // every lane of the wavefront is here: publish the velocities now
+                        LDS_ORDER_FENCE();
+#pragma nounroll
+                        for (int j = 0; j < rows; ++j) { // rare path: keep it small in the instruction cache
+                            const float4 q = pp[j];
+                            const float2 vj = pvel[j];
+                            const float dx = px - q.x, dy = py - q.y;
+                            const float d2 = (j == row) ? 1.0e30f : fmaf(dx, dx, dy * dy);
+                            const float inv = rsq_fast(d2);
+                            const float m0 = fmaxf(0.0f, (my_rs + q.z) - dist_refined(d2, inv));
+                            const float nx = dx * inv, ny = dy * inv;
+                            const float dv = (vj.y - vy) * nx - (vj.x - vx) * ny;     // (v_j - v_i) . t
+                            const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;
+                            fsx += fn * nx - ft * ny;
+                            fsy += fn * ny + ft * nx;
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (N3L) {
+            // zero the reaction accumulators for the next substep now: the LDS executes these stores while the VALU does
+            // the Euler tail, instead of in front of the next substep's first partner fetch
+            LDS_ORDER_FENCE();
+            float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 used per row = T float4: one per lane
+#pragma unroll
+            for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            LDS_ORDER_FENCE();
+        }
+        STAMP(2);
+        if (human) {
+            // -- social force, every lane evaluates all its partners: O(N) rows broadcast from LDS, :43-84
+            if constexpr (!N3L) {
+                // all_params_equal: every row's stored velocity (the reference evaluates all pairs
+                // before any in-place refresh); else: my refreshed velocity, partner j<i refreshed,
+                // j>i stored (prange == range order; identical from the 2nd fused substep on)
+                const float vix = PEQ ? vx : cvx, viy = PEQ ? vy : cvy;
+                const float4* pp = lds_p + cur * TP + pbase;
+                const float2* pvel = lds_v + cur * TP + pbase;
+                const float2* vr = lds_vr + cur * T + base;
+                auto partner_vel = [&](int j) {
+                    float2 v2 = pvel[j];
+                    if constexpr (!PEQ && HEADED > 0) { if (j < row) v2 = vr[j]; }
+                    return v2;
+                };
+                if constexpr (SOC == 2) {
+                    for (int j = 0; j < rows; ++j) {
+                        const float4 q = pp[j];
+                        const float2 vj = partner_vel(j);
+                        pair_force_moussaid(sp, px, py, vix, viy, q.x, q.y, vj.x, vj.y, my_rs + q.z, j == row, fsx, fsy);
+                    }
+                } else {
+                    // Helbing / Guo (:117-118).  Per partner the force is
+                    //   [A e^{rd/B} + k1 max(0,rd)] n + [C e^{rd/D} + k2 max(0,rd) dv] t      (C = 0: Helbing)
+                    // Main loop: the exponential parts for every partner, branch-free (one ds_read_b128,
+                    // ~13 VALU + 2 transcendental ops each; A and C folded into the exponent; the next group
+                    // of four is fetched from LDS while the current one is evaluated).  The k1 / k2 contact
+                    // parts are exact zeros unless rd > 0: they are added by a second pass that a wavefront
+                    // runs only when one of its lanes touched a partner in this substep.
+                    float eax = 0.0f, eay = 0.0f, ecx = 0.0f, ecy = 0.0f, rdmax = -1.0f;
+                    constexpr int U = 8;                  // partners in flight per lane (independent rsq -> exp chains)
+                    const float4* rp = pp + row + 1;      // partner k of mine = row (i + 1 + k) mod rows, k = 0 .. rows-2
+                    const int np = rows - 1;
+                    auto group = [&](const float4 (&q)[U], int rem, auto tail_tag) {
+                        constexpr bool TAIL = decltype(tail_tag)::value;
+                        float rdk[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const float dx = px - q[u].x, dy = py - q[u].y;
+                            float d2 = fmaf(dx, dx, dy * dy);
+                            if constexpr (TAIL) d2 = (u >= rem) ? 1.0e30f : d2; // padding slot (wave-uniform): dist 1e15 -> 0
+                            const float inv = rsq_fast(d2);
+                            const float rd = fmaf(-d2, inv, my_rs + q[u].z);          // rij - dist
+                            const float ga = exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv; // |A| e^{rd/B} / dist
+                            eax = fmaf(ga, dx, eax); eay = fmaf(ga, dy, eay);
+                            if constexpr (SOC == 1) {
+                                const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * inv; // |C| e^{rd/D} / dist
+                                ecx = fmaf(-gc, dy, ecx); ecy = fmaf(gc, dx, ecy);       // along t = (-ny, nx)
+                            }
+                            rdk[u] = rd;
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u += 2) rdmax = fmaxf(fmaxf(rdmax, rdk[u]), rdk[u + 1]); // v_max3_f32
+                    };
+                    auto run = [&](const float4 (&q)[U], int rem) {
+                        if (rem >= U) group(q, U, std::false_type{});
+                        else group(q, rem, std::true_type{});
+                    };
+                    // two register sets, filled alternately: the next group's LDS reads are in flight
+                    // while the current one is evaluated (no copies, no re-load at the point of use)
+                    float4 qa[U], qb[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) qa[u] = rp[u];
+                    for (int k0 = 0; k0 < np; k0 += 2 * U) {
+                        if (k0 + U < np) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) qb[u] = rp[k0 + U + u]; // rows past np are finite padding
+                        }
+                        asm volatile("" ::: "memory");
+                        run(qa, np - k0);
+                        if (k0 + U >= np) break;
+                        if (k0 + 2 * U < np) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u) qa[u] = rp[k0 + 2 * U + u];
+                        }
+                        asm volatile("" ::: "memory");
+                        run(qb, np - k0 - U);
+                    }
+                    fsx = sp.sA * eax; fsy = sp.sA * eay;
+                    if constexpr (SOC == 1) { fsx = fmaf(sp.sC, ecx, fsx); fsy = fmaf(sp.sC, ecy, fsy); }
+                    if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
+                        for (int j = 0; j < rows; ++j) {
+                            const float4 q = pp[j];
+                            const float2 vj = partner_vel(j);
+                            const float dx = px - q.x, dy = py - q.y;
+                            const float d2 = (j == row) ? 1.0e30f : fmaf(dx, dx, dy * dy);
+                            const float inv = rsq_fast(d2);
+                            const float m0 = fmaxf(0.0f, (my_rs + q.z) - dist_refined(d2, inv));
+                            const float nx = dx * inv, ny = dy * inv;
+                            const float dv = (vj.y - viy) * nx - (vj.x - vix) * ny;     // (v_j - v_i) . t
+                            const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;
+                            fsx += fn * nx - ft * ny;
+                            fsy += fn * ny + ft * nx;
+                        }
+                    }
+                }
+            }
+            STAMP(6);
+            // -- part B: total force, body frame, torque  :262-271, :165-182
+            const float fix = fdx + fox + fsx, fiy = fdy + foy + fsy;
+            float gfx = fix, gfy = fiy, torque = torque_a;
+            if constexpr (HEADED > 0) {
+                if constexpr (HEADED == 2) {  // torque on the total force
+                    const float kf = klam * norm2(fix, fiy);
+                    const float k_theta = inertia * kf;
+                    const float k_omega = inertia * (1.0f + alpha) * sqrt_fast(kf * inv_alpha);
+                    // bound_angle(theta - atan2(Fy, Fx)) is the signed angle from F to the heading:
+                    // atan2(|F| sin(theta - phi), |F| cos(theta - phi)) -- one atan2, no wrap needed
+                    const float delta = atan2_fast(s * fix - c * fiy, c * fix + s * fiy);
+                    torque = -k_theta * delta - k_omega * om;
+                }
+                gfx = fix * c + fiy * s;
+                gfy = ko * ((fox + fsx) * (-s) + (foy + fsy) * c) - kd * bvy;
+            }
+            // -- explicit Euler, :273-283 (position uses the velocity stored in the incoming row)
+            const float in_vx = cvx, in_vy = cvy; // what the reference leaves in agents_state[i,3:5]
+            px += vx * dt; py += vy * dt;
+            if constexpr (HEADED > 0) {
+                th = th_n;
+                bvx = fmaf(gfx, dt_m, bvx); bvy = fmaf(gfy, dt_m, bvy);
+                const float nb2 = fmaf(bvx, bvx, bvy * bvy);
+                const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
+                if (nb2 * ninv > vd) { const float sc = vd * ninv; bvx *= sc; bvy *= sc; }
+                om = fmaf(torque, dt_inertia, om);
+                sn = sn_n; cs = cs_n;
+                vx = cs * bvx + (-sn) * bvy;
+                vy = sn * bvx + cs * bvy;
+            } else {
+                vx = fmaf(gfx, dt_m, vx); vy = fmaf(gfy, dt_m, vy);
+                const float nb2 = fmaf(vx, vx, vy * vy);
+                const float ninv = rsq_fast(fmaxf(nb2, 1e-30f));
+                if (nb2 * ninv > vd) { const float sc = vd * ninv; vx *= sc; vy *= sc; }
+            }
+            if ((kmode & M_MUTATE_INPUT) && sub == 0) {
+                float* si = a.Sin + sidx * a.in_as;
+                if (HEADED > 0) { si[3 * a.in_fs] = in_vx; si[4 * a.in_fs] = in_vy; }
+                si[10 * a.in_fs] = gx; si[11 * a.in_fs] = gy;
+            }
+            publish(nxt);
+            publish_v(nxt);
+            if constexpr (!PEQ && HEADED > 0) lds_vr[nxt * T + tid] = make_float2(vx, vy);
+            STAMP(3);
+        } else if (is_robot) {
+            // the robot's move of the NEXT substep happens before that substep's update_humans
+            if (robot_moves && sub + 1 < a.nsub) robot_step();
+            publish(nxt);
+            publish_v(nxt);
+            if constexpr (!PEQ && HEADED > 0) lds_vr[nxt * T + tid] = make_float2(vx, vy);
+        }
+        // block of one wavefront: its LDS operations execute in order, program order is all the next substep needs
+        // (no s_waitcnt lgkmcnt(0) + s_barrier on the published rows)
+        if constexpr (MAXT == 64) LDS_ORDER_FENCE(); else __syncthreads();
+        STAMP(4);
+        // -- parallel-traffic respawn, motion_model_manager.py:407-422 (sequential inside a world)
+        if (a.flags & CS_RESPAWN) {
+            const float rdx = px - g0x, rdy = py - g0y;
+            const int flag = (human && respawn_here && fmaf(rdx, rdx, rdy * rdy) < 9.0f) ? 1 : 0; // |p - g| < 3
+            if constexpr (MAXT == 64) {
+                // one wavefront holds whole worlds: no barrier, no serial lane.  The reference respawns the flagged
+                // humans of a world in index order, each behind everybody else (:411-417): x_0 = max(max_x + 2 max_r,
+                // bound), and the c-th flagged one (c lower-indexed flagged rows in its world) lands at
+                // x_c = max(x_{c-1} + 2 max_r, bound) because x_{c-1} is then the rightmost human.
+                // ONE data-dependent branch in the common (nobody flagged) case: the vote is taken inside the branch, where
+                // only the flagged lanes are active -- exactly the lanes it has to count
+                if (flag) {
+                    const unsigned long long fm = __builtin_amdgcn_ballot_w64(true);
+                    const unsigned long long wm = (rows >= 64 ? ~0ull : ((1ull << rows) - 1ull)) << base;
+                    const int c = __builtin_popcountll(fm & wm & ((1ull << tid) - 1ull));
+                    const float4* pvn = lds_p + nxt * TP + pbase;
+                    float mx = pvn[0].x, mr = pvn[0].z;
+#pragma nounroll
+                    for (int j = 1; j < n; ++j) {
+                        mx = fmaxf(mx, pvn[j].x);
+                        mr = fmaxf(mr, pvn[j].z);
+                    }
+                    if (robot_row) { // consider_robot: the robot where it stands in THIS substep
+                        const float4 qr = lds_p[cur * TP + pbase + n];
+                        mx = fmaxf(mx, qr.x);
+                        mr = fmaxf(mr, qr.z);
+                    }
+                    float x = fmaxf(mx + mr * 2.0f, a.bx);
+                    for (int t = 0; t < c; ++t) x = fmaxf(x + mr * 2.0f, a.bx);
+                    px = x;
+                    py = (py >= 0.0f) ? fminf(py, a.by) : fmaxf(py, -a.by);
+                    publish(nxt);
+                    g0y = py;               // human.set_goals([[goals[0][0], position[1]]])   :418
+                    bvy = g0x; om = g0y;    // states[i,6:8] = goal  (reference writes cols 6:8) :421
+                    for (int g = 0; g < a.G; ++g) { gi[2 * g] = g0x; gi[2 * g + 1] = g0y; } //   :422
+                    gk = a.G; g1x = g0x; g1y = g0y;
+                }
+            } else if (__syncthreads_or(flag) != 0) {
+                lds_flag[tid] = flag;
+                lds_g0x[tid] = g0x;
+                __syncthreads();
+                if (valid && row == 0) {
+                    float4* pvn = lds_p + nxt * TP + pbase;
+                    for (int i = 0; i < n; ++i) {
+                        if (!lds_flag[base + i]) continue;
+                        float mx = pvn[0].x, mr = pvn[0].z;
+                        for (int j = 1; j < n; ++j) {
+                            mx = fmaxf(mx, pvn[j].x);
+                            mr = fmaxf(mr, pvn[j].z);
+                        }
+                        if (robot_row) { // consider_robot: the robot where it stands in THIS substep
+                            const float4 qr = lds_p[cur * TP + pbase + n];
+                            mx = fmaxf(mx, qr.x);
+                            mr = fmaxf(mr, qr.z);
+                        }
+                        float4 q = pvn[i];
+                        q.x = fmaxf(mx + mr * 2.0f, a.bx);
+                        q.y = (q.y >= 0.0f) ? fminf(q.y, a.by) : fmaxf(q.y, -a.by);
+                        pvn[i] = q;
+                        pvn[rows + i] = q;
+                    }
+                }
+                __syncthreads();
+                if (flag) {
+                    const float4 q = lds_p[nxt * TP + pbase + row];
+                    px = q.x; py = q.y;
+                    g0y = py;               // human.set_goals([[goals[0][0], position[1]]])   :418
+                    bvy = g0x; om = g0y;    // states[i,6:8] = goal  (reference writes cols 6:8) :421
+                    for (int g = 0; g < a.G; ++g) { gi[2 * g] = g0x; gi[2 * g + 1] = g0y; } //   :422
+                    gk = a.G; g1x = g0x; g1y = g0y;
+                }
+            }
+        }
+        STAMP(5);
+        LDS_ORDER_FENCE(); // rows republished by the respawn rule are read by other lanes in the next substep
+        cur = nxt;
+    }
+#ifdef CS_STAMPS
+    if (a.stamps != nullptr && (threadIdx.x & 63) == 0) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 12;
+        for (int k = 0; k < 12; ++k) o[k] = st_acc[k];
+    }
+#endif
+
+    if (a.trace != nullptr && (human || is_robot) && a.nsub > 0)
+        write_trace(a.trace + (((long)(a.nsub - 1) * a.W + w) * rows + row) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    if (kmode & M_PEEK) {
+        if (human) {
+            float* o = a.peek_out + ((long)w * n + row) * 8;
+            o[0] = px; o[1] = py; o[2] = th; o[3] = vx; o[4] = vy; o[5] = om;
+            o[6] = g0x; o[7] = g0y; // human.goals[0] (the goals array), not the state's goal columns (:297)
+        }
+        return;
+    }
+    if (human && gdirty && (kmode & M_COMMIT_GOALS)) { gi[0] = g0x; gi[1] = g0y; gi[2] = g1x; gi[3] = g1y; }
+    if (valid) {
+        float* o = a.Sout + sidx * a.out_as;
+        const long fs = a.out_fs;
+        if (human || is_robot) {
+            o[0] = px; o[fs] = py; o[2 * fs] = th; o[3 * fs] = vx; o[4 * fs] = vy; o[5 * fs] = bvx;
+            o[6 * fs] = bvy; o[7 * fs] = om; o[10 * fs] = gx; o[11 * fs] = gy;
+            if (a.Sout != a.Sin || is_robot) { o[8 * fs] = r; o[9 * fs] = m; o[12 * fs] = vd; }
+        }
+        if (is_robot && robot_moves && a.robot != nullptr) {
+            float* rb = a.robot + (long)w * 13;
+            rb[0] = px; rb[1] = py; rb[2] = th; rb[3] = vx; rb[4] = vy;
+        }
+        // invisible robot: advanced by the lane of row 0 (it does not interact with the crowd)
+        if (!robot_row && row == 0 && robot_moves && a.robot != nullptr) {
+            float* rb = a.robot + (long)w * 13;
+            float qx = rb[0], qy = rb[1], qt = rb[2], qvx = rb[3], qvy = rb[4];
+            for (int sub = 0; sub < a.nsub; ++sub) {
+                if (a.flags & CS_ROBOT_UNICYCLE) {
+                    const float c = cosf(qt + ay), s = sinf(qt + ay);
+                    qx += c * ax * dt; qy += s * ax * dt;
+                    qt = fmodf(qt + ay, 6.283185307179586f);
+                    if (qt < 0) qt += 6.283185307179586f;
+                    qvx = cosf(qt) * ax; qvy = sinf(qt) * ax;
+                } else {
+                    qx += ax * dt; qy += ay * dt; qvx = ax; qvy = ay;
+                }
+            }
+            rb[0] = qx; rb[1] = qy; rb[2] = qt; rb[3] = qvx; rb[4] = qvy;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// build selection (host side)
+// ------------------------------------------------------------------------------------------
+using kfn = void (*)(const KArgs);
+
+// Which instantiation of k_sfm_step a launch runs (crowdstep.hip select_variant decides; cs_step_variant reports it)
+struct Variant { int maxt, occ, rows_ct, lean; bool peq; };
+
+template <int MAXT, int OCC, int ROWS_CT, int LEAN>
+kfn pick_kernel(int type, bool peq)
+{
+#define CS_CASE(SOC, HD)                                                                                      \
+    if constexpr (LEAN != 0) return (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, LEAN>;                      \
+    else return peq ? (kfn)k_sfm_step<SOC, HD, true, MAXT, OCC, ROWS_CT, 0>                               \
+                    : (kfn)k_sfm_step<SOC, HD, false, MAXT, OCC, ROWS_CT, 0>;
+    switch (type) {
+        case 0: CS_CASE(0, 0) case 1: CS_CASE(1, 0) case 2: CS_CASE(2, 0)
+        case 3: CS_CASE(0, 1) case 4: CS_CASE(1, 1) case 5: CS_CASE(2, 1)
+        case 6: CS_CASE(0, 2) case 7: CS_CASE(1, 2) case 8: CS_CASE(2, 2)
+    }
+#undef CS_CASE
+    return nullptr;
+}
+
+// one lookup per translation unit of builds: the kernel of variant `v` for model `type`, or nullptr when this unit does not hold it
+#define CS_V(MT, OC, RC, LN) if (v.maxt == MT && v.occ == OC && v.rows_ct == RC && v.lean == LN) return pick_kernel<MT, OC, RC, LN>(type, v.peq);
+kfn sfm_builds_generic(const Variant& v, int type);   // sfmstep_generic.hip: one world per block
+kfn sfm_builds_leanrt(const Variant& v, int type);   // sfmstep_leanrt.hip: the lean builds with a run-time row count
+kfn sfm_builds_lean25(const Variant& v, int type);   // sfmstep_lean25.hip: 25 rows per world, plain crowd batch
+kfn sfm_builds_lean30(const Variant& v, int type);   // sfmstep_lean30.hip: 30 rows per world, plain crowd batch
+kfn sfm_builds_small(const Variant& v, int type);   // sfmstep_small.hip: 10 and 20 rows per world, plain crowd batch
+kfn sfm_builds_lean50(const Variant& v, int type);   // sfmstep_lean50.hip: 50 rows per world without / with walls
+kfn sfm_builds_robot26(const Variant& v, int type);   // sfmstep_robot26.hip: 25 humans + a visible robot
+kfn sfm_builds_robotx(const Variant& v, int type);   // sfmstep_robotx.hip: 5 / 10 / 50 humans + a visible robot
+
+} // namespace cstep

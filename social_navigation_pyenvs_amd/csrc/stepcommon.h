@@ -40,8 +40,8 @@ struct KArgs {
     const int* world_flags;
     float bx, by;
     float4* snap;          // optional [nsub][W][n] (x, y, vx, vy) of every human at the START of every substep (imitation block)
-    float* trace;          // optional [nsub][W][n][12] px, py, theta, vx, vy, bvx, bvy, omega, gx, gy, goals[0].x, goals[0].y of every
-                           // human AFTER every substep (respawn included): cs_step_trace, the per-substep parity tests
+    float* trace;          // optional [nsub][W][rows][12] px, py, theta, vx, vy, bvx, bvy, omega, gx, gy, goals[0].x, goals[0].y of every
+                           // row AFTER every substep (respawn included; the robot row as the NEXT substep will see it): cs_step_trace
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     unsigned long long* stamps; // diagnostic build only
 };
@@ -74,6 +74,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int PADR = 8;  // partner rows are read in groups of 8: readable (finite) padding behind each buffer
 
 __device__ __forceinline__ float norm2(float x, float y) { return sqrt_fast(fmaf(x, x, y * y)); }
+
+// |d| from d2 and inv = rsq(d2), refined by one Newton step to (almost) a correctly rounded square root.  The body-contact overlap
+// max(0, r_ij - dist) is a small difference of two O(1) numbers (4 mm of 0.6 m): ONE ulp of dist is 1.4e-5 of the k1 / k2 contact
+// force (120 kN/m), and d2 * v_rsq(d2) alone is ~2.5 ulp off -- measured 1.6e-5 per substep on a Moussaid contact against the
+// float32 oracle's 1e-6 (its sqrt is correctly rounded).  The exponential terms keep the unrefined distance (A / B = 25 kN/m,
+// and they dominate the instruction count).
+__device__ __forceinline__ float dist_refined(float d2, float inv)
+{
+    const float d0 = d2 * inv;
+    return fmaf(fmaf(-d0, d0, d2), 0.5f * inv, d0);
+}
 
 // one human's record of cs_step_trace (three 16-byte stores; the record stride is 48 bytes)
 __device__ __forceinline__ void write_trace(float* o, float px, float py, float th, float vx, float vy, float bvx, float bvy, float om,
@@ -181,7 +192,7 @@ __device__ __forceinline__ void pair_force_moussaid(const SocP& p, float pix, fl
     const float dx = pix - pjx, dy = piy - pjy;
     const float d2 = skip ? 1.0f : fmaf(dx, dx, dy * dy);
     const float inv = rsq_fast(d2);
-    const float dist = d2 * inv;
+    const float dist = dist_refined(d2, inv);
     const float nx = dx * inv, ny = dy * inv;
     const float rd = rij - dist;
     const float m0 = fmaxf(0.0f, rd);
@@ -213,7 +224,7 @@ __device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx
 {
     const float d2 = fmaf(dx, dx, dy * dy);
     const float inv = rsq_fast(d2);
-    const float dist = d2 * inv;
+    const float dist = dist_refined(d2, inv);
     const float nx = dx * inv, ny = dy * inv;
     const float m0 = fmaxf(0.0f, rij - dist);
     const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);

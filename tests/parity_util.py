@@ -122,14 +122,16 @@ def row_errors(got, ref, omega_in, dt, headed):
 
 
 def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, nsub, peq, *, respawn=None, respawn_bounds=None,
-                             robot_row=False, worlds=None, group=None, what="", bar=1e-5, omega_rtol=2e-4):
+                             robot_row=False, robot=None, action=None, worlds=None, group=None, what="", bar=1e-5, omega_rtol=2e-4):
     """Run cw.step_trace(dt, nsub) (cs_step's kernel build, state updated in place) and check EVERY substep of the fused
     launch: record k + 1 against orc.step_block(1 substep, respawn rule included) from the GPU's record k (float32 rows
     read as float64).  S0 [W, rows, 13], goals0 [W, n, G, 2] = what the batch was created from; `worlds` = the worlds to
-    check (default all).  Returns a dict of figures; asserts the bar described above on every substep of every checked world."""
+    check (default all).  `robot` [W, 13] + `action` [W, 2] (with robot_row): the visible robot of a Gym step, moved by its action
+    before every substep (social_nav_gym.py:240-243) and handed to the crowd as the last state row.
+    Returns a dict of figures; asserts the bar described above on every substep of every checked world."""
     from oracle import crowd_oracle as orc
 
-    trace = cw.step_trace(dt, nsub)                                     # [K, W, n, 12]
+    trace = cw.step_trace(dt, nsub, action) if action is not None else cw.step_trace(dt, nsub)     # [K, W, rows, 12]
     S0 = np.asarray(S0, dtype=np.float32); goals0 = np.asarray(goals0, dtype=np.float32)
     if S0.ndim == 2:
         S0, goals0 = S0[None], goals0[None]
@@ -144,6 +146,13 @@ def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, ns
     saf = np.ascontiguousarray(np.broadcast_to(np.asarray(0.0 if safety is None else safety, dtype=np.float32), (W, rows)))[sel].astype(np.float64)
     obs = None if obstacles is None else np.asarray(obstacles, dtype=np.float32).astype(np.float64)
     rsp = np.zeros(len(sel), bool) if respawn is None else np.broadcast_to(np.asarray(respawn).astype(bool), (W,))[sel]
+    R = None if robot is None else np.asarray(robot, dtype=np.float32).reshape(W, 13)[sel].astype(np.float64)
+    if R is not None:   # the robot row as substep 1 sees it: robot.step(action, dt) in float32 (robot_agent.py:114-118, holonomic)
+        S[:, n] = R
+        if action is not None:
+            A = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=np.float32), (W, 2)))[sel].astype(np.float64)
+            S[:, n, 0:2] = (R[:, 0:2] + A * float(np.float32(dt))).astype(np.float32)
+            S[:, n, 3:5] = A
     headed = type_ >= 3
     out = {"substeps": 0, "within": 0, "worst": 0.0, "worst_f32_oracle": 0.0, "ill_conditioned": 0, "goal_flips": 0, "lost_heading_rows": 0}
     for k in range(nsub):
@@ -155,11 +164,14 @@ def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, ns
             rp = (respawn_bounds[0], respawn_bounds[1], 0.0) if flag else (0.0, 0.0, 0.0)
             o = obs if (obs is None or obs.ndim == 4) else obs[sel][m]
             args = (type_, S[m], goals[m], o, Psel if Psel.ndim == 2 else Psel[m], dt, 1, saf[m], peq)
-            r64, g64, _ = orc.step_block(*args, robot_visible=robot_row, respawn=flag, respawn_par=rp)
+            # (the robot row of S is already the robot as THIS substep sees it -- the GPU's own float32 robot motion -- so the oracle
+            #  takes it as a standing row: a robot 1e-6 m off would be 2e-5 m/s on a human it touches, k1 = 120 kN/m)
+            kw = dict(robot_visible=robot_row, respawn=flag, respawn_par=rp, robot=None if R is None else S[m][:, n], action=None)
+            r64, g64, _ = orc.step_block(*args, **kw)
             with np.errstate(over="ignore", invalid="ignore"):
-                r32, _, _ = orc.step_block(*args, robot_visible=robot_row, respawn=flag, respawn_par=rp, dtype=np.float32)
+                r32, _, _ = orc.step_block(*args, dtype=np.float32, **kw)
             ref[m], ref32[m], gnext[m] = r64, r32, g64.reshape(-1, n, G, 2)
-        got = trace[k][sel].astype(np.float64)                           # [w, n, 12]
+        got = trace[k][sel][:, :n].astype(np.float64)                    # [w, n, 12]
         om_in = S[:, :n, 7]
         e_gpu, rel, lost = row_errors(got, ref[:, :n], om_in, dt, headed)
         e_f32, _, _ = row_errors(ref32[:, :n], ref[:, :n], om_in, dt, headed)
@@ -194,6 +206,8 @@ def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, ns
         # the next substep starts from the GPU's rows; goal lists follow the oracle's rotation with the GPU's (float32) head
         S[:, :n, 0:8] = got[..., 0:8]
         S[:, :n, 10:12] = got[..., 8:10]
+        if robot_row and trace.shape[2] > n:
+            S[:, n, 0:8] = trace[k][sel][:, n, 0:8]                       # the robot as the next substep sees it (GPU record)
         goals = gnext
         keep = ~np.isnan(goals[:, :, 0, 0])
         goals[:, :, 0][keep] = got[..., 10:12][keep]

@@ -21,8 +21,12 @@ def _worlds(cfg):
         S, goals, P, rb = sc.hybrid_worlds(W, n, model)
         rw, walls = (np.arange(W) % 2 == 1).astype(np.int32), None
     else:                  # one GPU's shard of cfg5: 8192 worlds x 50-agent HSFM + static obstacles (both flavours)
+        # THE worlds bench.py's cfg5 entry steps (generators.static_obstacle_crossing: one function for both, first 8192 of the 65536)
+        from social_navigation_pyenvs_amd import generators as gen
+
         W, n, model = 8192, 50, "hsfm_farina"  # (hsfm_new* blows up |omega| to 1e108 in the f64 reference itself here)
-        S, goals, P, walls = sc.static_obstacle_worlds(W, n, model)
+        cw0 = gen.static_obstacle_crossing(W, n, model, first_world=0, radius=14.0, n_static=3, walls=True)
+        S, goals, P, walls = cw0.get_states(), cw0.get_goals(), np.tile(sc.default_params(model), (n, 1)), sc.polygon_walls()
         rb, rw = None, None
     return W, n, model, S.astype(np.float32), goals.astype(np.float32), P.astype(np.float32), rb, rw, walls
 

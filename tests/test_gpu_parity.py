@@ -241,6 +241,51 @@ def test_every_substep_inside_the_fused_block(group):
     assert strict_cases > 0 and strict_ok >= strict_cases
 
 
+# the shapes around the benchmark's own and the build each must run (crowdstep.hip select_variant): compile-time row counts for
+# 20 / 30 humans and for 5 / 10 / 25 / 50 humans + the visible robot's row, lean run-time builds for any other count
+SHAPE_VARIANT = [(25, True, 41, "OCC=1,ROWS_CT=26,LEAN=3"), (5, True, 23, "OCC=4,ROWS_CT=6,LEAN=3"), (10, True, 23, "OCC=4,ROWS_CT=11,LEAN=3"),
+                 (50, True, 9, "OCC=3,ROWS_CT=51,LEAN=3"), (20, False, 41, "OCC=1,ROWS_CT=20,LEAN=1"), (30, False, 41, "OCC=1,ROWS_CT=30,LEAN=1"),
+                 (17, True, 23, "OCC=3,ROWS_CT=0,LEAN=3"), (17, False, 23, "OCC=3,ROWS_CT=0,LEAN=1"),
+                 (25, True, 4200, "OCC=4,ROWS_CT=26,LEAN=3"), (20, False, 6300, "OCC=4,ROWS_CT=20,LEAN=1"), (30, False, 4200, "OCC=4,ROWS_CT=30,LEAN=1")]
+
+
+@pytest.mark.parametrize("n,robot,W,variant", SHAPE_VARIANT)
+def test_shape_specialised_builds_every_substep(n, robot, W, variant):
+    """Every build of the specialisation table (ROWS_CT x LEAN, both register budgets: the crowded grids of > 2 waves per SIMD take
+    the OCC=4 builds) through cs_step: hybrid worlds (goal switches, respawns), the visible robot driven by an action through
+    d_robot (social_nav_gym.py:240-245, motion_model_manager.py:359), 20 fused substeps checked substep by substep at 1e-5."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    rng = np.random.default_rng(n + W)
+    for model in (["hsfm_farina", "sfm_guo", "hsfm_new_moussaid"] if W < 1000 else ["hsfm_farina"]):
+        S, goals, P, rb = sc.hybrid_worlds(W, n, model, seed0=31 + n)
+        rw = (np.arange(W) % 2 == 1).astype(np.int32)
+        R = A = None
+        if robot:
+            R = np.zeros((W, 13), np.float32)
+            R[:, 0:2] = rng.uniform(-3, 3, (W, 2)); R[:, 8] = 0.3; R[:, 9] = 80; R[:, 10:12] = -R[:, 0:2]; R[:, 12] = 1.0
+            A = rng.uniform(-0.8, 0.8, (W, 2)).astype(np.float32)
+            S = np.concatenate([S, R[:, None, :]], axis=1)
+        S32, g32, P32 = f32(S), f32(goals), f32(P)
+        cw = CrowdWorlds(S32, g32, P32, None, None, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw,
+                         robot_row=robot, robot=R, layout="soa" if W > 1000 else "aos")
+        assert variant in cw.step_variant(), cw.step_variant()
+        # two Gym steps in, so that the humans have distinct velocities (from rest every Moussaid pair sits exactly on sign(theta = 0))
+        for _ in range(2):
+            cw.step(0.0125, 20, A)
+        S_k, g_k, R_k = cw.get_states(), cw.get_goals(), (cw.get_robot() if robot else None)
+        sample = None if W < 1000 else rng.choice(W, 24, replace=False)
+        fam = "Moussaid" if model.endswith("moussaid") else "Helbing / Guo"
+        res = fused_substeps_vs_oracle(cw, SFMS.index(model), S_k, g_k, P32, None, None, 0.0125, 20, True, respawn=rw, respawn_bounds=rb,
+                                       robot_row=robot, robot=R_k, action=A, worlds=sample,
+                                       group=f"shape-specialised builds per substep inside the fused launch ({fam})", what=f"{variant} {model}")
+        assert res["within"] >= res["substeps"] - res["ill_conditioned"], (variant, model, res)
+        if robot:   # the robot rows moved by the action: 60 substeps of float32 accumulation
+            np.testing.assert_allclose(cw.get_robot()[:, 0:2], R[:, 0:2] + 60 * 0.0125 * A, atol=1e-5)
+            np.testing.assert_array_equal(cw.get_robot()[:, 3:5], A)
+
+
 def test_respawn_g7_with_and_without_robot():
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 

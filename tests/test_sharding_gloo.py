@@ -95,7 +95,7 @@ def _bench_worker(rank, world_size, port, q):
                strong=(strong["first"], strong["W"], float(strong["S"][:, :, 0:2].sum())),
                scaling=("strong" if args5.total_worlds is not None else "weak", "strong" if args.total_worlds is not None else "weak"),
                keys=[bench.spec_key(o) for o in bench.other_config_specs(args)],
-               cfg5_shard=bench.shard_of(bench.other_config_specs(args)[2], rank, world_size))
+               cfg5_shard=bench.shard_of([o for o in bench.other_config_specs(args) if o["name"] == "cfg5"][0], rank, world_size))
     out = [None] * world_size
     dist.all_gather_object(out, rec)
     slow = max_over_ranks(0.5 + rank, dist)
@@ -135,4 +135,5 @@ def test_bench_argument_and_seed_plumbing_two_ranks():
     assert abs(float(one["S"][:11, :, 0:2].sum()) - r0["strong"][2]) < 1e-9 and abs(float(one["S"][11:, :, 0:2].sum()) - r1["strong"][2]) < 1e-9
     # BASELINE configs[4]: 65536 worlds over the ranks, 32768 each at two ranks
     assert r0["cfg5_shard"] == (0, 32768) and r1["cfg5_shard"] == (32768, 32768)
-    assert r0["keys"] == ["sfm_helbing_10_circle", "orca_25_circle", "hsfm_farina_50_circle_walls_static"]
+    assert r0["keys"] == ["sfm_helbing_10_circle", "orca_25_circle_first20", "orca_25_circle_dense", "hsfm_farina_50_circle_walls_static",
+                          "hsfm_new_guo_25_hybrid", "hsfm_farina_25_hybrid_robot", "hsfm_farina_30_hybrid", "hsfm_farina_25_hybrid_peragent"]

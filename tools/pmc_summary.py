@@ -9,8 +9,11 @@ import os
 import sys
 
 SHAPES = {"cfg3": (4096, 25, "hsfm_farina_25_hybrid"), "cfg2": (4096, 10, "sfm_helbing_10_circle"), "cfg4": (4096, 25, "orca_25_circle"),
+          "cfg4_first20": (4096, 25, "orca_25_circle_first20"), "cfg4_dense": (4096, 25, "orca_25_circle_dense"),
           "cfg5": (8192, 50, "hsfm_farina_50_circle_walls_static"), "cfg3x4": (16384, 25, "hsfm_farina_25_hybrid_16384"),
-          "moussaid": (4096, 25, "hsfm_new_moussaid_25_hybrid")}
+          "moussaid": (4096, 25, "hsfm_new_moussaid_25_hybrid"), "cfg3_new_guo": (4096, 25, "hsfm_new_guo_25_hybrid"),
+          "robot26": (4096, 25, "hsfm_farina_25_hybrid_robot"), "n30": (4096, 30, "hsfm_farina_30_hybrid"),
+          "peragent": (4096, 25, "hsfm_farina_25_hybrid_peragent")}
 SUBSTEPS = 20
 SIMDS = 256 * 4
 
@@ -36,7 +39,11 @@ def main(d, out, tag):
             mm, k = means(f)
             m.update(mm)
             nd = max(nd, k)
-        e = {"dispatches_averaged": nd, "source": f"profiles/{tag}_{name}_pmc_*.csv (rocprofv3 --pmc, separate passes)"}
+        e = {"dispatches_averaged": nd, "worlds": W, "source": f"profiles/{tag}_{name}_pmc_*.csv (rocprofv3 --pmc, separate passes)"}
+        try:   # the library build the counters were collected on (bench.py: roofline.pmc_build_matches)
+            e["build_id"] = json.load(open(os.path.join(d, f"{name}_bench.json")))["build_id"]
+        except Exception:
+            e["build_id"] = None
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
             # FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950: FETCH_SIZE reads 1/2 of the bytes of 16-B-per-lane streaming loads and is
             # uncalibrated for the 4-B-per-lane loads of this kernel (MI355X_MICROARCH.md, HBM): reported as measured, not corrected.
