@@ -513,13 +513,17 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 #pragma unroll
                         for (int u = 0; u < UA; ++u) {
                             const float ga = ea[u] * inv[u];
-                            float fx = ga * dx[u], fy = ga * dy[u];
                             if constexpr (SOC == 1) {
                                 const float gc = ec[u] * (inv[u] * sp.sAC);
-                                fx = fmaf(-gc, dy[u], fx); fy = fmaf(gc, dx[u], fy);
+                                const float fx = fmaf(-gc, dy[u], ga * dx[u]), fy = fmaf(gc, dx[u], ga * dy[u]);
+                                ex += fx; ey += fy;
+                                ac[u].x += fx; ac[u].y += fy;
+                            } else {
+                                // Helbing: f = ga d goes into my sum and into the partner's slot by one FMA each (4 instead of
+                                // 2 multiplies + 4 adds; the two sums see the same product, rounded once per sum)
+                                ex = fmaf(ga, dx[u], ex); ey = fmaf(ga, dy[u], ey);
+                                ac[u].x = fmaf(ga, dx[u], ac[u].x); ac[u].y = fmaf(ga, dy[u], ac[u].y);
                             }
-                            ex += fx; ey += fy;
-                            ac[u].x += fx; ac[u].y += fy;
                         }
 #pragma unroll
                         for (int u = 0; u < UA; u += 2) rdmax = fmaxf(fmaxf(rdmax, rd[u]), rd[u + 1]);

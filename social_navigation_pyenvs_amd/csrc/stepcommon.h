@@ -96,26 +96,16 @@ __device__ __forceinline__ void write_trace(float* o, float px, float py, float 
     q[2] = make_float4(gx, gy, g0x, g0y);
 }
 
-// sin and cos together: Cody-Waite reduction by pi/2 + degree-7/8 minimax polynomials; abs error
-// < 1e-7 for |x| < 50 (theta is kept in [-pi, pi] by bound_angle)
+// sin and cos together: the hardware v_sin_f32 / v_cos_f32 (input in revolutions), 1 multiply + 2 quarter-rate instructions instead
+// of the 20-instruction Cody-Waite + minimax form the first rounds used.  Measured on MI355X over 2^26 points of [-pi, pi]
+// (tools/sincos_probe.hip): max |error| 2.7e-7 for both, the conversion to revolutions included -- 6e-7 on a velocity R(theta) bv
+// with |bv| <= 1.5, inside the 1e-5 parity bar with the rest of a substep's float32 rounding (worst measured per substep: see
+// profiles/*parity_report.json).  theta is kept in [-pi, pi] by wrap_angle (the instructions take |revolutions| <= 256).
 __device__ __forceinline__ void sincos_fast(float x, float& s, float& c)
 {
-    const float k = rintf(x * 0.6366197723675814f);
-    const int q = (int)k;
-    float r = fmaf(k, -1.5707963705062866f, x);
-    r = fmaf(k, 4.371139000186241e-08f, r);
-    const float r2 = r * r;
-    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    sp = fmaf(sp, r2, -1.6666654611e-1f);
-    sp = fmaf(sp * r2, r, r);
-    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    cp = fmaf(cp, r2, 4.166664568298827e-2f);
-    cp = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
-    const bool odd = (q & 1) != 0;
-    const float ss = odd ? cp : sp;
-    const float cc = odd ? sp : cp;
-    s = __uint_as_float(__float_as_uint(ss) ^ ((unsigned)(q & 2) << 30));        // quadrants 2,3: -sin
-    c = __uint_as_float(__float_as_uint(cc) ^ ((unsigned)((q + 1) & 2) << 30));  // quadrants 1,2: -cos
+    const float rev = x * 0.15915494309189535f;
+    s = __builtin_amdgcn_sinf(rev);
+    c = __builtin_amdgcn_cosf(rev);
 }
 
 // social_gym/src/utils.py:7-13 (Python % == fmod for the operand signs reaching each branch)
@@ -138,7 +128,13 @@ __device__ __forceinline__ float wrap_angle(float a)
 {
     const float k = rintf(a * 0.15915494309189535f);
     a = fmaf(k, -6.2831854820251465f, a);      // float(2 pi)
-    return fmaf(k, 1.7484556000744883e-07f, a); // float(2 pi) - 2 pi
+    a = fmaf(k, 1.7484556000744883e-07f, a);   // float(2 pi) - 2 pi
+    // second pass: the identity (k2 = 0, bit for bit) whenever the first one landed in [-pi, pi]; where |omega dt| is so large that
+    // float32 cannot hold the heading at all (the reference's own explicit Euler on omega has diverged: 1e11 rad per substep in
+    // crushed hsfm_new* crowds) the first pass leaves hundreds of radians, and the heading that is STORED must still be one whose
+    // sine / cosine the next substep gets to full accuracy (v_sin_f32 / v_cos_f32 lose 6e-8 per revolution of their argument)
+    const float k2 = rintf(a * 0.15915494309189535f);
+    return fmaf(k2, -6.2831854820251465f, a);
 }
 
 // atan2 with |error| < 2e-7 rad (degree-7 minimax in a^2 on [0,1], a = min/max); atan2(0, 0) = 0

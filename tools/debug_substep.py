@@ -29,16 +29,20 @@ for m in ["hsfm_farina", "sfm_guo", "hsfm_new_moussaid"]:
         cw.step(0.0125, 20, A)
     Sk, gk, Rk = cw.get_states().astype(np.float64), cw.get_goals().astype(np.float64), (cw.get_robot().astype(np.float64) if robot else None)
     tr = cw.step_trace(0.0125, 20, A).astype(np.float64)
+    if robot:   # the robot row as substep 1 sees it
+        Sk[:, n] = Rk
+        Sk[:, n, 0:2] = (Rk[:, 0:2] + A.astype(np.float64) * float(np.float32(0.0125))).astype(np.float32)
+        Sk[:, n, 3:5] = A
     t = SFMS.index(model)
     for k in range(20):
         worst = (0, None)
         nxt = []
         for w in range(W):
             kw = dict(robot_visible=robot, respawn=bool(rw[w]), respawn_par=(rb[0], rb[1], 0.0) if rw[w] else (0, 0, 0),
-                      robot=None if Rk is None else Rk[w], action=None if A is None else A[w].astype(np.float64))
+                      robot=None if Rk is None else Sk[w, n], action=None)
             r64, g64, rob = orc.step_block(t, Sk[w], gk[w], None, P32.astype(np.float64), 0.0125, 1, np.zeros(S.shape[1]), True, **kw)
             r32, _, _ = orc.step_block(t, Sk[w], gk[w], None, P32.astype(np.float64), 0.0125, 1, np.zeros(S.shape[1]), True, dtype=np.float32, **kw)
-            eg, _, _ = row_errors(tr[k, w], r64[:n], Sk[w, :n, 7], 0.0125, t >= 3)
+            eg, _, _ = row_errors(tr[k, w, :n], r64[:n], Sk[w, :n, 7], 0.0125, t >= 3)
             ef, _, _ = row_errors(r32[:n], r64[:n], Sk[w, :n, 7], 0.0125, t >= 3)
             if eg.max() > 5e-6:
                 i = int(np.argmax(eg))
@@ -48,8 +52,8 @@ for m in ["hsfm_farina", "sfm_guo", "hsfm_new_moussaid"]:
                       f"cols GPU-ref {np.round((tr[k,w,i,:8]-r64[i,:8])*1e6,2)} f32-ref {np.round((r32[i,:8]-r64[i,:8])*1e6,2)}; omega_in {Sk[w,i,7]:.3f} |F dv| {np.linalg.norm(r64[i,5:7]-Sk[w,i,5:7]):.3e}")
             nxt.append((g64, rob))
         for w in range(W):
-            Sk[w, :n, 0:8] = tr[k, w, :, 0:8]; Sk[w, :n, 10:12] = tr[k, w, :, 8:10]
+            Sk[w, :n, 0:8] = tr[k, w, :n, 0:8]; Sk[w, :n, 10:12] = tr[k, w, :n, 8:10]
             gk[w] = nxt[w][0].reshape(gk[w].shape)
-            keep = ~np.isnan(gk[w][:, 0, 0]); gk[w][:, 0][keep] = tr[k, w, :, 10:12][keep]
+            keep = ~np.isnan(gk[w][:, 0, 0]); gk[w][:, 0][keep] = tr[k, w, :n, 10:12][keep]
             if robot:
-                Rk[w] = nxt[w][1]; Sk[w, n] = Rk[w]
+                Sk[w, n, 0:8] = tr[k, w, n, 0:8]
