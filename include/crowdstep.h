@@ -271,7 +271,8 @@ int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* rob
  * cs_robot_model_velocities  replaces MotionModelManager.update_robot(t, dt, just_velocities=True) (motion_model_manager.py:615-629
  *   with euler_*_single_agent_update(..., just_velocities=True), :72-85): the robot's velocities (linear or body + angular) are
  *   integrated by its SFM / HSFM model, its position and yaw stay (SocialNavSim moves the pose at its own rate with
- *   update_robot_pose, :655-659).  Arguments as cs_robot_model_step; robot_type 0..8.
+ *   update_robot_pose, :655-659).  Arguments as cs_robot_model_step; robot_type 0..8, or CS_ORCA: the robot's doStep gives the new
+ *   velocity and the robot's simulator agent is put back on robot.position (:641-653).
  */
 int cs_robot_model_velocities(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
                               const float* d_human_margin, float* d_robot_memory, float dt, void* stream);

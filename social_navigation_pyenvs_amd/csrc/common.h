@@ -27,7 +27,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
 // name of the k_orca_step build orca_launch would run for `w` (cs_step_variant)
 int orca_variant(const cs_worlds* w, char* buf, size_t buflen);
 // the robot's own ORCA model, one doStep of the robot per world (orca.hip; cs_robot_model_step with CS_ORCA)
-int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream);
+int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream, int just_velocities = 0);
 // library-owned device scratch, one block per (device, stream, use); never allocated, grown or freed while `stream` is capturing
 // (CS_ERR_ARG then -- cs_reserve_scratch first), a block handed out during a capture is never freed before cs_release_scratch
 enum { SCRATCH_ORCA_BIG = 0, SCRATCH_SFM_BIG = 1, SCRATCH_IMITATION = 2 };

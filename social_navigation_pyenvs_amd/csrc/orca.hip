@@ -998,6 +998,8 @@ struct ORArgs {
     const float* hmargin;   // [W][rows]
     float* robot;           // [W][13]
     const float* verts;
+    int just_velocities;    // update_robot(just_velocities=True), motion_model_manager.py:641-653: the new velocity is kept, the position
+                            // stays (the reference puts the robot's simulator agent back on robot.position)
 };
 
 __global__ __launch_bounds__(64) void k_orca_robot_step(const ORArgs a)
@@ -1064,7 +1066,7 @@ __global__ __launch_bounds__(64) void k_orca_robot_step(const ORArgs a)
     const int failed = lp2(L, total, vmax, pvx, pvy, false, nvx, nvy);
     if (failed < total) lp3(L, P, total, nobst, failed, vmax, nvx, nvy);
     vx = nvx; vy = nvy;
-    px += vx * a.dt; py += vy * a.dt;
+    if (!a.just_velocities) { px += vx * a.dt; py += vy * a.dt; }
     rb[0] = px; rb[1] = py; rb[3] = vx; rb[4] = vy;
     if (a.write_row) {
         float* s = a.S + ((long)w * a.rows + a.n) * a.as;
@@ -1121,7 +1123,7 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
                          a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
     if (!mine) return;
     vx = nvx; vy = nvy;
-    px += vx * a.dt; py += vy * a.dt;
+    if (!a.just_velocities) { px += vx * a.dt; py += vy * a.dt; }
     rb[0] = px; rb[1] = py; rb[3] = vx; rb[4] = vy;
     if (a.write_row) {
         float* s = a.S + ((long)w * a.rows + a.n) * a.as;
@@ -1389,7 +1391,7 @@ int orca_variant(const cs_worlds* w, char* buf, size_t buflen)
     return CS_OK;
 }
 
-int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream)
+int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_human_margin, float dt, hipStream_t stream, int just_velocities)
 {
     if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
     if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
@@ -1404,7 +1406,7 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
     a.time_horizon_obst = w->orca_time_horizon_obst; a.robot_margin = robot_margin;
     a.S = w->d_state;
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * a.rows; }
-    a.hmargin = d_human_margin; a.robot = w->d_robot; a.verts = w->d_orca_vertices;
+    a.hmargin = d_human_margin; a.robot = w->d_robot; a.verts = w->d_orca_vertices; a.just_velocities = just_velocities ? 1 : 0;
     const size_t shmem = (size_t)(a.K + a.KO) * 64 * (2 * sizeof(float4) + 2 * sizeof(float));
     if (shmem > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_orca_robot_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

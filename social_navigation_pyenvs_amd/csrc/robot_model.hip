@@ -345,7 +345,6 @@ int cs_robot_model_step(const cs_worlds* w, int32_t robot_type, const float* rob
 int cs_robot_model_velocities(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin,
                               const float* d_human_margin, float* d_robot_memory, float dt, void* stream)
 {
-    if (robot_type == CS_ORCA) return fail(CS_ERR_ARG, "just_velocities is built for the SFM / HSFM robot models, not for the ORCA robot");
     return robot_step_impl(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, 1, stream);
 }
 
@@ -357,7 +356,7 @@ static int robot_step_impl(const cs_worlds* w, int32_t robot_type, const float* 
     if (w->layout != CS_LAYOUT_AOS && w->layout != CS_LAYOUT_SOA) return fail(CS_ERR_ARG, "bad layout");
     const float* hm = d_human_margin ? d_human_margin : w->d_safety;
     if (!hm) return fail(CS_ERR_ARG, "no human margins");
-    if (robot_type == CS_ORCA) return csimpl::orca_robot_launch(w, robot_margin, hm, dt, (hipStream_t)stream);
+    if (robot_type == CS_ORCA) return csimpl::orca_robot_launch(w, robot_margin, hm, dt, (hipStream_t)stream, just_velocities);
     if (robot_type < 0 || robot_type > 8)
         return fail(CS_ERR_TYPE, "The robot motion model '" + std::to_string(robot_type) + "' does not exist");
     if (!robot_params || !d_robot_memory) return fail(CS_ERR_ARG, "null argument");

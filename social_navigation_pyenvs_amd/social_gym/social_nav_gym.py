@@ -591,7 +591,8 @@ class BatchedSocialNavGym:
         """The per-decision array work of CADRL / SARL for every world, on the device: one-step look-ahead of the humans
         (``get_next_human_observable_states``, cadrl.py:258-259 -> cs_peek) and ``compute_rotated_states_and_reward``
         (cadrl.py:42-83 -> cs_lookahead) for all actions.  ``action_space`` [A, 2] (numpy or CUDA tensor).  Returns torch CUDA
-        tensors (rotated_states [W, A, N, 13], rewards [W, A]) ready for ONE batched value-network call -- no host copy.
+        tensors (rotated_states [W, A, N, 13] -- 15 columns with ``headed_obs`` (theta and omega visible) --, rewards [W, A]) ready for ONE
+        batched value-network call -- no host copy.
         Needs worlds generated on the device (``reset(..., device=True)``), like ``step_device``."""
         import ctypes as C
 
@@ -613,8 +614,6 @@ class BatchedSocialNavGym:
         cw, W, n = self.cw, self.W, self.n
         if cw.d_robot is None:
             raise ValueError("lookahead_device needs the robot rows")
-        if self.headed_obs:
-            raise NotImplementedError("lookahead_device builds the 13-column value-network rows (theta / omega not visible)")
         acts = torch.as_tensor(np.asarray(action_space, dtype=np.float32) if not torch.is_tensor(action_space) else action_space,
                                dtype=torch.float32, device="cuda").contiguous()
         A = acts.shape[0]
@@ -623,15 +622,16 @@ class BatchedSocialNavGym:
         peek = cw._buffer("peek", (W, n, 8))
         _lib.check(lib.cs_peek(C.byref(d), C.c_float(self.robot_time_step), C.c_void_p(peek.ptr), C.c_void_p(cw.stream)))
         if "la_cols" not in dl:
-            dl["la_cols"] = torch.as_tensor([0, 1, 3, 4], device="cuda")
+            # next humans: (px, py, vx, vy), or (x, y, yaw, Vx, Vy, Omega) with theta / omega visible (cadrl.py:42-83) = cs_peek's first six
+            dl["la_cols"] = torch.as_tensor([0, 1, 2, 3, 4, 5] if self.headed_obs else [0, 1, 3, 4], device="cuda")
             dl["la_robot_cols"] = torch.as_tensor([0, 1, 3, 4, 8, 10, 11, 12, 2], device="cuda")   # FullState order
             dl["la_robot"] = cw.d_robot.torch().view(W, 13)
         nxt = peek.torch().view(W, n, 8).index_select(2, dl["la_cols"]).contiguous()
         cur = dl["state"][:, :n].index_select(2, dl["cols"]).contiguous()
         rob = dl["la_robot"].index_select(1, dl["la_robot_cols"]).contiguous()
-        rot = torch.empty((W, A, n, 13), dtype=torch.float32, device="cuda")
+        rot = torch.empty((W, A, n, 15 if self.headed_obs else 13), dtype=torch.float32, device="cuda")
         rew = torch.empty((W, A), dtype=torch.float32, device="cuda")
-        _lib.check(lib.cs_lookahead(C.c_int(W), C.c_int(n), C.c_int(A), C.c_int(0), C.c_void_p(acts.data_ptr()),
+        _lib.check(lib.cs_lookahead(C.c_int(W), C.c_int(n), C.c_int(A), C.c_int(int(self.headed_obs)), C.c_void_p(acts.data_ptr()),
                                     C.c_void_p(nxt.data_ptr()), C.c_void_p(cur.data_ptr()), C.c_void_p(rob.data_ptr()), C.c_int(9),
                                     C.c_float(self.robot_time_step), C.c_void_p(rot.data_ptr()), C.c_void_p(rew.data_ptr()),
                                     C.c_void_p(cw.stream)))

@@ -406,9 +406,6 @@ class MotionModelManager:
 
     def update_robot(self, t, dt, just_velocities=False):
         """One substep of the robot under its motion model (:615-653)."""
-        if just_velocities and self.robot_orca:
-            raise NotImplementedError("just_velocities is built for the SFM / HSFM robot models (the ORCA robot keeps its simulator's "
-                                      "position, motion_model_manager.py:648-652: not built)")
         cw = self._device_with_robot_model()
         cw.robot_model_step(dt, just_velocities=just_velocities)
         self._readback_robot(cw)

@@ -336,6 +336,31 @@ def test_device_resident_lookahead_feeds_one_batched_value_network_call():
     assert torch.isfinite(moved).all() and (moved > 0).any()
 
 
+def test_device_resident_lookahead_with_theta_and_omega_visible():
+    """lookahead_device for a policy that sees headings (with_theta_and_omega_visible: 15-column value-network rows, cadrl.py:42-83
+    with theta_and_omega_visible=True) == the host function on downloaded arrays, bit for bit."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.crowd_nav.policy.cadrl import build_action_space_array, compute_rotated_states_and_reward
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W, n = 33, 7
+    env = BatchedSocialNavGym(_config("hybrid_scenario", human_num=n), W, headed_obs=True)
+    env.reset(phase="val", first_case=11, device=True)
+    acts = build_action_space_array(1.0)
+    for _ in range(4):
+        env.step_device(torch.as_tensor(np.tile([[0.3, 0.5]], (W, 1)), dtype=torch.float32, device="cuda"))
+    rot, rew = env.lookahead_device(acts)
+    assert rot.is_cuda and rot.shape == (W, 81, n, 15) and rew.shape == (W, 81)
+    cw = env.cw
+    nxt = cw.peek(env.robot_time_step)[:, :, 0:6]
+    cur = cw.get_states()[:, :n][:, :, [0, 1, 3, 4, 8, 2, 7]]
+    rob = cw.get_robot()[:, [0, 1, 3, 4, 8, 10, 11, 12, 2]]
+    hrot, hrew = compute_rotated_states_and_reward(acts, nxt, cur, rob, env.robot_time_step, True)
+    np.testing.assert_array_equal(rot.cpu().numpy(), hrot.astype(np.float32))
+    np.testing.assert_array_equal(rew.cpu().numpy(), hrew.astype(np.float32))
+    assert np.any(rot.cpu().numpy()[..., 14] != 0)          # omegas of the headed humans really are in the rows
+
+
 def test_more_than_64_humans_use_the_lane_per_world_kernel():
     """n <= 64 runs one wavefront per world, larger worlds one lane per world: both restate the same stream."""
     from social_navigation_pyenvs_amd.generators import generate_worlds

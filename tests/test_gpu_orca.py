@@ -375,6 +375,40 @@ def test_orca_cfg4_full_size():
     np.testing.assert_array_equal(gfull[sample], rg)
 
 
+def test_orca_dense_phase_soak_bit_identical():
+    """A slice of tools/orca_soak.py inside the GPU suite: 256 worlds of the cfg4 crossing (25 agents, R = 7) over 700 substeps --
+    out through the dense phase in which a third of the agents has an infeasible programme in every substep (linearProgram3 on
+    16-lane rows) and back to the rim, goal switches included -- checked against the C restatement after EVERY Gym step (35
+    blocks of 20 fused substeps), bit for bit: positions, velocities, preferred velocities, goal columns.  A world that ever
+    differs fails the test.  (The restatement's own parity with rvo2 is unpinned, like all of ORCA.)"""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n = 256, 25
+    pos, yaw, g = sc.circular_crossing(W, n, 7.0, 31337 + n)
+    S = sc.make_states(pos, yaw, g).astype(np.float32)
+    g = g.astype(np.float32)
+    d = g[:, :, 0] - S[:, :, 0:2]
+    S[:, :, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    margin = np.full((W, n), 0.01, np.float32)
+    cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa")
+    assert "k_orca_step<FAST10=1,MAXT=64>" in cw.step_variant(), cw.step_variant()
+    ref, rg = S, g
+    cols = [0, 1, 3, 4, 5, 6, 10, 11]
+    closest = np.inf
+    for block in range(35):
+        cw.step(0.0125, 20)
+        ref, rg, _ = orc.orca_step_block(ref, rg, margin, 0.0125, 20)
+        got = cw.get_states()
+        differ = np.any(got[..., cols] != ref[..., cols], axis=(1, 2))
+        assert not differ.any(), f"Gym step {block + 1}: {int(differ.sum())} worlds differ from the restatement (first: {int(np.argmax(differ))})"
+        dd = np.linalg.norm(ref[:, :, None, 0:2] - ref[:, None, :, 0:2], axis=-1) + 10.0 * np.eye(n)[None]
+        closest = min(closest, float(np.median(dd.min(axis=(1, 2)))))
+    np.testing.assert_array_equal(cw.get_goals(), rg)
+    assert closest < 0.75                                  # the crowds really met (agents of radius 0.31 passing shoulder to shoulder)
+    assert np.mean(np.linalg.norm(ref[..., 0:2] - S[..., 0:2], axis=-1)) > 5.0
+
+
 def test_ieee_div_sqrt_sequences_are_correctly_rounded():
     """The ORCA kernels' 8-instruction divide and 9-instruction square root (the compiler's FMA sequences without their
     exponent-range handling) give the compiler's (IEEE, correctly rounded) results bit for bit on 2^31 random operand pairs of

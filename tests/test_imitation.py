@@ -162,6 +162,16 @@ def test_orca_robot_model_matches_restatement(walls):
         cw.imitation_block(DT, 1)
         np.testing.assert_array_equal(cw.get_robot()[:, [0, 1, 3, 4]], ref_robot[:, [0, 1, 3, 4]])
     assert np.all(ref_robot[:, 0] > robot[:, 0] + 0.2)   # the robots did move towards their goals
+    # update_robot(t, dt, just_velocities=True) for the ORCA robot (motion_model_manager.py:641-653): the doStep's new velocity is
+    # kept, the robot's simulator agent is put back on robot.position -- the velocity of a full step, the position untouched
+    before = cw.get_robot()
+    Sg = cw.get_states()
+    full = np.stack([_orca_robot_oracle(Sg[w], n, before[w], verts, np.float32(0.06), np.float32(0.06), DT) for w in range(W)])
+    cw.robot_model_step(DT, just_velocities=True)
+    after = cw.get_robot()
+    np.testing.assert_array_equal(after[:, 3:5], full[:, 3:5])
+    np.testing.assert_array_equal(after[:, 0:2], before[:, 0:2])
+    assert np.any(full[:, 0:2] != before[:, 0:2])
 
 
 @pytest.mark.gpu

@@ -137,3 +137,68 @@ def test_bench_argument_and_seed_plumbing_two_ranks():
     assert r0["cfg5_shard"] == (0, 32768) and r1["cfg5_shard"] == (32768, 32768)
     assert r0["keys"] == ["sfm_helbing_10_circle", "orca_25_circle_first20", "orca_25_circle_dense", "hsfm_farina_50_circle_walls_static",
                           "hsfm_new_guo_25_hybrid", "hsfm_farina_25_hybrid_robot", "hsfm_farina_30_hybrid", "hsfm_farina_25_hybrid_peragent"]
+
+
+class _HostOnlyEnv:
+    """Stand-in for BatchedSocialNavGym on a box without a GPU: the worlds come from the package's host generators (functions of the
+    test case = global world id), a step moves every human by the action of its world -- enough to check that the sharded wrapper
+    hands every rank the right test cases, the right action rows and puts gathered shards back in world order."""
+
+    def __init__(self, config, n_worlds, **kw):
+        self.W, self.n = int(n_worlds), 5
+
+    def reset(self, phase="test", first_case=0, **kw):
+        pos, yaw, g = sc.circular_crossing(self.W, self.n, 7.0, 1000, first_world=first_case)
+        self.S = sc.make_states(pos, yaw, g).astype(np.float32)
+        return self.observe()
+
+    def observe(self):
+        return self.S[:, :, [0, 1, 3, 4, 8]].copy()
+
+    def step(self, actions):
+        self.S[:, :, 0:2] += np.asarray(actions, np.float32)[:, None, :] * 0.25
+        return self.observe(), np.zeros(self.W, np.float32), np.zeros(self.W, bool), np.zeros(self.W, bool), np.zeros(self.W, np.int32)
+
+
+def _sharded_worker(rank, world_size, port, q, total):
+    from social_navigation_pyenvs_amd.social_gym.sharded_gym import ShardedBatchedSocialNavGym
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    env = ShardedBatchedSocialNavGym(None, total, dist=dist, env_factory=_HostOnlyEnv)
+    obs = env.reset(phase="test", first_case=3)
+    full0 = env.gather(obs)                                        # every rank gets the whole batch, in world order
+    actions = np.stack([np.linspace(-1, 1, total), np.linspace(1, -1, total)], -1).astype(np.float32)   # one row per GLOBAL world
+    obs1, *_ = env.step(actions)                                   # each rank takes its own rows: no communication
+    on_learner = env.gather(torch.as_tensor(obs1), dst=0)          # tensors in -> tensors out, learner rank only
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, (env.first, env.W), full0, None if on_learner is None else on_learner.numpy()))
+
+
+def test_sharded_gym_gathered_observations_equal_the_single_process_batch():
+    """ShardedBatchedSocialNavGym under gloo with two ranks and a RAGGED split (21 worlds = 11 + 10): the gathered observations
+    are the single-process batch world for world, before and after a step driven by one global action array; the step itself
+    is collective-free (the only collective is gather's all_gather)."""
+    total = 21
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, total)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = _HostOnlyEnv(None, total)
+    ref0 = one.reset(first_case=3)
+    actions = np.stack([np.linspace(-1, 1, total), np.linspace(1, -1, total)], -1).astype(np.float32)
+    ref1 = one.step(actions)[0]
+    assert res[0][1] == (0, 11) and res[1][1] == (11, 10)
+    for rank, _, full0, learner in res:
+        np.testing.assert_array_equal(full0, ref0)
+        if rank == 0:
+            np.testing.assert_array_equal(learner, ref1)
+        else:
+            assert learner is None
