@@ -493,15 +493,123 @@ __device__ __forceinline__ void row_minmax16(float& mn, float& mx)
                  : "+v"(mn), "+v"(mx));
 }
 
+// min and max over the 8-lane half row of the calling lane, left in every lane of it: neighbour swap, quad swap, half-row mirror
+// (quad_perm:[1,0,3,2], quad_perm:[2,3,0,1], row_half_mirror) -- three steps instead of four.
+__device__ __forceinline__ void row_minmax8(float& mn, float& mx)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(mn), "+v"(mx));
+}
+
+// One sub-phase of a round of lp3_rows: the `npend` agents ticketed in R.sel (their records in R.q) are served 64 / RW at a time,
+// each by a group of RW lanes (RW = 16: a DPP row, any level; RW = 8: half a row, levels 0 .. 8 -- lane j of a group owns line j and
+// a level i needs the lines j < i).  All 64 lanes call it.
+// (Measured and rejected: a group that keeps its agent for ALL its violated lines instead of one per round -- the wavefront then waits
+//  for the longest chain of the eight agents of a pass while the other groups idle: 512 -> 548 us in the dense phase of cfg4; re-dealing
+//  the agents that still have a violated line every round packs the groups densely.)
+template <int RW>
+__device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int npend)
+{
+    constexpr int GROUPS = 64 / RW;
+    const int TL = L.T;
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    const int grp_sh = lane & (64 - RW), j = lane & (RW - 1), jj = j < 9 ? j : 8, slot = lane / RW;
+#pragma nounroll
+    for (int p0 = 0; p0 < npend; p0 += GROUPS) {
+        const int idx = p0 + slot;
+        const bool rowvalid = idx < npend;
+        const int e = rowvalid ? R.sel[wbase + idx] : 0;
+        const int a = e & 0xFFFF, lv = e >> 16;
+        const float4 qa = R.q[a];
+        const float4 li = L.p[lv * TL + a];
+        const float4 lj = L.p[jj * TL + a];
+        const bool task = rowvalid && j < lv;
+        // RVO2 linearProgram3: line j projected on line i
+        const float d = det2(li.z, li.w, lj.z, lj.w);
+        const bool par = fabsf(d) <= RVO_EPSILON;
+        const bool same = li.z * lj.z + li.w * lj.w > 0.0f;
+        const float sp = ieee_div(det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y), d);
+        float4 pr;
+        pr.x = par ? 0.5f * (li.x + lj.x) : li.x + sp * li.z;
+        pr.y = par ? 0.5f * (li.y + lj.y) : li.y + sp * li.w;
+        const float ex = lj.z - li.z, ey = lj.w - li.w;
+        const float en = ieee_sqrt(ex * ex + ey * ey);
+        const float inv = ieee_div(1.0f, en);
+        pr.z = ex * inv; pr.w = ey * inv;
+        const bool live = task && !(par && same);   // RVO2 drops a parallel line that points the same way
+        // what linearProgram1 computes from this line alone, should it become the violated one: the circle's chord
+        const float vm = qa.z;
+        const float dot = pr.x * pr.z + pr.y * pr.w;
+        const float disc = dot * dot + vm * vm - (pr.x * pr.x + pr.y * pr.y);
+        const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
+        const float2 aux = (disc < 0.0f) ? make_float2(INFINITY, -INFINITY) : make_float2(-dot - sq, -dot + sq);
+        if (task) { R.P[jj * 8 + slot] = pr; R.A[jj * 8 + slot] = aux; }
+        // linearProgram2(projLines, radius, (-dir.y, dir.x), directionOpt = true) starts on the circle
+        const float ox = -li.w, oy = li.z;
+        float qx = ox * vm, qy = oy * vm;
+        int k = -1;
+        bool fail2 = false, done = !rowvalid;
+        ORCA_LDS_FENCE();
+#pragma nounroll
+        for (int it = 0; it < 9; ++it) {
+            const bool viol = live && !done && (j > k) && (det2(pr.z, pr.w, pr.x - qx, pr.y - qy) > 0.0f);
+            const unsigned long long vmask = __builtin_amdgcn_ballot_w64(viol);
+            if (vmask == 0) break;
+            const unsigned rb = (unsigned)(vmask >> grp_sh) & ((1u << RW) - 1u);
+            const bool any = rb != 0;
+            const int kk = any ? (int)__builtin_ctz(rb) : 0;    // first violated line of my group
+            done = done || !any;                                // no line violated: linearProgram2 succeeded
+            const float4 lk = R.P[kk * 8 + slot];
+            const float2 ak = R.A[kk * 8 + slot];
+            // linearProgram1(projLines, kk, ...): lane j < kk evaluates line j against line kk
+            const bool in = live && (j < kk);
+            const float den = det2(lk.z, lk.w, pr.z, pr.w);
+            const float num = det2(pr.z, pr.w, lk.x - pr.x, lk.y - pr.y);
+            const float t = ieee_div(num, den);
+            const bool parl = fabsf(den) <= RVO_EPSILON;
+            // a parallel earlier line with this line on its wrong side fails linearProgram1 outright: it enters the
+            // reduction as the empty interval (tR = -inf, tL = +inf), which the tL > tR test below turns into the failure
+            const bool failp = in && parl && (num < 0.0f);
+            float rmin = failp ? -INFINITY : ((in && !parl && (den >= 0.0f)) ? t : INFINITY);
+            float rmax = failp ? INFINITY : ((in && !parl && !(den >= 0.0f)) ? t : -INFINITY);
+            if constexpr (RW == 16) row_minmax16(rmin, rmax); else row_minmax8(rmin, rmax);
+            const float tR = fminf(ak.y, rmin), tL = fmaxf(ak.x, rmax);
+            const bool ok = !(tL > tR);
+            const float tt = (ox * lk.z + oy * lk.w > 0.0f) ? tR : tL;
+            const bool run = any && !done;
+            const bool set = run && ok, bad = run && !ok;
+            qx = set ? lk.x + tt * lk.z : qx;
+            qy = set ? lk.y + tt * lk.w : qy;
+            k = set ? kk : k;
+            fail2 = fail2 || bad;                               // linearProgram2 failed: LP3 keeps the old result
+            done = done || bad;
+        }
+        const bool take = rowvalid && !fail2;
+        const float nrx = take ? qx : qa.x, nry = take ? qy : qa.y;
+        const float ndist = det2(li.z, li.w, li.x - nrx, li.y - nry);
+        if (rowvalid && j == 0) R.q[a] = make_float4(nrx, nry, qa.z, ndist);
+        ORCA_LDS_FENCE();
+    }
+}
+
 // Called by ALL 64 lanes of a wavefront (lanes without an agent pass cnt = failed = 0).  Lr: the caller's ten lines (also
 // stored in L's column L.tid); on return (rx, ry) is linearProgram3's result for lanes with failed < cnt.
-// A pass serves 4 * NC agents (NC contexts per lane, written as arrays so that their chains interleave; NC = 1 is what ships).
+// A round serves every agent's next violated line: those at levels 0 .. 8 (the lines j < 8 fit half a row) eight agents per pass on
+// 8-lane groups, those at level 9 (an agent with ten neighbours whose LAST line is violated: needs nine projected lines) four per
+// pass on whole rows.  Round 3: with rows of 16 for everybody a pass served four agents and nine of its sixteen lanes at most.
 __device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R, int cnt, int failed, float vmax, float& rx, float& ry)
 {
-    constexpr int NC = 1;   // contexts per lane and pass (two were measured: slower -- the row work is issue-bound)
-    const int TL = L.T, me = L.tid;
-    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
-    const int row_sh = lane & 48, j = lane & 15, jj = j < 9 ? j : 8;
+    const int me = L.tid;
+    const int wbase = threadIdx.x & ~63;
     float distance = 0.0f;
     int next_i = failed;
 #pragma nounroll
@@ -515,122 +623,27 @@ __device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R
             lvl = v ? i : lvl;
         }
         const bool pending = lvl >= 0;
-        const unsigned long long pm = __builtin_amdgcn_ballot_w64(pending);
-        if (pm == 0) break;
-        const int npend = __builtin_popcountll(pm);
-        if (pending) {
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u));
-            R.sel[wbase + rank] = me | (lvl << 16);
-            R.q[me] = make_float4(rx, ry, vmax, distance);
+        if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
+        if (pending) R.q[me] = make_float4(rx, ry, vmax, distance);
+        // sub-phase A: levels 0 .. 8 on 8-lane groups; sub-phase B: level 9 on 16-lane rows
+        const bool pa = pending && lvl <= 8, pb = pending && lvl == 9;
+        const unsigned long long ma = __builtin_amdgcn_ballot_w64(pa), mb = __builtin_amdgcn_ballot_w64(pb);
+        if (ma != 0) {
+            if (pa) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u));
+                R.sel[wbase + rank] = me | (lvl << 16);
+            }
+            ORCA_LDS_FENCE();
+            lp3_serve<8>(L, R, __builtin_popcountll(ma));
         }
-        ORCA_LDS_FENCE();
-#pragma nounroll
-        for (int p0 = 0; p0 < npend; p0 += 4 * NC) {
-            bool rowvalid[NC], live[NC], done[NC], fail2[NC];
-            int a[NC], lv[NC], k[NC];
-            float4 qa[NC], li[NC], pr[NC];
-            float2 aux[NC];
-            int slot[NC];
-            float qx[NC], qy[NC], ox[NC], oy[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int idx = p0 + 4 * c + (lane >> 4);
-                rowvalid[c] = idx < npend;
-                const int e = rowvalid[c] ? R.sel[wbase + idx] : 0;
-                a[c] = e & 0xFFFF; lv[c] = e >> 16;
-                slot[c] = 4 * c + (lane >> 4);
-            }
-            float4 lj[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                qa[c] = R.q[a[c]];
-                li[c] = L.p[lv[c] * TL + a[c]];
-                lj[c] = L.p[jj * TL + a[c]];
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const bool task = rowvalid[c] && j < lv[c];
-                // RVO2 linearProgram3: line j projected on line i
-                const float d = det2(li[c].z, li[c].w, lj[c].z, lj[c].w);
-                const bool par = fabsf(d) <= RVO_EPSILON;
-                const bool same = li[c].z * lj[c].z + li[c].w * lj[c].w > 0.0f;
-                const float sp = ieee_div(det2(lj[c].z, lj[c].w, li[c].x - lj[c].x, li[c].y - lj[c].y), d);
-                pr[c].x = par ? 0.5f * (li[c].x + lj[c].x) : li[c].x + sp * li[c].z;
-                pr[c].y = par ? 0.5f * (li[c].y + lj[c].y) : li[c].y + sp * li[c].w;
-                const float ex = lj[c].z - li[c].z, ey = lj[c].w - li[c].w;
-                const float en = ieee_sqrt(ex * ex + ey * ey);
-                const float inv = ieee_div(1.0f, en);
-                pr[c].z = ex * inv; pr[c].w = ey * inv;
-                live[c] = task && !(par && same);   // RVO2 drops a parallel line that points the same way
-                // what linearProgram1 computes from this line alone, should it become the violated one: the circle's chord
-                const float vm = qa[c].z;
-                const float dot = pr[c].x * pr[c].z + pr[c].y * pr[c].w;
-                const float disc = dot * dot + vm * vm - (pr[c].x * pr[c].x + pr[c].y * pr[c].y);
-                const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
-                aux[c] = (disc < 0.0f) ? make_float2(INFINITY, -INFINITY) : make_float2(-dot - sq, -dot + sq);
-                if (task) { R.P[jj * 8 + slot[c]] = pr[c]; R.A[jj * 8 + slot[c]] = aux[c]; }
-                // linearProgram2(projLines, radius, (-dir.y, dir.x), directionOpt = true) starts on the circle
-                ox[c] = -li[c].w; oy[c] = li[c].z;
-                qx[c] = ox[c] * vm; qy[c] = oy[c] * vm;
-                k[c] = -1; fail2[c] = false; done[c] = !rowvalid[c];
+        if (mb != 0) {
+            ORCA_LDS_FENCE();
+            if (pb) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u));
+                R.sel[wbase + rank] = me | (lvl << 16);
             }
             ORCA_LDS_FENCE();
-#pragma nounroll
-            for (int it = 0; it < 9; ++it) {
-                unsigned long long vmask[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const bool viol = live[c] && !done[c] && (j > k[c]) && (det2(pr[c].z, pr[c].w, pr[c].x - qx[c], pr[c].y - qy[c]) > 0.0f);
-                    vmask[c] = __builtin_amdgcn_ballot_w64(viol);
-                }
-                if ((vmask[0] | vmask[NC - 1]) == 0) break;
-                bool any[NC];
-                int kk[NC];
-                float4 lk[NC];
-                float2 ak[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const unsigned rb = (unsigned)(vmask[c] >> row_sh) & 0xFFFFu;
-                    any[c] = rb != 0;
-                    kk[c] = any[c] ? (int)__builtin_ctz(rb) : 0;    // first violated line of my row
-                    done[c] = done[c] || !any[c];                     // no line violated: linearProgram2 succeeded
-                    lk[c] = R.P[kk[c] * 8 + slot[c]];
-                    ak[c] = R.A[kk[c] * 8 + slot[c]];
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    // linearProgram1(projLines, kk, ...): lane j < kk evaluates line j against line kk
-                    const bool in = live[c] && (j < kk[c]);
-                    const float den = det2(lk[c].z, lk[c].w, pr[c].z, pr[c].w);
-                    const float num = det2(pr[c].z, pr[c].w, lk[c].x - pr[c].x, lk[c].y - pr[c].y);
-                    const float t = ieee_div(num, den);
-                    const bool parl = fabsf(den) <= RVO_EPSILON;
-                    // a parallel earlier line with this line on its wrong side fails linearProgram1 outright: it enters the
-                    // reduction as the empty interval (tR = -inf, tL = +inf), which the tL > tR test below turns into the failure
-                    const bool failp = in && parl && (num < 0.0f);
-                    float rmin = failp ? -INFINITY : ((in && !parl && (den >= 0.0f)) ? t : INFINITY);
-                    float rmax = failp ? INFINITY : ((in && !parl && !(den >= 0.0f)) ? t : -INFINITY);
-                    row_minmax16(rmin, rmax);
-                    const float tR = fminf(ak[c].y, rmin), tL = fmaxf(ak[c].x, rmax);
-                    const bool ok = !(tL > tR);
-                    const float tt = (ox[c] * lk[c].z + oy[c] * lk[c].w > 0.0f) ? tR : tL;
-                    const bool run = any[c] && !done[c];
-                    const bool set = run && ok, bad = run && !ok;
-                    qx[c] = set ? lk[c].x + tt * lk[c].z : qx[c];
-                    qy[c] = set ? lk[c].y + tt * lk[c].w : qy[c];
-                    k[c] = set ? kk[c] : k[c];
-                    fail2[c] = fail2[c] || bad;                       // linearProgram2 failed: LP3 keeps the old result
-                    done[c] = done[c] || bad;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const bool take = rowvalid[c] && !fail2[c];
-                const float nrx = take ? qx[c] : qa[c].x, nry = take ? qy[c] : qa[c].y;
-                const float ndist = det2(li[c].z, li[c].w, li[c].x - nrx, li[c].y - nry);
-                if (rowvalid[c] && j == 0) R.q[a[c]] = make_float4(nrx, nry, qa[c].z, ndist);
-            }
-            ORCA_LDS_FENCE();
+            lp3_serve<16>(L, R, __builtin_popcountll(mb));
         }
         if (pending) {
             const float4 qo = R.q[me];
