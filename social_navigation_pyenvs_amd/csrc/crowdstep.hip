@@ -268,7 +268,9 @@ void strides(const cs_worlds* w, int rows, long& as, long& fs)
 
 // Which instantiation of k_sfm_step a launch runs.  One function decides it for launch_step and for cs_step_variant (the
 // diagnostic entry the parity tests use to assert that every benched build is the one they compared with the oracle).
-Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool need_snap = false)
+struct RobotModel { int type; const float* params; float margin; const float* d_human_margin; float* d_memory; };
+
+Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool need_snap = false, bool robot_model = false)
 {
     const bool robot = (w->flags & CS_ROBOT_ROW) != 0;
     const int rows = w->n + (robot ? 1 : 0);
@@ -284,6 +286,10 @@ Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool nee
     const bool lean_mode = robot ? (mode & ~(int)M_ROBOT_FROM_ARRAY) == M_COMMIT_GOALS : mode == M_COMMIT_GOALS;
     int kind = 0;
     if (peq && w->G <= 2 && lean_mode) kind = robot ? (w->O == 0 ? 3 : 0) : (w->O == 0 ? 1 : 2);
+    if (robot_model) {   // the robot's own motion model inside the launch: the LEAN = 4 builds only (callers check fusable_imitation)
+        if (kind != 3) return Variant{0, 0, 0, 0, peq};
+        return Variant{64, rows == 26 ? 1 : 3, rows == 26 ? 26 : 0, 4, true};
+    }
     if (kind == 0) return Variant{64, 3, 0, 0, peq};
     // small plain worlds (10 humans: BASELINE.json configs[1]; 5: the reference's default environment): one world per 16-lane
     // DPP row, partners exchanged with row shifts instead of LDS (rowstep.hip).  CROWDSTEP_ROW16=0 keeps them on the LDS kernel.
@@ -309,13 +315,13 @@ Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool nee
 
 kfn variant_kernel(const Variant& v, int type)
 {
-    for (auto lookup : {sfm_builds_generic, sfm_builds_leanrt, sfm_builds_lean25, sfm_builds_lean30, sfm_builds_small, sfm_builds_lean50, sfm_builds_robot26, sfm_builds_robotx})
+    for (auto lookup : {sfm_builds_generic, sfm_builds_leanrt, sfm_builds_lean25, sfm_builds_lean30, sfm_builds_small, sfm_builds_lean50, sfm_builds_robot26, sfm_builds_robotx, sfm_builds_imit})
         if (kfn fn = lookup(v, type)) return fn;
     return nullptr;
 }
 
 int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, const float* d_action,
-                float* d_peek, hipStream_t stream, float4* d_snap = nullptr, float* d_trace = nullptr)
+                float* d_peek, hipStream_t stream, float4* d_snap = nullptr, float* d_trace = nullptr, const RobotModel* rm = nullptr)
 {
     int rc = check_worlds(w);
     if (rc) return rc;
@@ -347,7 +353,12 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
 #endif
     a.snap = d_snap;
     a.trace = d_trace;
-    const Variant v = select_variant(w, mode, g, d_snap != nullptr);
+    const Variant v = select_variant(w, mode, g, d_snap != nullptr, rm != nullptr);
+    if (rm) {
+        if (v.lean != 4) return fail(CS_ERR_ARG, "the robot's motion model runs inside the crowd's launch only for the plain crowd batch with a robot row");
+        a.rm_type = rm->type; a.rm_margin = rm->margin; a.rm_hmargin = rm->d_human_margin; a.rm_memory = rm->d_memory;
+        std::memcpy(a.rm_P, rm->params, sizeof(a.rm_P));
+    }
     const bool peq = v.peq;
     if (v.maxt == 16) return csimpl::row16_launch(a, stream);
     const kfn fn = variant_kernel(v, w->type);
@@ -537,7 +548,17 @@ int cs_imitation_block(const cs_worlds* w, int32_t robot_type, const float* robo
         return csimpl::robot_block_launch(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, n_substeps, snap,
                                           (hipStream_t)stream);
     }
-    for (int k = 0; k < n_substeps; ++k) {   // a visible robot and the crowd act on each other: the reference's strict alternation
+    // A VISIBLE robot and the crowd act on each other in every substep: update_robot runs INSIDE the crowd's substep loop, the robot
+    // being the last row of every world (k_sfm_step<..., LEAN = 4>, robot_model.h) -- one launch, bit-identical to the alternation below.
+    // Needs the plain crowd batch (all_params_equal, <= 2 goal slots, no walls) and SFM / HSFM models on both sides.
+    const bool fusable_visible = (w->flags & CS_ROBOT_ROW) && (w->flags & CS_ALL_PARAMS_EQUAL) && w->type >= 0 && w->type <= 8 && robot_type >= 0 &&
+                                 robot_type <= 8 && rows <= 64 && w->d_robot != nullptr && w->O == 0 && w->G <= 2 && robot_params && d_robot_memory &&
+                                 !(std::getenv("CROWDSTEP_IMITATION_FUSED") && std::getenv("CROWDSTEP_IMITATION_FUSED")[0] == '0');
+    if (fusable_visible) {
+        const RobotModel rm{robot_type, robot_params, robot_margin, d_human_margin ? d_human_margin : w->d_safety, d_robot_memory};
+        return launch_step(w, dt, n_substeps, M_COMMIT_GOALS | M_ROBOT_FROM_ARRAY, nullptr, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, &rm);
+    }
+    for (int k = 0; k < n_substeps; ++k) {   // ORCA on either side, walls with a visible robot: the reference's strict alternation
         int rc = cs_robot_model_step(w, robot_type, robot_params, robot_margin, d_human_margin, d_robot_memory, dt, stream);
         if (rc) return rc;
         rc = cs_step(w, dt, 1, nullptr, stream);

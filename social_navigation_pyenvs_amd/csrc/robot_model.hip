@@ -27,6 +27,7 @@
 
 #include "common.h"
 #include "crowdstep.h"
+#include "robot_model.h"
 
 namespace {
 
@@ -47,18 +48,9 @@ struct RArgs {
     int nsub;
 };
 
-constexpr float PI_F = 3.14159265358979323846f;
-constexpr float TWO_PI_F = 6.28318530717958647692f;
-
-// utils.py:7-13
-__device__ __forceinline__ float bound_angle(float a)
-{
-    if (a >= TWO_PI_F) a = fmodf(a, TWO_PI_F);
-    if (a <= -TWO_PI_F) a = fmodf(a, TWO_PI_F);
-    if (a > PI_F) a -= TWO_PI_F;
-    if (a < -PI_F) a += TWO_PI_F;
-    return a;
-}
+using rmodel::PI_F;
+using rmodel::TWO_PI_F;
+using rmodel::bound_angle;
 
 // sum over the 64 lanes, left in every lane: four DPP rotate-and-add steps inside each 16-lane row, then the four row sums through
 // scalar registers (v_readlane) -- a few dozen cycles instead of six dependent LDS-crossbar shuffles (~120 cycles each)
@@ -78,20 +70,20 @@ __device__ __forceinline__ float wave_sum(float v)
 
 __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
 {
-    const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    __shared__ float2 s_term[4][64];          // the humans' terms of the robot's social force, summed in index order (n <= 64)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = blockIdx.x * (blockDim.x >> 6) + wv;
     if (w >= a.W) return;
     float* rb = a.robot + (long)w * 13;
-    float px = rb[0], py = rb[1], yaw = rb[2], bvx = rb[5], bvy = rb[6], om = rb[7];
-    const float radius = rb[8], mass = rb[9], gx = rb[10], gy = rb[11], vd = rb[12];
+    rmodel::RState r;
+    r.px = rb[0]; r.py = rb[1]; r.yaw = rb[2]; r.vx = rb[3]; r.vy = rb[4]; r.bvx = rb[5]; r.bvy = rb[6]; r.om = rb[7];
+    r.radius = rb[8]; r.mass = rb[9]; r.gx = rb[10]; r.gy = rb[11]; r.vd = rb[12];
     const bool headed = a.type >= CS_HSFM_FARINA;
     const int soc = a.type % 3;                 // 0 Helbing, 1 Guo, 2 Moussaid
-    const bool torque_new = a.type >= CS_HSFM_NEW;
-    float vx = rb[3], vy = rb[4];
     const float* P = a.P;
-    const float rme = radius + a.robot_margin;
+    const float rme = r.radius + a.robot_margin;
     float* mem = a.memory + (long)w * 2;
-    float fdx = mem[0], fdy = mem[1];
+    r.fdx = mem[0]; r.fdy = mem[1];
     // one substep (cs_robot_model_step), or all substeps of an imitation block against the crowd's snapshots: every lane carries
     // the robot's state and integrates it identically (same inputs, same operations), lane 0 writes it back at the end
     // imitation block: the humans' records of the NEXT substep are requested while this one is integrated (a substep is a few hundred
@@ -103,10 +95,10 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
     float4 qnext = qpre;
     if (pre && lane < a.n && sub + 1 < a.nsub) qnext = a.snap[((long)(sub + 1) * a.W + w) * a.n + lane];
     float sn, cs;
-    sincosf(yaw, &sn, &cs);
-    if (headed) { vx = cs * bvx - sn * bvy; vy = sn * bvx + cs * bvy; }   // headed_agent_update_linear_velocity (:143-145)
+    rmodel::refresh_velocity(r, headed, sn, cs);                         // headed_agent_update_linear_velocity (:143-145)
 
-    // ---- social force: humans in strides of 64, then a butterfly sum
+    // ---- social force: one term per human (rmodel::pair_term), summed in index order -- the order the fused crowd launch
+    //      (k_sfm_step<..., LEAN = 4>) uses too; worlds of more than 64 humans: strided partial sums and a butterfly
     float fsx = 0.0f, fsy = 0.0f;
     for (int j = lane; j < a.n; j += 64) {
         const float* s = a.S + ((long)w * a.rows + j) * a.as;
@@ -115,54 +107,26 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         else if (a.snap != nullptr) { const float4 q = a.snap[((long)sub * a.W + w) * a.n + j]; hx = q.x; hy = q.y; hvx = q.z; hvy = q.w; }
         else { hx = s[0]; hy = s[a.fs]; hvx = s[3 * a.fs]; hvy = s[4 * a.fs]; }
         const float rij = rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + j];
-        // (single-instruction rsq / exp as in the crowd kernel: <= 1 ulp each, two orders of magnitude inside the parity bar)
-        const float dx = px - hx, dy = py - hy;
-        const float d2h = fmaxf(dx * dx + dy * dy, 1e-30f);    // (coincident robot and human: finite, as in the crowd kernel)
-        const float dinv = __builtin_amdgcn_rsqf(d2h);
-        const float dn = d2h * dinv;
-        const float nx = dx * dinv, ny = dy * dinv;
-        const float rd = rij - dn;
-        // body-contact overlap from a Newton-refined distance: one ulp of dist is 1.4e-5 of the k1 / k2 force (stepcommon.h dist_refined)
-        const float comp = fmaxf(0.0f, rij - fmaf(fmaf(-dn, dn, d2h), 0.5f * dinv, dn));
-        if (soc == 2) {
-            const float ivx = P[12] * (vx - hvx) - nx, ivy = P[12] * (vy - hvy) - ny;
-            const float inorm = sqrtf(ivx * ivx + ivy * ivy);
-            const float ix = ivx / inorm, iy = ivy / inorm;
-            const float th = bound_angle(atan2f(ny, nx) - atan2f(iy, ix) + PI_F);
-            const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
-            const float hxv = -iy, hyv = ix;
-            const float F = P[13] * inorm;
-            const float dvh = (hvx - vx) * hxv + (hvy - vy) * hyv;
-            const float e0 = P[9] * expf(-dn / F);
-            const float t1 = P[15] * F * th, t2 = P[14] * F * th;
-            const float e1 = expf(-(t1 * t1)), e2 = k * expf(-(t2 * t2));
-            fsx -= e0 * (e1 * ix + e2 * hxv) + P[10] * comp * ix + P[11] * comp * dvh * hxv;
-            fsy -= e0 * (e1 * iy + e2 * hyv) + P[10] * comp * iy + P[11] * comp * dvh * hyv;
-        } else {
-            const float tx = -ny, ty = nx;
-            const float dv = (hvx - vx) * tx + (hvy - vy) * ty;
-            const float fn = P[1] * __expf(rd / P[3]) + P[10] * comp;
-            float ft = P[11] * comp * dv;
-            if (soc == 1) ft += P[5] * __expf(rd / P[7]);
-            fsx += fn * nx + ft * tx;
-            fsy += fn * ny + ft * ty;
-        }
+        float tx, ty;
+        rmodel::pair_term(soc, P, r.px, r.py, r.vx, r.vy, hx, hy, hvx, hvy, rij, tx, ty);
+        fsx += tx; fsy += ty;
     }
-    fsx = wave_sum(fsx);
-    fsy = wave_sum(fsy);
+    if (a.n <= 64) {
+        s_term[wv][lane] = make_float2(fsx, fsy);        // (lanes >= n hold zeros and are not read)
+        asm volatile("" ::: "memory");                    // one wavefront: its LDS operations execute in order
+        float sx = 0.0f, sy = 0.0f;
+        for (int j = 0; j < a.n; ++j) { const float2 t = s_term[wv][j]; sx += t.x; sy += t.y; }
+        asm volatile("" ::: "memory");
+        fsx = sx; fsy = sy;
+    } else {
+        fsx = wave_sum(fsx);
+        fsy = wave_sum(fsy);
+    }
 
-    // ---- desired force (forces.py:9-16); within one radius of the goal the previous one is kept
-    {
-        const float ddx = gx - px, ddy = gy - py;
-        const float dist = sqrtf(ddx * ddx + ddy * ddy);
-        if (dist > radius) {
-            fdx = mass * (ddx / dist * vd - vx) / P[0];
-            fdy = mass * (ddy / dist * vd - vy) / P[0];
-        }
-    }
     // ---- obstacle force: one closest point per polygon (the LAST nearest segment point, `<=`)
     float fox = 0.0f, foy = 0.0f;
     if (a.O > 0) {
+        const float px = r.px, py = r.py, vx = r.vx, vy = r.vy;
         const float* ob = a.obstacles + (a.obstacles_shared ? 0 : (long)w * a.O * a.Smax * 4);
         for (int o = 0; o < a.O; ++o) {
             float bx = 0.0f, by = 0.0f, bd = 10000.0f;
@@ -193,45 +157,16 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         }
         if (soc != 1) { fox /= (float)a.O; foy /= (float)a.O; }   // Guo's single-agent obstacle force is not averaged
     }
-
-    float npx, npy, nyaw = yaw, nvx, nvy, nbx = bvx, nby = bvy, nom = om;
-    if (!headed) {
-        const float gfx = fdx + fox + fsx, gfy = fdy + foy + fsy;
-        npx = a.just_velocities ? px : px + vx * a.dt; npy = a.just_velocities ? py : py + vy * a.dt;
-        nvx = vx + gfx / mass * a.dt; nvy = vy + gfy / mass * a.dt;
-        const float sp = sqrtf(nvx * nvx + nvy * nvy);
-        if (sp > vd) { nvx = nvx / sp * vd; nvy = nvy / sp * vd; }
-    } else {
-        const float inertia = 0.5f * mass * radius * radius;
-        const float tx = torque_new ? fdx + fox + fsx : fdx, ty = torque_new ? fdy + foy + fsy : fdy;
-        const float tn = sqrtf(tx * tx + ty * ty);
-        const float k_theta = inertia * P[19] * tn;
-        const float k_omega = inertia * (1.0f + P[18]) * sqrtf(P[19] * tn / P[18]);
-        const float torque = -k_theta * bound_angle(yaw - atan2f(ty, tx)) - k_omega * om;
-        // global_force = [ (fd + fo + fs) . R[:,0] ,  ko * (fo + fs) . R[:,1] - kd * body_velocity[1] ]
-        const float g0 = (fdx + fox + fsx) * cs + (fdy + foy + fsy) * sn;
-        const float g1 = P[16] * ((fox + fsx) * -sn + (foy + fsy) * cs) - P[17] * bvy;
-        npx = a.just_velocities ? px : px + vx * a.dt; npy = a.just_velocities ? py : py + vy * a.dt;
-        nyaw = a.just_velocities ? yaw : bound_angle(yaw + om * a.dt);
-        nbx = bvx + g0 / mass * a.dt; nby = bvy + g1 / mass * a.dt;
-        nom = om + torque / inertia * a.dt;
-        const float sp = sqrtf(nbx * nbx + nby * nby);
-        if (sp > vd) { nbx = nbx / sp * vd; nby = nby / sp * vd; }
-        float s2, c2;
-        sincosf(nyaw, &s2, &c2);
-        nvx = c2 * nbx - s2 * nby; nvy = s2 * nbx + c2 * nby;
-    }
-    px = npx; py = npy; yaw = nyaw; vx = nvx; vy = nvy; bvx = nbx; bvy = nby; om = nom;
+    rmodel::integrate(r, a.type, P, fsx, fsy, fox, foy, sn, cs, a.dt, a.just_velocities);
     qpre = qnext;
     }   // substeps
     if (lane != 0) return;
-    const float npx = px, npy = py, nyaw = yaw, nvx = vx, nvy = vy, nbx = bvx, nby = bvy, nom = om;
-    rb[0] = npx; rb[1] = npy; rb[2] = nyaw; rb[3] = nvx; rb[4] = nvy; rb[5] = nbx; rb[6] = nby; rb[7] = nom;
-    mem[0] = fdx; mem[1] = fdy;
+    rb[0] = r.px; rb[1] = r.py; rb[2] = r.yaw; rb[3] = r.vx; rb[4] = r.vy; rb[5] = r.bvx; rb[6] = r.bvy; rb[7] = r.om;
+    mem[0] = r.fdx; mem[1] = r.fdy;
     if (a.write_row) {
         float* s = a.S + ((long)w * a.rows + a.n) * a.as;
         const long fs = a.fs;
-        s[0] = npx; s[fs] = npy; s[2 * fs] = nyaw; s[3 * fs] = nvx; s[4 * fs] = nvy; s[5 * fs] = nbx; s[6 * fs] = nby; s[7 * fs] = nom;
+        s[0] = r.px; s[fs] = r.py; s[2 * fs] = r.yaw; s[3 * fs] = r.vx; s[4 * fs] = r.vy; s[5 * fs] = r.bvx; s[6 * fs] = r.bvy; s[7 * fs] = r.om;
     }
 }
 

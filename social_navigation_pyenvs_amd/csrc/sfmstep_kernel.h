@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "crowdstep.h"
+#include "robot_model.h"
 #include "stepcommon.h"
 
 namespace cstep {
@@ -49,7 +50,8 @@ constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one 
 //   LEAN   = 1 / 2 / 3: pair-once build for the plain crowd batch: no walls (1), walls kept (2), or no walls + a robot as the last
 //            row (3: what a Gym with a VISIBLE robot steps; rows = humans + 1), goal lists of <= 2 entries, state committed in
 //            place -- the wall / robot / goal-list-in-memory code and their branches are compiled out wherever the build
-//            does not need them and the goal switch is predicated
+//            does not need them and the goal switch is predicated; 4 = 3 + the robot follows a HUMAN motion model of its own
+//            (imitation learning, social_nav_gym.py:252-274): update_robot runs inside the substep loop (robot_model.h)
 template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, int LEAN>
 __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 {
@@ -74,15 +76,17 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 
     const int tid = threadIdx.x;
     static_assert(!LEAN || (PEQ && MAXT == 64), "the lean build is a pair-once build");
-    constexpr bool NO_WALLS = LEAN == 1 || LEAN == 3;      // wall code compiled out
+    constexpr bool LEAN_ROBOT = LEAN == 3 || LEAN == 4;    // the robot is the last row
+    constexpr bool IMIT = LEAN == 4;                       // ... and follows its own human motion model
+    constexpr bool NO_WALLS = LEAN == 1 || LEAN_ROBOT;     // wall code compiled out
     const int rows = ROWS_CT > 0 ? ROWS_CT : a.rows;
-    const int n = LEAN == 3 ? rows - 1 : (LEAN ? rows : a.n);
-    const int kmode = LEAN == 3 ? ((int)M_COMMIT_GOALS | (a.mode & (int)M_ROBOT_FROM_ARRAY)) : (LEAN ? (int)M_COMMIT_GOALS : a.mode);
+    const int n = LEAN_ROBOT ? rows - 1 : (LEAN ? rows : a.n);
+    const int kmode = LEAN_ROBOT ? ((int)M_COMMIT_GOALS | (a.mode & (int)M_ROBOT_FROM_ARRAY)) : (LEAN ? (int)M_COMMIT_GOALS : a.mode);
     const int lw = tid / rows;
     const int row = tid - lw * rows;
     const int w = blockIdx.x * a.wpb + lw;
     const bool valid = (lw < a.wpb) && (w < a.W);
-    const bool robot_row = LEAN == 3 ? true : (LEAN ? false : (a.flags & CS_ROBOT_ROW) != 0);
+    const bool robot_row = LEAN_ROBOT ? true : (LEAN ? false : (a.flags & CS_ROBOT_ROW) != 0);
     const bool human = valid && row < n;
     const bool is_robot = valid && robot_row && row == n;
     const int base = lw * rows;        // first row of my world in the per-row arrays (lds_v, lds_vr, ...)
@@ -188,6 +192,17 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 
     float cs = 1.0f, sn = 0.0f; // cos / sin of my theta, carried from one substep to the next
 
+    // imitation learning (LEAN = 4): the robot lane integrates the robot's own motion model; the humans' lanes each hand it their
+    // term of its social force.  LDS (aliases of regions this build does not use): per world [state (x, y, vx, vy)] [radius + margin],
+    // and one float2 slot per lane for the terms.
+    float4* lds_rob = reinterpret_cast<float4*>(lds_vr);
+    float2* lds_rf = reinterpret_cast<float2*>(lds_g0x);
+    float rm_hm = 0.0f, rm_fdx = 0.0f, rm_fdy = 0.0f;
+    if constexpr (IMIT) {
+        if (human) rm_hm = a.rm_hmargin[sidx];
+        if (is_robot) { rm_fdx = a.rm_memory[(long)w * 2]; rm_fdy = a.rm_memory[(long)w * 2 + 1]; }
+    }
+
     // ---- prologue: publish substep-0 rows ----------------------------------------------
     if (is_robot && robot_moves) robot_step();
     const float my_rs = r + safety;
@@ -279,6 +294,43 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 if constexpr (N3L && SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
             }
         };
+        if constexpr (IMIT) {
+            // -- update_robot(t, dt) (motion_model_manager.py:615-629) BEFORE update_humans: the robot's model sees the humans as they
+            //    stand, the crowd then sees the moved robot (its row is re-published into THIS substep's buffer).  Same operations,
+            //    same order as k_robot_model_step (robot_model.h): the fused launch equals the alternating launches bit for bit.
+            const int rsoc = a.rm_type % 3;
+            const bool rheaded = a.rm_type >= 3;
+            float rsn = 0.0f, rcs = 1.0f;
+            rmodel::RState rs;
+            if (is_robot) {
+                rs.px = px; rs.py = py; rs.yaw = th; rs.vx = vx; rs.vy = vy; rs.bvx = bvx; rs.bvy = bvy; rs.om = om;
+                rs.radius = r; rs.mass = m; rs.gx = gx; rs.gy = gy; rs.vd = vd; rs.fdx = rm_fdx; rs.fdy = rm_fdy;
+                rmodel::refresh_velocity(rs, rheaded, rsn, rcs);
+                lds_rob[2 * lw] = make_float4(rs.px, rs.py, rs.vx, rs.vy);
+                lds_rob[2 * lw + 1] = make_float4(r + a.rm_margin, 0.0f, 0.0f, 0.0f);   // (the region is the prologue's scratch: rewritten here)
+            }
+            LDS_ORDER_FENCE();
+            if (human) {
+                const float4 rq = lds_rob[2 * lw];
+                const float rme = lds_rob[2 * lw + 1].x;
+                float tx, ty;
+                rmodel::pair_term(rsoc, a.rm_P, rq.x, rq.y, rq.z, rq.w, px, py, vx, vy, rme + r + rm_hm, tx, ty);
+                lds_rf[tid] = make_float2(tx, ty);
+            }
+            LDS_ORDER_FENCE();
+            if (is_robot) {
+                float sx = 0.0f, sy = 0.0f;
+                const float2* tf = lds_rf + base;
+#pragma nounroll
+                for (int j = 0; j < n; ++j) { const float2 t = tf[j]; sx += t.x; sy += t.y; }
+                rmodel::integrate(rs, a.rm_type, a.rm_P, sx, sy, 0.0f, 0.0f, rsn, rcs, dt, 0);
+                px = rs.px; py = rs.py; th = rs.yaw; vx = rs.vx; vy = rs.vy; bvx = rs.bvx; bvy = rs.bvy; om = rs.om;
+                rm_fdx = rs.fdx; rm_fdy = rs.fdy;
+                publish(cur);
+                publish_v(cur);
+            }
+            LDS_ORDER_FENCE();
+        }
         // lean build: request the first group's partner rows first thing; the goal test and part A below run while they
         // are in flight (with walls the rows would be held in registers across the segment loops: fetched at the head of
         // the group loop instead)
@@ -899,6 +951,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             float* rb = a.robot + (long)w * 13;
             rb[0] = px; rb[1] = py; rb[2] = th; rb[3] = vx; rb[4] = vy;
         }
+        if constexpr (IMIT) {
+            if (is_robot) {   // what cs_robot_model_step leaves: the robot's dynamic columns and its model's remembered desired force
+                float* rb = a.robot + (long)w * 13;
+                rb[0] = px; rb[1] = py; rb[2] = th; rb[3] = vx; rb[4] = vy; rb[5] = bvx; rb[6] = bvy; rb[7] = om;
+                a.rm_memory[(long)w * 2] = rm_fdx; a.rm_memory[(long)w * 2 + 1] = rm_fdy;
+            }
+        }
         // invisible robot: advanced by the lane of row 0 (it does not interact with the crowd)
         if (!robot_row && row == 0 && robot_moves && a.robot != nullptr) {
             float* rb = a.robot + (long)w * 13;
@@ -954,5 +1013,6 @@ kfn sfm_builds_small(const Variant& v, int type);   // sfmstep_small.hip: 10 and
 kfn sfm_builds_lean50(const Variant& v, int type);   // sfmstep_lean50.hip: 50 rows per world without / with walls
 kfn sfm_builds_robot26(const Variant& v, int type);   // sfmstep_robot26.hip: 25 humans + a visible robot
 kfn sfm_builds_robotx(const Variant& v, int type);   // sfmstep_robotx.hip: 5 / 10 / 50 humans + a visible robot
+kfn sfm_builds_imit(const Variant& v, int type);     // sfmstep_imit.hip: a visible robot under its own human motion model (imitation learning)
 
 } // namespace cstep

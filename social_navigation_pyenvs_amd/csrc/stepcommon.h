@@ -42,6 +42,12 @@ struct KArgs {
     float4* snap;          // optional [nsub][W][n] (x, y, vx, vy) of every human at the START of every substep (imitation block)
     float* trace;          // optional [nsub][W][rows][12] px, py, theta, vx, vy, bvx, bvy, omega, gx, gy, goals[0].x, goals[0].y of every
                            // row AFTER every substep (respawn included; the robot row as the NEXT substep will see it): cs_step_trace
+    // the robot under a human motion model inside the crowd's launch (k_sfm_step<..., LEAN = 4>, cs_imitation_block with a visible robot)
+    int rm_type;           // the robot's model 0..8
+    float rm_margin;       // robot.safety_space as its model adds it to the radius
+    const float* rm_hmargin; // [W][rows] the humans' safety space as the robot's model sees it
+    float* rm_memory;      // [W][2] robot.desired_force between substeps
+    float rm_P[20];        // the robot's parameters
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     unsigned long long* stamps; // diagnostic build only
 };

@@ -348,6 +348,38 @@ def test_imitation_block_two_launches_equal_the_alternating_launches(hmodel, rmo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hmodel,rmodel,n", [("hsfm_farina", "sfm_helbing", 25), ("hsfm_farina", "hsfm_new_guo", 25), ("sfm_guo", "hsfm_farina", 10),
+                                             ("hsfm_new_moussaid", "sfm_moussaid", 7), ("sfm_helbing", "hsfm_guo", 40)])
+def test_imitation_block_with_a_visible_robot_is_one_launch_and_equals_the_alternating_launches(hmodel, rmodel, n):
+    """cs_imitation_block with a VISIBLE robot (robot and crowd act on each other in every substep): the robot's own motion model runs
+    inside the crowd's fused launch as the last row of every world (k_sfm_step<..., LEAN = 4>) == 20 x { cs_robot_model_step ;
+    cs_step(1) }, bit for bit -- robot rows, crowd rows, goal lists, the robot model's remembered desired force -- over three blocks
+    (hybrid worlds: goal switches and respawns that take the robot's position into account)."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W = 37
+    S, goals, P, rb = sc.hybrid_worlds(W, n, hmodel, seed0=11)
+    rng = np.random.default_rng(n)
+    robot = np.zeros((W, 13), np.float32)
+    robot[:, 0:2] = rng.uniform(-3, 3, (W, 2)); robot[:, 2] = rng.uniform(-3, 3, W); robot[:, 8] = 0.3; robot[:, 9] = 80
+    robot[:, 10:12] = -robot[:, 0:2]; robot[:, 12] = 1.0
+    S = np.concatenate([S, robot[:, None, :]], axis=1)
+    res = []
+    for fused in (True, False):
+        cw = CrowdWorlds(S, goals, P, None, None, type=hmodel, all_params_equal=True, respawn_bounds=rb,
+                         respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), robot_row=True, robot=robot)
+        cw.set_robot_model(rmodel, sc.default_params(rmodel), 0.01 + 0.05, np.full((W, n + 1), 0.06, np.float32))
+        for _ in range(3):
+            cw.imitation_block(0.0125, 20, graph=fused)
+        res.append((cw.get_states(), cw.get_robot(), cw.get_goals(), cw.d_robot_memory.download()))
+    for a, b in zip(res[0], res[1]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res[0][0][:, n, 0:8], res[0][1][:, 0:8])          # the robot row of the state IS the robot
+    assert np.max(np.abs(res[0][1][:, 0:2] - robot[:, 0:2])) > 0.1
+
+
+@pytest.mark.gpu
 def test_first_ever_imitation_block_captured_into_a_graph():
     """Library scratch and stream capture (include/crowdstep.h, cs_reserve_scratch): the very first cs_imitation_block of a
     process-new (stream, size) may not allocate inside a capture -- it is refused with CS_ERR_ARG and the capture stays usable;
