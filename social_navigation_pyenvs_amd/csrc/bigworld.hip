@@ -12,15 +12,14 @@
 //
 // Supported: all nine types, all_params_equal or per-agent parameters, polygon walls, goal lists of any length, the robot as the
 // last row of the state array (a source, never updated), cs_step / cs_update_humans_parallel (in or out of place).
-// Not built for these worlds (refused loudly): the respawn rule, a robot driven through cs_worlds.d_robot, cs_peek.
+// Round 3: the parallel-traffic respawn rule (k_bw_respawn), a robot handed over and moved through cs_worlds.d_robot (k_bw_robot),
+// cs_peek (nothing committed), and the cell lists by an in-tree counting sort (no library kernel on the path).
 //
 // gfx950 only: no portability macros, no CPU fallback.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>   // stable device radix sort (ROCm toolchain header) for the cell lists
 
 #include "common.h"
 #include "crowdstep.h"
@@ -39,6 +38,13 @@ struct GArgs {
     const int2* cellxy; const int* start; const int* sorted;   // the grid (csimpl::grid_build)
     float* inv_cell;   // [W] device scalars: 1 / cell edge of every world
     float2* in_v;      // [W][rows] refreshed linear velocity of the incoming rows (out-of-place update: written back afterwards)
+    int peek;          // cs_peek: goal lists are not rotated in memory, the head each human WOULD have goes to peek_goal
+    float2* peek_goal; // [W][n]
+    float* peek_out;   // [W][n][8]
+    float bx, by;      // respawn bounds
+    const int* world_flags;
+    float* robot;      // [W][13] cs_worlds.d_robot (robot rows handed over through the array, motion_model_manager.py:359)
+    const float* action;
 };
 
 // reach of the pair force in every world: max over rows of (r + safety) twice, plus 36 e-folding lengths of the slowest-decaying
@@ -80,9 +86,13 @@ __global__ __launch_bounds__(256) void k_bw_reach(const GArgs a)
 }
 
 // ---- the uniform grid (shared with the ORCA grid path, orca.hip) -------------------------------------------------------
-// key of row i of world w = w * NB + bucket(cell of i); a STABLE radix sort of (key, i) gives every bucket's rows in index
-// order, so the walk over a cell -- and with it the floating-point order of the force sums -- is the same in every run (a
-// scatter through atomics would not be: fused substeps and repeated launches must agree bit for bit).
+// key of row i of world w = w * NB + bucket(cell of i).  The cell lists are built by a hand-written COUNTING SORT whose result does
+// not depend on the order in which the hardware executes anything: (1) histogram of the keys (integer atomics: a count is
+// order-independent), (2) exclusive scan -> start[], (3) scatter of the rows into their bucket's segment in whatever order the
+// atomics hand out, (4) every row counts the rows of its segment with a SMALLER index: that count is its final place.  Every
+// bucket's rows therefore stand in index order, so the walk over a cell -- and with it the floating-point order of the force sums
+// -- is the same in every run (fused substeps and repeated launches must agree bit for bit).  Buckets hold ~0.5 rows on average
+// (NB >= 2 rows), so step (4) reads a handful of entries per row.
 __global__ void k_grid_keys(csimpl::GridView g, const float* S, long as, long fs, const float* d_inv_cell, float inv_cell)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
@@ -91,19 +101,80 @@ __global__ void k_grid_keys(csimpl::GridView g, const float* S, long as, long fs
     const float ic = d_inv_cell ? d_inv_cell[w] : inv_cell;
     const int cx = (int)floorf(s[0] * ic), cy = (int)floorf(s[fs] * ic);
     const long k = (long)w * g.rows + i;
+    const unsigned key = (unsigned)(w * g.NB + csimpl::cell_bucket(cx, cy, g.NB));
     g.cellxy[k] = make_int2(cx, cy);
-    g.keys[k] = (unsigned)(w * g.NB + csimpl::cell_bucket(cx, cy, g.NB));
-    g.idx[k] = i;
+    g.keys[k] = key;
+    atomicAdd(&g.fill[key], 1);
 }
 
-// start[b] = first position of key b in the sorted list, for every b in 0 .. W * NB (a key that owns nothing points at the next one)
-__global__ void k_grid_mark(csimpl::GridView g, int total)
+// exclusive scan of `in` [M] into `out` [M] in three launches: 1024 entries per block (a wavefront-level scan of the four entries of
+// every lane, the four wavefront totals through LDS), the block totals scanned by one block, the offsets added back
+__global__ __launch_bounds__(256) void k_scan_blocks(const int* in, int* out, int* bsum, int M)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > total) return;
-    const int kcur = p < total ? (int)g.keys_sorted[p] : g.W * g.NB;
-    const int kprev = p > 0 ? (int)g.keys_sorted[p - 1] : -1;
-    for (int b = kprev + 1; b <= kcur; ++b) g.start[b] = p;
+    __shared__ int wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long base = (long)blockIdx.x * 1024 + t * 4;
+    int v[4], run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (base + k < M) ? in[base + k] : 0; run += v[k]; }
+    int inc = run;                                       // inclusive scan of the lanes' totals inside the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int k = 0; k < wv; ++k) wbase += wsum[k];
+    int ex = wbase + inc - run;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (base + k < M) out[base + k] = ex; ex += v[k]; }
+    if (t == 255) bsum[blockIdx.x] = wbase + inc;
+}
+__global__ __launch_bounds__(256) void k_scan_sums(int* bsum, int nblk)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nblk; c0 += 256) {
+        const int v = (c0 + t < nblk) ? bsum[c0 + t] : 0;
+        int inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int wbase = carry_s;
+        for (int k = 0; k < wv; ++k) wbase += wsum[k];
+        if (c0 + t < nblk) bsum[c0 + t] = wbase + inc - v;
+        __syncthreads();
+        if (t == 255) carry_s = wbase + inc;
+        __syncthreads();
+    }
+}
+__global__ void k_scan_add(int* out, const int* bsum, int M, int total)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) out[i] += bsum[i >> 10];
+    else if (i == M) out[i] = total;
+}
+
+__global__ void k_grid_scatter(csimpl::GridView g)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= g.rows) return;
+    const unsigned key = g.keys[(long)w * g.rows + i];
+    g.tmp[g.start[key] + atomicAdd(&g.fill[key], 1)] = i;
+}
+
+__global__ void k_grid_rank(csimpl::GridView g)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= g.rows) return;
+    const unsigned key = g.keys[(long)w * g.rows + i];
+    const int p0 = g.start[key], p1 = g.start[key + 1];
+    int rank = 0;
+    for (int p = p0; p < p1; ++p) rank += (g.tmp[p] < i) ? 1 : 0;
+    g.sorted[p0 + rank] = i;
 }
 
 template <int SOC, int HEADED, bool PEQ>
@@ -139,11 +210,16 @@ __global__ __launch_bounds__(256) void k_bw_sfm_step(const GArgs a)
             int k = a.G;
             for (int g = a.G - 1; g >= 0; --g)
                 if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) k = g;
-            const float r0 = gi[0], r1 = gi[1];
-            for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
-            if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
-            gx = gi[0]; gy = gi[1];
-        }
+            if (a.peek) {                     // nothing is committed: the head the rotated list would have
+                gx = k > 1 ? gi[2] : gi[0]; gy = k > 1 ? gi[3] : gi[1];
+            } else {
+                const float r0 = gi[0], r1 = gi[1];
+                for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
+                if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
+                gx = gi[0]; gy = gi[1];
+            }
+            if (a.peek) a.peek_goal[(long)w * n + i] = make_float2(gx, gy);
+        } else if (a.peek) a.peek_goal[(long)w * n + i] = make_float2(gi[0], gi[1]);   // human.goals[0] (the goals array, :297)
     }
     float cs = 1.0f, sn = 0.0f, cvx = vx, cvy = vy;
     if constexpr (HEADED > 0) {
@@ -289,6 +365,96 @@ __global__ void k_bw_mutate(const GArgs a)
     si[10 * a.fs] = so[10 * a.fs]; si[11 * a.fs] = so[11 * a.fs];
 }
 
+// cs_peek: [n][8] rows x, y, yaw, Vx, Vy, Omega, Gx, Gy of the stepped rows (motion_model_manager.py:691-709, :294-298)
+__global__ void k_bw_peek_rows(const GArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= a.n) return;
+    const float* s = a.Sout + ((long)w * a.rows + i) * a.as;
+    float* o = a.peek_out + ((long)w * a.n + i) * 8;
+    const float2 g = a.peek_goal[(long)w * a.n + i];
+    o[0] = s[0]; o[1] = s[a.fs]; o[2] = s[2 * a.fs]; o[3] = s[3 * a.fs]; o[4] = s[4 * a.fs]; o[5] = s[7 * a.fs]; o[6] = g.x; o[7] = g.y;
+}
+
+// The robot handed over through cs_worlds.d_robot: robot.step(action, dt) (robot_agent.py:114-136) and states[-1] = robot row
+// (motion_model_manager.py:359) before a substep; one lane per world.  S: the rows the substep is about to read.
+__global__ void k_bw_robot(const GArgs a, float* S)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.W) return;
+    float* rb = a.robot + (long)w * 13;
+    if (a.action != nullptr) {
+        const float ax = a.action[(long)w * 2], ay = a.action[(long)w * 2 + 1];
+        if (a.flags & CS_ROBOT_UNICYCLE) {
+            float c, sn;
+            sincos_fast(rb[2] + ay, sn, c);
+            rb[0] += c * ax * a.dt; rb[1] += sn * ax * a.dt;
+            float th = fmodf(rb[2] + ay, 6.283185307179586f);
+            if (th < 0) th += 6.283185307179586f;
+            rb[2] = th;
+            sincos_fast(th, sn, c);
+            rb[3] = c * ax; rb[4] = sn * ax;
+        } else {
+            rb[0] += ax * a.dt; rb[1] += ay * a.dt; rb[3] = ax; rb[4] = ay;
+        }
+    }
+    float* s = S + ((long)w * a.rows + a.n) * a.as;
+    for (int f = 0; f < 13; ++f) s[f * a.fs] = rb[f];
+}
+
+// The parallel-traffic respawn rule (motion_model_manager.py:407-422) on the stepped rows of worlds beyond one block: one block per
+// world.  The reference respawns the flagged humans (|p - goals[0]| < 3) of a world in index order, each behind everybody else:
+// x_0 = max(max_x + 2 max_r, bound) and the c-th flagged one (c lower-indexed flagged humans in its world) lands at
+// x_c = max(x_{c-1} + 2 max_r, bound) because x_{c-1} is then the rightmost human (the rule of the crowd kernel, sfmstep_kernel.h).
+__global__ __launch_bounds__(256) void k_bw_respawn(const GArgs a)
+{
+    __shared__ float red[2][256];
+    __shared__ int wcnt[4];
+    __shared__ int carry_s;
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, n = a.n, rows = a.rows;
+    if (a.world_flags != nullptr && !(a.world_flags[w] & 1)) return;
+    float* Sw = a.Sout + (long)w * rows * a.as;
+    const long fs = a.fs;
+    float mx = -INFINITY, mr = 0.0f;
+    for (int i = t; i < rows; i += 256) {          // consider_robot: the robot row takes part in both maxima
+        const float* s = Sw + (long)i * a.as;
+        mx = fmaxf(mx, s[0]);
+        mr = fmaxf(mr, s[8 * fs] + a.safety[(long)w * rows + i]);
+    }
+    red[0][t] = mx; red[1][t] = mr;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { red[0][t] = fmaxf(red[0][t], red[0][t + off]); red[1][t] = fmaxf(red[1][t], red[1][t + off]); }
+        __syncthreads();
+    }
+    mx = red[0][0]; mr = red[1][0];
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + t;
+        float* s = Sw + (long)(i < n ? i : 0) * a.as;
+        float* gi = a.goals + ((long)w * n + (i < n ? i : 0)) * a.G * 2;
+        const float px = s[0], py = s[fs], g0x = gi[0], g0y = gi[1];
+        const float rdx = px - g0x, rdy = py - g0y;
+        const bool flag = i < n && fmaf(rdx, rdx, rdy * rdy) < 9.0f;
+        const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
+        if (lane == 0) wcnt[wv] = __builtin_popcountll(fm);
+        __syncthreads();
+        int c = carry_s + __builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+        for (int k = 0; k < wv; ++k) c += wcnt[k];
+        if (flag) {
+            float x = fmaxf(mx + mr * 2.0f, a.bx);
+            for (int k = 0; k < c; ++k) x = fmaxf(x + mr * 2.0f, a.bx);
+            const float ny = (py >= 0.0f) ? fminf(py, a.by) : fmaxf(py, -a.by);
+            s[0] = x; s[fs] = ny;
+            s[6 * fs] = g0x; s[7 * fs] = ny;                            // states[i,6:8] = goal (the reference writes columns 6:8, :421)
+            for (int g = 0; g < a.G; ++g) { gi[2 * g] = g0x; gi[2 * g + 1] = ny; }   // human.set_goals([[goals[0][0], position[1]]]) :418, :422
+        }
+        __syncthreads();
+        if (t == 0) carry_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+}
+
 using gfn = void (*)(const GArgs);
 
 template <bool PEQ>
@@ -308,33 +474,36 @@ namespace csimpl {
 
 size_t grid_bytes(int W, int rows, int NB)
 {
-    const size_t total = (size_t)W * rows;
-    size_t temp = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, temp, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr, total, 0, 32, (hipStream_t)0);
-    return total * (sizeof(int2) + 2 * sizeof(unsigned) + 2 * sizeof(int)) + ((size_t)W * NB + 2) * sizeof(int) + temp + 1024;
+    const size_t total = (size_t)W * rows, M = (size_t)W * NB;
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return pad(total * sizeof(int2)) + pad(total * sizeof(unsigned)) + 2 * pad(total * sizeof(int)) + pad((M + 2) * sizeof(int)) + pad((M + 1) * sizeof(int)) +
+           pad(((M + 1023) / 1024 + 1) * sizeof(int)) + 1024;
 }
 
 int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const float* d_inv_cell, float inv_cell, void* mem, GridView& g, hipStream_t stream)
 {
-    const size_t total = (size_t)W * rows;
+    const size_t total = (size_t)W * rows, M = (size_t)W * NB;
     if ((long long)W * NB >= (1ll << 31) || total >= (1ull << 31)) return fail(CS_ERR_ARG, "worlds beyond one block: W x buckets (or W x rows) does not fit the 32-bit grid keys");
     char* p = (char*)mem;
     auto take = [&](size_t bytes) { char* q = p; p += (bytes + 255) & ~(size_t)255; return q; };
     g.W = W; g.rows = rows; g.NB = NB;
     g.cellxy = (int2*)take(total * sizeof(int2));
     g.keys = (unsigned*)take(total * sizeof(unsigned));
-    g.keys_sorted = (unsigned*)take(total * sizeof(unsigned));
-    g.idx = (int*)take(total * sizeof(int));
+    g.tmp = (int*)take(total * sizeof(int));
     g.sorted = (int*)take(total * sizeof(int));
-    g.start = (int*)take(((size_t)W * NB + 2) * sizeof(int));
-    size_t temp = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, temp, g.keys, g.keys_sorted, g.idx, g.sorted, total, 0, 32, stream));
-    void* tmp = take(temp);
-    int bits = 1;
-    while ((1ll << bits) < (long long)W * NB) ++bits;
-    hipLaunchKernelGGL(k_grid_keys, dim3((rows + 255) / 256, W), dim3(256), 0, stream, g, S, as, fs, d_inv_cell, inv_cell);
-    HIP_TRY(rocprim::radix_sort_pairs(tmp, temp, g.keys, g.keys_sorted, g.idx, g.sorted, total, 0, (unsigned)bits, stream));
-    hipLaunchKernelGGL(k_grid_mark, dim3((unsigned)((total + 256) / 256)), dim3(256), 0, stream, g, (int)total);
+    g.start = (int*)take((M + 2) * sizeof(int));
+    g.fill = (int*)take((M + 1) * sizeof(int));
+    const int nblk = (int)((M + 1023) / 1024);
+    int* bsum = (int*)take((size_t)(nblk + 1) * sizeof(int));
+    const dim3 rgrid((rows + 255) / 256, W);
+    HIP_TRY(hipMemsetAsync(g.fill, 0, (M + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(k_grid_keys, rgrid, dim3(256), 0, stream, g, S, as, fs, d_inv_cell, inv_cell);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(nblk), dim3(256), 0, stream, g.fill, g.start, bsum, (int)M);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, bsum, nblk);
+    hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, stream, g.start, bsum, (int)M, (int)total);
+    HIP_TRY(hipMemsetAsync(g.fill, 0, (M + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(k_grid_scatter, rgrid, dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(k_grid_rank, rgrid, dim3(256), 0, stream, g);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -350,7 +519,7 @@ size_t sfm_big_scratch_bytes(const cs_worlds* w)
 {
     const int W = w->W, rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     const size_t state_bytes = ((size_t)W * rows * 13 * sizeof(float) + 255) & ~(size_t)255;
-    const size_t misc = (((size_t)W * sizeof(float) + 255) & ~(size_t)255) + (size_t)W * rows * sizeof(float2) + 256;
+    const size_t misc = (((size_t)W * sizeof(float) + 255) & ~(size_t)255) + 2 * ((((size_t)W * rows * sizeof(float2)) + 255) & ~(size_t)255) + 256;
     return 2 * state_bytes + misc + grid_bytes(W, rows, big_world_buckets(rows));
 }
 
@@ -359,13 +528,12 @@ size_t sfm_big_scratch_bytes(const cs_worlds* w)
 int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, int mutate_input, bool robot_from_array, const float* d_action,
                    float* d_peek, hipStream_t stream)
 {
-    if (d_peek) return fail(CS_ERR_ARG, "cs_peek is not built for worlds beyond one block");
-    if (w->flags & CS_RESPAWN) return fail(CS_ERR_ARG, "the respawn rule is not built for worlds beyond one block");
-    if (robot_from_array || d_action) return fail(CS_ERR_ARG, "worlds beyond one block take the robot as the last state row (no cs_worlds.d_robot, no action)");
     const int W = w->W, n = w->n, rows = n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    if (robot_from_array && !(w->flags & CS_ROBOT_ROW)) robot_from_array = false;
+    const bool robot_moves = d_action != nullptr && w->d_robot != nullptr;
     const int NB = big_world_buckets(rows);
     const size_t state_bytes = ((size_t)W * rows * 13 * sizeof(float) + 255) & ~(size_t)255;
-    const size_t misc = (((size_t)W * sizeof(float) + 255) & ~(size_t)255) + (size_t)W * rows * sizeof(float2) + 256;
+    const size_t pad_w = (((size_t)W * sizeof(float) + 255) & ~(size_t)255), pad_v = (((size_t)W * rows * sizeof(float2) + 255) & ~(size_t)255);
     char* base = nullptr;
     {
         const int rcs = scratch((void**)&base, sfm_big_scratch_bytes(w), SCRATCH_SFM_BIG, stream);
@@ -376,15 +544,39 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
     a.W = W; a.n = n; a.rows = rows; a.G = w->G; a.O = w->O; a.Smax = w->Smax; a.NB = NB; a.type = w->type; a.flags = w->flags; a.dt = dt;
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)W * rows; }
     a.goals = w->d_goals; a.params = w->d_params; a.safety = w->d_safety; a.obstacles = w->d_obstacles;
+    a.bx = w->respawn_bound_x; a.by = w->respawn_bound_y; a.world_flags = w->d_world_flags; a.robot = w->d_robot; a.action = d_action;
     float* SA = (float*)base;
     float* SB = (float*)(base + state_bytes);
     a.inv_cell = (float*)(base + 2 * state_bytes);
-    a.in_v = (float2*)(base + 2 * state_bytes + (((size_t)W * sizeof(float) + 255) & ~(size_t)255));
-    void* grid_mem = base + 2 * state_bytes + misc;
+    a.in_v = (float2*)(base + 2 * state_bytes + pad_w);
+    a.peek_goal = (float2*)(base + 2 * state_bytes + pad_w + pad_v);
+    a.peek = d_peek ? 1 : 0; a.peek_out = d_peek;
+    void* grid_mem = base + 2 * state_bytes + pad_w + 2 * pad_v + 256;
     const bool peq = (w->flags & CS_ALL_PARAMS_EQUAL) != 0;
     const gfn step = peq ? pick_big<true>(w->type) : pick_big<false>(w->type);
     if (!step) return fail(CS_ERR_TYPE, "Type " + std::to_string(w->type) + " does not exist for this implementation");
-    const float* cur = w->d_state;
+    if (d_peek) {
+        // one Euler step of size dt, nothing committed (motion_model_manager.py:691-709): the rows go to a scratch buffer, the goal
+        // lists stay, the robot row is the one handed over (it does not move)
+        float* in = w->d_state;
+        if (robot_from_array) {   // the robot row of d_robot without touching the caller's rows: step from a copy
+            HIP_TRY(hipMemcpyAsync(SB, w->d_state, (size_t)W * rows * 13 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            a.action = nullptr;
+            hipLaunchKernelGGL(k_bw_robot, dim3((W + 63) / 64), dim3(64), 0, stream, a, SB);
+            in = SB;
+        }
+        a.Sin = in; a.Sout = SA;
+        hipLaunchKernelGGL(k_bw_reach, dim3(W), dim3(256), 0, stream, a);
+        GridView g;
+        const int rcg = grid_build(in, a.as, a.fs, W, rows, NB, a.inv_cell, 0.0f, grid_mem, g, stream);
+        if (rcg) return rcg;
+        a.cellxy = g.cellxy; a.start = g.start; a.sorted = g.sorted;
+        hipLaunchKernelGGL(step, dim3((rows + 255) / 256, W), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_bw_peek_rows, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        return CS_OK;
+    }
+    float* cur = w->d_state;
     for (int sub = 0; sub < n_substeps; ++sub) {
         const bool last = sub + 1 == n_substeps;
         float* nxt = last ? d_out : ((sub & 1) ? SB : SA);
@@ -392,6 +584,11 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
         a.Sin = cur; a.Sout = nxt;
         a.mutate = (mutate_input && sub == 0) ? 1 : 0;
         a.Smut = w->d_state;
+        // robot.step(action, dt) ; states[-1] = robot row, before update_humans (social_nav_gym.py:240-243, motion_model_manager.py:359)
+        if (robot_from_array || robot_moves) {
+            a.action = robot_moves ? d_action : nullptr;
+            hipLaunchKernelGGL(k_bw_robot, dim3((W + 63) / 64), dim3(64), 0, stream, a, cur);
+        }
         if (sub == 0) hipLaunchKernelGGL(k_bw_reach, dim3(W), dim3(256), 0, stream, a);   // radii, parameters and speed limits hold for the launch
         GridView g;
         int rcg = grid_build(cur, a.as, a.fs, W, rows, NB, a.inv_cell, 0.0f, grid_mem, g, stream);
@@ -399,6 +596,7 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
         a.cellxy = g.cellxy; a.start = g.start; a.sorted = g.sorted;
         hipLaunchKernelGGL(step, dim3((rows + 255) / 256, W), dim3(256), 0, stream, a);
         if (a.mutate) hipLaunchKernelGGL(k_bw_mutate, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
+        if (w->flags & CS_RESPAWN) hipLaunchKernelGGL(k_bw_respawn, dim3(W), dim3(256), 0, stream, a);
         cur = nxt;
     }
     HIP_TRY(hipGetLastError());

@@ -39,8 +39,8 @@ size_t orca_big_scratch_bytes(const cs_worlds* w);
 int big_world_min_rows(int dflt);
 int device_simds();   // CUs x 4 of the current device
 // the uniform grid of worlds beyond one block (bigworld.hip): rows binned into hashed buckets of square cells, every bucket's rows in
-// index order (stable radix sort); start[w * NB + b] .. start[w * NB + b + 1] = bucket b of world w in `sorted` (row indices)
-struct GridView { int W, rows, NB; int2* cellxy; unsigned* keys; unsigned* keys_sorted; int* idx; int* sorted; int* start; };
+// index order (hand-written counting sort, bigworld.hip); start[w * NB + b] .. start[w * NB + b + 1] = bucket b of world w in `sorted` (row indices)
+struct GridView { int W, rows, NB; int2* cellxy; unsigned* keys; int* tmp; int* sorted; int* start; int* fill; };
 __host__ __device__ inline int cell_bucket(int cx, int cy, int NB) { return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u)) & (NB - 1); }
 size_t grid_bytes(int W, int rows, int NB);
 int big_world_buckets(int rows);   // hashed buckets of a world's grid: the power of two >= 2 * rows (1024 .. 2^20)

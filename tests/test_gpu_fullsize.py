@@ -334,3 +334,93 @@ def test_grid_path_on_small_worlds_equals_the_lds_kernel():
     ref, _, _ = orc.step_block(SFMS.index("hsfm_guo"), S.astype(np.float64), goals.astype(np.float64), None, P.astype(np.float64), 0.0125, 4,
                                np.zeros((W, n)), True)
     assert np.max(np.abs(res["grid"][..., [0, 1, 3, 4]] - ref[..., [0, 1, 3, 4]])) < 2e-5
+
+
+def test_grid_path_respawn_robot_through_d_robot_and_peek_equal_the_lds_kernel():
+    """SURVEY.md §8 row f3 remainder on the grid path (forced onto small worlds, CROWDSTEP_BIGWORLD_MIN_ROWS=1): the parallel-traffic
+    respawn rule, a visible robot handed over AND moved through cs_worlds.d_robot by an action, and cs_peek -- against the LDS kernel
+    on the same hybrid batch: rows within float32 rounding, goal lists and robot rows exact, peek commits nothing."""
+    import os
+
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n = 9, 25
+    S, goals, P, rb = sc.hybrid_worlds(W, n, "hsfm_farina", seed0=3)
+    rw = (np.arange(W) % 2 == 1).astype(np.int32)
+    rng = np.random.default_rng(1)
+    for w in range(1, W, 2):                               # traffic worlds: three humans at the edge of the respawn zone
+        for k, i in enumerate(rng.choice(n, 3, replace=False)):
+            S[w, i, 0] = goals[w, i, 0, 0] + 3.0 + 0.004 * (k + 1)
+            S[w, i, 3] = -0.9; S[w, i, 5] = 0.9
+    R = np.zeros((W, 13), np.float32)
+    R[:, 0:2] = rng.uniform(-3, 3, (W, 2)); R[:, 8] = 0.3; R[:, 9] = 80; R[:, 10:12] = -R[:, 0:2]; R[:, 12] = 1.0
+    A = rng.uniform(-0.8, 0.8, (W, 2)).astype(np.float32)
+    St = np.concatenate([S, R[:, None, :]], axis=1).astype(np.float32)
+    res = {}
+    for mode in ("grid", "lds"):
+        if mode == "grid":
+            os.environ["CROWDSTEP_BIGWORLD_MIN_ROWS"] = "1"
+        try:
+            cw = CrowdWorlds(St, goals, P, None, None, type="hsfm_farina", all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw,
+                             robot_row=True, robot=R, layout="soa" if mode == "grid" else "aos")
+            assert ("k_bw_sfm_step" in cw.step_variant()) == (mode == "grid")
+            before = cw.get_states().copy()
+            pk = cw.peek(0.25)
+            np.testing.assert_array_equal(cw.get_states(), before)              # nothing committed
+            np.testing.assert_array_equal(cw.get_goals(), goals.astype(np.float32))
+            cw.step(0.0125, 20, A)
+            res[mode] = (cw.get_states(), cw.get_goals(), cw.get_robot(), pk)
+        finally:
+            os.environ.pop("CROWDSTEP_BIGWORLD_MIN_ROWS", None)
+    g, l = res["grid"], res["lds"]
+    assert np.max(np.abs(g[0][..., [0, 1, 3, 4]] - l[0][..., [0, 1, 3, 4]])) < 3e-4      # respawned humans land at contact distance (25 kN/m)
+    moved = np.abs(l[0][:, :n, 0] - St[:, :n, 0]) > 1.0
+    assert moved.any() and np.array_equal(moved, np.abs(g[0][:, :n, 0] - St[:, :n, 0]) > 1.0)
+    assert np.max(np.abs(np.nan_to_num(g[1]) - np.nan_to_num(l[1]))) < 1e-4
+    np.testing.assert_array_equal(g[2], l[2])                                             # the robot rows moved by the action
+    np.testing.assert_allclose(g[2][:, 0:2], R[:, 0:2] + 20 * 0.0125 * A, atol=5e-6)
+    np.testing.assert_array_equal(g[0][:, n, 0:5], g[2][:, 0:5])                          # ... and are the last state row
+    assert np.max(np.abs(g[3] - l[3])) < 1e-4                                             # peek: one Euler step of 0.25 s
+
+
+def test_world_of_4096_rows_with_the_respawn_rule_matches_the_oracle():
+    """A parallel-traffic world far beyond one block (4096 humans in a 74 m x 96 m field, everybody walking to x = -38) with the
+    respawn rule: the humans inside the 3 m zone of their goal -- several in the same substep -- are respawned behind the rightmost
+    one in index order (k_bw_respawn); five substeps against the f64 oracle, the respawned rows and the goal lists included."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    n, model = 4096, "hsfm_farina"
+    rng = np.random.default_rng(77)
+    cols, lanes = 32, 128
+    gx_, gy_ = np.meshgrid(np.arange(cols), np.arange(lanes))
+    pos = np.stack([gx_.ravel() * 2.3 - 35.0, (gy_.ravel() - lanes / 2) * 0.75], -1) + rng.uniform(-0.05, 0.05, (n, 2))
+    S = np.zeros((1, n, 13))
+    S[0, :, 0:2] = pos
+    S[0, :, 2] = np.pi; S[0, :, 3] = -0.9; S[0, :, 5] = 0.9
+    S[0, :, 8] = 0.3; S[0, :, 9] = 75; S[0, :, 12] = 1.0
+    goals = np.zeros((1, n, 1, 2))
+    goals[0, :, 0, 0] = -38.0; goals[0, :, 0, 1] = pos[:, 1]
+    near = rng.choice(np.flatnonzero(gx_.ravel() == 0), 40, replace=False)   # forty humans of the first column on the edge of the zone
+    S[0, near, 0] = -35.0 + rng.uniform(0.0, 0.05, 40)
+    S[0, :, 10:12] = goals[0, :, 0]
+    P = np.tile(sc.default_params(model), (n, 1))
+    bounds = (40.0, 50.0)
+    S32, g32, P32 = S.astype(np.float32), goals.astype(np.float32), P.astype(np.float32)
+    cw = CrowdWorlds(S32, g32, P32, None, None, type=model, all_params_equal=True, respawn_bounds=bounds)
+    assert "k_bw_sfm_step" in cw.step_variant(), cw.step_variant()
+    cw.step(0.0125, 5)
+    got, gg = cw.get_states()[0], cw.get_goals()[0]
+    ref, rg, _ = orc.step_block(SFMS.index(model), S32[0].astype(np.float64), g32[0].astype(np.float64), None, P32.astype(np.float64), 0.0125, 5,
+                                np.zeros(n), True, respawn=True, respawn_par=(bounds[0], bounds[1], 0.0))
+    moved = np.abs(ref[:, 0] - S32[0, :, 0]) > 30.0
+    assert moved.sum() >= 20 and np.array_equal(moved, np.abs(got[:, 0] - S32[0, :, 0]) > 30.0)
+    # the c-th respawned human stands at x_0 + c * 2 max_r, accumulated in float32 as the rule is sequential: c ulps of 88 m at most
+    assert np.max(np.abs(got[moved][:, 0] - ref[moved][:, 0])) < 40 * 8e-6
+    assert np.max(np.abs(got[:, [1, 3, 4]] - ref[:, [1, 3, 4]])) < 5e-5          # five substeps, rows 0.75 m apart (contacts)
+    assert np.max(np.abs(got[~moved][:, 0] - ref[~moved][:, 0])) < 5e-5
+    assert np.max(np.abs(gg - rg)) < 1e-4
+    order = np.argsort(np.flatnonzero(moved))                     # respawned in index order, each behind the previous one
+    xs = got[moved][:, 0]
+    assert np.all(np.diff(xs) > 0.59)
