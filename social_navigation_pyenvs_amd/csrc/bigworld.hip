@@ -405,21 +405,26 @@ __global__ void k_bw_robot(const GArgs a, float* S)
 // The parallel-traffic respawn rule (motion_model_manager.py:407-422) on the stepped rows of worlds beyond one block: one block per
 // world.  The reference respawns the flagged humans (|p - goals[0]| < 3) of a world in index order, each behind everybody else:
 // x_0 = max(max_x + 2 max_r, bound) and the c-th flagged one (c lower-indexed flagged humans in its world) lands at
-// x_c = max(x_{c-1} + 2 max_r, bound) because x_{c-1} is then the rightmost human (the rule of the crowd kernel, sfmstep_kernel.h).
-__global__ __launch_bounds__(256) void k_bw_respawn(const GArgs a)
+// x_c = max(x_{c-1} + 2 max_r, bound) because x_{c-1} is then the rightmost human (the rule of the crowd kernels, sfmstep_kernel.h /
+// orca.hip).  orca = 0: SFM / HSFM rows (max_r over radius + safety space; the reference also writes the goal into state columns
+// 6:8, :421); orca = 1: RVO2 agents (max_r over the plain radii -- safety_space is 0 for ORCA humans, :154-158 --, the goal goes to
+// the state's goal columns, the preferred velocity of the step stays).
+struct RespawnArgs { int W, n, rows, G, orca; float* S; long as, fs; float* goals; const float* extra; float bx, by; const int* world_flags; };
+
+__global__ __launch_bounds__(256) void k_bw_respawn(const RespawnArgs a)
 {
     __shared__ float red[2][256];
     __shared__ int wcnt[4];
     __shared__ int carry_s;
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, n = a.n, rows = a.rows;
     if (a.world_flags != nullptr && !(a.world_flags[w] & 1)) return;
-    float* Sw = a.Sout + (long)w * rows * a.as;
+    float* Sw = a.S + (long)w * rows * a.as;
     const long fs = a.fs;
     float mx = -INFINITY, mr = 0.0f;
     for (int i = t; i < rows; i += 256) {          // consider_robot: the robot row takes part in both maxima
         const float* s = Sw + (long)i * a.as;
         mx = fmaxf(mx, s[0]);
-        mr = fmaxf(mr, s[8 * fs] + a.safety[(long)w * rows + i]);
+        mr = fmaxf(mr, a.orca ? s[8 * fs] : s[8 * fs] + a.extra[(long)w * rows + i]);
     }
     red[0][t] = mx; red[1][t] = mr;
     if (t == 0) carry_s = 0;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256) void k_bw_respawn(const GArgs a)
         float* gi = a.goals + ((long)w * n + (i < n ? i : 0)) * a.G * 2;
         const float px = s[0], py = s[fs], g0x = gi[0], g0y = gi[1];
         const float rdx = px - g0x, rdy = py - g0y;
-        const bool flag = i < n && fmaf(rdx, rdx, rdy * rdy) < 9.0f;
+        const bool flag = i < n && (a.orca ? sqrtf(rdx * rdx + rdy * rdy) < 3.0f : fmaf(rdx, rdx, rdy * rdy) < 9.0f);
         const unsigned long long fm = __builtin_amdgcn_ballot_w64(flag);
         if (lane == 0) wcnt[wv] = __builtin_popcountll(fm);
         __syncthreads();
@@ -446,7 +451,8 @@ __global__ __launch_bounds__(256) void k_bw_respawn(const GArgs a)
             for (int k = 0; k < c; ++k) x = fmaxf(x + mr * 2.0f, a.bx);
             const float ny = (py >= 0.0f) ? fminf(py, a.by) : fmaxf(py, -a.by);
             s[0] = x; s[fs] = ny;
-            s[6 * fs] = g0x; s[7 * fs] = ny;                            // states[i,6:8] = goal (the reference writes columns 6:8, :421)
+            if (a.orca) { s[10 * fs] = g0x; s[11 * fs] = ny; }
+            else { s[6 * fs] = g0x; s[7 * fs] = ny; }                  // states[i,6:8] = goal (the reference writes columns 6:8, :421)
             for (int g = 0; g < a.G; ++g) { gi[2 * g] = g0x; gi[2 * g + 1] = ny; }   // human.set_goals([[goals[0][0], position[1]]]) :418, :422
         }
         __syncthreads();
@@ -506,6 +512,13 @@ int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const 
     hipLaunchKernelGGL(k_grid_rank, rgrid, dim3(256), 0, stream, g);
     HIP_TRY(hipGetLastError());
     return CS_OK;
+}
+
+void big_respawn_launch(float* S, long as, long fs, int W, int n, int rows, float* goals, int G, const float* extra, int orca, float bx, float by,
+                        const int* world_flags, hipStream_t stream)
+{
+    RespawnArgs r{W, n, rows, G, orca, S, as, fs, goals, extra, bx, by, world_flags};
+    hipLaunchKernelGGL(k_bw_respawn, dim3(W), dim3(256), 0, stream, r);
 }
 
 int big_world_buckets(int rows)
@@ -596,7 +609,7 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
         a.cellxy = g.cellxy; a.start = g.start; a.sorted = g.sorted;
         hipLaunchKernelGGL(step, dim3((rows + 255) / 256, W), dim3(256), 0, stream, a);
         if (a.mutate) hipLaunchKernelGGL(k_bw_mutate, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
-        if (w->flags & CS_RESPAWN) hipLaunchKernelGGL(k_bw_respawn, dim3(W), dim3(256), 0, stream, a);
+        if (w->flags & CS_RESPAWN) big_respawn_launch(nxt, a.as, a.fs, W, n, rows, w->d_goals, w->G, w->d_safety, 0, a.bx, a.by, w->d_world_flags, stream);
         cur = nxt;
     }
     HIP_TRY(hipGetLastError());

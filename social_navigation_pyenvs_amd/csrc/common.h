@@ -43,6 +43,9 @@ int device_simds();   // CUs x 4 of the current device
 struct GridView { int W, rows, NB; int2* cellxy; unsigned* keys; int* tmp; int* sorted; int* start; int* fill; };
 __host__ __device__ inline int cell_bucket(int cx, int cy, int NB) { return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u)) & (NB - 1); }
 size_t grid_bytes(int W, int rows, int NB);
+// the parallel-traffic respawn rule on the stepped rows of worlds beyond one block (bigworld.hip k_bw_respawn); orca: RVO2 agent rows
+void big_respawn_launch(float* S, long as, long fs, int W, int n, int rows, float* goals, int G, const float* extra, int orca, float bx, float by,
+                        const int* world_flags, hipStream_t stream);
 int big_world_buckets(int rows);   // hashed buckets of a world's grid: the power of two >= 2 * rows (1024 .. 2^20)
 int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const float* d_inv_cell, float inv_cell, void* mem, GridView& g, hipStream_t stream);
 // SFM / HSFM worlds beyond one block (bigworld.hip)

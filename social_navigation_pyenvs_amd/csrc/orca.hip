@@ -1160,6 +1160,7 @@ struct BigArgs {
     float* goals; const float* margin;
     const int2* cellxy; const int* start; const int* sorted;   // the grid (csimpl::grid_build, bigworld.hip)
     int lp3_static;
+    float* peek_out;       // cs_peek: [W][n][8] rows of the stepped state; goal lists are not rotated in memory
 };
 
 __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
@@ -1227,14 +1228,21 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
     if (sqrtf(ddx * ddx + ddy * ddy) < r) { // update_goals: strict <  (:66-70)
         int k = a.G;
         for (int g = 0; g < a.G; ++g) if (isnan(gi[2 * g])) { k = g; break; }
-        const float r0 = gi[0], r1 = gi[1];
-        for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
-        if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
-        g0x = gi[0]; g0y = gi[1];
+        if (a.peek_out == nullptr) {
+            const float r0 = gi[0], r1 = gi[1];
+            for (int g = 0; g + 1 < k; ++g) { gi[2 * g] = gi[2 * g + 2]; gi[2 * g + 1] = gi[2 * g + 3]; }
+            if (k > 0) { gi[2 * (k - 1)] = r0; gi[2 * (k - 1) + 1] = r1; }
+            g0x = gi[0]; g0y = gi[1];
+        } else if (k > 1) { g0x = gi[2]; g0y = gi[3]; }   // cs_peek commits nothing: the head the rotated list would have
         ddx = g0x - px; ddy = g0y - py;
     }
     const float nrm = sqrtf(ddx * ddx + ddy * ddy);
     if (nrm > vmax) { pvx = ddx / nrm; pvy = ddy / nrm; } else { pvx = ddx; pvy = ddy; }
+    if (a.peek_out != nullptr) {   // get_human_states(include_goal=True, headed=False) of the next state (:294-298)
+        float* q = a.peek_out + ((long)w * n + i) * 8;
+        q[0] = px; q[1] = py; q[2] = srow[2 * fs]; q[3] = vx; q[4] = vy; q[5] = srow[7 * fs]; q[6] = g0x; q[7] = g0y;
+        return;
+    }
     float* o = a.Sout + ((long)w * n + i) * a.as;
     o[0] = px; o[fs] = py; o[3 * fs] = vx; o[4 * fs] = vy; o[5 * fs] = pvx; o[6 * fs] = pvy; o[10 * fs] = g0x; o[11 * fs] = g0y;
 }
@@ -1295,8 +1303,6 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
 {
     if (w->flags & CS_ROBOT_ROW) return fail(CS_ERR_ARG, "ORCA worlds beyond one block (grid neighbour search) have no robot row");
     if (d_action) return fail(CS_ERR_ARG, "ORCA worlds beyond one block take no robot action");
-    if (d_peek) return fail(CS_ERR_ARG, "cs_peek is not built for ORCA worlds beyond one block");
-    if (w->flags & CS_RESPAWN) return fail(CS_ERR_ARG, "the respawn rule is not built for ORCA worlds beyond one block");
     if (w->orca_max_neighbors != 10 || w->orca_n_vertices != 0)
         return fail(CS_ERR_ARG, "ORCA worlds beyond one block need max_neighbors = 10 and no static obstacles");
     const int n = w->n, W = w->W;
@@ -1322,6 +1328,7 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     HIP_TRY(hipMemcpyAsync(S2, w->d_state, state_bytes, hipMemcpyDeviceToDevice, stream));   // the columns a step does not write
     const float* cur = w->d_state;
     float* nxt = S2;
+    a.peek_out = d_peek;                       // cs_peek: one substep, rows to d_peek, nothing committed (no respawn: post_update=False, :705)
     for (int sub = 0; sub < n_substeps; ++sub) {
         a.Sin = cur; a.Sout = nxt;
         GridView g;
@@ -1329,6 +1336,9 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
         if (rcg) return rcg;
         a.cellxy = g.cellxy; a.start = g.start; a.sorted = g.sorted;
         hipLaunchKernelGGL(k_bw_orca_step, dim3((n + 63) / 64, W), dim3(64), 0, stream, a);
+        if (d_peek) { HIP_TRY(hipGetLastError()); return CS_OK; }
+        if (w->flags & CS_RESPAWN)
+            big_respawn_launch(nxt, a.as, a.fs, W, n, n, w->d_goals, w->G, nullptr, 1, w->respawn_bound_x, w->respawn_bound_y, w->d_world_flags, stream);
         const float* t = cur; cur = nxt; nxt = const_cast<float*>(t);
     }
     HIP_TRY(hipGetLastError());

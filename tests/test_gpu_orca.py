@@ -491,6 +491,54 @@ def test_orca_world_of_4096_agents_through_the_grid():
     assert np.max(np.abs(ref[..., 0:2] - S[..., 0:2])) > 0.01          # they did move
 
 
+def test_orca_grid_path_respawn_and_peek_equal_the_restatement():
+    """SURVEY.md §8 row f3 remainder for ORCA worlds on the grid path (forced onto small worlds): the parallel-traffic respawn rule
+    (k_bw_respawn in its RVO2-agent form: plain radii, goal columns) and cs_peek (one step, nothing committed) -- bit-identical to
+    the restatement over 3 x 20 substeps with several humans entering the 3 m zone, and to the one-block kernel's peek."""
+    import os
+
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W, n = 6, 40
+    pos, yaw, g = sc.parallel_traffic(W, n, 30.0, 8.0, seed0=5)
+    S = sc.make_states(pos, yaw, g).astype(np.float32)
+    g = g.astype(np.float32)
+    rng = np.random.default_rng(2)
+    for w in range(W):
+        for k, i in enumerate(rng.choice(n, 4, replace=False)):
+            S[w, i, 0] = g[w, i, 0, 0] + 3.0 + 0.01 * (k + 1)              # on the edge of the respawn zone
+    d = g[:, :, 0] - S[:, :, 0:2]
+    S[:, :, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    S[:, :, 10:12] = g[:, :, 0]
+    margin = np.full((W, n), 0.01, np.float32)
+    bounds = (15.0, 4.0)
+    res = {}
+    for mode in ("grid", "block"):
+        if mode == "grid":
+            os.environ["CROWDSTEP_BIGWORLD_MIN_ROWS"] = "1"
+        try:
+            cw = CrowdWorlds(S, g, None, margin, None, type="orca", respawn_bounds=bounds)
+            before = cw.get_states().copy()
+            pk = cw.peek(0.25)
+            np.testing.assert_array_equal(cw.get_states(), before)
+            np.testing.assert_array_equal(cw.get_goals(), g)
+            for _ in range(3):
+                cw.step(0.0125, 20)
+            res[mode] = (cw.get_states(), cw.get_goals(), pk)
+        finally:
+            os.environ.pop("CROWDSTEP_BIGWORLD_MIN_ROWS", None)
+    ref, rg = S, g
+    for _ in range(3):
+        ref, rg, _ = orc.orca_step_block(ref, rg, margin, 0.0125, 20, respawn=True, bounds=bounds)
+    cols = [0, 1, 3, 4, 5, 6, 10, 11]
+    for mode in ("grid", "block"):
+        np.testing.assert_array_equal(res[mode][0][..., cols], ref[..., cols])
+        np.testing.assert_array_equal(res[mode][1], rg)
+    np.testing.assert_array_equal(res["grid"][2], res["block"][2])
+    assert np.any(np.abs(ref[..., 0] - S[..., 0]) > 5.0)                   # somebody was respawned
+
+
 @pytest.mark.parametrize("layout", ["aos", "soa"])
 def test_orca_grid_path_on_small_worlds_equals_the_restatement(layout):
     """The grid path forced onto several small worlds at once (CROWDSTEP_BIGWORLD_MIN_ROWS): negative cell coordinates, buckets
