@@ -322,6 +322,25 @@ int cs_actual_collision_reward(const cs_worlds* w, float T, const float* d_globa
  *   Updates rows (x, y, yaw, Vx, Vy, BVx, BVy, Omega, goal columns) and rotates d_goals in place.
  */
 int cs_update_humans_rk45(const cs_worlds* w, float dt, float* d_memory, int32_t* d_nfev, void* stream);
+/*   With CS_RESPAWN the parallel-traffic respawn rule runs behind the solve, as update_humans(post_update=True) does on the agent
+ *   objects (motion_model_manager.py:405-422, the non-parallel form: positions and goal lists; max over radius + safety space).
+ *
+ * cs_complete_rk45_simulation  replaces MotionModelManager.complete_rk45_simulation(t, dt, final_time) (motion_model_manager.py:461-498):
+ *   ONE solve_ivp(f_rk45_*, (t, t + final_time), y0, method='RK45', t_eval=np.arange(t, final_time, dt)) per world -- the same
+ *   right-hand side and step-size control as cs_update_humans_rk45, the solution at the n_eval = len(arange(t, final_time, dt)) times
+ *   k * dt taken from scipy's RK45 dense output (rk.py RkDenseOutput: y_old + h Q [x, x^2, x^3, x^4], Q = K^T P) of the step that
+ *   contains them.  d_human_states [W][n_eval][n][6] (x, y, yaw, BVx, BVy, Omega: headed types) or [..][4] (x, y, Vx, Vy): the raw
+ *   solution components, as the reference returns them.  The rows of w->d_state are left at the state of t + final_time.
+ *
+ * cs_robot_model_rk45  replaces MotionModelManager.update_robot(t, dt) for a robot whose SFM / HSFM motion model was set with
+ *   runge_kutta=True (motion_model_manager.py:631-640, f_rk45_robot_* :661-687): scipy's RK45 around compute_robot_forces (:591-613,
+ *   the single-agent force functions; the humans stand still during the solve).  Arguments as cs_robot_model_step; robot_type 0..8;
+ *   up to 64 humans per world.  d_nfev [W] or NULL.
+ */
+int cs_complete_rk45_simulation(const cs_worlds* w, float dt, float final_time, float* d_memory, float* d_human_states, int n_eval,
+                                int32_t* d_nfev, void* stream);
+int cs_robot_model_rk45(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin, const float* d_human_margin,
+                        float* d_robot_memory, float dt, int32_t* d_nfev, void* stream);
 
 /*
  * cs_gym_bookkeeping  the host bookkeeping of SocialNavGym between two steps, for W worlds on the device (one lane per world):

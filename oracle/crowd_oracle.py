@@ -523,9 +523,10 @@ def closest_points(walls, p):
     return out
 
 
-def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls, dt, just_velocities=False):
-    """One update_robot(t, dt) of an SFM / HSFM robot.  row = [x, y, yaw, vx, vy, bvx, bvy, omega, radius, mass, gx, gy,
-    desired_speed, safety_space, desired_force_x, desired_force_y] (copied); returns the new row."""
+def _robot_forces(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls):
+    """compute_robot_forces (motion_model_manager.py:591-613) on a robot row (see robot_model_substep): returns
+    (vel, R, fd, fo, fs) -- the linear velocity (refreshed from the body velocity for headed models), the rotation matrix of the
+    yaw, and the desired (kept within one radius of the goal), obstacle and social forces."""
     r = np.array(row, dtype=np.float64)
     headed = model.startswith("hsfm")
     guo, mou = model.endswith("guo"), model.endswith("moussaid")
@@ -583,6 +584,18 @@ def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety,
                 fs += (P[1] * np.exp(rd / P[3]) + P[10] * max(0, rd)) * n_ij + (P[5] * np.exp(rd / P[7]) + P[11] * max(0, rd) * dv) * t_ij
             else:
                 fs += (P[1] * np.exp(rd / P[3]) + P[10] * max(0, rd)) * n_ij + P[11] * max(0, rd) * dv * t_ij
+    return vel, R, fd, fo, fs
+
+
+def robot_model_substep(row, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls, dt, just_velocities=False):
+    """One update_robot(t, dt) of an SFM / HSFM robot.  row = [x, y, yaw, vx, vy, bvx, bvy, omega, radius, mass, gx, gy,
+    desired_speed, safety_space, desired_force_x, desired_force_y] (copied); returns the new row."""
+    r = np.array(row, dtype=np.float64)
+    headed = model.startswith("hsfm")
+    pos, yaw, bvel, om = r[0:2].copy(), r[2], r[5:7].copy(), r[7]
+    radius, mass, vd = r[8], r[9], r[12]
+    inertia = 0.5 * mass * radius * radius
+    vel, R, fd, fo, fs = _robot_forces(r, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls)
     if not headed:
         gf = fd + fo + fs
         if not just_velocities:                      # motion_model_manager.py:73
@@ -770,4 +783,101 @@ class Rk45Crowd:
                 r[i, 3:5] = np.array([[c, -s], [s, c]]) @ r[i, 5:7]
         for i in range(len(r)):
             r[i, 10:12] = self.goals[i][0]
+        return self.nfev
+
+    def complete_simulation(self, t, dt, final_time):
+        """MotionModelManager.complete_rk45_simulation(t, dt, final_time) (motion_model_manager.py:461-498): ONE solve over
+        (t, t + final_time) with t_eval = arange(t, final_time, dt) -> human_states [len(t_eval), n, 6 | 4] (the raw solution
+        components).  The rows are left as the LAST right-hand-side evaluation leaves them (the reference does not set them
+        from the solution afterwards)."""
+        from scipy.integrate import solve_ivp
+
+        r = self.rows
+        self.nfev = 0
+        y0 = (r[:, [0, 1, 2, 5, 6, 7]] if self.headed else r[:, [0, 1, 3, 4]]).ravel().copy()
+        times = np.arange(t, final_time, dt, dtype=np.float64)
+        sol = solve_ivp(self.rhs, (t, t + final_time), y0, method="RK45", t_eval=times)
+        ns = 6 if self.headed else 4
+        out = sol.y.T.reshape(len(times), len(r), ns).copy()
+        for i in range(len(r)):
+            r[i, 10:12] = self.goals[i][0]
+        return out
+
+    def respawn(self, bound_x, bound_y):
+        """The parallel-traffic respawn rule on the agent objects (motion_model_manager.py:405-422, `self.parallel` False): the humans
+        within 3 m of their goal are moved behind everybody else in index order; position and goal list only."""
+        r = self.rows
+        for i in range(len(r)):
+            g0 = self.goals[i][0]
+            if np.linalg.norm(r[i, 0:2] - g0) < 3:
+                xs = [r[j, 0] for j in range(len(r))]
+                rs = [r[j, 8] + r[j, 13] for j in range(len(r))]
+                if self.robot is not None:
+                    xs.append(self.robot[0]); rs.append(self.robot[4] + self.robot[5])
+                r[i, 0] = max(max(xs) + max(rs) * 2, bound_x)
+                r[i, 1] = min(r[i, 1], bound_y) if r[i, 1] >= 0 else max(r[i, 1], -bound_y)
+                self.goals[i] = [np.array([g0[0], r[i, 1]])]
+                r[i, 10:12] = self.goals[i][0]
+
+
+class Rk45Robot:
+    """update_robot(t, dt) of a robot whose SFM / HSFM model runs under RK45 (motion_model_manager.py:631-640): scipy's solve_ivp
+    around f_rk45_robot_* (:661-687) = the trial state written into the robot (:88-103), compute_robot_forces (:591-613: the force
+    part of robot_model_substep above, humans standing), ydot.  row as in robot_model_substep."""
+
+    def __init__(self, row, P, model, hum_pos, hum_vel, hum_radius, hum_safety, walls):
+        self.row = np.array(row, dtype=np.float64)
+        self.P, self.model = np.asarray(P, dtype=np.float64), model
+        self.h = (np.asarray(hum_pos, np.float64), np.asarray(hum_vel, np.float64), np.asarray(hum_radius, np.float64), np.asarray(hum_safety, np.float64))
+        self.walls = walls
+        self.headed = model.startswith("hsfm")
+        self.nfev = 0
+
+    def _set_state(self, y):
+        r = self.row
+        r[0:2] = y[0:2]
+        if self.headed:
+            r[2] = _bound_angle(y[2])
+            bv = np.array(y[3:5])
+            sp = np.linalg.norm(bv)
+            r[5:7] = bv / sp * r[12] if sp > r[12] else bv
+            r[7] = y[5]
+        else:
+            v = np.array(y[2:4])
+            sp = np.linalg.norm(v)
+            r[3:5] = v / sp * r[12] if sp > r[12] else v
+
+    def rhs(self, t, y):
+        self.nfev += 1
+        self._set_state(y)
+        r = self.row
+        vel, R, fd, fo, fs = _robot_forces(r, self.P, self.model, *self.h, self.walls)
+        r[3:5] = vel
+        r[14:16] = fd
+        P, mass, radius = self.P, r[9], r[8]
+        if not self.headed:
+            gf = fd + fo + fs
+            return np.array([vel[0], vel[1], gf[0] / mass, gf[1] / mass])
+        inertia = 0.5 * mass * radius * radius
+        tot = fd if self.model in ("hsfm_farina", "hsfm_guo", "hsfm_moussaid") else fd + fo + fs
+        tn = np.linalg.norm(tot)
+        k_theta = inertia * P[19] * tn
+        k_omega = inertia * (1 + P[18]) * np.sqrt(P[19] * tn / P[18])
+        torque = -k_theta * _bound_angle(r[2] - np.arctan2(tot[1], tot[0])) - k_omega * r[7]
+        g0 = np.dot(fd + fo + fs, R[:, 0])
+        g1 = P[16] * np.dot(fo + fs, R[:, 1]) - P[17] * r[6]
+        bv = r[5:7]
+        return np.array([np.dot(R[0, :], bv), np.dot(R[1, :], bv), r[7], g0 / mass, g1 / mass, torque / inertia])
+
+    def update(self, t, dt):
+        from scipy.integrate import solve_ivp
+
+        r = self.row
+        self.nfev = 0
+        y0 = r[[0, 1, 2, 5, 6, 7]].copy() if self.headed else r[[0, 1, 3, 4]].copy()
+        sol = solve_ivp(self.rhs, (t, t + dt), y0, method="RK45")
+        self._set_state(sol.y[:, -1])
+        if self.headed:
+            c, s = np.cos(r[2]), np.sin(r[2])
+            r[3:5] = np.array([[c, -s], [s, c]]) @ r[5:7]
         return self.nfev

@@ -257,10 +257,42 @@ class CrowdWorlds:
             mem = self.d_rk_memory = DeviceBuffer.from_numpy(np.zeros((self.W, self.n, 2), np.float32))
         if desired_force is not None:
             mem.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(desired_force, dtype=np.float32), (self.W, self.n, 2))), self.stream)
-        d = self.descriptor(respawn=False)
+        d = self.descriptor()     # (with respawn bounds set: the parallel-traffic respawn rule runs behind the solve)
         nfev = self._buffer("rk_nfev", (self.W,), np.int32)
         check(_lib.load().cs_update_humans_rk45(C.byref(d), C.c_float(dt), C.c_void_p(mem.ptr), C.c_void_p(nfev.ptr),
                                                 C.c_void_p(self.stream)))
+        return nfev.download(self.stream)
+
+    def complete_rk45_simulation(self, dt: float, final_time: float, n_eval: int, desired_force=None):
+        """MotionModelManager.complete_rk45_simulation(t, dt, final_time) (motion_model_manager.py:461-498) of every world: ONE
+        adaptive RK45 solve over final_time, the solution at the ``n_eval`` times k * dt from the solver's dense output.
+        Returns (human_states [W, n_eval, n, 6 | 4], nfev [W]); the rows are left at the final state."""
+        if self.type > 8:
+            raise ValueError(f"Type {self.type} does not exist for this implementation")
+        mem = getattr(self, "d_rk_memory", None)
+        if mem is None:
+            mem = self.d_rk_memory = DeviceBuffer.from_numpy(np.zeros((self.W, self.n, 2), np.float32))
+        if desired_force is not None:
+            mem.upload(np.ascontiguousarray(np.broadcast_to(np.asarray(desired_force, dtype=np.float32), (self.W, self.n, 2))), self.stream)
+        d = self.descriptor(respawn=False)
+        ns = 6 if self.type >= 3 else 4
+        out = self._buffer("rk_dense", (self.W, int(n_eval), self.n, ns))
+        nfev = self._buffer("rk_nfev", (self.W,), np.int32)
+        check(_lib.load().cs_complete_rk45_simulation(C.byref(d), C.c_float(dt), C.c_float(final_time), C.c_void_p(mem.ptr), C.c_void_p(out.ptr),
+                                                      C.c_int(int(n_eval)), C.c_void_p(nfev.ptr), C.c_void_p(self.stream)))
+        return out.download(self.stream), nfev.download(self.stream)
+
+    def robot_model_rk45(self, dt: float) -> np.ndarray:
+        """update_robot(t, dt) of a robot whose SFM / HSFM model is integrated with RK45 (motion_model_manager.py:631-640), every world,
+        in place on the robot rows.  Returns the number of right-hand-side evaluations [W]."""
+        if getattr(self, "robot_model", None) is None:
+            raise ValueError("no robot motion model set")
+        d = self.descriptor()
+        pr = (C.c_float * 20)(*[float(x) for x in self.robot_params])
+        nfev = self._buffer("robot_rk_nfev", (self.W,), np.int32)
+        check(_lib.load().cs_robot_model_rk45(C.byref(d), C.c_int(self.robot_model), pr, C.c_float(self.robot_margin),
+                                              C.c_void_p(_ptr(self.d_human_margin)), C.c_void_p(_ptr(self.d_robot_memory)), C.c_float(dt),
+                                              C.c_void_p(nfev.ptr), C.c_void_p(self.stream)))
         return nfev.download(self.stream)
 
     # ------------------------------------------------------------------ the robot under a human motion model

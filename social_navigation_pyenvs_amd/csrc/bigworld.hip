@@ -408,7 +408,8 @@ __global__ void k_bw_robot(const GArgs a, float* S)
 // x_c = max(x_{c-1} + 2 max_r, bound) because x_{c-1} is then the rightmost human (the rule of the crowd kernels, sfmstep_kernel.h /
 // orca.hip).  orca = 0: SFM / HSFM rows (max_r over radius + safety space; the reference also writes the goal into state columns
 // 6:8, :421); orca = 1: RVO2 agents (max_r over the plain radii -- safety_space is 0 for ORCA humans, :154-158 --, the goal goes to
-// the state's goal columns, the preferred velocity of the step stays).
+// the state's goal columns, the preferred velocity of the step stays); orca = 2: the reference's NON-parallel path (agent objects, what
+// its RK45 integration runs on: radius + safety space, position and goal list only -- the column 6:8 write is `if self.parallel`).
 struct RespawnArgs { int W, n, rows, G, orca; float* S; long as, fs; float* goals; const float* extra; float bx, by; const int* world_flags; };
 
 __global__ __launch_bounds__(256) void k_bw_respawn(const RespawnArgs a)
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256) void k_bw_respawn(const RespawnArgs a)
     for (int i = t; i < rows; i += 256) {          // consider_robot: the robot row takes part in both maxima
         const float* s = Sw + (long)i * a.as;
         mx = fmaxf(mx, s[0]);
-        mr = fmaxf(mr, a.orca ? s[8 * fs] : s[8 * fs] + a.extra[(long)w * rows + i]);
+        mr = fmaxf(mr, a.orca == 1 ? s[8 * fs] : s[8 * fs] + a.extra[(long)w * rows + i]);
     }
     red[0][t] = mx; red[1][t] = mr;
     if (t == 0) carry_s = 0;

@@ -22,6 +22,7 @@
 
 #include "common.h"
 #include "crowdstep.h"
+#include "robot_model.h"
 
 namespace {
 
@@ -37,6 +38,11 @@ struct KArgsRk {
     const float* obstacles;
     float* memory;   // [W][n][2]
     int* nfev;       // [W] or null
+    // complete_rk45_simulation (motion_model_manager.py:461-498): ONE solve over [0, t_final] with the solution at the n_eval times
+    // k * eval_dt through scipy's dense output; dense [W][n_eval][n][4 | 6] (raw solution components), null for update_humans
+    float t_final, eval_dt;
+    int n_eval;
+    float* dense;
 };
 
 constexpr float PI_F = 3.14159265358979323846f;
@@ -90,6 +96,125 @@ __device__ __forceinline__ void pair_force(int kind, const float* P, float p1x, 
         fx = fn * nx + ft * tx;
         fy = fn * ny + ft * ty;
     }
+}
+
+// ---- scipy's explicit Dormand-Prince pair with its step-size control, shared by the crowd's and the robot's solve --------------
+// (scipy/integrate/_ivp/rk.py RK45 + common.py select_initial_step, version 1.15.3: rtol 1e-3, atol 1e-6, SAFETY 0.9, factors
+// 0.2 .. 10).  rhs(y_trial, out): the right-hand side (it does not depend on t); rms(v, scale): the RMS norm over the whole solve's
+// state vector, identical in every lane; on_accept(t_old, t_new, h, y_old, K): called for every accepted step before K[0] takes
+// f(t_new, y_new) -- the dense output of complete_rk45_simulation hangs there.  On return y = y(T).
+template <int NS, class Rhs, class Rms, class OnAccept>
+__device__ __forceinline__ void rk45_solve(float (&y)[NS], float T, Rhs&& rhs, Rms&& rms, OnAccept&& on_accept)
+{
+    const float rtol = 1e-3f, atol = 1e-6f;
+    float K[7][NS];
+    rhs(y, K[0]);
+    // ---- select_initial_step (common.py)
+    float h_abs;
+    {
+        float sc[NS], df[NS], y1[NS], f1[NS];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) sc[c] = atol + fabsf(y[c]) * rtol;
+        const float d0 = rms(y, sc), d1 = rms(K[0], sc);
+        float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
+        h0 = fminf(h0, T);
+#pragma unroll
+        for (int c = 0; c < NS; ++c) y1[c] = y[c] + h0 * K[0][c];
+        rhs(y1, f1);
+#pragma unroll
+        for (int c = 0; c < NS; ++c) df[c] = f1[c] - K[0][c];
+        const float d2 = rms(df, sc) / h0;
+        float h1;
+        if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
+        else h1 = powf(0.01f / fmaxf(d1, d2), 0.2f);
+        h_abs = fminf(fminf(100.0f * h0, h1), T);
+    }
+    // ---- RK45 steps until t_bound (rk.py RungeKutta._step_impl); Dormand-Prince tableau
+    constexpr float A10 = 1.0f / 5;
+    constexpr float A20 = 3.0f / 40, A21 = 9.0f / 40;
+    constexpr float A30 = 44.0f / 45, A31 = -56.0f / 15, A32 = 32.0f / 9;
+    constexpr float A40 = 19372.0f / 6561, A41 = -25360.0f / 2187, A42 = 64448.0f / 6561, A43 = -212.0f / 729;
+    constexpr float A50 = 9017.0f / 3168, A51 = -355.0f / 33, A52 = 46732.0f / 5247, A53 = 49.0f / 176, A54 = -5103.0f / 18656;
+    constexpr float B0 = 35.0f / 384, B2 = 500.0f / 1113, B3 = 125.0f / 192, B4 = -2187.0f / 6784, B5 = 11.0f / 84;
+    constexpr float E0 = -71.0f / 57600, E2 = 71.0f / 16695, E3 = -71.0f / 1920, E4 = 17253.0f / 339200, E5 = -22.0f / 525, E6 = 1.0f / 40;
+    float t = 0.0f;
+    int guard = 0;
+    while (t < T && guard < 100000) {
+        ++guard;
+        const float min_step = 10.0f * (nextafterf(t, INFINITY) - t);
+        if (h_abs < min_step) h_abs = min_step;
+        bool rejected = false;
+        for (;;) {
+            float h = h_abs;
+            float t_new = t + h;
+            if (t_new - T > 0.0f) t_new = T;
+            h = t_new - t;
+            h_abs = fabsf(h);
+            float yt[NS], ynew[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A10 * K[0][c]);
+            rhs(yt, K[1]);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A20 * K[0][c] + A21 * K[1][c]);
+            rhs(yt, K[2]);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A30 * K[0][c] + A31 * K[1][c] + A32 * K[2][c]);
+            rhs(yt, K[3]);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A40 * K[0][c] + A41 * K[1][c] + A42 * K[2][c] + A43 * K[3][c]);
+            rhs(yt, K[4]);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A50 * K[0][c] + A51 * K[1][c] + A52 * K[2][c] + A53 * K[3][c] + A54 * K[4][c]);
+            rhs(yt, K[5]);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) ynew[c] = y[c] + h * (B0 * K[0][c] + B2 * K[2][c] + B3 * K[3][c] + B4 * K[4][c] + B5 * K[5][c]);
+            rhs(ynew, K[6]);
+            float err[NS], sc[NS];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                sc[c] = atol + fmaxf(fabsf(y[c]), fabsf(ynew[c])) * rtol;
+                err[c] = (E0 * K[0][c] + E2 * K[2][c] + E3 * K[3][c] + E4 * K[4][c] + E5 * K[5][c] + E6 * K[6][c]) * h;
+            }
+            const float error_norm = rms(err, sc);
+            if (error_norm < 1.0f) {
+                float factor = (error_norm == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * powf(error_norm, -0.2f));
+                if (rejected) factor = fminf(1.0f, factor);
+                h_abs *= factor;
+                on_accept(t, t_new, h, y, K);
+                t = t_new;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) { y[c] = ynew[c]; K[0][c] = K[6][c]; }
+                break;
+            }
+            h_abs *= fmaxf(0.2f, 0.9f * powf(error_norm, -0.2f));
+            rejected = true;
+            if (h_abs < min_step || !(error_norm == error_norm)) { t = T; break; }   // TOO_SMALL_STEP / NaN: give up like a failed solve
+        }
+    }
+}
+
+// scipy's RkDenseOutput for RK45 (rk.py: Q = K^T P, y(t) = y_old + h Q [x, x^2, x^3, x^4], x = (t - t_old) / h): component c at x
+template <int NS>
+__device__ __forceinline__ float rk45_dense(const float (&K)[7][NS], int c, float y_old, float h, float x)
+{
+    constexpr float P[7][4] = {
+        {1.0f, (float)(-8048581381.0 / 2820520608.0), (float)(8663915743.0 / 2820520608.0), (float)(-12715105075.0 / 11282082432.0)},
+        {0.0f, 0.0f, 0.0f, 0.0f},
+        {0.0f, (float)(131558114200.0 / 32700410799.0), (float)(-68118460800.0 / 10900136933.0), (float)(87487479700.0 / 32700410799.0)},
+        {0.0f, (float)(-1754552775.0 / 470086768.0), (float)(14199869525.0 / 1410260304.0), (float)(-10690763975.0 / 1880347072.0)},
+        {0.0f, (float)(127303824393.0 / 49829197408.0), (float)(-318862633887.0 / 49829197408.0), (float)(701980252875.0 / 199316789632.0)},
+        {0.0f, (float)(-282668133.0 / 205662961.0), (float)(2019193451.0 / 616988883.0), (float)(-1453857185.0 / 822651844.0)},
+        {0.0f, (float)(40617522.0 / 29380423.0), (float)(-110615467.0 / 29380423.0), (float)(69997945.0 / 29380423.0)}};
+    float q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int st = 0; st < 7; ++st) s += K[st][c] * P[st][j];
+        q[j] = s;
+    }
+    const float x2 = x * x;
+    return y_old + h * (q[0] * x + q[1] * x2 + q[2] * (x2 * x) + q[3] * (x2 * x2));
 }
 
 template <bool HEADED>
@@ -240,7 +365,6 @@ __global__ __launch_bounds__(64) void k_rk45_step(const KArgsRk a)
         }
     };
 
-    const float rtol = 1e-3f, atol = 1e-6f;
     const float invN = 1.0f / (float)(n * NS);
     auto rms = [&](const float (&v)[NS], const float (&sc)[NS]) {
         float s = 0.0f;
@@ -250,92 +374,23 @@ __global__ __launch_bounds__(64) void k_rk45_step(const KArgsRk a)
         }
         return sqrtf(wave_sum(s) * invN);
     };
-
-    float K[7][NS];
-    rhs(y, K[0]);
-    // ---- select_initial_step (common.py)
-    float h_abs;
-    {
-        float sc[NS], df[NS], y1[NS], f1[NS];
+    // update_humans: one solve over dt.  complete_rk45_simulation: one solve over t_final, the solution at the times k * eval_dt
+    // taken from the dense output of the step that contains them (solve_ivp(..., t_eval=...): a time equal to a step's end belongs
+    // to that step, t_eval[0] = t0 to the first one)
+    const float T = a.dense != nullptr ? a.t_final : a.dt;
+    int ke = 0;
+    rk45_solve<NS>(y, T, rhs, rms, [&](float t_old, float t_new, float h, const float (&y_old)[NS], const float (&K)[7][NS]) {
+        if (a.dense == nullptr) return;
+        while (ke < a.n_eval && (float)ke * a.eval_dt <= t_new) {
+            const float x = ((float)ke * a.eval_dt - t_old) / h;
+            if (human) {
+                float* o = a.dense + (((long)w * a.n_eval + ke) * n + lane) * NS;
 #pragma unroll
-        for (int c = 0; c < NS; ++c) sc[c] = atol + fabsf(y[c]) * rtol;
-        const float d0 = rms(y, sc), d1 = rms(K[0], sc);
-        float h0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6f : 0.01f * d0 / d1;
-        h0 = fminf(h0, a.dt);
-#pragma unroll
-        for (int c = 0; c < NS; ++c) y1[c] = y[c] + h0 * K[0][c];
-        rhs(y1, f1);
-#pragma unroll
-        for (int c = 0; c < NS; ++c) df[c] = f1[c] - K[0][c];
-        const float d2 = rms(df, sc) / h0;
-        float h1;
-        if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
-        else h1 = powf(0.01f / fmaxf(d1, d2), 0.2f);
-        h_abs = fminf(fminf(100.0f * h0, h1), a.dt);
-    }
-    // ---- RK45 steps until t_bound (rk.py RungeKutta._step_impl); Dormand-Prince tableau
-    constexpr float C1 = 1.0f / 5, C2 = 3.0f / 10, C3 = 4.0f / 5, C4 = 8.0f / 9;
-    constexpr float A10 = 1.0f / 5;
-    constexpr float A20 = 3.0f / 40, A21 = 9.0f / 40;
-    constexpr float A30 = 44.0f / 45, A31 = -56.0f / 15, A32 = 32.0f / 9;
-    constexpr float A40 = 19372.0f / 6561, A41 = -25360.0f / 2187, A42 = 64448.0f / 6561, A43 = -212.0f / 729;
-    constexpr float A50 = 9017.0f / 3168, A51 = -355.0f / 33, A52 = 46732.0f / 5247, A53 = 49.0f / 176, A54 = -5103.0f / 18656;
-    constexpr float B0 = 35.0f / 384, B2 = 500.0f / 1113, B3 = 125.0f / 192, B4 = -2187.0f / 6784, B5 = 11.0f / 84;
-    constexpr float E0 = -71.0f / 57600, E2 = 71.0f / 16695, E3 = -71.0f / 1920, E4 = 17253.0f / 339200, E5 = -22.0f / 525, E6 = 1.0f / 40;
-    (void)C1; (void)C2; (void)C3; (void)C4;   // the right-hand side does not depend on t
-    float t = 0.0f;
-    int guard = 0;
-    while (t < a.dt && guard < 100000) {
-        ++guard;
-        const float min_step = 10.0f * (nextafterf(t, INFINITY) - t);
-        if (h_abs < min_step) h_abs = min_step;
-        bool rejected = false;
-        for (;;) {
-            float h = h_abs;
-            float t_new = t + h;
-            if (t_new - a.dt > 0.0f) t_new = a.dt;
-            h = t_new - t;
-            h_abs = fabsf(h);
-            float yt[NS], ynew[NS];
-#pragma unroll
-            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A10 * K[0][c]);
-            rhs(yt, K[1]);
-#pragma unroll
-            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A20 * K[0][c] + A21 * K[1][c]);
-            rhs(yt, K[2]);
-#pragma unroll
-            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A30 * K[0][c] + A31 * K[1][c] + A32 * K[2][c]);
-            rhs(yt, K[3]);
-#pragma unroll
-            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A40 * K[0][c] + A41 * K[1][c] + A42 * K[2][c] + A43 * K[3][c]);
-            rhs(yt, K[4]);
-#pragma unroll
-            for (int c = 0; c < NS; ++c) yt[c] = y[c] + h * (A50 * K[0][c] + A51 * K[1][c] + A52 * K[2][c] + A53 * K[3][c] + A54 * K[4][c]);
-            rhs(yt, K[5]);
-#pragma unroll
-            for (int c = 0; c < NS; ++c) ynew[c] = y[c] + h * (B0 * K[0][c] + B2 * K[2][c] + B3 * K[3][c] + B4 * K[4][c] + B5 * K[5][c]);
-            rhs(ynew, K[6]);
-            float err[NS], sc[NS];
-#pragma unroll
-            for (int c = 0; c < NS; ++c) {
-                sc[c] = atol + fmaxf(fabsf(y[c]), fabsf(ynew[c])) * rtol;
-                err[c] = (E0 * K[0][c] + E2 * K[2][c] + E3 * K[3][c] + E4 * K[4][c] + E5 * K[5][c] + E6 * K[6][c]) * h;
+                for (int c = 0; c < NS; ++c) o[c] = rk45_dense<NS>(K, c, y_old[c], h, x);
             }
-            const float error_norm = rms(err, sc);
-            if (error_norm < 1.0f) {
-                float factor = (error_norm == 0.0f) ? 10.0f : fminf(10.0f, 0.9f * powf(error_norm, -0.2f));
-                if (rejected) factor = fminf(1.0f, factor);
-                h_abs *= factor;
-                t = t_new;
-#pragma unroll
-                for (int c = 0; c < NS; ++c) { y[c] = ynew[c]; K[0][c] = K[6][c]; }
-                break;
-            }
-            h_abs *= fmaxf(0.2f, 0.9f * powf(error_norm, -0.2f));
-            rejected = true;
-            if (h_abs < min_step || !(error_norm == error_norm)) { t = a.dt; break; }   // TOO_SMALL_STEP / NaN: give up like a failed solve
+            ++ke;
         }
-    }
+    });
     // ---- set_new_*_state_from_rk45_solution(y[:, -1]) (+ the linear velocity of headed agents), :377-384
     if (human) {
         px = y[0]; py = y[1];
@@ -361,11 +416,104 @@ __global__ __launch_bounds__(64) void k_rk45_step(const KArgsRk a)
     if (a.nfev != nullptr && lane == 0) a.nfev[w] = nfev;
 }
 
-} // namespace
+// ---- the ROBOT under RK45 (motion_model_manager.py:631-640, 661-687): solve_ivp around f_rk45_robot_* -- the trial state written
+// into the robot (:88-103), compute_robot_forces (:591-613: the single-agent force functions of robot_model.h, humans fixed for the
+// whole solve), ydot = [v, F / m] or [R bv, omega, F_body / m, torque / I].  One wavefront per world: lane j hands in human j's
+// term of the social force, every lane carries the robot's state and takes the same decisions.
+struct KArgsRobotRk {
+    int W, n, rows, O, Smax, type, write_row, obstacles_shared;
+    float dt, robot_margin;
+    float P[20];
+    float* S; long as, fs;
+    const float* hmargin;
+    float* robot;
+    float* memory;
+    const float* obstacles;
+    int* nfev;
+};
 
-extern "C" {
+template <bool HEADED>
+__global__ __launch_bounds__(64) void k_robot_rk45(const KArgsRobotRk a)
+{
+    constexpr int NS = HEADED ? 6 : 4;
+    __shared__ float2 s_term[64];
+    const int w = blockIdx.x, lane = threadIdx.x;
+    float* rb = a.robot + (long)w * 13;
+    rmodel::RState r;
+    r.px = rb[0]; r.py = rb[1]; r.yaw = rb[2]; r.vx = rb[3]; r.vy = rb[4]; r.bvx = rb[5]; r.bvy = rb[6]; r.om = rb[7];
+    r.radius = rb[8]; r.mass = rb[9]; r.gx = rb[10]; r.gy = rb[11]; r.vd = rb[12];
+    float* mem = a.memory + (long)w * 2;
+    r.fdx = mem[0]; r.fdy = mem[1];
+    const int soc = a.type % 3;
+    const float rme = r.radius + a.robot_margin;
+    // the humans stand still during the robot's solve: one human per lane (rows <= 64)
+    float hx = 0.0f, hy = 0.0f, hvx = 0.0f, hvy = 0.0f, hrij = 0.0f;
+    if (lane < a.n) {
+        const float* s = a.S + ((long)w * a.rows + lane) * a.as;
+        hx = s[0]; hy = s[a.fs]; hvx = s[3 * a.fs]; hvy = s[4 * a.fs];
+        hrij = rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + lane];
+    }
+    const float* ob = a.O > 0 ? a.obstacles + (a.obstacles_shared ? 0 : (long)w * a.O * a.Smax * 4) : nullptr;
+    int nfev = 0;
+    float y[NS];
+    if (HEADED) { y[0] = r.px; y[1] = r.py; y[2] = r.yaw; y[3] = r.bvx; y[4] = r.bvy; y[5] = r.om; }
+    else { y[0] = r.px; y[1] = r.py; y[2] = r.vx; y[3] = r.vy; }
 
-int cs_update_humans_rk45(const cs_worlds* w, float dt, float* d_memory, int32_t* d_nfev, void* stream)
+    auto set_state = [&](const float (&yt)[NS]) {   // set_new_*_state_from_rk45_solution(robot, y), :88-103
+        r.px = yt[0]; r.py = yt[1];
+        if (HEADED) {
+            r.yaw = rmodel::bound_angle(yt[2]);
+            r.bvx = yt[3]; r.bvy = yt[4];
+            const float sp = sqrtf(r.bvx * r.bvx + r.bvy * r.bvy);
+            if (sp > r.vd) { r.bvx = r.bvx / sp * r.vd; r.bvy = r.bvy / sp * r.vd; }
+            r.om = yt[5];
+        } else {
+            r.vx = yt[2]; r.vy = yt[3];
+            const float sp = sqrtf(r.vx * r.vx + r.vy * r.vy);
+            if (sp > r.vd) { r.vx = r.vx / sp * r.vd; r.vy = r.vy / sp * r.vd; }
+        }
+    };
+    auto rhs = [&](const float (&yt)[NS], float (&out)[NS]) {
+        ++nfev;
+        set_state(yt);
+        float sn, cs;
+        rmodel::refresh_velocity(r, HEADED, sn, cs);
+        float tx = 0.0f, ty = 0.0f;
+        if (lane < a.n) rmodel::pair_term(soc, a.P, r.px, r.py, r.vx, r.vy, hx, hy, hvx, hvy, hrij, tx, ty);
+        asm volatile("" ::: "memory");
+        s_term[lane] = make_float2(tx, ty);
+        asm volatile("" ::: "memory");
+        float fsx = 0.0f, fsy = 0.0f;
+        for (int j = 0; j < a.n; ++j) { const float2 t = s_term[j]; fsx += t.x; fsy += t.y; }
+        float fox, foy;
+        rmodel::obstacle_force(ob, a.O, a.Smax, soc, a.P, r.px, r.py, r.vx, r.vy, rme, fox, foy);
+        rmodel::derivative(r, a.type, a.P, fsx, fsy, fox, foy, sn, cs, out);
+    };
+    const float invN = 1.0f / (float)NS;
+    auto rms = [&](const float (&v)[NS], const float (&sc)[NS]) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) { const float q = v[c] / sc[c]; s += q * q; }
+        return sqrtf(s * invN);
+    };
+    rk45_solve<NS>(y, a.dt, rhs, rms, [](float, float, float, const float (&)[NS], const float (&)[7][NS]) {});
+    set_state(y);
+    if (HEADED) {   // headed_agent_update_linear_velocity(robot) after the solve (:640)
+        float sn, cs;
+        rmodel::refresh_velocity(r, true, sn, cs);
+    }
+    if (lane != 0) return;
+    rb[0] = r.px; rb[1] = r.py; rb[2] = r.yaw; rb[3] = r.vx; rb[4] = r.vy; rb[5] = r.bvx; rb[6] = r.bvy; rb[7] = r.om;
+    mem[0] = r.fdx; mem[1] = r.fdy;
+    if (a.write_row) {
+        float* s = a.S + ((long)w * a.rows + a.n) * a.as;
+        const long fs = a.fs;
+        s[0] = r.px; s[fs] = r.py; s[2 * fs] = r.yaw; s[3 * fs] = r.vx; s[4 * fs] = r.vy; s[5 * fs] = r.bvx; s[6 * fs] = r.bvy; s[7 * fs] = r.om;
+    }
+    if (a.nfev != nullptr) a.nfev[w] = nfev;
+}
+
+int rk45_launch(const cs_worlds* w, float dt, float t_final, float eval_dt, int n_eval, float* d_memory, float* d_dense, int32_t* d_nfev, void* stream)
 {
     if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
     if (w->type < 0 || w->type > 8) return fail(CS_ERR_TYPE, "Type " + std::to_string(w->type) + " does not exist for this implementation");
@@ -383,8 +531,58 @@ int cs_update_humans_rk45(const cs_worlds* w, float dt, float* d_memory, int32_t
     if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * rows; }
     a.goals = w->d_goals; a.params = w->d_params; a.safety = w->d_safety; a.obstacles = w->d_obstacles;
     a.memory = d_memory; a.nfev = d_nfev;
+    a.t_final = t_final; a.eval_dt = eval_dt; a.n_eval = n_eval; a.dense = d_dense;
     if (w->type >= CS_HSFM_FARINA) hipLaunchKernelGGL(k_rk45_step<true>, dim3(w->W), dim3(64), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_rk45_step<false>, dim3(w->W), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    // post_update of update_humans: the parallel-traffic respawn rule on the agents (motion_model_manager.py:407-422, non-parallel path)
+    if (d_dense == nullptr && (w->flags & CS_RESPAWN))
+        csimpl::big_respawn_launch(w->d_state, a.as, a.fs, w->W, w->n, rows, w->d_goals, w->G, w->d_safety, 2, w->respawn_bound_x, w->respawn_bound_y,
+                                   w->d_world_flags, (hipStream_t)stream);
+    return CS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int cs_update_humans_rk45(const cs_worlds* w, float dt, float* d_memory, int32_t* d_nfev, void* stream)
+{
+    return rk45_launch(w, dt, 0.0f, 0.0f, 0, d_memory, nullptr, d_nfev, stream);
+}
+
+int cs_complete_rk45_simulation(const cs_worlds* w, float dt, float final_time, float* d_memory, float* d_human_states, int n_eval,
+                                int32_t* d_nfev, void* stream)
+{
+    if (!d_human_states || n_eval <= 0) return fail(CS_ERR_ARG, "complete_rk45_simulation needs the output array and its number of evaluation times");
+    if (!(final_time > 0.0f)) return fail(CS_ERR_ARG, "final_time must be positive");
+    return rk45_launch(w, dt, final_time, dt, n_eval, d_memory, d_human_states, d_nfev, stream);
+}
+
+int cs_robot_model_rk45(const cs_worlds* w, int32_t robot_type, const float* robot_params, float robot_margin, const float* d_human_margin,
+                        float* d_robot_memory, float dt, int32_t* d_nfev, void* stream)
+{
+    if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
+    if (w->W <= 0 || w->n <= 0 || !w->d_state || !w->d_robot) return fail(CS_ERR_ARG, "bad cs_worlds (a robot needs d_robot)");
+    if (w->layout != CS_LAYOUT_AOS && w->layout != CS_LAYOUT_SOA) return fail(CS_ERR_ARG, "bad layout");
+    const float* hm = d_human_margin ? d_human_margin : w->d_safety;
+    if (!hm || !robot_params || !d_robot_memory) return fail(CS_ERR_ARG, "null argument");
+    if (robot_type < 0 || robot_type > 8) return fail(CS_ERR_TYPE, "Runge-Kutta integration of the robot takes one of the nine SFM / HSFM models");
+    if (w->O < 0 || (w->O > 0 && (!w->d_obstacles || w->Smax <= 0))) return fail(CS_ERR_ARG, "bad obstacle description");
+    if (!(dt > 0.0f)) return fail(CS_ERR_ARG, "dt must be positive");
+    if (w->n > 64) return fail(CS_ERR_ARG, "the robot's RK45 step supports up to 64 humans per world");
+    KArgsRobotRk a;
+    std::memset(&a, 0, sizeof(a));
+    a.W = w->W; a.n = w->n; a.rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    a.write_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0;
+    a.O = w->O; a.Smax = w->Smax; a.type = robot_type; a.obstacles_shared = (w->flags & CS_OBSTACLES_SHARED) ? 1 : 0;
+    a.dt = dt; a.robot_margin = robot_margin;
+    std::memcpy(a.P, robot_params, sizeof(a.P));
+    a.S = w->d_state;
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)w->W * a.rows; }
+    a.hmargin = hm; a.robot = w->d_robot; a.memory = d_robot_memory; a.obstacles = w->d_obstacles; a.nfev = d_nfev;
+    if (robot_type >= CS_HSFM_FARINA) hipLaunchKernelGGL(k_robot_rk45<true>, dim3(w->W), dim3(64), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_robot_rk45<false>, dim3(w->W), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

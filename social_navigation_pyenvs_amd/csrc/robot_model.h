@@ -84,6 +84,78 @@ __device__ __forceinline__ void refresh_velocity(RState& r, bool headed, float& 
     if (headed) { r.vx = cs * r.bvx - sn * r.bvy; r.vy = sn * r.bvx + cs * r.bvy; }
 }
 
+// obstacle force of the single-agent functions (forces.py:27-53): one closest point per polygon (the LAST nearest segment point,
+// `<=`, obstacle.py:53-66), Helbing averaged over the polygons, Guo a plain sum.  ob: [O][Smax][2][2] NaN-padded, or null.
+__device__ __forceinline__ void obstacle_force(const float* ob, int O, int Smax, int soc, const float* P, float px, float py, float vx, float vy,
+                                               float rme, float& fox, float& foy)
+{
+#pragma clang fp contract(off)
+    fox = 0.0f; foy = 0.0f;
+    if (ob == nullptr || O <= 0) return;
+    for (int o = 0; o < O; ++o) {
+        float bx = 0.0f, by = 0.0f, bd = 10000.0f;
+        for (int sg = 0; sg < Smax; ++sg) {
+            const float* q = ob + ((long)o * Smax + sg) * 4;
+            const float ax = q[0], ay = q[1], ex = q[2], ey = q[3];
+            if (isnan(ax) || isnan(ay) || isnan(ex) || isnan(ey)) continue;
+            const float sx = ex - ax, sy = ey - ay;
+            const float len = sqrtf(sx * sx + sy * sy);
+            float t = ((px - ax) * sx + (py - ay) * sy) / (len * len);
+            t = fminf(fmaxf(0.0f, t), 1.0f);
+            const float hx = ax + t * sx, hy = ay + t * sy;
+            const float d = sqrtf((hx - px) * (hx - px) + (hy - py) * (hy - py));
+            if (d <= bd) { bx = hx; by = hy; bd = d; }
+        }
+        const float dx = px - bx, dy = py - by;
+        const float dn = sqrtf(dx * dx + dy * dy);
+        const float nx = dx / dn, ny = dy / dn, tx = -ny, ty = nx;
+        const float dv = -(vx * tx + vy * ty);
+        const float rd = rme - dn;
+        const float comp = fmaxf(0.0f, rd);
+        const float fn = P[2] * expf(rd / P[4]) + P[10] * comp;
+        float ft;
+        if (soc == 1) ft = (-P[6] * expf(rd / P[8]) - P[11] * comp) * dv;
+        else ft = -P[11] * comp * dv;
+        fox += fn * nx + ft * tx;
+        foy += fn * ny + ft * ty;
+    }
+    if (soc != 1) { fox /= (float)O; foy /= (float)O; }   // Guo's single-agent obstacle force is not averaged
+}
+
+// the right-hand side of the robot's RK45 solve (motion_model_manager.py:661-687) from the forces of compute_robot_forces: the
+// desired force (kept within one radius of the goal), then ydot = [v, F / m] or [R bv, omega, F_body / m, torque / I]
+template <int NS>
+__device__ __forceinline__ void derivative(RState& r, int type, const float* P, float fsx, float fsy, float fox, float foy, float sn, float cs,
+                                           float (&out)[NS])
+{
+#pragma clang fp contract(off)
+    const bool torque_new = type >= 6;
+    {
+        const float ddx = r.gx - r.px, ddy = r.gy - r.py;
+        const float dist = sqrtf(ddx * ddx + ddy * ddy);
+        if (dist > r.radius) {
+            r.fdx = r.mass * (ddx / dist * r.vd - r.vx) / P[0];
+            r.fdy = r.mass * (ddy / dist * r.vd - r.vy) / P[0];
+        }
+    }
+    const float fdx = r.fdx, fdy = r.fdy;
+    if constexpr (NS == 4) {
+        out[0] = r.vx; out[1] = r.vy;
+        out[2] = (fdx + fox + fsx) / r.mass; out[3] = (fdy + foy + fsy) / r.mass;
+    } else {
+        const float inertia = 0.5f * r.mass * r.radius * r.radius;
+        const float tx = torque_new ? fdx + fox + fsx : fdx, ty = torque_new ? fdy + foy + fsy : fdy;
+        const float tn = sqrtf(tx * tx + ty * ty);
+        const float k_theta = inertia * P[19] * tn;
+        const float k_omega = inertia * (1.0f + P[18]) * sqrtf(P[19] * tn / P[18]);
+        const float torque = -k_theta * bound_angle(r.yaw - atan2f(ty, tx)) - k_omega * r.om;
+        const float g0 = (fdx + fox + fsx) * cs + (fdy + foy + fsy) * sn;
+        const float g1 = P[16] * ((fox + fsx) * -sn + (foy + fsy) * cs) - P[17] * r.bvy;
+        out[0] = cs * r.bvx - sn * r.bvy; out[1] = sn * r.bvx + cs * r.bvy; out[2] = r.om;
+        out[3] = g0 / r.mass; out[4] = g1 / r.mass; out[5] = torque / inertia;
+    }
+}
+
 // desired force (forces.py:9-16; within one radius of the goal the previous one is kept), total force, torque (forces.py:279-290)
 // and the Euler update (motion_model_manager.py:72-86: position first, then velocity, speed clamp; headed: yaw, body velocity,
 // angular velocity, linear velocity from the NEW yaw).  (fsx, fsy): the summed social force; (fox, foy): the obstacle force.

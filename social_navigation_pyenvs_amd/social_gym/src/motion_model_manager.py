@@ -241,9 +241,7 @@ class MotionModelManager:
         """One substep of every human (:354-422): Euler SFM / HSFM, or ORCA; parallel-traffic respawn when
         ``post_update``."""
         if self.runge_kutta and not (self.orca or self.sm):   # RK45 of the SFM / HSFM crowd (:374-384); ORCA is Euler only
-            if post_update and self.parallel_traffic_humans_respawn:
-                raise NotImplementedError("RK45 integration with the parallel-traffic respawn rule is not built")
-            cw = self._device(respawn=False)
+            cw = self._device(respawn=bool(post_update and self.parallel_traffic_humans_respawn))   # respawn behind the solve (:405-422)
             if not hasattr(self, "_desired_force"):   # agent.desired_force of the single-agent force functions (forces.py:12-16)
                 self._desired_force = np.zeros((len(self.humans), 2), dtype=PRECISION)
             self.rk45_nfev = int(cw.update_humans_rk45(dt, desired_force=self._desired_force[None])[0])
@@ -259,6 +257,24 @@ class MotionModelManager:
             n = len(self.humans)
             self.states[n, 0:2] = self.robot.position
             self.states[n, 3:5] = self.robot.linear_velocity
+
+    def complete_rk45_simulation(self, t: float, dt: float, final_time: float):
+        """ONE adaptive RK45 solve over (t, t + final_time) with the solution sampled at np.arange(t, final_time, dt) through the
+        solver's dense output (:461-498) -> human_states [len(times), n, 6 | 4] (x, y, yaw, BVx, BVy, Omega | x, y, Vx, Vy).  The humans
+        are left as the last right-hand-side evaluation leaves them (the state at t + final_time), like the reference's."""
+        if not self.runge_kutta or self.orca or self.sm:
+            raise ValueError("complete_rk45_simulation integrates an SFM / HSFM crowd created with runge_kutta=True")
+        times = np.arange(t, final_time, dt, dtype=PRECISION)
+        cw = self._device(respawn=False)
+        if not hasattr(self, "_desired_force"):
+            self._desired_force = np.zeros((len(self.humans), 2), dtype=PRECISION)
+        out, nfev = cw.complete_rk45_simulation(dt, final_time, len(times), desired_force=self._desired_force[None])
+        self.rk45_nfev = int(nfev[0])
+        self._readback(cw)
+        self._desired_force = cw.d_rk_memory.download(cw.stream)[0].astype(PRECISION)
+        for i, h in enumerate(self.humans):
+            h.desired_force = self._desired_force[i]
+        return out[0].astype(PRECISION)
 
     def update_humans_block(self, dt: float, n_substeps: int, action=None, unicycle=False):
         """``n_substeps`` x { robot.step(action, dt) ; update_humans(t, dt) } fused in one launch -- the loop of
@@ -354,14 +370,15 @@ class MotionModelManager:
 
     # ------------------------------------------------------------------ the robot under a human motion model (:552-653)
     def set_robot_motion_model(self, motion_model_title: str, runge_kutta: bool):
-        """The robot follows one of the human motion models ("sfm_helbing" ... "hsfm_new_moussaid", "orca"); Euler only."""
+        """The robot follows one of the human motion models ("sfm_helbing" ... "hsfm_new_moussaid", "orca"); ``runge_kutta``: the
+        SFM / HSFM robot is integrated by scipy's RK45 (cs_robot_model_rk45) instead of Euler (:631-640)."""
         if motion_model_title not in SFMS + ["orca"]:
             if motion_model_title == "sfm_roboticsupo":
                 raise NotImplementedError("sfm_roboticsupo is outside this build (DESIGN.md §9)")
             raise Exception(f"The robot motion model '{motion_model_title}' does not exist")
-        if runge_kutta:
-            raise NotImplementedError("RK45 integration of the ROBOT is not built (the crowd has it: cs_update_humans_rk45)")
-        self.robot_runge_kutta = runge_kutta
+        if runge_kutta and motion_model_title == "orca":
+            raise ValueError("ORCA is Euler only")
+        self.robot_runge_kutta = bool(runge_kutta)
         self.robot_motion_model_title = motion_model_title
         self.robot_orca = motion_model_title == "orca"
         self.robot.orca = self.robot_orca
@@ -407,7 +424,12 @@ class MotionModelManager:
     def update_robot(self, t, dt, just_velocities=False):
         """One substep of the robot under its motion model (:615-653)."""
         cw = self._device_with_robot_model()
-        cw.robot_model_step(dt, just_velocities=just_velocities)
+        if getattr(self, "robot_runge_kutta", False) and not self.robot_orca:
+            if just_velocities:   # the reference's own error (:631)
+                raise ValueError("Runge-kutta integration cannot be used if robot and environment sampling times are different")
+            self.robot_rk45_nfev = int(cw.robot_model_rk45(dt)[0])
+        else:
+            cw.robot_model_step(dt, just_velocities=just_velocities)
         self._readback_robot(cw)
 
     def imitation_block(self, dt: float, n_substeps: int):

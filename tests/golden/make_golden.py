@@ -821,6 +821,107 @@ def gen_g12_rk45():
     print("g12_rk45:", len(cases), "cases ->", save_cases("g12_rk45", cases))
 
 
+def gen_g14_rk45_more():
+    """The rest of the RK45 surface:
+      complete - MotionModelManager.complete_rk45_simulation(0, dt, final_time) (motion_model_manager.py:461-498): one solve with
+                 t_eval, the returned human_states, the humans as the solve leaves them, the number of RHS evaluations;
+      respawn  - update_humans of an RK45 crowd in a parallel-traffic scene with the respawn rule armed (:374-384 + :405-422);
+      robot    - update_robot(t, dt) of a robot whose SFM / HSFM model is integrated with RK45 (:631-640, :661-687), humans standing."""
+    cases = []
+    seed = 0
+
+    def count_rhs(mm, names):
+        counter = {"n": 0}
+        for name in names:
+            orig = getattr(mm, name)
+            def wrapped(tt, y, _o=orig):
+                counter["n"] += 1
+                return _o(tt, y)
+            setattr(mm, name, wrapped)
+        return counter
+
+    # ---- complete_rk45_simulation
+    for t, model in enumerate(SFMS):
+        for n, radius, dt, final in ((4, 2.0, 0.25, 2.0), (8, 2.6, 0.1, 1.5)):
+            seed += 1
+            rng = np.random.default_rng(140_000 + seed)
+            walls = my_walls(rng) if seed % 2 else None
+            cfg = crossing_config(rng, model, n, radius, walls=walls, attrs=bool(seed % 4 == 1))
+            cfg["runge_kutta"] = True
+            sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=False)
+            mm = sim.motion_model_manager
+            counter = count_rhs(mm, ("f_rk45_headed", "f_rk45_not_headed"))
+            for k in range(int(round(0.3 * radius / 0.0125))):     # walk in: distinct velocities, some interaction
+                mm.update_humans(k * 0.0125, 0.0125)
+            r0, g0 = humans_snapshot(mm)
+            counter["n"] = 0
+            hs = mm.complete_rk45_simulation(0.0, dt, final)
+            r1, g1 = humans_snapshot(mm)
+            cases.append(dict(family="complete", model=model, type=t, n=n, dt=dt, final_time=final, all_params_equal=bool(mm.all_equal_humans),
+                              walls=walls_to_array(walls) if walls else np.zeros((0, 1, 2, 2)), rows0=r0, goals0=g0, rows1=r1, goals1=g1,
+                              human_states=np.asarray(hs, dtype=float), nfev=counter["n"],
+                              params=np.array([h.get_parameters(model) for h in mm.humans])))
+    # ---- RK45 + respawn (parallel traffic through the Gym's scenario generator, manager in RK45 mode)
+    for model in ("sfm_helbing", "hsfm_farina", "sfm_guo", "hsfm_new_guo"):
+        for robot_visible in (False, True):
+            seed += 1
+            env, _ = make_env(model, "parallel_traffic", 6, robot_visible)
+            env.reset(phase="test", test_case=20 + seed)
+            mm = env.motion_model_manager
+            mm.runge_kutta = True
+            mm.parallel = False
+            counter = count_rhs(mm, ("f_rk45_headed", "f_rk45_not_headed"))
+            for k in range(8):
+                mm.update_humans(k * DT, DT)
+            for i in (1, 3, 4):          # three humans on the edge of the 3 m zone: they respawn in the next calls, two in one call
+                mm.humans[i].position[0] = mm.humans[i].goals[0][0] + 3.0 + (0.002 if i < 4 else 0.02)
+            rows, goals, nfev = [], [], []
+            r0, g0 = humans_snapshot(mm)
+            rows.append(r0); goals.append(g0)
+            for k in range(6):
+                counter["n"] = 0
+                mm.update_humans((8 + k) * DT, DT)
+                r1, g1 = humans_snapshot(mm)
+                rows.append(r1); goals.append(g1); nfev.append(counter["n"])
+            rb = np.array([*env.robot.position, *env.robot.linear_velocity, env.robot.radius, env.robot.safety_space], dtype=float)
+            cases.append(dict(family="respawn", model=model, type=SFMS.index(model), n=6, dt=DT, robot_visible=robot_visible,
+                              all_params_equal=bool(mm.all_equal_humans), respawn_bounds=[float(x) for x in mm.respawn_bounds],
+                              rows=np.array(rows), goals=np.array(goals), nfev=np.array(nfev), robot=rb,
+                              params=np.array([h.get_parameters(model) for h in mm.humans])))
+            env.parallel_traffic_humans_respawn = False
+    # ---- the robot under RK45
+    human_models = ["sfm_helbing", "hsfm_new_guo", "hsfm_farina", "sfm_moussaid", "sfm_guo"]
+    for rmodel in SFMS:
+        for with_walls in (False, True):
+            seed += 1
+            rng = np.random.default_rng(140_000 + seed)
+            hmodel = human_models[seed % len(human_models)]
+            n = int(rng.integers(3, 9))
+            walls = my_walls(rng) if with_walls else None
+            robot = {"pos": [float(rng.uniform(-1.5, -0.5)), float(rng.uniform(-1, 1))], "yaw": float(rng.uniform(-0.5, 0.5)),
+                     "radius": 0.3, "goals": [[float(rng.uniform(3.5, 4.5)), float(rng.uniform(-1, 1))]]}
+            cfg = crossing_config(rng, hmodel, n, 2.2, walls=walls, robot=robot, robot_visible=False, attrs=bool(seed % 2))
+            sim = ns.sim.SocialNavSim(cfg, scenario="custom_config", parallelize_humans=True)
+            sim.set_human_motion_model_as_robot_policy(rmodel, True)
+            mm = sim.motion_model_manager
+            assert mm.robot_runge_kutta
+            if seed % 3 == 0:
+                mm.set_safety_space(0.07)
+            for k in range(30):              # the crowd walks in (Euler), the robot stands
+                mm.update_humans(k * DT, DT)
+            counter = count_rhs(mm, ("f_rk45_robot_headed", "f_rk45_robot_not_headed"))
+            dt = DT if seed % 2 else 0.25
+            robots, nfev = [robot_row(sim.robot)], []
+            for k in range(12):
+                counter["n"] = 0
+                mm.update_robot(k * dt, dt)
+                robots.append(robot_row(sim.robot)); nfev.append(counter["n"])
+            cases.append(dict(family="robot", robot_model=rmodel, model=hmodel, n=n, dt=dt, walls=walls_to_array(walls) if walls else np.zeros((0, 1, 2, 2)),
+                              mm_states=mm.states.copy(), human_safety=np.array([h.safety_space for h in mm.humans], dtype=float),
+                              robots=np.array(robots), nfev=np.array(nfev), robot_params=sim.robot.get_parameters(rmodel)))
+    print("g14_rk45_more:", len(cases), "cases ->", save_cases("g14_rk45_more", cases))
+
+
 # ----------------------------------------------------------------------------- G13 blocks at the BASELINE.json sizes
 def gen_g13_block_sizes():
     """20-substep blocks (= one Gym step) through MotionModelManager.update_humans at the row counts of the BASELINE.json
@@ -887,7 +988,7 @@ def gen_g13_block_sizes():
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
               g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
-              g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45,
+              g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45, g14_rk45_more=gen_g14_rk45_more,
               g13_block_sizes=gen_g13_block_sizes)
 
 if __name__ == "__main__":

@@ -176,8 +176,10 @@ def test_robot_state_access_and_robot_motion_model_setup():
     np.testing.assert_allclose(env.robot.position, st[0:2])
     with pytest.raises(Exception, match="does not exist"):
         mm.set_robot_motion_model("nonsense", False)
-    with pytest.raises(NotImplementedError):
-        mm.set_robot_motion_model("sfm_helbing", True)            # RK45
+    mm.set_robot_motion_model("sfm_helbing", True)                # RK45 of the robot (cs_robot_model_rk45)
+    assert mm.robot_runge_kutta and not mm.robot_orca
+    with pytest.raises(ValueError):
+        mm.set_robot_motion_model("orca", True)                   # ORCA is Euler only
     env.set_human_motion_model_as_robot_policy("hsfm_new_guo", False)
     assert mm.robot_motion_model_title == "hsfm_new_guo" and env.robot.headed and not env.robot.orca
     assert env.robot.Ci == 120.0 and env.robot.k_lambda == 0.1    # robot.set_parameters(model)

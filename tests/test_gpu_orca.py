@@ -144,11 +144,13 @@ def test_orca_large_world_limits():
     S[0, :, 8] = 0.3
     S[0, :, 12] = 1.0
     g = np.zeros((1, 513, 1, 2), np.float32)
-    # beyond 512 rows a world takes the grid path (test_orca_world_of_4096_agents_through_the_grid); what that path does not build
-    # is refused loudly: static obstacles, a robot row, the respawn rule
+    # beyond 512 rows a world takes the grid path (test_orca_world_of_4096_agents_through_the_grid; respawn rule and peek:
+    # test_orca_grid_path_respawn_and_peek_equal_the_restatement); what that path does not build is refused loudly: a robot row,
+    # static obstacles, maxNeighbors other than 10
     CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca").step(0.0125, 1)
+    CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca", respawn_bounds=(7.0, 1.5)).step(0.0125, 1)
     with pytest.raises(ValueError, match="beyond one block"):
-        CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca", respawn_bounds=(7.0, 1.5)).step(0.0125, 1)
+        CrowdWorlds(S, g[:, :512], None, np.zeros((1, 513), np.float32), None, type="orca", robot_row=True).step(0.0125, 1)
     # the generic variant keeps (K + obstacle lines) x 40 B per agent in the LDS: 300 agents with a square of walls do not fit
     verts = orc.process_obstacles([[[-50, -50], [50, -50], [50, 50], [-50, 50]]])
     with pytest.raises(ValueError, match="LDS"):
