@@ -366,6 +366,9 @@ int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* 
  */
 int cs_gym_observe(const cs_worlds* w, int theta_and_omega_visible, float* d_obs, void* stream);
 int cs_copy_worlds_masked(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, void* stream);
+/* the same with the generator's per-world status (cs_generate_worlds d_status): a world whose generation failed (status != 0: the
+ * bounded rejection sampling gave up, or the traffic is too dense) is NOT copied over the live one -- the caller sees the status. */
+int cs_copy_worlds_masked_status(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, const int32_t* d_status, void* stream);
 
 /*
  * cs_gym_bookkeeping_next_step  cs_gym_bookkeeping for Gymnasium's NEXT_STEP autoreset mode: a world whose episode ended in the

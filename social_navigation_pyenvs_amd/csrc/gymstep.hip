@@ -32,12 +32,14 @@ struct CopyArgs {
     const float* rs; float* rd;
     const int* fsrc; int* fdst;
     const int* mask;
+    const int* status;   // optional: cs_generate_worlds' per-world status; a world that could not be generated (non-zero) is NOT copied
 };
 
 __global__ __launch_bounds__(64) void k_copy_worlds_masked(const CopyArgs a)
 {
     const int w = blockIdx.x;
     if (!a.mask[w]) return;
+    if (a.status != nullptr && a.status[w] != 0) return;   // a half-built world never replaces a live one
     const int t = threadIdx.x;
     for (int k = t; k < a.rows * 13; k += 64) {
         const int row = k / 13, f = k - row * 13;
@@ -70,6 +72,11 @@ int cs_gym_observe(const cs_worlds* w, int theta_and_omega_visible, float* d_obs
 
 int cs_copy_worlds_masked(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, void* stream)
 {
+    return cs_copy_worlds_masked_status(src, dst, d_mask, nullptr, stream);
+}
+
+int cs_copy_worlds_masked_status(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, const int32_t* d_status, void* stream)
+{
     if (!src || !dst || !d_mask) return fail(CS_ERR_ARG, "null argument");
     if (src->W != dst->W || src->n != dst->n || src->G != dst->G || src->layout != dst->layout || ((src->flags ^ dst->flags) & CS_ROBOT_ROW))
         return fail(CS_ERR_ARG, "source and destination worlds differ in shape");
@@ -79,7 +86,7 @@ int cs_copy_worlds_masked(const cs_worlds* src, const cs_worlds* dst, const int3
     a.Ss = src->d_state; a.Sd = dst->d_state;
     a.as = src->layout == CS_LAYOUT_AOS ? 13 : 1; a.fs = src->layout == CS_LAYOUT_AOS ? 1 : (long)src->W * a.rows;
     a.gs = src->d_goals; a.gd = dst->d_goals; a.rs = src->d_robot; a.rd = dst->d_robot;
-    a.fsrc = src->d_world_flags; a.fdst = const_cast<int*>(dst->d_world_flags); a.mask = d_mask;
+    a.fsrc = src->d_world_flags; a.fdst = const_cast<int*>(dst->d_world_flags); a.mask = d_mask; a.status = d_status;
     hipLaunchKernelGGL(k_copy_worlds_masked, dim3(a.W), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;

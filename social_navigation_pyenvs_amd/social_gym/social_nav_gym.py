@@ -403,6 +403,7 @@ class BatchedSocialNavGym:
                   gtime=torch.zeros(W, dtype=torch.float32, device="cuda"),
                   seeds=torch.as_tensor(self._seeds_host.astype(np.int64), device="cuda").to(torch.int32),
                   mask=torch.zeros(W, dtype=torch.int32, device="cuda"),
+                  gen_status=torch.zeros(W, dtype=torch.int32, device="cuda"),   # cs_generate_worlds' status of the masked auto-reset
                   out=self.cw._buffer("reward_out", (W, 7)).torch(),
                   state=self.cw.d_state.torch().view(W, self.cw.rows, 13),
                   gen=gen.make_generator(self.cw, self._gen_scenario, **self._gen_kw),
@@ -464,14 +465,17 @@ class BatchedSocialNavGym:
             if auto_reset:
                 dl["fork"].record(A)
                 dl["fork"].wait(B)
-                gen.generate_worlds_device(dl["staging"], dl["gen"], dl["seeds"], dl["mask"])   # (the staging batch launches on stream B)
+                # (the staging batch launches on stream B; a world whose bounded rejection sampling fails keeps status != 0 and is
+                #  not copied over the live one: failed_resets() counts them)
+                gen.generate_worlds_device(dl["staging"], dl["gen"], dl["seeds"], dl["mask"], d_status=dl["gen_status"])
             _lib.check(lib.cs_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
                                    C.c_void_p(A)))
             if auto_reset:
                 dl["join"].record(B)
                 dl["join"].wait(A)
                 ds = dl["staging"].descriptor()
-                _lib.check(lib.cs_copy_worlds_masked(C.byref(ds), C.byref(d), C.c_void_p(dl["mask"].data_ptr()), C.c_void_p(A)))
+                _lib.check(lib.cs_copy_worlds_masked_status(C.byref(ds), C.byref(d), C.c_void_p(dl["mask"].data_ptr()),
+                                                            C.c_void_p(dl["gen_status"].data_ptr()), C.c_void_p(A)))
             _lib.check(lib.cs_gym_observe(C.byref(d), C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
         dl[key] = graph
         return graph
@@ -502,10 +506,10 @@ class BatchedSocialNavGym:
         dg = st.descriptor()
         nbytes = int(lib.cs_generate_scratch_bytes(C.c_int(self.W)))
         scratch = st._buffer("gen_mt19937", (nbytes // 4,), np.uint32)
-        a_gen = (C.byref(dl["gen"]), C.byref(dg), P(dl["seeds"]), P(masks[parity]), C.c_void_p(None), C.c_void_p(None), C.c_void_p(scratch.ptr),
+        a_gen = (C.byref(dl["gen"]), C.byref(dg), P(dl["seeds"]), P(masks[parity]), P(dl["ns_status"][parity]), C.c_void_p(None), C.c_void_p(scratch.ptr),
                  C.c_void_p(dl["ns_streams"][parity]))
         ds = dl["ns_staging"][parity ^ 1].descriptor()
-        a_copy = (C.byref(ds), dref, P(masks[parity ^ 1]), A)
+        a_copy = (C.byref(ds), dref, P(masks[parity ^ 1]), P(dl["ns_status"][parity ^ 1]), A)
         a_obs = (dref, C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
         keep = (d, dg, ds, cfg)                    # the structs the byref arguments point into
         dl[key] = dict(rew=a_rew, bk=a_bk, step=a_step, gen=a_gen, copy=a_copy, obs=a_obs, keep=keep)
@@ -520,6 +524,7 @@ class BatchedSocialNavGym:
         if "ns_masks" not in dl:
             W = self.W
             dl["ns_masks"] = [torch.zeros(W, dtype=torch.int32, device="cuda") for _ in range(2)]
+            dl["ns_status"] = [torch.zeros(W, dtype=torch.int32, device="cuda") for _ in range(2)]
             dl["ns_staging"] = [dl["staging"], self.cw.staging_copy()]
             dl["ns_streams"] = [dl["stream_b"], _lib.stream_create()]
             for st, sb in zip(dl["ns_staging"], dl["ns_streams"]):
@@ -550,7 +555,7 @@ class BatchedSocialNavGym:
         dl["ns_gen_ev"][parity].record(B)
         chk(lib.cs_step(*c["step"]))                                 # the 20 fused substeps
         dl["ns_gen_ev"][parity ^ 1].wait(A)                          # the worlds that ended in the PREVIOUS step are ready by now
-        chk(lib.cs_copy_worlds_masked(*c["copy"]))                   # ... copied in
+        chk(lib.cs_copy_worlds_masked_status(*c["copy"]))            # ... copied in (unless their generation failed: failed_resets())
         chk(lib.cs_gym_observe(*c["obs"]))
         cur.wait_stream(side)
         reward, terminated, truncated, info = dl["results"][parity]
@@ -569,7 +574,11 @@ class BatchedSocialNavGym:
 
         dl = self._device_loop_state()
         if auto_reset == "next_step":
+            dl["mode"] = "next_step"
             return self._step_device_next_step(dl, actions)
+        if dl.get("mode") == "next_step" and "ns_masks" in dl and any(bool(m.any().item()) for m in dl["ns_masks"]):
+            raise RuntimeError("a NEXT_STEP auto-reset is pending for some world: keep auto_reset=\"next_step\" (or reset()) before changing the mode")
+        dl["mode"] = "same_step" if auto_reset else "none"
         parity = dl["parity"]
         dl["parity"] ^= 1
         graph = self._step_graph(dl, parity, auto_reset)
@@ -582,6 +591,16 @@ class BatchedSocialNavGym:
         cur.wait_stream(side)                      # ... and with whoever reads the results
         reward, terminated, truncated, info = dl["results"][parity]
         return dl["obs"], reward, terminated, truncated, info
+
+    def failed_resets(self) -> int:
+        """Worlds whose last device-side auto-reset could not be generated (cs_generate_worlds status != 0: the bounded rejection
+        sampling gave up, or the traffic is too dense -- the reference loops forever / raises there).  Such a world is NOT replaced:
+        it keeps its finished episode's rows.  Synchronises."""
+        dl = self._device_loop_state()
+        n = int((dl["gen_status"] != 0).sum().item())
+        for st in dl.get("ns_status", []):
+            n += int((st != 0).sum().item())
+        return n
 
     def action_buffer(self):
         """The persistent [W, 2] action tensor the step graph reads: write actions into it and pass it to ``step_device``."""

@@ -381,3 +381,33 @@ def test_more_than_64_humans_use_the_lane_per_world_kernel():
             hr = np.array([data["humans"][i]["radius"] for i in range(n)])
             np.testing.assert_allclose(S[w, :, 0:2], hp.astype(np.float32), **F32_TOL)
             np.testing.assert_array_equal(S[w, :, 8], hr.astype(np.float32))
+
+
+def test_failed_regeneration_never_replaces_a_live_world():
+    """The masked auto-reset of step_device: cs_generate_worlds into a staging batch with a status array, then
+    cs_copy_worlds_masked_status -- a world whose bounded rejection sampling gives up (status != 0; forced here with max_tries = 2) keeps its live rows, the others are replaced by the regenerated ones."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd import _lib
+    from social_navigation_pyenvs_amd import generators as gen
+
+    W, n = 64, 10
+    live, staging = _blank(W, n, 2), _blank(W, n, 2)
+    gen.generate_worlds(live, "circle_crossing", 100 + np.arange(W))                   # the live episode
+    before = live.get_states().copy()
+    g = gen.make_generator(staging, "circle_crossing", max_tries=2)                   # ten humans, two attempts each: some worlds fail
+    seeds = _lib.DeviceBuffer.from_numpy((5000 + np.arange(W)).astype(np.uint32), dtype=np.uint32)
+    mask = np.zeros(W, np.int32); mask[::2] = 1                                        # every second world's episode ended
+    d_mask = _lib.DeviceBuffer.from_numpy(mask, dtype=np.int32)
+    d_status = _lib.DeviceBuffer.from_numpy(np.zeros(W, np.int32), dtype=np.int32)
+    gen.generate_worlds_device(staging, g, seeds, d_mask, d_status=d_status)
+    ds, dd = staging.descriptor(), live.descriptor()
+    _lib.check(_lib.load().cs_copy_worlds_masked_status(C.byref(ds), C.byref(dd), C.c_void_p(d_mask.ptr), C.c_void_p(d_status.ptr), C.c_void_p(None)))
+    status, after, fresh = d_status.download(), live.get_states(), staging.get_states()
+    failed = (status != 0) & (mask != 0)
+    replaced = (status == 0) & (mask != 0)
+    assert failed.sum() >= 2 and replaced.sum() >= 2, (int(failed.sum()), int(replaced.sum()))
+    np.testing.assert_array_equal(after[failed], before[failed])                      # untouched
+    np.testing.assert_array_equal(after[mask == 0], before[mask == 0])
+    np.testing.assert_array_equal(after[replaced], fresh[replaced])
+    assert np.any(after[replaced] != before[replaced])
