@@ -60,6 +60,32 @@ _lib = None
 hip_runtime_path = None  # the libamdhip64 this process uses (None: whatever the dynamic loader resolves, i.e. /opt/rocm)
 
 
+def _elf_dynamic(path: str):
+    """(SONAME, [NEEDED ...]) of a 64-bit little-endian ELF shared object, read from its dynamic section (no external tool)."""
+    import struct
+
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+        return None, []
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+    sections = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+    soname, needed = None, []
+    for (_, typ, _, _, off, size, link, _, _, entsize) in sections:
+        if typ != 6:        # SHT_DYNAMIC
+            continue
+        stroff = sections[link][4]
+        cstr = lambda o: data[stroff + o:data.index(b"\0", stroff + o)].decode()
+        for k in range(size // (entsize or 16)):
+            tag, val = struct.unpack_from("<qQ", data, off + k * 16)
+            if tag == 1:
+                needed.append(cstr(val))
+            elif tag == 14:
+                soname = cstr(val)
+    return soname, needed
+
+
 def _preload_hip_runtime() -> None:
     """ONE HIP runtime per process, whatever the import order.  PyTorch-ROCm bundles its own libamdhip64.so (+ HSA
     runtime) under torch/lib, with the same SONAME (libamdhip64.so.7) as the system one libcrowdstep.so is linked
@@ -88,9 +114,37 @@ def _preload_hip_runtime() -> None:
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
         if not os.path.exists(cand):
             return
+        # preload only when the loader would really bind libcrowdstep.so to it: torch's copy must carry the SONAME libcrowdstep.so
+        # NEEDs (e.g. libamdhip64.so.7).  A ROCm-6 wheel beside a ROCm-7 system runtime has another SONAME: preloading it would map
+        # two runtimes where there was one -- fall back to the system runtime and say so.
+        try:
+            soname, _ = _elf_dynamic(cand)
+            _, needed = _elf_dynamic(LIB_PATH)
+            want = [x for x in needed if x.startswith("libamdhip64")]
+        except Exception:
+            soname, want = None, []
+        if want and soname not in want:
+            import warnings
+
+            warnings.warn(f"torch bundles {soname or 'an unreadable libamdhip64'}, libcrowdstep.so needs {want[0]}: not preloading torch's HIP runtime "
+                          "(CROWDSTEP_HIP_RUNTIME=system); tensors of the two runtimes cannot be shared")
+            return
         path = cand
     C.CDLL(path, mode=C.RTLD_GLOBAL)
     hip_runtime_path = path
+
+
+def mapped_hip_runtimes() -> list:
+    """The libamdhip64 files mapped into this process (/proc/self/maps): exactly one when the preload did its job."""
+    seen = []
+    try:
+        for line in open("/proc/self/maps"):
+            f = line.split()[-1]
+            if "libamdhip64" in f and f not in seen:
+                seen.append(f)
+    except OSError:
+        pass
+    return seen
 
 
 def load():

@@ -87,7 +87,10 @@ class PyRVOSimulator:
         for name, val in (("neighborDist", neighborDist), ("maxNeighbors", maxNeighbors), ("timeHorizon", timeHorizon)):
             if val is not None and float(val) != float(d[name]):
                 raise NotImplementedError(f"per-agent {name} is not supported (the reference uses ORCA_DEFAULTS for every agent)")
-        # (any number of agents: worlds of more than 512 take the grid neighbour search of the kernel, csrc/orca.hip)
+        # (any number of agents: worlds of more than 512 take the grid neighbour search of the kernel, csrc/orca.hip -- which is built
+        #  for maxNeighbors = 10 without static obstacles: say so HERE, not at the first doStep)
+        if len(self._pos) + 1 > 512:
+            self._check_big_world()
         self._pos.append([float(pos[0]), float(pos[1])])
         v = d["velocity"] if velocity is None else velocity
         self._vel.append([float(v[0]), float(v[1])])
@@ -97,10 +100,18 @@ class PyRVOSimulator:
         self._cw = None
         return len(self._pos) - 1
 
+    def _check_big_world(self):
+        if self._polygons:
+            raise NotImplementedError("static obstacles are not built for ORCA worlds of more than 512 agents (grid neighbour search)")
+        if int(self._defaults["maxNeighbors"]) != 10:
+            raise NotImplementedError("ORCA worlds of more than 512 agents (grid neighbour search) are built for maxNeighbors = 10")
+
     def addObstacle(self, vertices):
         """Counter-clockwise polygon (or two vertices: a wall seen from its right side).  Returns the number of the
         obstacle's first vertex, like RVO2."""
         first = sum(len(p) for p in self._polygons)
+        if len(self._pos) > 512:
+            raise NotImplementedError("static obstacles are not built for ORCA worlds of more than 512 agents (grid neighbour search)")
         self._polygons.append([(float(v[0]), float(v[1])) for v in vertices])
         return first
 

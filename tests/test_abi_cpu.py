@@ -109,3 +109,31 @@ def test_integration_doc_stub_matches_the_struct():
     stub = ns["stub"]
     assert [(f[0], f[1]) for f in stub._fields_] == [(f[0], f[1]) for f in cs_worlds._fields_]
     assert C.sizeof(stub) == C.sizeof(cs_worlds)
+
+
+def test_hip_runtime_preload_checks_the_soname_and_maps_one_runtime(tmp_path, monkeypatch):
+    """_lib.load() preloads torch's bundled libamdhip64 only when its SONAME is the one libcrowdstep.so NEEDs (so that the loader
+    binds the library to it and a later `import torch` finds the same file mapped): exactly ONE libamdhip64 in /proc/self/maps here;
+    a bundled runtime with another SONAME is not preloaded (a warning, the system runtime instead of two mapped runtimes)."""
+    import subprocess
+    import sys
+
+    from social_navigation_pyenvs_amd import _lib
+
+    _lib.load()
+    soname, needed = _lib._elf_dynamic(_lib.LIB_PATH)
+    want = [x for x in needed if x.startswith("libamdhip64")]
+    assert len(want) == 1
+    if _lib.hip_runtime_path:
+        assert _lib._elf_dynamic(_lib.hip_runtime_path)[0] == want[0]
+    assert len(_lib.mapped_hip_runtimes()) == 1, _lib.mapped_hip_runtimes()
+    # a bundled runtime whose SONAME differs: simulated by pointing the check at a library that is not a HIP runtime at all
+    code = ("import warnings, sys; sys.path.insert(0, %r)\n"
+            "from social_navigation_pyenvs_amd import _lib\n"
+            "real = _lib._elf_dynamic\n"
+            "_lib._elf_dynamic = lambda p: ('libamdhip64.so.6', []) if 'torch' in p else real(p)\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always'); _lib.load()\n"
+            "assert _lib.hip_runtime_path is None and any('not preloading' in str(x.message) for x in w), (_lib.hip_runtime_path, [str(x.message) for x in w])\n"
+            "assert len(_lib.mapped_hip_runtimes()) == 1\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    subprocess.check_call([sys.executable, "-c", code])
