@@ -13,7 +13,7 @@ SHAPES = {"cfg3": (4096, 25, "hsfm_farina_25_hybrid"), "cfg2": (4096, 10, "sfm_h
           "cfg5": (8192, 50, "hsfm_farina_50_circle_walls_static"), "cfg3x4": (16384, 25, "hsfm_farina_25_hybrid_16384"),
           "moussaid": (4096, 25, "hsfm_new_moussaid_25_hybrid"), "cfg3_new_guo": (4096, 25, "hsfm_new_guo_25_hybrid"),
           "robot26": (4096, 25, "hsfm_farina_25_hybrid_robot"), "n30": (4096, 30, "hsfm_farina_30_hybrid"),
-          "peragent": (4096, 25, "hsfm_farina_25_hybrid_peragent")}
+          "peragent": (4096, 25, "hsfm_farina_25_hybrid_peragent"), "cfg5_nowalls": (8192, 50, "hsfm_farina_50_circle_static")}
 SUBSTEPS = 20
 SIMDS = 256 * 4
 

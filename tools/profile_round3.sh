@@ -19,7 +19,8 @@ CFG[cfg3_new_guo]="--model hsfm_new_guo"
 CFG[robot26]="--robot"
 CFG[n30]="--agents 30"
 CFG[peragent]="--per-agent-params"
-NAMES=${@:-cfg3 cfg2 cfg4_first20 cfg4_dense cfg5}
+CFG[cfg5_nowalls]="--worlds 8192 --agents 50 --model hsfm_farina --scenario circle --static 3 --device-generator"
+NAMES=${@:-cfg3 cfg2 cfg4_first20 cfg4_dense cfg5 cfg5_nowalls cfg3_new_guo robot26 n30 peragent}
 # the default bench command itself under the kernel trace: its k_sfm_step<..., 25, 1> row is the kernel behind `value`
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/main_stats -- python3 bench.py > $O/main_bench.json 2> $O/main_stats.log || { echo "main stats run failed"; tail -5 $O/main_stats.log; exit 1; }
 cp $(find $O/main_stats -name "*kernel_stats.csv" | head -1) $O/main_kernel_stats.csv && head -4 $O/main_kernel_stats.csv | cut -c1-160
