@@ -331,14 +331,15 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             }
             LDS_ORDER_FENCE();
         }
-        // lean build: request the first group's partner rows first thing; the goal test and part A below run while they
-        // are in flight (with walls the rows would be held in registers across the segment loops: fetched at the head of
-        // the group loop instead)
-        if constexpr (LEAN) { if (valid && Hf >= UA) fetch(qa, va, 0); }
+        // lean build without walls: request the first group's partner rows first thing; the goal test and part A below run
+        // while they are in flight.  With walls the rows would be held in registers across the segment loops -- 17 spilled
+        // VGPRs whose scratch reloads cost 250 vs 200 us on the 8192 x 50 shard -- so they are fetched at the head of the
+        // group loop instead (fetching between the segment loops and the heading / torque arithmetic spills as well)
+        if constexpr (LEAN && NO_WALLS) { if (valid && Hf >= UA) fetch(qa, va, 0); }
         // even row counts: the antipodal partner (evaluated by both ends, no hand-over) is requested up front as well
         float4 qz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float2 vz = make_float2(0.0f, 0.0f);
-        if constexpr (LEAN) {
+        if constexpr (LEAN && NO_WALLS) {
             if (valid && (rows & 1) == 0) {
                 qz = rp[Hf];
                 if constexpr (SOC == 2) vz = rv[Hf];
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             if (valid) {
                 float2* acc = lds_acc + pbase + row + 1;                 // acc[u * 2T + k]: that partner's slot in row u
                 float ex = 0.0f, ey = 0.0f, rdmax = -1.0f;
-                if constexpr (!LEAN) { if (Hf >= UA) fetch(qa, va, 0); }
+                if constexpr (!(LEAN && NO_WALLS)) { if (Hf >= UA) fetch(qa, va, 0); }
                 auto pair_once = [&](const float4 q, const float2 vq, float& fx, float& fy) {
                     const float dx = px - q.x, dy = py - q.y;
                     if constexpr (SOC == 2) {
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 }
                 if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself (lean build: row fetched at the top)
                     float fx, fy;
-                    if constexpr (!LEAN) {
+                    if constexpr (!(LEAN && NO_WALLS)) {
                         qz = rp[Hf];
                         if constexpr (SOC == 2) vz = rv[Hf];
                     }
