@@ -281,11 +281,11 @@ Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool nee
     const bool crowded = g.grid > 2 * csimpl::device_simds();
     // The plain crowd batch (what Gym scenarios and the bench step): all_params_equal -> every pair once, <= 2 goal slots, committed
     // in place -> a LEAN build: 1 = no walls, no robot row; 2 = walls; 3 = no walls + the robot as the last row (a Gym with a
-    // visible robot: cs_step hands the robot rows over through d_robot, M_ROBOT_FROM_ARRAY).  Everything else (walls AND a robot row,
+    // visible robot: cs_step hands the robot rows over through d_robot, M_ROBOT_FROM_ARRAY); 5 = walls + robot row.  Everything else (
     // per-agent parameters, longer goal lists, peek / out-of-place modes) runs the generic build.
     const bool lean_mode = robot ? (mode & ~(int)M_ROBOT_FROM_ARRAY) == M_COMMIT_GOALS : mode == M_COMMIT_GOALS;
     int kind = 0;
-    if (peq && w->G <= 2 && lean_mode) kind = robot ? (w->O == 0 ? 3 : 0) : (w->O == 0 ? 1 : 2);
+    if (peq && w->G <= 2 && lean_mode) kind = robot ? (w->O == 0 ? 3 : 5) : (w->O == 0 ? 1 : 2);
     if (robot_model) {   // the robot's own motion model inside the launch: the LEAN = 4 builds only (callers check fusable_imitation)
         if (kind != 3) return Variant{0, 0, 0, 0, peq};
         return Variant{64, rows == 26 ? 1 : 3, rows == 26 ? 26 : 0, 4, true};

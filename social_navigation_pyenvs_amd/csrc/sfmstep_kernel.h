@@ -51,7 +51,8 @@ constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one 
 //            row (3: what a Gym with a VISIBLE robot steps; rows = humans + 1), goal lists of <= 2 entries, state committed in
 //            place -- the wall / robot / goal-list-in-memory code and their branches are compiled out wherever the build
 //            does not need them and the goal switch is predicated; 4 = 3 + the robot follows a HUMAN motion model of its own
-//            (imitation learning, social_nav_gym.py:252-274): update_robot runs inside the substep loop (robot_model.h)
+//            (imitation learning, social_nav_gym.py:252-274): update_robot runs inside the substep loop (robot_model.h);
+//            5 = 3 with the walls kept (a Gym with a visible robot in a walled scene)
 template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, int LEAN>
 __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 {
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 
     const int tid = threadIdx.x;
     static_assert(!LEAN || (PEQ && MAXT == 64), "the lean build is a pair-once build");
-    constexpr bool LEAN_ROBOT = LEAN == 3 || LEAN == 4;    // the robot is the last row
+    constexpr bool LEAN_ROBOT = LEAN == 3 || LEAN == 4 || LEAN == 5;   // the robot is the last row (5: with walls)
     constexpr bool IMIT = LEAN == 4;                       // ... and follows its own human motion model
-    constexpr bool NO_WALLS = LEAN == 1 || LEAN_ROBOT;     // wall code compiled out
+    constexpr bool NO_WALLS = LEAN == 1 || LEAN == 3 || LEAN == 4;     // wall code compiled out
     const int rows = ROWS_CT > 0 ? ROWS_CT : a.rows;
     const int n = LEAN_ROBOT ? rows - 1 : (LEAN ? rows : a.n);
     const int kmode = LEAN_ROBOT ? ((int)M_COMMIT_GOALS | (a.mode & (int)M_ROBOT_FROM_ARRAY)) : (LEAN ? (int)M_COMMIT_GOALS : a.mode);

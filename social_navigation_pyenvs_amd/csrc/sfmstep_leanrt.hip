@@ -8,7 +8,7 @@ namespace cstep {
 
 kfn sfm_builds_leanrt(const Variant& v, int type)
 {
-    CS_V(64, 3, 0, 1) CS_V(64, 3, 0, 2) CS_V(64, 3, 0, 3)
+    CS_V(64, 3, 0, 1) CS_V(64, 3, 0, 2) CS_V(64, 3, 0, 3) CS_V(64, 3, 0, 5)
     return nullptr;
 }
 

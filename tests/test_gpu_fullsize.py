@@ -159,7 +159,7 @@ def test_fused_block_equals_repeated_single_substeps_bitwise():
     np.testing.assert_array_equal(a.get_goals(), b.get_goals())
 
 
-@pytest.mark.parametrize("n,model,robot", [(80, "hsfm_farina", False), (150, "sfm_guo", True), (64, "sfm_helbing", True)])
+@pytest.mark.parametrize("n,model,robot", [(80, "hsfm_farina", False), (150, "sfm_guo", True), (64, "sfm_helbing", True), (300, "hsfm_new_guo", False)])
 def test_large_worlds_one_block_per_world(n, model, robot):
     """rows > 64: one world per block of up to 1024 threads (multi-wave barriers, block-wide contact / respawn votes)."""
     from social_navigation_pyenvs_amd import scenarios as sc

@@ -246,6 +246,7 @@ def test_every_substep_inside_the_fused_block(group):
 SHAPE_VARIANT = [(25, True, 41, "OCC=1,ROWS_CT=26,LEAN=3"), (5, True, 23, "OCC=4,ROWS_CT=6,LEAN=3"), (10, True, 23, "OCC=4,ROWS_CT=11,LEAN=3"),
                  (50, True, 9, "OCC=3,ROWS_CT=51,LEAN=3"), (20, False, 41, "OCC=1,ROWS_CT=20,LEAN=1"), (30, False, 41, "OCC=1,ROWS_CT=30,LEAN=1"),
                  (17, True, 23, "OCC=3,ROWS_CT=0,LEAN=3"), (17, False, 23, "OCC=3,ROWS_CT=0,LEAN=1"),
+                 (25, True, 41, "OCC=3,ROWS_CT=0,LEAN=5"), (25, False, 41, "OCC=3,ROWS_CT=0,LEAN=2"),   # LEAN 2 / 5: three polygon walls
                  (25, True, 4200, "OCC=4,ROWS_CT=26,LEAN=3"), (20, False, 6300, "OCC=4,ROWS_CT=20,LEAN=1"), (30, False, 4200, "OCC=4,ROWS_CT=30,LEAN=1")]
 
 
@@ -258,6 +259,7 @@ def test_shape_specialised_builds_every_substep(n, robot, W, variant):
     from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
 
     rng = np.random.default_rng(n + W)
+    walls = sc.polygon_walls().astype(np.float32) if ("LEAN=2" in variant or "LEAN=5" in variant) else None
     for model in (["hsfm_farina", "sfm_guo", "hsfm_new_moussaid"] if W < 1000 else ["hsfm_farina"]):
         S, goals, P, rb = sc.hybrid_worlds(W, n, model, seed0=31 + n)
         rw = (np.arange(W) % 2 == 1).astype(np.int32)
@@ -268,7 +270,7 @@ def test_shape_specialised_builds_every_substep(n, robot, W, variant):
             A = rng.uniform(-0.8, 0.8, (W, 2)).astype(np.float32)
             S = np.concatenate([S, R[:, None, :]], axis=1)
         S32, g32, P32 = f32(S), f32(goals), f32(P)
-        cw = CrowdWorlds(S32, g32, P32, None, None, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw,
+        cw = CrowdWorlds(S32, g32, P32, None, walls, type=model, all_params_equal=True, respawn_bounds=rb, respawn_worlds=rw,
                          robot_row=robot, robot=R, layout="soa" if W > 1000 else "aos")
         assert variant in cw.step_variant(), cw.step_variant()
         # two Gym steps in, so that the humans have distinct velocities (from rest every Moussaid pair sits exactly on sign(theta = 0))
@@ -277,7 +279,7 @@ def test_shape_specialised_builds_every_substep(n, robot, W, variant):
         S_k, g_k, R_k = cw.get_states(), cw.get_goals(), (cw.get_robot() if robot else None)
         sample = None if W < 1000 else rng.choice(W, 24, replace=False)
         fam = "Moussaid" if model.endswith("moussaid") else "Helbing / Guo"
-        res = fused_substeps_vs_oracle(cw, SFMS.index(model), S_k, g_k, P32, None, None, 0.0125, 20, True, respawn=rw, respawn_bounds=rb,
+        res = fused_substeps_vs_oracle(cw, SFMS.index(model), S_k, g_k, P32, None, walls, 0.0125, 20, True, respawn=rw, respawn_bounds=rb,
                                        robot_row=robot, robot=R_k, action=A, worlds=sample,
                                        group=f"shape-specialised builds per substep inside the fused launch ({fam})", what=f"{variant} {model}")
         assert res["within"] >= res["substeps"] - res["ill_conditioned"], (variant, model, res)

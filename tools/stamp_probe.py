@@ -48,7 +48,7 @@ if len(sys.argv) > 4 and sys.argv[4] in ("circle", "walls"):   # cfg2-style: cir
     cw = CrowdWorlds(S, goals, P, None, sc.polygon_walls() if sys.argv[4] == "walls" else None, type=model, all_params_equal=True, layout="soa")
 else:
     S, goals, P, rb = sc.hybrid_worlds(W, n, model)
-    cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
+    cw = CrowdWorlds(S, goals, P, None, sc.polygon_walls() if (len(sys.argv) > 4 and sys.argv[4] == "hybridwalls") else None, type=model, all_params_equal=True, respawn_bounds=rb,
                      respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), layout="soa")
 g, b, wpb = cw.launch_geometry()
 buf = _lib.DeviceBuffer((g * (b // 64), 12), np.uint64)
