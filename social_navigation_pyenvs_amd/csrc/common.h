@@ -36,6 +36,7 @@ int scratch_release_all();
 inline size_t imitation_scratch_bytes(const cs_worlds* w, int n_substeps) { return (size_t)n_substeps * w->W * w->n * 4 * sizeof(float); }
 size_t sfm_big_scratch_bytes(const cs_worlds* w);
 size_t orca_big_scratch_bytes(const cs_worlds* w);
+bool orca_uses_grid(const cs_worlds* w);   // ORCA worlds that take the grid path (more than 512 rows, or LDS columns beyond a block)
 int big_world_min_rows(int dflt);
 int device_simds();   // CUs x 4 of the current device
 // the uniform grid of worlds beyond one block (bigworld.hip): rows binned into hashed buckets of square cells, every bucket's rows in

@@ -575,7 +575,7 @@ int cs_reserve_scratch(const cs_worlds* w, int n_substeps, void* stream)
     void* p = nullptr;
     int rc = CS_OK;
     if (w->type == CS_ORCA) {
-        if (rows > csimpl::big_world_min_rows(512)) rc = csimpl::scratch(&p, csimpl::orca_big_scratch_bytes(w), csimpl::SCRATCH_ORCA_BIG, (hipStream_t)stream);
+        if (csimpl::orca_uses_grid(w)) rc = csimpl::scratch(&p, csimpl::orca_big_scratch_bytes(w), csimpl::SCRATCH_ORCA_BIG, (hipStream_t)stream);
         return rc;
     }
     if (w->type < 0 || w->type > 8) return CS_OK;   // (social momentum keeps no library scratch)

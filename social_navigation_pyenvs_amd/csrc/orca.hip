@@ -1154,43 +1154,56 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
 // neighbour list, the ORCA lines and the solve are bit-identical to the restatement's index-order walk.  State is double-buffered
 // in HBM (every agent reads the old rows, RVO2's doStep is a Jacobi update), one launch per substep.
 struct BigArgs {
-    int W, n, G, NB;
-    float dt, neighbor_dist, time_horizon, inv_cell;
+    int W, n, rows, G, NB, robot_row;
+    int K, KO, nv;         // generic build: maxNeighbors, obstacle neighbours kept, obstacle vertices
+    float dt, neighbor_dist, time_horizon, time_horizon_obst, inv_cell;
     const float* Sin; float* Sout; long as, fs;
     float* goals; const float* margin;
     const int2* cellxy; const int* start; const int* sorted;   // the grid (csimpl::grid_build, bigworld.hip)
     int lp3_static;
     float* peek_out;       // cs_peek: [W][n][8] rows of the stepped state; goal lists are not rotated in memory
+    float* robot;          // [W][13] cs_worlds.d_robot: the true robot (moved by the action), copied into its state row AFTER the step
+    const float* action;   // [W][2] or null
+    const float* verts;    // RVO2 obstacle vertex records (generic build)
 };
 
+// FAST10: maxNeighbors = 10 without static obstacles, the register-resident solve of the crowd kernel.  Otherwise the generic
+// LDS-column code (any maxNeighbors <= 16, obstacle lines): the neighbour columns are filled in (distSq, row) order -- what RVO2's
+// index-order insertion with its strict < yields -- so the grid's visiting order does not matter here either.
+template <bool FAST10>
 __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
 {
-    __shared__ float4 lds_ln[10 * 64];
-    __shared__ float4 lds_pr[72];
-    __shared__ float2 lds_pa[72];
-    __shared__ float4 lds_q[64];
-    __shared__ int lds_sel[64];
-    const int tid = threadIdx.x, i = blockIdx.x * 64 + tid, w = blockIdx.y, n = a.n;
+    extern __shared__ __align__(16) unsigned char bw_smem[];
+    const int KL = FAST10 ? 10 : a.K + a.KO;
+    float4* lds_ln = reinterpret_cast<float4*>(bw_smem);                         // [KL][64] ORCA lines
+    float4* lds_pr = lds_ln + KL * 64;                                           // FAST10: [72] lp3_rows projections; generic: [KL][64] LP3 projections
+    float2* lds_pa = reinterpret_cast<float2*>(lds_pr + (FAST10 ? 72 : KL * 64)); // FAST10: [72] chords
+    float4* lds_q = reinterpret_cast<float4*>(lds_pa + (FAST10 ? 72 : 0));       // FAST10: [64]
+    int* lds_sel = reinterpret_cast<int*>(lds_q + (FAST10 ? 64 : 0));            // FAST10: [64]
+    float* lds_nd = reinterpret_cast<float*>(lds_sel + (FAST10 ? 64 : 0));       // generic: [K][64] neighbour distSq
+    int* lds_ni = reinterpret_cast<int*>(lds_nd + (FAST10 ? 0 : a.K * 64));      // generic: [K][64] neighbour row
+    float* lds_od = reinterpret_cast<float*>(lds_ni + (FAST10 ? 0 : a.K * 64));  // generic: [KO][64] obstacle edge distSq
+    int* lds_oi = reinterpret_cast<int*>(lds_od + (FAST10 ? 0 : a.KO * 64));     // generic: [KO][64] obstacle edge
+    const int tid = threadIdx.x, i = blockIdx.x * 64 + tid, w = blockIdx.y, n = a.n, rows = a.rows;
     const bool human = i < n;
-    const float* Sw = a.Sin + (long)w * n * a.as;
+    const bool is_robot = a.robot_row && i == n;
+    const float* Sw = a.Sin + (long)w * rows * a.as;
     const long fs = a.fs;
     float px = 0, py = 0, vx = 0, vy = 0, pvx = 0, pvy = 0, r = 0, vmax = 0, margin = 0;
-    const float* srow = Sw + (long)(human ? i : 0) * a.as;
+    const float* srow = Sw + (long)(i < rows ? i : 0) * a.as;
     if (human) {
         px = srow[0]; py = srow[fs]; vx = srow[3 * fs]; vy = srow[4 * fs];
         pvx = srow[5 * fs]; pvy = srow[6 * fs]; r = srow[8 * fs]; vmax = srow[12 * fs];
-        margin = a.margin[(long)w * n + i];
+        margin = a.margin[(long)w * rows + i];
     }
+    const int2* cxy = a.cellxy + (long)w * rows;
+    const int* st = a.start + (long)w * a.NB;          // positions in the job-wide sorted list
+    const int* so = a.sorted;
+    const float* mg = a.margin + (long)w * rows;
+    const float range2 = a.neighbor_dist * a.neighbor_dist;
     // Agent::computeNeighbors through the grid: the 3 x 3 cells around mine hold every agent closer than neighborDist
-    double key[10];
-#pragma unroll
-    for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
-    if (human) {
-        const float range2 = a.neighbor_dist * a.neighbor_dist;
-        const int2 mc = a.cellxy[(long)w * n + i];
-        const int* st = a.start + (long)w * a.NB;      // positions in the job-wide sorted list
-        const int* so = a.sorted;
-        const int2* cxy = a.cellxy + (long)w * n;
+    auto walk = [&](auto&& visit) {
+        const int2 mc = cxy[i];
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int cx = mc.x + dx, cy = mc.y + dy;
@@ -1202,22 +1215,82 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
                     const float* sb = Sw + (long)b * a.as;
                     const float ddx = px - sb[0], ddy = py - sb[fs];
                     const float dsq = ddx * ddx + ddy * ddy;
-                    if (dsq < range2) key_insert10(key, __hiloint2double((int)__float_as_uint(dsq), b));
+                    if (dsq < range2) visit(dsq, b);
                 }
             }
-    }
+    };
     float nvx = 0.0f, nvy = 0.0f;
-    unsigned long long ost_last = 0;
-    const Lines L{lds_ln, 64, tid};
-    const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
-    const float* mg = a.margin + (long)w * n;
-    orca_solve_fast10(human, a.lp3_static != 0, key, human ? i : 0,
-                      [&](int b, float4& q, float& rad) {
-                          const float* sb = Sw + (long)b * a.as;
-                          q = make_float4(sb[0], sb[fs], sb[3 * fs], sb[4 * fs]);
-                          rad = sb[8 * fs] + mg[b];
-                      },
-                      px, py, vx, vy, r + margin, vmax, pvx, pvy, a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
+    if constexpr (FAST10) {
+        double key[10];
+#pragma unroll
+        for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
+        if (human) walk([&](float dsq, int b) { key_insert10(key, __hiloint2double((int)__float_as_uint(dsq), b)); });
+        unsigned long long ost_last = 0;
+        const Lines L{lds_ln, 64, tid};
+        const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
+        orca_solve_fast10(human, a.lp3_static != 0, key, human ? i : 0,
+                          [&](int b, float4& q, float& rad) {
+                              const float* sb = Sw + (long)b * a.as;
+                              q = make_float4(sb[0], sb[fs], sb[3 * fs], sb[4 * fs]);
+                              rad = sb[8 * fs] + mg[b];
+                          },
+                          px, py, vx, vy, r + margin, vmax, pvx, pvy, a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
+    } else if (human) {
+        const int K = a.K;
+        int cnt = 0;
+        if (K > 0)
+            walk([&](float dsq, int b) {
+                // insertAgentNeighbor over an index-order walk keeps the K smallest (distSq, row) pairs, ties by row: the same list
+                // from any visiting order when the comparison is lexicographic
+                auto before = [&](int s) { const float d = lds_nd[s * 64 + tid]; return dsq < d || (dsq == d && b < lds_ni[s * 64 + tid]); };
+                int s;
+                if (cnt < K) s = cnt++;
+                else if (before(K - 1)) s = K - 1;
+                else return;
+                while (s != 0 && before(s - 1)) {
+                    lds_nd[s * 64 + tid] = lds_nd[(s - 1) * 64 + tid];
+                    lds_ni[s * 64 + tid] = lds_ni[(s - 1) * 64 + tid];
+                    --s;
+                }
+                lds_nd[s * 64 + tid] = dsq;
+                lds_ni[s * 64 + tid] = b;
+            });
+        const Lines L{lds_ln, 64, tid}, P{lds_pr, 64, tid};
+        int nobst = 0;
+        if (a.nv > 0) {
+            const float rng = a.time_horizon_obst * vmax + (r + margin);   // rangeSq = sqr(timeHorizonObst * maxSpeed + radius)
+            const int no = obstacle_neighbors(a.verts, a.nv, a.KO, px, py, rng * rng, lds_od, lds_oi, 64, tid);
+            nobst = obstacle_lines(a.verts, lds_oi, no, 64, tid, px, py, vx, vy, r + margin, 1.0f / a.time_horizon_obst, L);
+        }
+        const float invT = 1.0f / a.time_horizon;
+        const float invDt = 1.0f / a.dt;
+        for (int k = 0; k < cnt; ++k) {
+            const int b = lds_ni[k * 64 + tid];
+            const float* sb = Sw + (long)b * a.as;
+            L.set(nobst + k, orca_line(px, py, vx, vy, make_float4(sb[0], sb[fs], sb[3 * fs], sb[4 * fs]), (r + margin) + (sb[8 * fs] + mg[b]), invT, invDt));
+        }
+        const int total = nobst + cnt;
+        const int failed = lp2(L, total, vmax, pvx, pvy, false, nvx, nvy);
+        if (failed < total) lp3(L, P, total, nobst, failed, vmax, nvx, nvy);
+    }
+    // the true robot: robot.step(action, dt) (holonomic), then set_state_orca(robot) AFTER doStep (motion_model_manager.py:389): the
+    // humans of this substep saw the row as the previous substep left it
+    if (a.peek_out == nullptr && (is_robot || (!a.robot_row && i == 0 && a.robot != nullptr && a.action != nullptr))) {
+        float rbx = srow[0], rby = srow[fs], rbvx = srow[3 * fs], rbvy = srow[4 * fs];
+        if (a.robot != nullptr) {
+            float* rb = a.robot + (long)w * 13;
+            rbx = rb[0]; rby = rb[1]; rbvx = rb[3]; rbvy = rb[4];
+            if (a.action != nullptr) {
+                const float ax = a.action[(long)w * 2], ay = a.action[(long)w * 2 + 1];
+                rbx += ax * a.dt; rby += ay * a.dt; rbvx = ax; rbvy = ay;
+                rb[0] = rbx; rb[1] = rby; rb[3] = rbvx; rb[4] = rbvy;
+            }
+        }
+        if (is_robot) {
+            float* o = a.Sout + ((long)w * rows + i) * a.as;
+            o[0] = rbx; o[fs] = rby; o[3 * fs] = rbvx; o[4 * fs] = rbvy;
+        }
+    }
     if (!human) return;
     // Agent::update, then the reference's read-back + update_goals_orca (motion_model_manager.py:390-394, :125-133)
     vx = nvx; vy = nvy;
@@ -1243,7 +1316,7 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
         q[0] = px; q[1] = py; q[2] = srow[2 * fs]; q[3] = vx; q[4] = vy; q[5] = srow[7 * fs]; q[6] = g0x; q[7] = g0y;
         return;
     }
-    float* o = a.Sout + ((long)w * n + i) * a.as;
+    float* o = a.Sout + ((long)w * rows + i) * a.as;
     o[0] = px; o[fs] = py; o[3 * fs] = vx; o[4 * fs] = vy; o[5 * fs] = pvx; o[6 * fs] = pvy; o[10 * fs] = g0x; o[11 * fs] = g0y;
 }
 
@@ -1293,21 +1366,44 @@ int big_world_min_rows(int dflt)
     return v < dflt ? (v < 1 ? 1 : v) : dflt;
 }
 
+// dynamic LDS of the one-block kernel (k_orca_step) for these worlds: [2][T] rows + radii / respawn scratch, and either the
+// register-resident build's line copies (maxNeighbors = 10, no obstacles) or the generic build's per-agent columns
+static size_t orca_block_shmem(const cs_worlds* w, bool lp3_static)
+{
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    const int T = rows <= 64 ? 64 : (rows <= 256 ? 256 : 512);
+    const int wpb = rows <= 64 ? 64 / rows : 1;
+    const int TL = wpb * rows;
+    const int K = w->orca_max_neighbors, nv = w->orca_n_vertices;
+    const int KO = nv > 0 ? (nv < KOBST ? nv : KOBST) : 0;
+    const bool fast10 = K == 10 && nv == 0;
+    return (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
+           (fast10 ? (size_t)10 * TL * sizeof(float4) + (lp3_static ? 0 : 72 * (sizeof(float4) + sizeof(float2))) + (size_t)T * (sizeof(float4) + sizeof(int))
+                   : (size_t)(K + KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
+}
+
+// worlds of more than 512 rows, and worlds whose generic-build columns outgrow a block's 160 KB of LDS, take the grid path
+bool orca_uses_grid(const cs_worlds* w)
+{
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    return rows > big_world_min_rows(512) || orca_block_shmem(w, true) > 160 * 1024;
+}
+
 size_t orca_big_scratch_bytes(const cs_worlds* w)
 {
-    const size_t state_bytes = (size_t)w->W * w->n * 13 * sizeof(float);
-    return ((state_bytes + 255) & ~(size_t)255) + grid_bytes(w->W, w->n, big_world_buckets(w->n));
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    const size_t state_bytes = (size_t)w->W * rows * 13 * sizeof(float);
+    return ((state_bytes + 255) & ~(size_t)255) + grid_bytes(w->W, rows, big_world_buckets(rows));
 }
 
 static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream)
 {
-    if (w->flags & CS_ROBOT_ROW) return fail(CS_ERR_ARG, "ORCA worlds beyond one block (grid neighbour search) have no robot row");
-    if (d_action) return fail(CS_ERR_ARG, "ORCA worlds beyond one block take no robot action");
-    if (w->orca_max_neighbors != 10 || w->orca_n_vertices != 0)
-        return fail(CS_ERR_ARG, "ORCA worlds beyond one block need max_neighbors = 10 and no static obstacles");
     const int n = w->n, W = w->W;
-    const int NB = big_world_buckets(n);
-    const size_t state_bytes = (size_t)W * n * 13 * sizeof(float);
+    const bool robot_row = (w->flags & CS_ROBOT_ROW) != 0;
+    const int rows = n + (robot_row ? 1 : 0);
+    if (d_action && !w->d_robot) return fail(CS_ERR_ARG, "a robot action needs cs_worlds.d_robot");
+    const int NB = big_world_buckets(rows);
+    const size_t state_bytes = (size_t)W * rows * 13 * sizeof(float);
     const size_t state_pad = (state_bytes + 255) & ~(size_t)255;
     char* base = nullptr;
     {
@@ -1316,15 +1412,24 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     }
     BigArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.W = W; a.n = n; a.G = w->G; a.NB = NB; a.dt = dt; a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
+    a.W = W; a.n = n; a.rows = rows; a.robot_row = robot_row ? 1 : 0; a.G = w->G; a.NB = NB; a.dt = dt;
+    a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
     // cell edge = neighborDist (a floor keeps a degenerate neighborDist = 0 from dividing by zero: nobody is a neighbour then)
     a.inv_cell = 1.0f / (w->orca_neighbor_dist > 1e-3f ? w->orca_neighbor_dist : 1e-3f);
-    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)W * n; }
+    if (w->layout == CS_LAYOUT_AOS) { a.as = 13; a.fs = 1; } else { a.as = 1; a.fs = (long)W * rows; }
     a.goals = w->d_goals; a.margin = w->d_safety;
+    a.robot = w->d_robot; a.action = d_action;
+    a.K = w->orca_max_neighbors; a.nv = w->orca_n_vertices; a.verts = w->d_orca_vertices; a.time_horizon_obst = w->orca_time_horizon_obst;
+    a.KO = a.nv > 0 ? (a.nv < KOBST ? a.nv : KOBST) : 0;
+    const bool fast10 = a.K == 10 && a.nv == 0;   // the register-resident solve has no obstacle lines
     float* S2 = (float*)base;
     void* grid_mem = base + state_pad;
     const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
     a.lp3_static = (lp3_env && std::strcmp(lp3_env, "static") == 0) ? 1 : 0;
+    const size_t shmem = fast10 ? (size_t)(10 * 64 + 72 + 64) * sizeof(float4) + 72 * sizeof(float2) + 64 * sizeof(int)
+                                : (size_t)(a.K + a.KO) * 64 * (2 * sizeof(float4)) + (size_t)(a.K + a.KO) * 64 * (sizeof(float) + sizeof(int));
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_bw_orca_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     HIP_TRY(hipMemcpyAsync(S2, w->d_state, state_bytes, hipMemcpyDeviceToDevice, stream));   // the columns a step does not write
     const float* cur = w->d_state;
     float* nxt = S2;
@@ -1332,13 +1437,14 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     for (int sub = 0; sub < n_substeps; ++sub) {
         a.Sin = cur; a.Sout = nxt;
         GridView g;
-        const int rcg = grid_build(cur, a.as, a.fs, W, n, NB, nullptr, a.inv_cell, grid_mem, g, stream);
+        const int rcg = grid_build(cur, a.as, a.fs, W, rows, NB, nullptr, a.inv_cell, grid_mem, g, stream);
         if (rcg) return rcg;
         a.cellxy = g.cellxy; a.start = g.start; a.sorted = g.sorted;
-        hipLaunchKernelGGL(k_bw_orca_step, dim3((n + 63) / 64, W), dim3(64), 0, stream, a);
+        if (fast10) hipLaunchKernelGGL(k_bw_orca_step<true>, dim3((rows + 63) / 64, W), dim3(64), shmem, stream, a);
+        else hipLaunchKernelGGL(k_bw_orca_step<false>, dim3((rows + 63) / 64, W), dim3(64), shmem, stream, a);
         if (d_peek) { HIP_TRY(hipGetLastError()); return CS_OK; }
         if (w->flags & CS_RESPAWN)
-            big_respawn_launch(nxt, a.as, a.fs, W, n, n, w->d_goals, w->G, nullptr, 1, w->respawn_bound_x, w->respawn_bound_y, w->d_world_flags, stream);
+            big_respawn_launch(nxt, a.as, a.fs, W, n, rows, w->d_goals, w->G, nullptr, 1, w->respawn_bound_x, w->respawn_bound_y, w->d_world_flags, stream);
         const float* t = cur; cur = nxt; nxt = const_cast<float*>(t);
     }
     HIP_TRY(hipGetLastError());
@@ -1359,7 +1465,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
     if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
-    if (rows > big_world_min_rows(512)) return orca_big_launch(w, dt, n_substeps, d_action, d_peek, stream);
+    if (orca_uses_grid(w)) return orca_big_launch(w, dt, n_substeps, d_action, d_peek, stream);
     OArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = w->W; a.n = w->n; a.rows = rows; a.G = w->G; a.flags = w->flags; a.nsub = n_substeps;
@@ -1384,11 +1490,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     // worlds of more than 64 rows keep the statically unrolled walk (their blocks have no LDS left for the projected lines)
     const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
     a.lp3_static = (T > 64 || (lp3_env && std::strcmp(lp3_env, "static") == 0)) ? 1 : 0;
-    const size_t shmem = (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
-                         (fast10 ? (size_t)10 * TL * sizeof(float4) + (a.lp3_static ? 0 : 72 * (sizeof(float4) + sizeof(float2))) + (size_t)T * (sizeof(float4) + sizeof(int))
-                                 : (size_t)(a.K + a.KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
-    if (shmem > 160 * 1024) return fail(CS_ERR_ARG, "ORCA worlds of this many rows need max_neighbors = 10 and no static obstacles "
-                                                    "(the per-agent line columns do not fit the LDS)");
+    const size_t shmem = orca_block_shmem(w, a.lp3_static != 0);
     auto launch = [&](auto kernel) -> int {
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1410,6 +1512,10 @@ int orca_variant(const cs_worlds* w, char* buf, size_t buflen)
     const int T = rows <= 64 ? 64 : (rows <= 256 ? 256 : 512);
     const bool fast10 = w->orca_max_neighbors == 10 && w->orca_n_vertices == 0;
     const int wpb = rows <= 64 ? 64 / rows : 1;
+    if (orca_uses_grid(w)) {
+        std::snprintf(buf, buflen, "k_bw_orca_step<FAST10=%d> grid=(%d,%d) block=64 (one launch per substep)", fast10 ? 1 : 0, (rows + 63) / 64, w->W);
+        return CS_OK;
+    }
     std::snprintf(buf, buflen, "k_orca_step<FAST10=%d,MAXT=%d> grid=%d block=%d wpb=%d", fast10 ? 1 : 0, T, (w->W + wpb - 1) / wpb, T, wpb);
     return CS_OK;
 }

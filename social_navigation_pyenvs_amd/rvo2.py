@@ -11,7 +11,8 @@ The reference reaches RVO2 through the ``rvo2.PyRVOSimulator`` object API (SURVE
 programmes and ``position += velocity * timeStep`` (RVO2 ``Agent::computeNeighbors / computeNewVelocity / update``,
 restated in csrc/orca.hip; parity with the third-party library itself is unpinned).
 
-Supported: any number of agents (10 neighbours and no obstacles above 64; above 512 the neighbours come from a uniform grid in HBM), per-agent radius / maxSpeed / position / velocity / preferred velocity;
+Supported: any number of agents (above 512, or when a world's obstacle / neighbour columns outgrow a block's LDS, the neighbours come
+from a uniform grid in HBM: csrc/orca.hip k_bw_orca_step), per-agent radius / maxSpeed / position / velocity / preferred velocity;
 ``neighborDist``, ``maxNeighbors``, ``timeHorizon`` must be the same for every agent (the reference never varies
 them: ORCA_DEFAULTS, motion_model_manager.py:14).  Static obstacles: ``addObstacle(vertices)`` (counter-clockwise
 polygons, or two vertices for a one-sided wall) + ``processObstacles()`` build RVO2's vertex records (point, unit direction
@@ -87,10 +88,6 @@ class PyRVOSimulator:
         for name, val in (("neighborDist", neighborDist), ("maxNeighbors", maxNeighbors), ("timeHorizon", timeHorizon)):
             if val is not None and float(val) != float(d[name]):
                 raise NotImplementedError(f"per-agent {name} is not supported (the reference uses ORCA_DEFAULTS for every agent)")
-        # (any number of agents: worlds of more than 512 take the grid neighbour search of the kernel, csrc/orca.hip -- which is built
-        #  for maxNeighbors = 10 without static obstacles: say so HERE, not at the first doStep)
-        if len(self._pos) + 1 > 512:
-            self._check_big_world()
         self._pos.append([float(pos[0]), float(pos[1])])
         v = d["velocity"] if velocity is None else velocity
         self._vel.append([float(v[0]), float(v[1])])
@@ -100,18 +97,10 @@ class PyRVOSimulator:
         self._cw = None
         return len(self._pos) - 1
 
-    def _check_big_world(self):
-        if self._polygons:
-            raise NotImplementedError("static obstacles are not built for ORCA worlds of more than 512 agents (grid neighbour search)")
-        if int(self._defaults["maxNeighbors"]) != 10:
-            raise NotImplementedError("ORCA worlds of more than 512 agents (grid neighbour search) are built for maxNeighbors = 10")
-
     def addObstacle(self, vertices):
         """Counter-clockwise polygon (or two vertices: a wall seen from its right side).  Returns the number of the
         obstacle's first vertex, like RVO2."""
         first = sum(len(p) for p in self._polygons)
-        if len(self._pos) > 512:
-            raise NotImplementedError("static obstacles are not built for ORCA worlds of more than 512 agents (grid neighbour search)")
         self._polygons.append([(float(v[0]), float(v[1])) for v in vertices])
         return first
 

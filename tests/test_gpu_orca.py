@@ -136,7 +136,10 @@ def test_orca_worlds_of_more_than_64_rows(n, robot):
         np.testing.assert_array_equal(cw.get_robot()[:, [0, 1, 3, 4]], rrobot[:, [0, 1, 3, 4]])
 
 
-def test_orca_large_world_limits():
+def test_orca_large_worlds_have_no_limits():
+    """Beyond 512 rows -- or when the generic build's per-agent columns outgrow a block's LDS -- a world takes the grid path, which
+    builds everything the one-block kernel does: robot row, respawn, static obstacles, any maxNeighbors (the parity of each:
+    test_orca_grid_path_robot_row_obstacles_and_other_neighbour_counts)."""
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
     S = np.zeros((1, 513, 13), np.float32)
@@ -144,17 +147,16 @@ def test_orca_large_world_limits():
     S[0, :, 8] = 0.3
     S[0, :, 12] = 1.0
     g = np.zeros((1, 513, 1, 2), np.float32)
-    # beyond 512 rows a world takes the grid path (test_orca_world_of_4096_agents_through_the_grid; respawn rule and peek:
-    # test_orca_grid_path_respawn_and_peek_equal_the_restatement); what that path does not build is refused loudly: a robot row,
-    # static obstacles, maxNeighbors other than 10
     CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca").step(0.0125, 1)
     CrowdWorlds(S, g, None, np.zeros((1, 513), np.float32), None, type="orca", respawn_bounds=(7.0, 1.5)).step(0.0125, 1)
-    with pytest.raises(ValueError, match="beyond one block"):
-        CrowdWorlds(S, g[:, :512], None, np.zeros((1, 513), np.float32), None, type="orca", robot_row=True).step(0.0125, 1)
-    # the generic variant keeps (K + obstacle lines) x 40 B per agent in the LDS: 300 agents with a square of walls do not fit
+    cw = CrowdWorlds(S, g[:, :512], None, np.zeros((1, 513), np.float32), None, type="orca", robot_row=True, robot=S[:, -1].copy())
+    assert "k_bw_orca_step<FAST10=1>" in cw.step_variant(), cw.step_variant()
+    cw.step(0.0125, 1, np.array([[0.5, 0.0]], np.float32))
+    # the generic variant keeps (K + obstacle lines) x 40 B per agent in the LDS: 300 agents with a square of walls do not fit a block
     verts = orc.process_obstacles([[[-50, -50], [50, -50], [50, 50], [-50, 50]]])
-    with pytest.raises(ValueError, match="LDS"):
-        CrowdWorlds(S[:, :300], g[:, :300], None, np.zeros((1, 300), np.float32), None, type="orca", orca_vertices=verts).step(0.0125, 1)
+    cw = CrowdWorlds(S[:, :300], g[:, :300], None, np.zeros((1, 300), np.float32), None, type="orca", orca_vertices=verts)
+    assert "k_bw_orca_step<FAST10=0>" in cw.step_variant(), cw.step_variant()
+    cw.step(0.0125, 1)
 
 
 def test_orca_peek_does_not_commit():
@@ -568,6 +570,77 @@ def test_orca_grid_path_on_small_worlds_equals_the_restatement(layout):
     cols = [0, 1, 3, 4, 5, 6, 10, 11]
     np.testing.assert_array_equal(got[..., cols], ref[..., cols])
     np.testing.assert_array_equal(ggoals, rgoals)
+
+
+@pytest.mark.parametrize("case", ["robot_action", "robot_respawn", "obstacles", "k5", "k16_obstacles_robot"])
+def test_orca_grid_path_robot_row_obstacles_and_other_neighbour_counts(case):
+    """SURVEY.md §8 row f3, the rest of the ORCA grid path (forced onto small worlds so that the restatement checks it quickly): the robot
+    as the last row, moved by its action through cs_worlds.d_robot and seen one substep late (motion_model_manager.py:389), the respawn
+    rule with the robot row in its maxima, static obstacles and maxNeighbors other than 10 (the generic LDS-column solve with its
+    neighbour columns filled in (distSq, row) order) -- bit-identical to the C restatement and to the one-block kernel."""
+    import os
+
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rng = np.random.default_rng(len(case))
+    robot = "robot" in case
+    verts = None
+    kw = {}
+    if "obstacles" in case:
+        W, n = 6, 30
+        S, goals, verts, _ = _scene_with_polygons(rng, W, n + int(robot))
+        goals = goals[:, :n]
+        S[:, n:, 5:7] = 0.0
+        kw["verts"] = verts
+    elif case == "robot_respawn":
+        from social_navigation_pyenvs_amd import scenarios as sc
+        W, n = 5, 40
+        pos, yaw, g = sc.parallel_traffic(W, n + 1, 30.0, 8.0, seed0=9)
+        S = sc.make_states(pos, yaw, g).astype(np.float32)
+        goals = g[:, :n].astype(np.float32)
+        for w in range(W):
+            for k, i in enumerate(rng.choice(n, 4, replace=False)):
+                S[w, i, 0] = goals[w, i, 0, 0] + 3.0 + 0.01 * (k + 1)
+        S[:, n, 0] = 14.0                                               # the robot is the rightmost row: it sets the respawn abscissa
+        d = goals[:, :, 0] - S[:, :n, 0:2]
+        S[:, :n, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+        S[:, :n, 10:12] = goals[:, :, 0]
+        kw.update(respawn=True, bounds=(15.0, 4.0))
+    else:
+        W, n = 5, 90
+        S, goals = _lattice_world(W, n + int(robot), rng, spacing=1.1)
+        goals = goals[:, :n]
+    rows = n + int(robot)
+    K = 5 if case == "k5" else (16 if case.startswith("k16") else 10)
+    margin = np.full((W, rows), 0.01, np.float32)
+    robots = S[:, -1].copy() if robot else None
+    action = rng.normal(0, 0.5, (W, 2)).astype(np.float32) if robot else None
+    res = {}
+    for mode in ("grid", "block"):
+        if mode == "grid":
+            os.environ["CROWDSTEP_BIGWORLD_MIN_ROWS"] = "1"
+        try:
+            cw = CrowdWorlds(S, goals, None, margin, None, type="orca", robot_row=robot, robot=robots, orca_vertices=verts,
+                             respawn_bounds=kw.get("bounds"))
+            cw.orca_params["max_neighbors"] = K
+            assert ("k_bw_orca_step" in cw.step_variant()) == (mode == "grid"), cw.step_variant()
+            for _ in range(2):
+                cw.step(0.0125, 20, action)
+            res[mode] = (cw.get_states(), cw.get_goals(), cw.get_robot() if robot else None)
+        finally:
+            os.environ.pop("CROWDSTEP_BIGWORLD_MIN_ROWS", None)
+    ref, rg, rr = S, goals, robots
+    for _ in range(2):
+        ref, rg, rr = orc.orca_step_block(ref, rg, margin, 0.0125, 20, robot_visible=robot, robot=rr, action=action, max_nb=K, **kw)
+    cols = [0, 1, 3, 4, 5, 6, 10, 11]
+    np.testing.assert_array_equal(res["grid"][0], res["block"][0])
+    np.testing.assert_array_equal(res["grid"][1], res["block"][1])
+    np.testing.assert_array_equal(res["grid"][0][:, :n][..., cols], ref[:, :n][..., cols])
+    np.testing.assert_array_equal(res["grid"][1], rg)
+    if robot:
+        np.testing.assert_array_equal(res["grid"][2][:, [0, 1, 3, 4]], rr[:, [0, 1, 3, 4]])
+        np.testing.assert_array_equal(res["grid"][0][:, n, [0, 1, 3, 4]], rr[:, [0, 1, 3, 4]])
+    assert np.max(np.abs(ref[:, :n, 0:2] - S[:, :n, 0:2])) > 0.05
 
 
 def test_rvo2_module_with_a_thousand_agents():
