@@ -22,6 +22,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "orca_sortnet.h"
 
 #pragma clang fp contract(off)
 
@@ -674,6 +675,7 @@ __device__ __forceinline__ void key_insert10(double (&key)[10], double x)
     }
 }
 __device__ __forceinline__ double key_sentinel() { return __hiloint2double(0x7F7FFFFF, (int)0xFFFFFFFFu); }
+#define ORCA_CE(a, b) { const double ce_lo_ = fmin(a, b); b = fmax(a, b); a = ce_lo_; }
 
 // From the ten neighbour keys on: ORCA lines, linearProgram2, linearProgram3.  fetch(b, q, rad): (x, y, vx, vy) and radius +
 // margin of row b (LDS rows of the world in the crowd kernel, global rows found through the grid in the big-world kernel).
@@ -764,16 +766,38 @@ __device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4*
 {
     OSTAMP(0);
     double key[10];
-#pragma unroll
-    for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
     const float range2 = neighbor_dist * neighbor_dist;
-    for (int b = 0; b < rows; ++b) {
+    auto candidate = [&](int b) -> double {   // row b's key, or the sentinel (out of range, myself, a lane without an agent)
         const float4 q = pv[b];
         const float ddx = px - q.x, ddy = py - q.y;
         const float dsq = ddx * ddx + ddy * ddy;
         const bool in = active && (dsq < range2) && (b != row);
-        key_insert10(key, in ? __hiloint2double((int)__float_as_uint(dsq), b) : key_sentinel());
+        return in ? __hiloint2double((int)__float_as_uint(dsq), b) : key_sentinel();
+    };
+    // The ten smallest keys in order are a function of the key SET: rows are taken eight at a time through a 19-comparator sorting
+    // network and merged into the list by a pruned odd-even merge (25 comparators; orca_sortnet.h, generated and checked by
+    // tools/gen_sortnet.py) -- 44 compare-exchanges per eight rows where one-at-a-time insertion takes 80; the rows left over are inserted.
+    int b0 = 0;
+    if (rows >= 8) {
+        double C[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) C[c] = candidate(c);
+        ORCA_SORT8(ORCA_CE, C)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) key[c] = C[c];
+        key[8] = key[9] = key_sentinel();
+#pragma nounroll
+        for (b0 = 8; b0 + 8 <= rows; b0 += 8) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) C[c] = candidate(b0 + c);
+            ORCA_SORT8(ORCA_CE, C)
+            ORCA_MERGE10_8(ORCA_CE, key, C)
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
     }
+    for (int b = b0; b < rows; ++b) key_insert10(key, candidate(b));
     orca_solve_fast10(active, lp3_static, key, row, [&](int b, float4& q, float& rad) { q = pv[b]; rad = rr[b]; }, px, py, vx, vy, my_r, vmax,
                       pvx, pvy, time_horizon, dt, L, R, nvx, nvy, g_ost, g_ost_last);
 }

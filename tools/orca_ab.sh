@@ -1,8 +1,11 @@
 #!/bin/bash
-# usage (GPU box): tools/orca_ab.sh  -- cfg4 kernel time, lp3_rows vs the static walk, r1 protocol (dense phase) and cycle average
-for mode in rows static; do
-  for proto in "--steps 20 --warmup 3 --repeats 1" "--steps 20 --warmup 3 --repeats 7"; do
-    CROWDSTEP_ORCA_LP3=$mode python3 bench.py --model orca --scenario circle --no-other-configs --no-cpu-baseline $proto 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$mode | $proto | kernel_ms avg %.4f min %.4f max %.4f' % (r['kernel_avg_ms'], r['kernel_min_ms'], r['kernel_max_ms']))"
-  done
-done
+# cfg4 (4096 x 25 ORCA, circle crossing) kernel time in its two named phases; usage: tools/orca_ab.sh <tag>
+B="python3 bench.py --no-cpu-baseline --no-other-configs --model orca --scenario circle --steps 20"
+$B --warmup 0 > gpurun_out/orca_first20_$1.json 2>gpurun_out/orca_ab.err
+$B --warmup 25 > gpurun_out/orca_dense_$1.json 2>>gpurun_out/orca_ab.err
+python3 - "$1" <<'PY'
+import json,sys
+for ph in ("first20","dense"):
+    d=json.loads(open(f"gpurun_out/orca_{ph}_{sys.argv[1]}.json").read().strip().splitlines()[-1]); r=d["roofline"]
+    print(ph, sys.argv[1], round(r["kernel_avg_ms"]*1e3,1), "us", r["variant"])
+PY
