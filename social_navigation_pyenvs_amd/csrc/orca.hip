@@ -362,8 +362,9 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
     const float wLenSq = wx * wx + wy * wy;
     const float dot1 = wx * rpx + wy * rpy;
     const bool circ = coll || (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq);
-    const float root = sqrtf(circ ? wLenSq : distSq - RSq);   // |w|  or  the leg length
-    const float inv = 1.0f / (circ ? root : distSq);
+    const float root = ieee_sqrt(circ ? wLenSq : distSq - RSq);   // |w|  or  the leg length
+    const float den = circ ? root : distSq;
+    const float inv = (den == 0.0f) ? INFINITY : ieee_div(1.0f, den);   // (w == 0 exactly: 1 / +0 as the operator gives it)
     // cut-off circle (of the time horizon, or of the time step when the discs overlap)
     const float uwx = wx * inv, uwy = wy * inv;
     const float sc = R * kT - root;
@@ -706,8 +707,8 @@ __device__ void orca_solve_fast10(bool active, bool lp3_static, const double (&k
     // linearProgram2(lines, maxSpeed, prefVelocity, directionOpt = false)
     float rx, ry;
     if (pvx * pvx + pvy * pvy > vmax * vmax) {
-        const float nrm = sqrtf(pvx * pvx + pvy * pvy);
-        const float inv = 1.0f / nrm;
+        const float nrm = ieee_sqrt(pvx * pvx + pvy * pvy);
+        const float inv = ieee_div(1.0f, nrm);
         rx = pvx * inv * vmax; ry = pvy * inv * vmax;
     } else { rx = pvx; ry = pvy; }
     int failed = cnt;
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
             vx = nvx; vy = nvy;
             px += vx * dt; py += vy * dt;
             float ddx = g0x - px, ddy = g0y - py;
-            if (sqrtf(ddx * ddx + ddy * ddy) < r) { // update_goals: strict <  (:66-70)
+            if (ieee_sqrt(ddx * ddx + ddy * ddy) < r) { // update_goals: strict <  (:66-70)
                 int k = a.G;
                 for (int g = 0; g < a.G; ++g) if (isnan(gi[2 * g])) { k = g; break; }
                 if (a.peek_out == nullptr) {
@@ -953,8 +954,8 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
                 } else if (k > 1) { g0x = gi[2]; g0y = gi[3]; }
                 ddx = g0x - px; ddy = g0y - py;
             }
-            const float nrm = sqrtf(ddx * ddx + ddy * ddy);
-            if (nrm > vmax) { pvx = ddx / nrm; pvy = ddy / nrm; } else { pvx = ddx; pvy = ddy; }
+            const float nrm = ieee_sqrt(ddx * ddx + ddy * ddy);
+            if (nrm > vmax) { pvx = ieee_div(ddx, nrm); pvy = ieee_div(ddy, nrm); } else { pvx = ddx; pvy = ddy; }
             lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
         } else if (is_robot) {
             // set_state_orca(robot) AFTER doStep (:389): the simulator's robot agent takes the true state (moved by the
@@ -965,7 +966,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
         __syncthreads();
         if (a.flags & CS_RESPAWN) { // motion_model_manager.py:407-422, sequential inside a world
             const float rdx = px - g0x, rdy = py - g0y;
-            const int flag = (human && respawn_here && sqrtf(rdx * rdx + rdy * rdy) < 3.0f) ? 1 : 0;
+            const int flag = (human && respawn_here && ieee_sqrt(rdx * rdx + rdy * rdy) < 3.0f) ? 1 : 0;
             bool any_flag;
             if constexpr (MAXT == 64) any_flag = __builtin_amdgcn_ballot_w64(flag != 0) != 0;
             else any_flag = __syncthreads_or(flag) != 0;        // a world spans several wavefronts: block-wide vote
