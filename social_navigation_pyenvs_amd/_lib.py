@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libcrowdstep.so")
+# CROWDSTEP_LIB: another build of the library (same-box A/B of two kernel builds: tools/ab_lib.sh); never set in production
+LIB_PATH = os.environ.get("CROWDSTEP_LIB") or os.path.join(_PKG, "libcrowdstep.so")
 
 CS_OK = 0
 CS_ERR_ARG, CS_ERR_TYPE, CS_ERR_HIP, CS_ERR_NO_DEVICE = -1, -2, -3, -4

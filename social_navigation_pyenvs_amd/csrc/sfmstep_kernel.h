@@ -278,11 +278,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
         STAMP(7);
-        // imitation block: what the robot's own integrator sees of the crowd at this substep (it runs before update_humans)
-        if (a.snap != nullptr && human) a.snap[((long)sub * a.W + w) * n + row] = make_float4(px, py, vx, vy);
-        // cs_step_trace: my row as the previous substep left it (the last one is written behind the loop)
-        if (a.trace != nullptr && (human || is_robot) && sub > 0)
-            write_trace(a.trace + (((long)(sub - 1) * a.W + w) * rows + row) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
+        if (a.snap != nullptr || a.trace != nullptr) {   // (one scalar branch for both recorders: neither is on in a plain cs_step)
+            // imitation block: what the robot's own integrator sees of the crowd at this substep (it runs before update_humans)
+            if (a.snap != nullptr && human) a.snap[((long)sub * a.W + w) * n + row] = make_float4(px, py, vx, vy);
+            // cs_step_trace: my row as the previous substep left it (the last one is written behind the loop)
+            if (a.trace != nullptr && (human || is_robot) && sub > 0)
+                write_trace(a.trace + (((long)(sub - 1) * a.W + w) * rows + row) * 12, px, py, th, vx, vy, bvx, bvy, om, gx, gy, g0x, g0y);
+        }
         const int Hf = (rows - 1) >> 1;
         const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
         const float2* rv = lds_v + cur * TP + pbase + row + 1;
@@ -333,9 +335,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             LDS_ORDER_FENCE();
         }
         // lean build without walls: request the first group's partner rows first thing; the goal test and part A below run
-        // while they are in flight.  With walls the rows would be held in registers across the segment loops -- 17 spilled
-        // VGPRs whose scratch reloads cost 250 vs 200 us on the 8192 x 50 shard -- so they are fetched at the head of the
-        // group loop instead (fetching between the segment loops and the heading / torque arithmetic spills as well)
+        // while they are in flight.  With walls the rows would be held in registers across the segment loops (17 spilled VGPRs
+        // in the 50-row build at the three-wave budget), so they are fetched at the head of the group loop instead (fetching
+        // between the segment loops and the heading / torque arithmetic spills as well); worth 1 % on the 8192 x 50 shard
         if constexpr (LEAN && NO_WALLS) { if (valid && Hf >= UA) fetch(qa, va, 0); }
         // even row counts: the antipodal partner (evaluated by both ends, no hand-over) is requested up front as well
         float4 qz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
