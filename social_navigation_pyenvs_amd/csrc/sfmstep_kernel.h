@@ -207,6 +207,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     // ---- prologue: publish substep-0 rows ----------------------------------------------
     if (is_robot && robot_moves) robot_step();
     const float my_rs = r + safety;
+    // Helbing / Guo exponents with MY radius + safety space folded into the offset: (r_ij - d) cB + lA = (rs_j - d) cB + (lA + rs_i cB),
+    // one add less per pair; the contact test rd > 0 becomes max(rs_j - d) > -rs_i
+    float lAi = 0.0f, lCi = 0.0f;
     for (int i = tid; i < 2 * TP; i += T) { // padding stays finite
         lds_p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         lds_v[i] = make_float2(0.0f, 0.0f);
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     int cur = 0;
+    lAi = fmaf(sp.cB, my_rs, sp.lA); lCi = fmaf(sp.cD, my_rs, sp.lC);
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
         STAMP(7);
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         if constexpr (N3L) {
             if (valid) {
                 float2* acc = lds_acc + pbase + row + 1;                 // acc[u * 2T + k]: that partner's slot in row u
-                float ex = 0.0f, ey = 0.0f, rdmax = -1.0f;
+                float ex = 0.0f, ey = 0.0f, rdmax = -1.0e30f;   // max over my partners of rs_j - dist
                 if constexpr (!(LEAN && NO_WALLS)) { if (Hf >= UA) fetch(qa, va, 0); }
                 auto pair_once = [&](const float4 q, const float2 vq, float& fx, float& fy) {
                     const float dx = px - q.x, dy = py - q.y;
@@ -514,11 +518,11 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         // zeros unless rd > 0 and are added by the contact pass below
                         const float d2 = fmaf(dx, dx, dy * dy);
                         const float inv = rsq_fast(d2);
-                        const float rd = fmaf(-d2, inv, my_rs + q.z);             // rij - dist
-                        const float ga = exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv; // |A| e^{rd/B} / dist
+                        const float rd = fmaf(-d2, inv, q.z);                     // rs_j - dist  (= rij - dist - rs_i)
+                        const float ga = exp2_fast(fmaf(rd, sp.cB, lAi)) * inv;   // |A| e^{(rij - dist)/B} / dist
                         fx = ga * dx; fy = ga * dy;
                         if constexpr (SOC == 1) {
-                            const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * (inv * sp.sAC); // +-|C| e^{rd/D} / dist
+                            const float gc = exp2_fast(fmaf(rd, sp.cD, lCi)) * (inv * sp.sAC); // +-|C| e^{(rij - dist)/D} / dist
                             fx = fmaf(-gc, dy, fx); fy = fmaf(gc, dx, fy);                       // along t = (-ny, nx)
                         }
                         rdmax = fmaxf(rdmax, rd);
@@ -555,9 +559,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < UA; ++u) {
-                            rd[u] = fmaf(-d2[u], inv[u], my_rs + q[u].z);
-                            ea[u] = fmaf(rd[u], sp.cB, sp.lA);
-                            if constexpr (SOC == 1) ec[u] = fmaf(rd[u], sp.cD, sp.lC);
+                            rd[u] = fmaf(-d2[u], inv[u], q[u].z);
+                            ea[u] = fmaf(rd[u], sp.cB, lAi);
+                            if constexpr (SOC == 1) ec[u] = fmaf(rd[u], sp.cD, lCi);
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -649,10 +653,11 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 }
                 STAMP(9);
                 LDS_ORDER_FENCE(); // the reaction slots of this lane were written by its partners
-                float rx = 0.0f, ry = 0.0f;
                 const float2* rr = lds_acc + pbase + row;
+                float rx, ry;
+                { const float2 lo = rr[0], hi = rr[rows]; rx = lo.x + hi.x; ry = lo.y + hi.y; }
 #pragma unroll
-                for (int u = 0; u < UA; ++u) {
+                for (int u = 1; u < UA; ++u) {
                     const float2 lo = rr[u * AR], hi = rr[u * AR + rows];
                     rx += lo.x + hi.x; ry += lo.y + hi.y;
                 }
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 STAMP(10);
                 if constexpr (SOC != 2) {
                     fsx *= sp.sA; fsy *= sp.sA;
-                    if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
+                    if (__builtin_amdgcn_ballot_w64(rdmax > -my_rs) != 0) { // contact somewhere in this wavefront
                         const float4* pp = lds_p + cur * TP + pbase;
                         float2* pvel = lds_v + cur * TP + pbase;
                         pvel[row] = make_float2(vx, vy); // every lane of the wavefront is here: publish the velocities now
@@ -792,7 +797,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             }
             STAMP(6);
             // -- part B: total force, body frame, torque  :262-271, :165-182
-            const float fix = fdx + fox + fsx, fiy = fdy + foy + fsy;
+            // (no-walls builds: fo = 0 is a compile-time fact, and x + 0 is not an identity the compiler may drop)
+            const float fix = NO_WALLS ? fdx + fsx : fdx + fox + fsx, fiy = NO_WALLS ? fdy + fsy : fdy + foy + fsy;
+            const float fpx = NO_WALLS ? fsx : fox + fsx, fpy = NO_WALLS ? fsy : foy + fsy;   // what acts across the heading: fo + fs
             float gfx = fix, gfy = fiy, torque = torque_a;
             if constexpr (HEADED > 0) {
                 if constexpr (HEADED == 2) {  // torque on the total force
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     torque = -k_theta * delta - k_omega * om;
                 }
                 gfx = fix * c + fiy * s;
-                gfy = ko * ((fox + fsx) * (-s) + (foy + fsy) * c) - kd * bvy;
+                gfy = ko * (fpx * (-s) + fpy * c) - kd * bvy;
             }
             // -- explicit Euler, :273-283 (position uses the velocity stored in the incoming row)
             const float in_vx = cvx, in_vy = cvy; // what the reference leaves in agents_state[i,3:5]
