@@ -39,7 +39,10 @@ __device__ __forceinline__ void for_each_index(F&& f, std::integer_sequence<int,
 // load above the store.  This compiler-only fence pins the program order of the LDS accesses around it.
 #define LDS_ORDER_FENCE() asm volatile("" ::: "memory")
 
-constexpr int UA = 4; // reaction accumulator rows of the pair-once loop (independent LDS read-modify-write chains)
+// reaction accumulator rows of the pair-once loop (independent LDS read-modify-write chains) = partners per group.  Measured at
+// 4096 x 25 (same-box A/B): 6 rows 38.5 us, 4 rows 35.9, 3 rows 34.2, 2 rows 32.5, 1 row 32.8 -- every row costs a 1 KB zeroing store
+// and two 512 B reads in the reaction sum per wavefront-substep, and the LDS pipe of a CU (128 B/clk, 8 wavefronts) is ~40 % busy
+constexpr int UA = 2;
 constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one wavefront: 2 x 64 doubled rows)
 
 //   OCC    = waves per SIMD the register allocation must allow: 4 (<= 128 VGPRs, a few spills) when the grid holds more
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             }
                         }
 #pragma unroll
-                        for (int u = 0; u < UA; u += 2) rdmax = fmaxf(fmaxf(rdmax, rd[u]), rd[u + 1]);
+                        for (int u = 0; u < UA; ++u) rdmax = fmaxf(rdmax, rd[u]);   // (pairs of them fuse into v_max3_f32)
                     }
 #pragma unroll
                     for (int u = 0; u < UA; ++u) acc[u * AR + kk + u] = ac[u];
