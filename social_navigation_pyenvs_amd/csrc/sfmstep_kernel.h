@@ -282,6 +282,18 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 #endif
     int cur = 0;
     lAi = fmaf(sp.cB, my_rs, sp.lA); lCi = fmaf(sp.cD, my_rs, sp.lC);
+    // compile-time row counts: radius + safety space of my partners (ring distance k + 1) never changes during a launch -- held in
+    // registers, so that a substep reads 8-byte (x, y) partner rows from the LDS instead of 12-byte ones (the LDS pipe is a co-bottleneck)
+    constexpr int RSN = (ROWS_CT > 0 && N3L) ? (ROWS_CT - 1) / 2 + 1 : 1;
+    float rsj[RSN];
+#pragma unroll
+    for (int k = 0; k < RSN; ++k) rsj[k] = 0.0f;
+    if constexpr (ROWS_CT > 0 && N3L) {
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < RSN; ++k) rsj[k] = lds_p[pbase + row + 1 + k].z;
+        }
+    }
     for (int sub = 0; sub < a.nsub; ++sub) {
         const int nxt = cur ^ 1;
         STAMP(7);
@@ -300,7 +312,12 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
-                q[u] = rp[kk + u];
+                if constexpr (ROWS_CT > 0 && N3L) {   // (kk is a compile-time constant at every call of these builds)
+                    const float2 xy = *reinterpret_cast<const float2*>(&rp[kk + u]);
+                    q[u] = make_float4(xy.x, xy.y, rsj[kk + u], 0.0f);
+                } else {
+                    q[u] = rp[kk + u];
+                }
                 if constexpr (N3L && SOC == 2) vq[u] = rv[kk + u]; else vq[u] = make_float2(0.0f, 0.0f);
             }
         };
@@ -351,7 +368,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         float2 vz = make_float2(0.0f, 0.0f);
         if constexpr (LEAN && NO_WALLS) {
             if (valid && (rows & 1) == 0) {
-                qz = rp[Hf];
+                if constexpr (ROWS_CT > 0 && N3L) { const float2 xy = *reinterpret_cast<const float2*>(&rp[(ROWS_CT - 1) / 2]); qz = make_float4(xy.x, xy.y, rsj[(ROWS_CT - 1) / 2], 0.0f); }
+                else qz = rp[Hf];
                 if constexpr (SOC == 2) vz = rv[Hf];
             }
         }
@@ -648,7 +666,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself (lean build: row fetched at the top)
                     float fx, fy;
                     if constexpr (!(LEAN && NO_WALLS)) {
-                        qz = rp[Hf];
+                        if constexpr (ROWS_CT > 0 && N3L) { const float2 xy = *reinterpret_cast<const float2*>(&rp[(ROWS_CT - 1) / 2]); qz = make_float4(xy.x, xy.y, rsj[(ROWS_CT - 1) / 2], 0.0f); }
+                        else qz = rp[Hf];
                         if constexpr (SOC == 2) vz = rv[Hf];
                     }
                     pair_once(qz, vz, fx, fy);
