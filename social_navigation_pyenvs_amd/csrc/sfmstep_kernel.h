@@ -269,12 +269,6 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     }
     __syncthreads();
 
-    if constexpr (N3L) {
-        float4* z = reinterpret_cast<float4*>(lds_acc);
-#pragma unroll
-        for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        LDS_ORDER_FENCE();
-    }
 #ifdef CS_STAMPS
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long st_last;
@@ -288,10 +282,20 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     float rsj[RSN];
 #pragma unroll
     for (int k = 0; k < RSN; ++k) rsj[k] = 0.0f;
+    // ... and the reaction slot of partner k: (row + 1 + k) mod rows.  With the modulo every slot of an accumulator row is written by
+    // exactly one lane in every group, so the FIRST group stores instead of accumulating (no zeroing pass, no read), and a receiver reads
+    // one slot per row instead of a low and a high copy -- a quarter of the loop's LDS bytes at 25 rows
+    int aoff[RSN];
+#pragma unroll
+    for (int k = 0; k < RSN; ++k) aoff[k] = 0;
     if constexpr (ROWS_CT > 0 && N3L) {
         if (valid) {
 #pragma unroll
-            for (int k = 0; k < RSN; ++k) rsj[k] = lds_p[pbase + row + 1 + k].z;
+            for (int k = 0; k < RSN; ++k) {
+                rsj[k] = lds_p[pbase + row + 1 + k].z;
+                const int t = row + 1 + k;
+                aoff[k] = t >= ROWS_CT ? t - ROWS_CT : t;
+            }
         }
     }
     for (int sub = 0; sub < a.nsub; ++sub) {
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         //    forces, the Farina torque, the new heading and its sine / cosine), then the partner groups, and only the
         //    short force-dependent tail (body-frame projection, Euler step, publish) follows the reaction sum.
         float fsx = 0.0f, fsy = 0.0f;
-        // (the reaction accumulators were zeroed behind the previous substep's reaction sum, off the critical path)
+        // (the reaction accumulators need no zeroing: the first partner group of a substep stores into them)
         STAMP(8);
         // -- part A of the per-agent update: everything that does not need this substep's social force
         const float c = cs, s = sn;          // rotation matrix of the incoming heading, :254-256
@@ -528,6 +532,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         if constexpr (N3L) {
             if (valid) {
                 float2* acc = lds_acc + pbase + row + 1;                 // acc[u * 2T + k]: that partner's slot in row u
+                float2* accw = lds_acc + pbase;                          // compile-time row builds: slot aoff[k] of the world
                 float ex = 0.0f, ey = 0.0f, rdmax = -1.0e30f;   // max over my partners of rs_j - dist
                 if constexpr (!(LEAN && NO_WALLS)) { if (Hf >= UA) fetch(qa, va, 0); }
                 auto pair_once = [&](const float4 q, const float2 vq, float& fx, float& fy) {
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 // accumulator row pitch: 2 KiB, out of reach of the ds_read2_b64 / ds_write2_b64 offset fields on purpose:
                 // the paired forms take 8 / 13 LDS cycles, two single b64 accesses 4 / 12 (MI355X_MICROARCH.md, LDS table)
                 constexpr int AR = ACC_PITCH;
-                auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], float2 (&ac)[UA], int kk) {
+                auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], float2 (&ac)[UA], const int (&so)[UA]) {
                     if constexpr (SOC == 2) {
 #pragma unroll
                         for (int u = 0; u < UA; ++u) {
@@ -610,9 +615,11 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         for (int u = 0; u < UA; ++u) rdmax = fmaxf(rdmax, rd[u]);   // (pairs of them fuse into v_max3_f32)
                     }
 #pragma unroll
-                    for (int u = 0; u < UA; ++u) acc[u * AR + kk + u] = ac[u];
+                    for (int u = 0; u < UA; ++u) accw[u * AR + so[u]] = ac[u];
                     LDS_ORDER_FENCE(); // the next group's slots were written by other lanes in this group
                 };
+                // reaction slot of the partner at ring distance k + 1: its row index inside the world, (row + 1 + k) mod rows
+                auto slot_rt = [&](int k) { const int t = row + 1 + k; return t >= rows ? t - rows : t; };
                 int k0 = 0;
                 if constexpr (ROWS_CT > 0) {
                     // rows known at compile time: the groups are laid out one after the other, no loop, no scalar branches
@@ -621,46 +628,76 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     float2 vb[UA], ac[UA];
                     for_each_index([&](auto gtag) {
                         constexpr int g = decltype(gtag)::value;
+                        int so[UA];
 #pragma unroll
-                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + g * UA + u];
+                        for (int u = 0; u < UA; ++u) {
+                            so[u] = aoff[g * UA + u];
+                            ac[u] = g == 0 ? make_float2(0.0f, 0.0f) : accw[u * AR + so[u]];   // the first group stores: no zeroing pass
+                        }
                         if constexpr (g + 1 < NG) {
                             if constexpr (g & 1) fetch(qa, va, (g + 1) * UA); else fetch(qb, vb, (g + 1) * UA);
                         }
                         asm volatile("" ::: "memory");
-                        if constexpr (g & 1) group(qb, vb, ac, g * UA); else group(qa, va, ac, g * UA);
+                        if constexpr (g & 1) group(qb, vb, ac, so); else group(qa, va, ac, so);
                     }, std::make_integer_sequence<int, NG>{});
                     k0 = NG * UA;
                 } else if (Hf >= UA) {
                     float4 qb[UA];
                     float2 vb[UA], ac[UA];
+                    int so[UA];
+                    bool first = true;
                     for (;;) {
 #pragma unroll
-                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + k0 + u];
+                        for (int u = 0; u < UA; ++u) {
+                            so[u] = slot_rt(k0 + u);
+                            ac[u] = first ? make_float2(0.0f, 0.0f) : accw[u * AR + so[u]];   // (uniform: the first group stores)
+                        }
+                        first = false;
                         const bool more_b = k0 + 2 * UA <= Hf;
                         if (more_b) fetch(qb, vb, k0 + UA);
                         asm volatile("" ::: "memory");
-                        group(qa, va, ac, k0);
+                        group(qa, va, ac, so);
                         k0 += UA;
                         if (!more_b) break;
 #pragma unroll
-                        for (int u = 0; u < UA; ++u) ac[u] = acc[u * AR + k0 + u];
+                        for (int u = 0; u < UA; ++u) { so[u] = slot_rt(k0 + u); ac[u] = accw[u * AR + so[u]]; }
                         const bool more_a = k0 + 2 * UA <= Hf;
                         if (more_a) fetch(qa, va, k0 + UA);
                         asm volatile("" ::: "memory");
-                        group(qb, vb, ac, k0);
+                        group(qb, vb, ac, so);
                         k0 += UA;
                         if (!more_a) break;
                     }
                 }
-                for (int k = k0; k < Hf; ++k) {
+                if constexpr (ROWS_CT > 0) {
+                    constexpr int HC = (ROWS_CT - 1) / 2;
+                    if constexpr (HC % UA != 0) {   // (UA = 2: at most one partner left over)
+                        static_assert(HC % UA == 1 || UA > 2, "remainder of the compile-time group layout");
+#pragma unroll
+                        for (int k = (HC / UA) * UA; k < HC; ++k) {
+                            float fx, fy;
+                            float2 vq = make_float2(0.0f, 0.0f);
+                            if constexpr (SOC == 2) vq = rv[k];
+                            const float2 xy = *reinterpret_cast<const float2*>(&rp[k]);
+                            pair_once(make_float4(xy.x, xy.y, rsj[k], 0.0f), vq, fx, fy);
+                            ex += fx; ey += fy;
+                            float2 ac = (k == 0) ? make_float2(0.0f, 0.0f) : accw[aoff[k]];   // (partner 0 without a full group: first writer of row 0)
+                            ac.x += fx; ac.y += fy;
+                            accw[aoff[k]] = ac;
+                            LDS_ORDER_FENCE();
+                        }
+                    }
+                } else
+                for (int k = k0; k < Hf; ++k) {   // (fewer than UA partners left; k - k0 is the accumulator row they go to when no group ran)
                     float fx, fy;
                     float2 vq = make_float2(0.0f, 0.0f);
                     if constexpr (SOC == 2) vq = rv[k];
                     pair_once(rp[k], vq, fx, fy);
                     ex += fx; ey += fy;
-                    float2 ac = acc[k];
+                    const int so = slot_rt(k);
+                    float2 ac = (k == 0) ? make_float2(0.0f, 0.0f) : accw[so];   // partner 0 of a world without a full group: first writer of row 0
                     ac.x += fx; ac.y += fy;
-                    acc[k] = ac;
+                    accw[so] = ac;
                     LDS_ORDER_FENCE();
                 }
                 if ((rows & 1) == 0) { // antipodal partner: each end evaluates it for itself (lean build: row fetched at the top)
@@ -676,13 +713,14 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 STAMP(9);
                 LDS_ORDER_FENCE(); // the reaction slots of this lane were written by its partners
                 const float2* rr = lds_acc + pbase + row;
-                float rx, ry;
-                { const float2 lo = rr[0], hi = rr[rows]; rx = lo.x + hi.x; ry = lo.y + hi.y; }
+                // one slot per accumulator row; a row no group wrote in this substep (fewer partners than rows: worlds of <= 4 rows) holds
+                // nothing.  (Left-over partners of a world without any full group all go to row 0 -- one of them at most with UA = 2.)
+                const int nr = Hf >= UA ? UA : (Hf > 0 ? 1 : 0);
+                float rx = 0.0f, ry = 0.0f;
+                if (nr > 0) { const float2 lo = rr[0]; rx = lo.x; ry = lo.y; }
 #pragma unroll
-                for (int u = 1; u < UA; ++u) {
-                    const float2 lo = rr[u * AR], hi = rr[u * AR + rows];
-                    rx += lo.x + hi.x; ry += lo.y + hi.y;
-                }
+                for (int u = 1; u < UA; ++u)
+                    if (u < nr) { const float2 lo = rr[u * AR]; rx += lo.x; ry += lo.y; }
                 fsx = ex - rx; fsy = ey - ry;
                 STAMP(10);
                 if constexpr (SOC != 2) {
@@ -709,15 +747,6 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     }
                 }
             }
-        }
-        if constexpr (N3L) {
-            // zero the reaction accumulators for the next substep now: the LDS executes these stores while the VALU does
-            // the Euler tail, instead of in front of the next substep's first partner fetch
-            LDS_ORDER_FENCE();
-            float4* z = reinterpret_cast<float4*>(lds_acc); // 2T float2 used per row = T float4: one per lane
-#pragma unroll
-            for (int u = 0; u < UA; ++u) z[u * (ACC_PITCH / 2) + tid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            LDS_ORDER_FENCE();
         }
         STAMP(2);
         if (human) {

@@ -5,4 +5,4 @@ export CROWDSTEP_LIB=$PWD/social_navigation_pyenvs_amd/libcrowdstep_base.so; run
 unset CROWDSTEP_LIB; run tree
 done
 for v in base tree; do if [ $v = base ]; then export CROWDSTEP_LIB=$PWD/social_navigation_pyenvs_amd/libcrowdstep_base.so; else unset CROWDSTEP_LIB; fi
-run cfg5nw_$v "--worlds 8192 --agents 50 --scenario circle --static 3 --device-generator --steps 50"; run n30_$v "--agents 30"; run guo_$v "--model hsfm_new_guo"; run mou_$v "--model hsfm_new_moussaid"; run robot_$v "--robot"; done
+run cfg5nw_$v "--worlds 8192 --agents 50 --scenario circle --static 3 --device-generator --steps 50"; run cfg5_$v "--worlds 8192 --agents 50 --scenario circle --static 3 --walls --device-generator --steps 50"; run n30_$v "--agents 30"; run guo_$v "--model hsfm_new_guo"; run mou_$v "--model hsfm_new_moussaid"; run robot_$v "--robot"; run x4_$v "--worlds 16384"; done
