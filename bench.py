@@ -523,7 +523,7 @@ def main():
                             f"{' + a visible robot' if args.robot else ''}{', per-agent parameters' if args.per_agent_params else ''}, "
                             f"{n_sub} fused substeps of {args.dt} s per step (one Gym step), state resident in HBM ({args.layout})",
                 "worlds_per_gpu": W, "worlds_total": total_worlds, "agents": args.agents, "substeps_per_step": n_sub,
-                "model": args.model, "scenario": args.scenario, "parallelism": f"worlds sharded x{world_size}, no collective",
+                "motion_model": args.model, "scenario": args.scenario, "parallelism": f"worlds sharded x{world_size}, no collective",
                 "launch": {"grid": g, "block": b, "worlds_per_block": wpb},
                 "timed_region": "eager launches, one HIP event pair per launch" if args.eager else
                                 "[untimed: worlds restored to the post-warm-up snapshot] barrier + sync | ONE replay of a HIP graph holding exactly K "
