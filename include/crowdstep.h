@@ -381,6 +381,29 @@ int cs_gym_bookkeeping_next_step(int W, const float* d_out, int32_t* d_counter, 
                                  float* d_global_time, const float* d_clock, int clock_len, float* d_reward, uint8_t* d_terminated,
                                  uint8_t* d_truncated, int32_t* d_info, void* stream);
 
+/*
+ * cs_collision_reward_gym  cs_collision_reward and the episode bookkeeping behind it in ONE launch (the lane that writes a world's
+ *   reward row also does that world's bookkeeping): what cs_collision_reward + cs_gym_bookkeeping (book->d_prev_mask == NULL) or
+ *   cs_collision_reward + cs_gym_bookkeeping_next_step (d_prev_mask given) leave behind, bit for bit, with one graph node less on
+ *   the critical path of a vectorised Gym step (a dependent kernel node costs ~8 us in a HIP graph replay).  d_global_time is
+ *   read (time-limit test) and then advanced.  Worlds of more than 64 humans take the two launches.
+ */
+typedef struct cs_gym_book {
+    int32_t* d_counter;          /* [W] steps of the running episode */
+    uint32_t* d_seeds;           /* [W] seed of the running episode: += W when the episode ends */
+    int32_t* d_mask;             /* [W] out: episode ended in this step */
+    const int32_t* d_prev_mask;  /* [W] NEXT_STEP mode: worlds being reset during this step; NULL: same-step rules */
+    const float* d_clock;        /* [clock_len] float32 sums of the time step */
+    int32_t clock_len;
+    int32_t auto_reset;          /* same-step rules: restart counter / advance seed of finished worlds */
+    float* d_reward;             /* [W] typed copies of the reward row */
+    uint8_t* d_terminated;
+    uint8_t* d_truncated;
+    int32_t* d_info;
+} cs_gym_book;
+int cs_collision_reward_gym(const cs_worlds* w, const float* d_action, float T, float* d_global_time,
+                            const float* reward_cfg /* host, 5 floats */, float* d_out, const cs_gym_book* book, void* stream);
+
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);
 int cs_state_soa_to_aos(const float* d_soa, float* d_aos, int W, int rows, void* stream);

@@ -37,11 +37,20 @@ ABI_SYMBOLS = [
     "cs_generate_scratch_bytes", "cs_generate_worlds", "cs_laser_scan", "cs_robot_model_step", "cs_actual_collision_reward",
     "cs_update_humans_rk45", "cs_gym_bookkeeping", "cs_step_variant", "cs_debug_divsqrt_check", "cs_gym_observe", "cs_copy_worlds_masked", "cs_imitation_block", "cs_gym_bookkeeping_next_step", "cs_robot_model_velocities",
     "cs_step_trace", "cs_reserve_scratch", "cs_release_scratch", "cs_complete_rk45_simulation", "cs_robot_model_rk45", "cs_copy_worlds_masked_status",
+    "cs_collision_reward_gym",
 ]
 
 
 class CrowdstepError(RuntimeError):
     pass
+
+
+class cs_gym_book(C.Structure):   # include/crowdstep.h cs_gym_book: the bookkeeping buffers of cs_collision_reward_gym
+    _fields_ = [
+        ("d_counter", C.c_void_p), ("d_seeds", C.c_void_p), ("d_mask", C.c_void_p), ("d_prev_mask", C.c_void_p), ("d_clock", C.c_void_p),
+        ("clock_len", C.c_int32), ("auto_reset", C.c_int32),
+        ("d_reward", C.c_void_p), ("d_terminated", C.c_void_p), ("d_truncated", C.c_void_p), ("d_info", C.c_void_p),
+    ]
 
 
 class cs_worlds(C.Structure):

@@ -157,11 +157,19 @@ __global__ void k_collision_reward(int W, int n, int rows, const float* S, long 
 
 // The same, one lane per (world, human) for n <= 64: the humans' swept distances are evaluated in parallel (the rows are
 // read once, coalesced), then one lane per world walks them in index order with the reference's early `break`.
+// episode bookkeeping of a vectorised Gym step (cs_gym_bookkeeping / _next_step, robot_model.hip), done by the lane that wrote the
+// world's reward row when cs_collision_reward_gym asks for it (mode 0: none, 1: same-step rules, 2: NEXT_STEP rules)
+struct GymBook {
+    int mode, clock_len, auto_reset;
+    int* counter; unsigned* seeds; int* mask; const int* prev; float* gtime; const float* clock;
+    float* reward; unsigned char* terminated; unsigned char* truncated; int* info;
+};
+
 __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int rows, int wpb, const float* S, long as, long fs,
                                                               const float* robot, const float* action, float T,
                                                               const float* gtime, float time_limit, float success_reward,
                                                               float collision_penalty, float discomfort_dist,
-                                                              float discomfort_factor, float* out)
+                                                              float discomfort_factor, float* out, const GymBook bk)
 {
     __shared__ float s_closest[64];
     const int tid = threadIdx.x;
@@ -207,6 +215,26 @@ __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int 
     float* o = out + (long)w * 7;
     o[0] = (float)collision; o[1] = dmin; o[2] = (float)reaching; o[3] = reward;
     o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
+    if (bk.mode == 0) return;
+    // the same statements as k_gym_bookkeeping / k_gym_bookkeeping_next_step, on the values just written
+    if (bk.mode == 2 && bk.prev[w]) {
+        bk.reward[w] = 0.0f; bk.terminated[w] = 0; bk.truncated[w] = 0; bk.info[w] = 0;
+        bk.mask[w] = 0; bk.counter[w] = 0; bk.gtime[w] = bk.clock[0];
+        return;
+    }
+    bk.reward[w] = reward; bk.terminated[w] = term ? 1 : 0; bk.truncated[w] = trunc ? 1 : 0; bk.info[w] = info;
+    const bool done = term || trunc;
+    int c = bk.counter[w] + 1;
+    if (bk.mode == 2) {
+        bk.mask[w] = done ? 1 : 0;
+        if (done) bk.seeds[w] += (unsigned)W;
+    } else if (bk.auto_reset) {
+        bk.mask[w] = done ? 1 : 0;
+        if (done) { bk.seeds[w] += (unsigned)W; c = 0; }
+    }
+    c = c < bk.clock_len - 1 ? c : bk.clock_len - 1;
+    bk.counter[w] = c;
+    bk.gtime[w] = bk.clock[c];
 }
 
 __global__ void k_transpose_state(const float* src, float* dst, long total_rows, int to_soa)
@@ -492,13 +520,49 @@ int cs_collision_reward(const cs_worlds* w, const float* d_action, float T, cons
         const int wpb = 64 / w->n, grid = (w->W + wpb - 1) / wpb;
         hipLaunchKernelGGL(k_collision_reward_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w->W, w->n, rows, wpb,
                            (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, d_global_time,
-                           reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out);
+                           reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out, GymBook{});
     } else {
         const int block = 64, grid = (w->W + block - 1) / block;
         hipLaunchKernelGGL(k_collision_reward, dim3(grid), dim3(block), 0, (hipStream_t)stream, w->W, w->n, rows,
                            (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, d_global_time,
                            reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out);
     }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_collision_reward_gym(const cs_worlds* w, const float* d_action, float T, float* d_global_time, const float* reward_cfg,
+                            float* d_out, const cs_gym_book* book, void* stream)
+{
+    if (!w || !book) return fail(CS_ERR_ARG, "null argument");
+    if (w->W <= 0 || w->n <= 0 || !w->d_state) return fail(CS_ERR_ARG, "bad cs_worlds");
+    if (w->layout != CS_LAYOUT_AOS && w->layout != CS_LAYOUT_SOA) return fail(CS_ERR_ARG, "bad layout");
+    if (!d_action || !d_global_time || !reward_cfg || !d_out || !w->d_robot) return fail(CS_ERR_ARG, "null argument");
+    if (book->clock_len <= 0 || !book->d_counter || !book->d_seeds || !book->d_mask || !book->d_clock || !book->d_reward ||
+        !book->d_terminated || !book->d_truncated || !book->d_info)
+        return fail(CS_ERR_ARG, "null buffer in cs_gym_book");
+    if (w->n > 64) {   // the lane-per-world reward kernel: the two launches
+        const int rc = cs_collision_reward(w, d_action, T, d_global_time, reward_cfg, d_out, stream);
+        if (rc) return rc;
+        if (book->d_prev_mask)
+            return cs_gym_bookkeeping_next_step(w->W, d_out, book->d_counter, book->d_seeds, book->d_mask, book->d_prev_mask, d_global_time,
+                                                book->d_clock, book->clock_len, book->d_reward, book->d_terminated, book->d_truncated,
+                                                book->d_info, stream);
+        return cs_gym_bookkeeping(w->W, d_out, book->d_counter, book->d_seeds, book->d_mask, d_global_time, book->d_clock, book->clock_len,
+                                  book->auto_reset, book->d_reward, book->d_terminated, book->d_truncated, book->d_info, stream);
+    }
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    long as, fs;
+    strides(w, rows, as, fs);
+    GymBook bk;
+    bk.mode = book->d_prev_mask ? 2 : 1; bk.clock_len = book->clock_len; bk.auto_reset = book->auto_reset;
+    bk.counter = book->d_counter; bk.seeds = book->d_seeds; bk.mask = book->d_mask; bk.prev = book->d_prev_mask; bk.gtime = d_global_time;
+    bk.clock = book->d_clock; bk.reward = book->d_reward; bk.terminated = book->d_terminated; bk.truncated = book->d_truncated;
+    bk.info = book->d_info;
+    const int wpb = 64 / w->n, grid = (w->W + wpb - 1) / wpb;
+    hipLaunchKernelGGL(k_collision_reward_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w->W, w->n, rows, wpb,
+                       (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, (const float*)d_global_time,
+                       reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out, bk);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

@@ -778,7 +778,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     // of four is fetched from LDS while the current one is evaluated).  The k1 / k2 contact
                     // parts are exact zeros unless rd > 0: they are added by a second pass that a wavefront
                     // runs only when one of its lanes touched a partner in this substep.
-                    float eax = 0.0f, eay = 0.0f, ecx = 0.0f, ecy = 0.0f, rdmax = -1.0f;
+                    float eax = 0.0f, eay = 0.0f, ecx = 0.0f, ecy = 0.0f, rdmax = -1.0e30f;   // max over the partners of rs_j - dist
                     constexpr int U = 8;                  // partners in flight per lane (independent rsq -> exp chains)
                     const float4* rp = pp + row + 1;      // partner k of mine = row (i + 1 + k) mod rows, k = 0 .. rows-2
                     const int np = rows - 1;
@@ -791,11 +791,11 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             float d2 = fmaf(dx, dx, dy * dy);
                             if constexpr (TAIL) d2 = (u >= rem) ? 1.0e30f : d2; // padding slot (wave-uniform): dist 1e15 -> 0
                             const float inv = rsq_fast(d2);
-                            const float rd = fmaf(-d2, inv, my_rs + q[u].z);          // rij - dist
-                            const float ga = exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv; // |A| e^{rd/B} / dist
+                            const float rd = fmaf(-d2, inv, q[u].z);                  // rs_j - dist: my own rs sits in the exponent offsets (lAi, lCi)
+                            const float ga = exp2_fast(fmaf(rd, sp.cB, lAi)) * inv;   // |A| e^{(rij - dist)/B} / dist
                             eax = fmaf(ga, dx, eax); eay = fmaf(ga, dy, eay);
                             if constexpr (SOC == 1) {
-                                const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * inv; // |C| e^{rd/D} / dist
+                                const float gc = exp2_fast(fmaf(rd, sp.cD, lCi)) * inv;   // |C| e^{(rij - dist)/D} / dist
                                 ecx = fmaf(-gc, dy, ecx); ecy = fmaf(gc, dx, ecy);       // along t = (-ny, nx)
                             }
                             rdk[u] = rd;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     }
                     fsx = sp.sA * eax; fsy = sp.sA * eay;
                     if constexpr (SOC == 1) { fsx = fmaf(sp.sC, ecx, fsx); fsy = fmaf(sp.sC, ecy, fsy); }
-                    if (__builtin_amdgcn_ballot_w64(rdmax > 0.0f) != 0) { // contact somewhere in this wavefront
+                    if (__builtin_amdgcn_ballot_w64(rdmax > -my_rs) != 0) { // contact somewhere in this wavefront
                         for (int j = 0; j < rows; ++j) {
                             const float4 q = pp[j];
                             const float2 vj = partner_vel(j);

@@ -433,7 +433,7 @@ class BatchedSocialNavGym:
     def _step_graph(self, dl, parity, auto_reset):
         r"""One vectorised Gym step as ONE HIP graph of library launches (captured once per result set):
 
-            stream A:  cs_collision_reward -> cs_gym_bookkeeping --fork--> cs_step --------join--> cs_copy_worlds_masked -> cs_gym_observe
+            stream A:  cs_collision_reward_gym (reward + bookkeeping) --fork--> cs_step --------join--> cs_copy_worlds_masked -> cs_gym_observe
             stream B:                                              \--> masked cs_generate_worlds (into a staging batch) --/
 
         Which worlds end is known from the reward of the state BEFORE the substeps (social_nav_gym.py:229-233), so their
@@ -453,15 +453,15 @@ class BatchedSocialNavGym:
         reward, terminated, truncated, info = dl["results"][parity]
         act = dl["act"]
         with _lib.Graph.capture(A) as graph:
-            _lib.check(lib.cs_collision_reward(C.byref(d), C.c_void_p(act.data_ptr()), C.c_float(self.robot_time_step),
-                                               C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()), C.c_void_p(A)))
-            # typed results of this step, step counter, float32 clock, reset mask and next seeds: one small launch
-            _lib.check(lib.cs_gym_bookkeeping(C.c_int(self.W), C.c_void_p(dl["out"].data_ptr()), C.c_void_p(dl["counter"].data_ptr()),
-                                              C.c_void_p(dl["seeds"].data_ptr()), C.c_void_p(dl["mask"].data_ptr()),
-                                              C.c_void_p(dl["gtime"].data_ptr()), C.c_void_p(dl["clock"].data_ptr()),
-                                              C.c_int(dl["clock"].numel()), C.c_int(int(bool(auto_reset))),
-                                              C.c_void_p(reward.data_ptr()), C.c_void_p(terminated.data_ptr()),
-                                              C.c_void_p(truncated.data_ptr()), C.c_void_p(info.data_ptr()), C.c_void_p(A)))
+            # reward of the state before the substeps + typed results, step counter, float32 clock, reset mask and next seeds: ONE launch
+            # (cs_collision_reward_gym = cs_collision_reward ; cs_gym_bookkeeping without the graph node between them)
+            book = _lib.cs_gym_book(d_counter=dl["counter"].data_ptr(), d_seeds=dl["seeds"].data_ptr(), d_mask=dl["mask"].data_ptr(),
+                                    d_prev_mask=None, d_clock=dl["clock"].data_ptr(), clock_len=dl["clock"].numel(),
+                                    auto_reset=int(bool(auto_reset)), d_reward=reward.data_ptr(), d_terminated=terminated.data_ptr(),
+                                    d_truncated=truncated.data_ptr(), d_info=info.data_ptr())
+            _lib.check(lib.cs_collision_reward_gym(C.byref(d), C.c_void_p(act.data_ptr()), C.c_float(self.robot_time_step),
+                                                   C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()), C.byref(book),
+                                                   C.c_void_p(A)))
             if auto_reset:
                 dl["fork"].record(A)
                 dl["fork"].wait(B)
@@ -482,8 +482,8 @@ class BatchedSocialNavGym:
 
     def _next_step_pieces(self, dl, parity):
         """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's launches with every ctypes argument bound once
-        (six direct launches cost less host time than three graph replays with event calls between them).
-        head = cs_collision_reward, cs_gym_bookkeeping_next_step(mask_p, prev = mask_{1-p});  gen = masked cs_generate_worlds into
+        (five direct launches cost less host time than three graph replays with event calls between them).
+        head = cs_collision_reward_gym (reward + the NEXT_STEP bookkeeping: mask_p, prev = mask_{1-p});  gen = masked cs_generate_worlds into
         staging_p on stream B_p;  body = cs_step;  tail = cs_copy_worlds_masked(staging_{1-p} -> live, mask_{1-p}), cs_gym_observe"""
         import ctypes as C
 
@@ -498,9 +498,11 @@ class BatchedSocialNavGym:
         reward, terminated, truncated, info = dl["results"][parity]
         act, masks = dl["act"], dl["ns_masks"]
         P = lambda t: C.c_void_p(t.data_ptr())
-        a_rew = (dref, P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg, P(dl["out"]), A)
-        a_bk = (C.c_int(self.W), P(dl["out"]), P(dl["counter"]), P(dl["seeds"]), P(masks[parity]), P(masks[parity ^ 1]), P(dl["gtime"]),
-                P(dl["clock"]), C.c_int(dl["clock"].numel()), P(reward), P(terminated), P(truncated), P(info), A)
+        book = _lib.cs_gym_book(d_counter=dl["counter"].data_ptr(), d_seeds=dl["seeds"].data_ptr(), d_mask=masks[parity].data_ptr(),
+                                d_prev_mask=masks[parity ^ 1].data_ptr(), d_clock=dl["clock"].data_ptr(), clock_len=dl["clock"].numel(),
+                                auto_reset=1, d_reward=reward.data_ptr(), d_terminated=terminated.data_ptr(),
+                                d_truncated=truncated.data_ptr(), d_info=info.data_ptr())
+        a_rew = (dref, P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg, P(dl["out"]), C.byref(book), A)
         a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), A)
         st = dl["ns_staging"][parity]
         dg = st.descriptor()
@@ -511,8 +513,8 @@ class BatchedSocialNavGym:
         ds = dl["ns_staging"][parity ^ 1].descriptor()
         a_copy = (C.byref(ds), dref, P(masks[parity ^ 1]), P(dl["ns_status"][parity ^ 1]), A)
         a_obs = (dref, C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
-        keep = (d, dg, ds, cfg)                    # the structs the byref arguments point into
-        dl[key] = dict(rew=a_rew, bk=a_bk, step=a_step, gen=a_gen, copy=a_copy, obs=a_obs, keep=keep)
+        keep = (d, dg, ds, cfg, book)              # the structs the byref arguments point into
+        dl[key] = dict(rew=a_rew, step=a_step, gen=a_gen, copy=a_copy, obs=a_obs, keep=keep)
         return dl[key]
 
     def _step_device_next_step(self, dl, actions):
@@ -546,8 +548,7 @@ class BatchedSocialNavGym:
         if actions is not dl["act"]:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
-        chk(lib.cs_collision_reward(*c["rew"]))                     # reward of the state before the substeps ...
-        chk(lib.cs_gym_bookkeeping_next_step(*c["bk"]))              # ... who ends now, who is being reset
+        chk(lib.cs_collision_reward_gym(*c["rew"]))                 # reward of the state before the substeps; who ends now, who is being reset
         dl["ns_mask_ev"][parity].record(A)
         B = dl["ns_streams"][parity]
         dl["ns_mask_ev"][parity].wait(B)

@@ -411,3 +411,62 @@ def test_failed_regeneration_never_replaces_a_live_world():
     np.testing.assert_array_equal(after[mask == 0], before[mask == 0])
     np.testing.assert_array_equal(after[replaced], fresh[replaced])
     assert np.any(after[replaced] != before[replaced])
+
+
+@pytest.mark.parametrize("next_step", [False, True])
+def test_fused_reward_and_bookkeeping_equals_the_two_launches(next_step):
+    """cs_collision_reward_gym (the lane that writes a world's reward row also does its episode bookkeeping) leaves exactly what
+    cs_collision_reward followed by cs_gym_bookkeeping / cs_gym_bookkeeping_next_step leaves: reward rows, typed results, step counters,
+    clocks, reset masks, seeds -- on worlds that collide, reach the goal, time out, are uncomfortable or are being reset."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd import _lib
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+
+    W, n = 300, 7
+    rng = np.random.default_rng(17 + int(next_step))
+    cw = _blank(W, n, 2)
+    generate_worlds(cw, "circle_crossing", np.arange(W) + 5, circle_radius=4.0, insert_robot=True)
+    rb = cw.get_robot()
+    S = cw.get_states()
+    rb[: W // 4, 0:2] = S[: W // 4, 2, 0:2] + 0.05             # some robots on top of a human: collision
+    rb[W // 4: W // 2, 0:2] = rb[W // 4: W // 2, 10:12] - 0.01  # some next to their goal: ReachGoal
+    cw.d_robot.upload(rb.astype(np.float32))
+    act = rng.uniform(-0.6, 0.6, (W, 2)).astype(np.float32)
+    clock = np.cumsum(np.full(240, 0.25, np.float32), dtype=np.float32)
+    clock = np.concatenate([[np.float32(0)], clock]).astype(np.float32)
+    counter0 = rng.integers(0, 200, W).astype(np.int32)
+    counter0[::9] = 199                                          # ... some at the time limit: Timeout
+    gtime0 = clock[counter0]
+    seeds0 = (np.arange(W) + 1000).astype(np.uint32)
+    prev = (rng.uniform(size=W) < 0.2).astype(np.int32)
+    cfg = (C.c_float * 5)(50.0, 1.0, -0.25, 0.2, 0.5)
+    lib, d = _lib.load(), cw.descriptor()
+    res = []
+    for fused in (False, True):
+        B = lambda a, t: _lib.DeviceBuffer.from_numpy(np.ascontiguousarray(a), dtype=t)
+        b = dict(act=B(act, np.float32), gtime=B(gtime0, np.float32), out=_lib.DeviceBuffer((W, 7)), counter=B(counter0, np.int32),
+                 seeds=B(seeds0, np.uint32), mask=B(np.full(W, 7), np.int32), prev=B(prev, np.int32), clock=B(clock, np.float32),
+                 reward=_lib.DeviceBuffer((W,)), term=_lib.DeviceBuffer((W,), np.uint8), trunc=_lib.DeviceBuffer((W,), np.uint8),
+                 info=_lib.DeviceBuffer((W,), np.int32))
+        P = lambda k: C.c_void_p(b[k].ptr)
+        if fused:
+            book = _lib.cs_gym_book(d_counter=b["counter"].ptr, d_seeds=b["seeds"].ptr, d_mask=b["mask"].ptr,
+                                    d_prev_mask=b["prev"].ptr if next_step else None, d_clock=b["clock"].ptr, clock_len=len(clock), auto_reset=1,
+                                    d_reward=b["reward"].ptr, d_terminated=b["term"].ptr, d_truncated=b["trunc"].ptr, d_info=b["info"].ptr)
+            _lib.check(lib.cs_collision_reward_gym(C.byref(d), P("act"), C.c_float(0.25), P("gtime"), cfg, P("out"), C.byref(book), C.c_void_p(cw.stream)))
+        else:
+            _lib.check(lib.cs_collision_reward(C.byref(d), P("act"), C.c_float(0.25), P("gtime"), cfg, P("out"), C.c_void_p(cw.stream)))
+            if next_step:
+                _lib.check(lib.cs_gym_bookkeeping_next_step(C.c_int(W), P("out"), P("counter"), P("seeds"), P("mask"), P("prev"), P("gtime"), P("clock"),
+                                                            C.c_int(len(clock)), P("reward"), P("term"), P("trunc"), P("info"), C.c_void_p(cw.stream)))
+            else:
+                _lib.check(lib.cs_gym_bookkeeping(C.c_int(W), P("out"), P("counter"), P("seeds"), P("mask"), P("gtime"), P("clock"), C.c_int(len(clock)),
+                                                  C.c_int(1), P("reward"), P("term"), P("trunc"), P("info"), C.c_void_p(cw.stream)))
+        cw.sync()
+        res.append({k: b[k].download() for k in ("out", "counter", "seeds", "mask", "gtime", "reward", "term", "trunc", "info")})
+    for k in res[0]:
+        np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
+    info = res[1]["info"] if not next_step else res[1]["out"][:, 6].astype(np.int32)
+    assert set(np.unique(info)) >= {0, 2, 3, 4}, np.unique(info)   # Nothing, ReachGoal, Collision, Timeout all occurred
+    assert res[1]["mask"].sum() > 20
