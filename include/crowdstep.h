@@ -371,6 +371,17 @@ int cs_copy_worlds_masked(const cs_worlds* src, const cs_worlds* dst, const int3
 int cs_copy_worlds_masked_status(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, const int32_t* d_status, void* stream);
 
 /*
+ * cs_step_observe  cs_step followed by cs_gym_observe in ONE launch: the SFM / HSFM step kernels write the observation of the stepped
+ *   humans from their registers (other crowd models and worlds beyond one block: the two launches).  d_obs as in cs_gym_observe.
+ * cs_copy_worlds_masked_observe  cs_copy_worlds_masked_status that also rewrites the observation rows of the worlds it copies (d_obs
+ *   [W][n][5|7], NULL: plain copy) -- with cs_step_observe a vectorised Gym step with auto-reset needs no separate observation launch.
+ */
+int cs_step_observe(const cs_worlds* w, float dt, int n_substeps, const float* d_action, int theta_and_omega_visible, float* d_obs,
+                    void* stream);
+int cs_copy_worlds_masked_observe(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, const int32_t* d_status,
+                                  int theta_and_omega_visible, float* d_obs, void* stream);
+
+/*
  * cs_gym_bookkeeping_next_step  cs_gym_bookkeeping for Gymnasium's NEXT_STEP autoreset mode: a world whose episode ended in the
  *   previous step (d_prev_mask[w] != 0) spends this step being reset -- its results are those of a reset step (reward 0, not
  *   terminated, not truncated, Nothing), its step counter and clock restart -- and a world that ends now is flagged in d_mask

@@ -349,7 +349,8 @@ kfn variant_kernel(const Variant& v, int type)
 }
 
 int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, const float* d_action,
-                float* d_peek, hipStream_t stream, float4* d_snap = nullptr, float* d_trace = nullptr, const RobotModel* rm = nullptr)
+                float* d_peek, hipStream_t stream, float4* d_snap = nullptr, float* d_trace = nullptr, const RobotModel* rm = nullptr,
+                float* d_obs = nullptr, int obs_cols = 0)
 {
     int rc = check_worlds(w);
     if (rc) return rc;
@@ -381,6 +382,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
 #endif
     a.snap = d_snap;
     a.trace = d_trace;
+    a.obs = d_obs; a.obs_cols = obs_cols;
     const Variant v = select_variant(w, mode, g, d_snap != nullptr, rm != nullptr);
     if (rm) {
         if (v.lean != 4) return fail(CS_ERR_ARG, "the robot's motion model runs inside the crowd's launch only for the plain crowd batch with a robot row");
@@ -480,6 +482,24 @@ int cs_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action,
     int mode = M_COMMIT_GOALS;
     if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
     return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream);
+}
+
+int cs_step_observe(const cs_worlds* w, float dt, int n_substeps, const float* d_action, int theta_and_omega_visible, float* d_obs,
+                    void* stream)
+{
+    if (!w || !d_obs) return fail(CS_ERR_ARG, "null argument");
+    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    // the SFM / HSFM kernels of one block write the observation from their registers; everything else steps, then reads it back
+    if (w->type < 0 || w->type > 8 || rows > csimpl::big_world_min_rows(1024)) {
+        const int rc = cs_step(w, dt, n_substeps, d_action, stream);
+        return rc ? rc : cs_gym_observe(w, theta_and_omega_visible, d_obs, stream);
+    }
+    if (d_action && !w->d_robot) return fail(CS_ERR_ARG, "robot action given but cs_worlds.d_robot is null");
+    int mode = M_COMMIT_GOALS;
+    if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
+    return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, d_obs,
+                       theta_and_omega_visible ? 7 : 5);
 }
 
 int cs_step_trace(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_trace, void* stream)

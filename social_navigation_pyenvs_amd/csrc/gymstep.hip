@@ -33,6 +33,7 @@ struct CopyArgs {
     const int* fsrc; int* fdst;
     const int* mask;
     const int* status;   // optional: cs_generate_worlds' per-world status; a world that could not be generated (non-zero) is NOT copied
+    float* obs; int C;   // optional: the Gym's observation rows [W][n][C] of the copied worlds are rewritten from the new rows
 };
 
 __global__ __launch_bounds__(64) void k_copy_worlds_masked(const CopyArgs a)
@@ -50,6 +51,13 @@ __global__ __launch_bounds__(64) void k_copy_worlds_masked(const CopyArgs a)
     for (int k = t; k < a.n * a.G * 2; k += 64) a.gd[g0 + k] = a.gs[g0 + k];
     if (a.rs && a.rd && t < 13) a.rd[(long)w * 13 + t] = a.rs[(long)w * 13 + t];
     if (a.fsrc && a.fdst && t == 0) a.fdst[w] = a.fsrc[w];
+    if (a.obs != nullptr) {   // same columns as k_gym_observe, read from the source rows
+        for (int k = t; k < a.n * a.C; k += 64) {
+            const int i = k / a.C, c = k - i * a.C;
+            const int col = c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 3 : c == 3 ? 4 : c == 4 ? 8 : c == 5 ? 2 : 7;
+            a.obs[((long)w * a.n + i) * a.C + c] = a.Ss[((long)w * a.rows + i) * a.as + col * a.fs];
+        }
+    }
 }
 
 } // namespace
@@ -77,6 +85,12 @@ int cs_copy_worlds_masked(const cs_worlds* src, const cs_worlds* dst, const int3
 
 int cs_copy_worlds_masked_status(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, const int32_t* d_status, void* stream)
 {
+    return cs_copy_worlds_masked_observe(src, dst, d_mask, d_status, 0, nullptr, stream);
+}
+
+int cs_copy_worlds_masked_observe(const cs_worlds* src, const cs_worlds* dst, const int32_t* d_mask, const int32_t* d_status,
+                                  int theta_and_omega_visible, float* d_obs, void* stream)
+{
     if (!src || !dst || !d_mask) return fail(CS_ERR_ARG, "null argument");
     if (src->W != dst->W || src->n != dst->n || src->G != dst->G || src->layout != dst->layout || ((src->flags ^ dst->flags) & CS_ROBOT_ROW))
         return fail(CS_ERR_ARG, "source and destination worlds differ in shape");
@@ -87,6 +101,7 @@ int cs_copy_worlds_masked_status(const cs_worlds* src, const cs_worlds* dst, con
     a.as = src->layout == CS_LAYOUT_AOS ? 13 : 1; a.fs = src->layout == CS_LAYOUT_AOS ? 1 : (long)src->W * a.rows;
     a.gs = src->d_goals; a.gd = dst->d_goals; a.rs = src->d_robot; a.rd = dst->d_robot;
     a.fsrc = src->d_world_flags; a.fdst = const_cast<int*>(dst->d_world_flags); a.mask = d_mask; a.status = d_status;
+    a.obs = d_obs; a.C = theta_and_omega_visible ? 7 : 5;
     hipLaunchKernelGGL(k_copy_worlds_masked, dim3(a.W), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;

@@ -275,6 +275,11 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
         const long fs = a.out_fs;
         o[0] = px; o[fs] = py; o[2 * fs] = th; o[3 * fs] = vx; o[4 * fs] = vy; o[5 * fs] = bvx;
         o[6 * fs] = bvy; o[7 * fs] = om; o[10 * fs] = gx; o[11 * fs] = gy;
+        if (a.obs != nullptr) {   // cs_step_observe: the Gym's observation of the stepped humans (sfmstep_kernel.h epilogue)
+            float* ob = a.obs + ((long)w * ROWS + r) * a.obs_cols;
+            ob[0] = px; ob[1] = py; ob[2] = vx; ob[3] = vy; ob[4] = rad;
+            if (a.obs_cols == 7) { ob[5] = th; ob[6] = om; }
+        }
     }
     // invisible robot: advanced by the lane of row 0 (it does not interact with the crowd)
     if (inw && r == 0 && robot_moves && a.robot != nullptr) {

@@ -1009,6 +1009,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             o[6 * fs] = bvy; o[7 * fs] = om; o[10 * fs] = gx; o[11 * fs] = gy;
             if (a.Sout != a.Sin || is_robot) { o[8 * fs] = r; o[9 * fs] = m; o[12 * fs] = vd; }
         }
+        // the Gym's observation of the stepped crowd (SocialNavGym.compute_humans_observable_state, social_nav_gym.py:100-105) straight
+        // from the registers: what cs_gym_observe would read back from the rows just written
+        if (a.obs != nullptr && human) {
+            float* ob = a.obs + ((long)w * n + row) * a.obs_cols;
+            ob[0] = px; ob[1] = py; ob[2] = vx; ob[3] = vy; ob[4] = r;
+            if (a.obs_cols == 7) { ob[5] = th; ob[6] = om; }
+        }
         if (is_robot && robot_moves && a.robot != nullptr) {
             float* rb = a.robot + (long)w * 13;
             rb[0] = px; rb[1] = py; rb[2] = th; rb[3] = vx; rb[4] = vy;

@@ -24,6 +24,8 @@ struct KArgs {
     int W, n, rows, G, O, Smax;
     int type, flags, mode;
     int nsub, wpb;
+    float* obs;            // cs_step_observe: [W][n][obs_cols] observable states of the stepped humans (px, py, vx, vy, radius [, theta, omega]) or null
+    int obs_cols;
     int seg_tab;           // wall segments staged in LDS per block (0: read them from global memory in every substep)
     int ws;                // LDS rows between the doubled row blocks of consecutive worlds of a block (>= 2 * rows)
     float dt;

@@ -433,7 +433,7 @@ class BatchedSocialNavGym:
     def _step_graph(self, dl, parity, auto_reset):
         r"""One vectorised Gym step as ONE HIP graph of library launches (captured once per result set):
 
-            stream A:  cs_collision_reward_gym (reward + bookkeeping) --fork--> cs_step --------join--> cs_copy_worlds_masked -> cs_gym_observe
+            stream A:  cs_collision_reward_gym (reward + bookkeeping) --fork--> cs_step_observe --------join--> cs_copy_worlds_masked_observe
             stream B:                                              \--> masked cs_generate_worlds (into a staging batch) --/
 
         Which worlds end is known from the reward of the state BEFORE the substeps (social_nav_gym.py:229-233), so their
@@ -468,23 +468,25 @@ class BatchedSocialNavGym:
                 # (the staging batch launches on stream B; a world whose bounded rejection sampling fails keeps status != 0 and is
                 #  not copied over the live one: failed_resets() counts them)
                 gen.generate_worlds_device(dl["staging"], dl["gen"], dl["seeds"], dl["mask"], d_status=dl["gen_status"])
-            _lib.check(lib.cs_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
-                                   C.c_void_p(A)))
+            # the substeps, and the observation of the stepped crowd from the step kernel's registers (cs_step_observe) ...
+            _lib.check(lib.cs_step_observe(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
+                                           C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
             if auto_reset:
                 dl["join"].record(B)
                 dl["join"].wait(A)
                 ds = dl["staging"].descriptor()
-                _lib.check(lib.cs_copy_worlds_masked_status(C.byref(ds), C.byref(d), C.c_void_p(dl["mask"].data_ptr()),
-                                                            C.c_void_p(dl["gen_status"].data_ptr()), C.c_void_p(A)))
-            _lib.check(lib.cs_gym_observe(C.byref(d), C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
+                # ... rewritten for the regenerated worlds by the masked copy itself: no separate observation launch
+                _lib.check(lib.cs_copy_worlds_masked_observe(C.byref(ds), C.byref(d), C.c_void_p(dl["mask"].data_ptr()),
+                                                             C.c_void_p(dl["gen_status"].data_ptr()), C.c_int(int(self.headed_obs)),
+                                                             C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
         dl[key] = graph
         return graph
 
     def _next_step_pieces(self, dl, parity):
         """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's launches with every ctypes argument bound once
-        (five direct launches cost less host time than three graph replays with event calls between them).
+        (four direct launches cost less host time than three graph replays with event calls between them).
         head = cs_collision_reward_gym (reward + the NEXT_STEP bookkeeping: mask_p, prev = mask_{1-p});  gen = masked cs_generate_worlds into
-        staging_p on stream B_p;  body = cs_step;  tail = cs_copy_worlds_masked(staging_{1-p} -> live, mask_{1-p}), cs_gym_observe"""
+        staging_p on stream B_p;  body = cs_step_observe;  tail = cs_copy_worlds_masked_observe(staging_{1-p} -> live, mask_{1-p})"""
         import ctypes as C
 
         key = ("ns", parity)
@@ -503,7 +505,7 @@ class BatchedSocialNavGym:
                                 auto_reset=1, d_reward=reward.data_ptr(), d_terminated=terminated.data_ptr(),
                                 d_truncated=truncated.data_ptr(), d_info=info.data_ptr())
         a_rew = (dref, P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg, P(dl["out"]), C.byref(book), A)
-        a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), A)
+        a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
         st = dl["ns_staging"][parity]
         dg = st.descriptor()
         nbytes = int(lib.cs_generate_scratch_bytes(C.c_int(self.W)))
@@ -511,10 +513,9 @@ class BatchedSocialNavGym:
         a_gen = (C.byref(dl["gen"]), C.byref(dg), P(dl["seeds"]), P(masks[parity]), P(dl["ns_status"][parity]), C.c_void_p(None), C.c_void_p(scratch.ptr),
                  C.c_void_p(dl["ns_streams"][parity]))
         ds = dl["ns_staging"][parity ^ 1].descriptor()
-        a_copy = (C.byref(ds), dref, P(masks[parity ^ 1]), P(dl["ns_status"][parity ^ 1]), A)
-        a_obs = (dref, C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
+        a_copy = (C.byref(ds), dref, P(masks[parity ^ 1]), P(dl["ns_status"][parity ^ 1]), C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
         keep = (d, dg, ds, cfg, book)              # the structs the byref arguments point into
-        dl[key] = dict(rew=a_rew, step=a_step, gen=a_gen, copy=a_copy, obs=a_obs, keep=keep)
+        dl[key] = dict(rew=a_rew, step=a_step, gen=a_gen, copy=a_copy, keep=keep)
         return dl[key]
 
     def _step_device_next_step(self, dl, actions):
@@ -554,10 +555,9 @@ class BatchedSocialNavGym:
         dl["ns_mask_ev"][parity].wait(B)
         chk(lib.cs_generate_worlds(*c["gen"]))                       # beside this step's substeps and the next step
         dl["ns_gen_ev"][parity].record(B)
-        chk(lib.cs_step(*c["step"]))                                 # the 20 fused substeps
+        chk(lib.cs_step_observe(*c["step"]))                         # the 20 fused substeps + the observation of the stepped crowd
         dl["ns_gen_ev"][parity ^ 1].wait(A)                          # the worlds that ended in the PREVIOUS step are ready by now
-        chk(lib.cs_copy_worlds_masked_status(*c["copy"]))            # ... copied in (unless their generation failed: failed_resets())
-        chk(lib.cs_gym_observe(*c["obs"]))
+        chk(lib.cs_copy_worlds_masked_observe(*c["copy"]))           # ... copied in (unless their generation failed: failed_resets()), observation rows included
         cur.wait_stream(side)
         reward, terminated, truncated, info = dl["results"][parity]
         return dl["obs"], reward, terminated, truncated, info

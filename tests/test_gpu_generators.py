@@ -470,3 +470,61 @@ def test_fused_reward_and_bookkeeping_equals_the_two_launches(next_step):
     info = res[1]["info"] if not next_step else res[1]["out"][:, 6].astype(np.int32)
     assert set(np.unique(info)) >= {0, 2, 3, 4}, np.unique(info)   # Nothing, ReachGoal, Collision, Timeout all occurred
     assert res[1]["mask"].sum() > 20
+
+
+@pytest.mark.parametrize("n,model,robot_row,headed", [(25, "hsfm_farina", False, True), (5, "sfm_helbing", False, False), (10, "hsfm_new_guo", True, True),
+                                                      (7, "orca", False, False)])
+def test_step_observe_and_copy_observe_equal_the_separate_launches(n, model, robot_row, headed):
+    """cs_step_observe (the step kernels write the Gym's observation of the stepped humans from their registers; ORCA: the two launches
+    inside the library) == cs_step ; cs_gym_observe, and cs_copy_worlds_masked_observe == cs_copy_worlds_masked_status ; cs_gym_observe on
+    the copied worlds -- rows and observations, bit for bit."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd import _lib, scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W = 37
+    rng = np.random.default_rng(n)
+    if model == "orca":
+        pos, yaw, g = sc.circular_crossing(W, n, 4.0, 77)
+        S = sc.make_states(pos, yaw, g).astype(np.float32)
+        dd = g[:, :, 0] - S[:, :, 0:2]
+        S[:, :, 5:7] = dd / np.linalg.norm(dd, axis=-1, keepdims=True)
+        mk = lambda: CrowdWorlds(S, g, None, np.full((W, n), 0.01, np.float32), None, type="orca", robot=np.zeros((W, 13), np.float32))
+    else:
+        S, g, P, rb = sc.hybrid_worlds(W, n, model, seed0=3)
+        R = np.zeros((W, 13), np.float32)
+        R[:, 0:2] = rng.uniform(-3, 3, (W, 2)); R[:, 8] = 0.3; R[:, 9] = 80; R[:, 12] = 1.0
+        St = np.concatenate([S, R[:, None, :]], axis=1) if robot_row else S
+        mk = lambda: CrowdWorlds(St, g, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
+                                 respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), robot_row=robot_row, robot=R)
+    act = rng.uniform(-0.5, 0.5, (W, 2)).astype(np.float32)
+    lib, Ccols = _lib.load(), (7 if headed else 5)
+    a, b = mk(), mk()
+    d_act = _lib.DeviceBuffer.from_numpy(act)
+    obs_a, obs_b = _lib.DeviceBuffer((W, n, Ccols)), _lib.DeviceBuffer((W, n, Ccols))
+    for _ in range(3):
+        da, db = a.descriptor(), b.descriptor()
+        _lib.check(lib.cs_step(C.byref(da), C.c_float(0.0125), C.c_int(20), C.c_void_p(d_act.ptr), C.c_void_p(a.stream)))
+        _lib.check(lib.cs_gym_observe(C.byref(da), C.c_int(int(headed)), C.c_void_p(obs_a.ptr), C.c_void_p(a.stream)))
+        _lib.check(lib.cs_step_observe(C.byref(db), C.c_float(0.0125), C.c_int(20), C.c_void_p(d_act.ptr), C.c_int(int(headed)), C.c_void_p(obs_b.ptr),
+                                       C.c_void_p(b.stream)))
+        a.sync(); b.sync()
+        np.testing.assert_array_equal(a.get_states(), b.get_states())
+        np.testing.assert_array_equal(obs_a.download(), obs_b.download())
+    assert np.abs(obs_a.download()[..., 2:4]).max() > 0.05
+    # the masked copy with observation rows
+    src = mk()
+    mask = (rng.uniform(size=W) < 0.4).astype(np.int32)
+    status = np.zeros(W, np.int32); status[np.flatnonzero(mask)[:2]] = 1        # two generations "failed": not copied, rows kept
+    d_mask, d_status = _lib.DeviceBuffer.from_numpy(mask, np.int32), _lib.DeviceBuffer.from_numpy(status, np.int32)
+    ds, da, db = src.descriptor(), a.descriptor(), b.descriptor()
+    _lib.check(lib.cs_copy_worlds_masked_status(C.byref(ds), C.byref(da), C.c_void_p(d_mask.ptr), C.c_void_p(d_status.ptr), C.c_void_p(a.stream)))
+    _lib.check(lib.cs_gym_observe(C.byref(da), C.c_int(int(headed)), C.c_void_p(obs_a.ptr), C.c_void_p(a.stream)))
+    _lib.check(lib.cs_copy_worlds_masked_observe(C.byref(ds), C.byref(db), C.c_void_p(d_mask.ptr), C.c_void_p(d_status.ptr), C.c_int(int(headed)),
+                                                 C.c_void_p(obs_b.ptr), C.c_void_p(b.stream)))
+    a.sync(); b.sync()
+    np.testing.assert_array_equal(a.get_states(), b.get_states())
+    np.testing.assert_array_equal(obs_a.download(), obs_b.download())
+    copied = (mask == 1) & (status == 0)
+    np.testing.assert_array_equal(b.get_states()[copied], src.get_states()[copied])
