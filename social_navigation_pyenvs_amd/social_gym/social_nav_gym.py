@@ -545,7 +545,9 @@ class BatchedSocialNavGym:
         lib, chk = _lib.load(), _lib.check
         side, cur = dl["stream"], torch.cuda.current_stream()
         A = side.cuda_stream
-        side.wait_stream(cur)
+        same = cur.cuda_stream == A
+        if not same:
+            side.wait_stream(cur)
         if actions is not dl["act"]:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
@@ -558,7 +560,8 @@ class BatchedSocialNavGym:
         chk(lib.cs_step_observe(*c["step"]))                         # the 20 fused substeps + the observation of the stepped crowd
         dl["ns_gen_ev"][parity ^ 1].wait(A)                          # the worlds that ended in the PREVIOUS step are ready by now
         chk(lib.cs_copy_worlds_masked_observe(*c["copy"]))           # ... copied in (unless their generation failed: failed_resets()), observation rows included
-        cur.wait_stream(side)
+        if not same:
+            cur.wait_stream(side)
         reward, terminated, truncated, info = dl["results"][parity]
         return dl["obs"], reward, terminated, truncated, info
 
@@ -584,12 +587,15 @@ class BatchedSocialNavGym:
         dl["parity"] ^= 1
         graph = self._step_graph(dl, parity, auto_reset)
         side, cur = dl["stream"], torch.cuda.current_stream()
-        side.wait_stream(cur)                      # device-side ordering with whatever produced the actions
+        same = cur.cuda_stream == side.cuda_stream   # the caller already works on the library's stream (`with torch.cuda.stream(env.device_stream())`)
+        if not same:
+            side.wait_stream(cur)                  # device-side ordering with whatever produced the actions
         if actions is not dl["act"]:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
         graph.launch()
-        cur.wait_stream(side)                      # ... and with whoever reads the results
+        if not same:
+            cur.wait_stream(side)                  # ... and with whoever reads the results
         reward, terminated, truncated, info = dl["results"][parity]
         return dl["obs"], reward, terminated, truncated, info
 
@@ -602,6 +608,11 @@ class BatchedSocialNavGym:
         for st in dl.get("ns_status", []):
             n += int((st != 0).sum().item())
         return n
+
+    def device_stream(self):
+        """The torch stream the device-resident step runs on.  A loop that does its own GPU work inside ``with torch.cuda.stream(env.device_stream())``
+        is ordered with the step by the stream itself: step_device then skips its two cross-stream waits (four HIP calls per step)."""
+        return self._device_loop_state()["stream"]
 
     def action_buffer(self):
         """The persistent [W, 2] action tensor the step graph reads: write actions into it and pass it to ``step_device``."""

@@ -63,6 +63,22 @@ for _ in range(K):
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(f"graph replay without the auto-reset branch: {el / K * 1e6:.1f} us per batched step")
+with torch.cuda.stream(env.device_stream()):       # the caller's own work on the library's stream: no cross-stream waits in step_device
+    for _ in range(20):
+        env.step_device(buf, auto_reset=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        env.step_device(buf, auto_reset=False)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(f"   the same from inside `with torch.cuda.stream(env.device_stream())`: {el / K * 1e6:.1f} us per batched step")
+    t0 = time.perf_counter()
+    for _ in range(K):
+        env.step_device(buf)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(f"   ... with same-step auto-reset: {el / K * 1e6:.1f} us per batched step")
 
 env2 = BatchedSocialNavGym(cfg, W)
 env2.reset(phase="train", first_case=0, device=True)
