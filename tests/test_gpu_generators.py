@@ -528,3 +528,32 @@ def test_step_observe_and_copy_observe_equal_the_separate_launches(n, model, rob
     np.testing.assert_array_equal(obs_a.download(), obs_b.download())
     copied = (mask == 1) & (status == 0)
     np.testing.assert_array_equal(b.get_states()[copied], src.get_states()[copied])
+
+
+def test_step_device_from_the_library_stream_equals_the_cross_stream_call():
+    """A loop inside `with torch.cuda.stream(env.device_stream())` (step_device then skips its cross-stream waits) returns what the
+    ordinary call returns, auto-resets included."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W = 96
+    cfg = _config("circle_crossing", human_num=6)
+    envs = [BatchedSocialNavGym(cfg, W) for _ in range(2)]
+    for e in envs:
+        e.reset(phase="test", first_case=11, device=True)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    acts = [torch.rand(W, 2, device="cuda", generator=gen) * 1.6 - 0.8 for _ in range(40)]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for a in acts:
+        outs[0].append([t.clone() for t in envs[0].step_device(a)])
+    with torch.cuda.stream(envs[1].device_stream()):
+        for a in acts:
+            outs[1].append([t.clone() for t in envs[1].step_device(a)])
+    torch.cuda.synchronize()
+    ended = 0
+    for x, y in zip(*outs):
+        for tx, ty in zip(x, y):
+            assert torch.equal(tx, ty)
+        ended += int((x[2] | x[3]).sum())
+    assert ended > 0   # some episodes did end and were regenerated on the way
