@@ -101,3 +101,14 @@ t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(f"   of which host-side launch time {t_host / K * 1e6:.1f} us per step (total {el / K * 1e6:.1f})")
+with torch.cuda.stream(env2.device_stream()):
+    for _ in range(20):
+        env2.step_device(buf2, auto_reset="next_step")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        env2.step_device(buf2, auto_reset="next_step")
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(f"   NEXT_STEP from inside `with torch.cuda.stream(env.device_stream())`: {el / K * 1e6:.1f} us per batched step, {W * K / el:.3e} Gym steps/s")
+
