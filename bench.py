@@ -20,7 +20,12 @@ reset: with W = 20, K = 200 that is the span of a whole reference episode, time_
 `ms_per_step` is the MEDIAN over the repeats of (MAX over ranks of the elapsed wall time) / K; HIP events on the launch
 stream around every replay give the kernel duration of the same samples (mean and median reported; kernel <= wall).
 
-Prints ONE JSON line on rank 0 with
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): bench.py starts its own N ranks -- N fresh child processes, one
+per GPU, before this process imports torch or touches HIP -- relays rank 0's line and exits with the children's worst exit code
+(launch_ranks).  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks the launcher made are used as they are.
+
+Prints ONE COMPACT JSON line (< 4 KB: compact_line) on rank 0; the full blocks (every other_configs roofline, the PMC figures and
+their sources) go to gpurun_out/bench_full.json and to stderr.  The line carries
   roofline      algorithmic bytes per launch / average kernel duration against the 8 TB/s HBM3E peak (the contract's
                 figure: a NORMALISED ALGORITHMIC THROUGHPUT -- the 20 fused substeps keep the state in registers / LDS,
                 so real HBM traffic is ~3 % of peak), plus `frac_vs_copy` (against a device-copy bandwidth measured in
@@ -28,6 +33,9 @@ Prints ONE JSON line on rank 0 with
                 with their source files and with `pmc_build_matches`: whether they were measured on the library build that is
                 running now), `valu_frac` (PMC VALU instructions per launch x 4 issue cycles / (1024 SIMDs x kernel cycles at
                 2.4 GHz): the bound that really holds for these kernels)
+  ranks         per rank: device index, PCI address, kernel time -- which card every rank sat on; `dist` = backend, world size, RCCL version
+  gym_step      the device-resident Gym step (reward + bookkeeping, 20 substeps + observation, masked copy): us per batched step without
+                resets, with same-step auto-reset and in NEXT_STEP mode (N = 1, rank 0)
   other_configs kernel time and roofline fraction of BASELINE.json configs[1], [3] (two named phases of the crossing) and [4]
                 (cfg5 = `--total-worlds 65536` x 50 HSFM humans of which 3 immobile + 3 polygon walls, strong-split over the
                 ranks), and of the shapes beside the benchmark's own (visible robot, 30 humans, per-agent parameters,
@@ -81,6 +89,8 @@ def parse(argv=None):
     ap.add_argument("--eager", action="store_true", help="launch every step from Python (default: one HIP graph of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-gym-step", action="store_true", help="skip the device-resident Gym step figures (gym_step)")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"), help="where the full (uncompacted) result goes")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the N > 1 code path on a one-GPU box")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --same-device: rehearse the N > 1 path with several ranks on ONE GPU")
@@ -346,6 +356,14 @@ class Runner:
         self.dist.all_gather(out, t)
         return [float(x.item()) for x in out]
 
+    def gather_objects(self, obj) -> list:
+        """every rank's record, in rank order"""
+        if self.dist is None or self.dist.get_world_size() == 1:
+            return [obj]
+        out = [None] * self.dist.get_world_size()
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def copy_bandwidth(self, nbytes=1 << 30, reps=10):
         """Device-to-device copy bandwidth measured in this run (read + written bytes / time): the practical HBM ceiling
         (MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy) beside the 8 TB/s vendor peak."""
@@ -425,8 +443,199 @@ def roofline_block(spec, W, kern_ms, copy_gbs, cw):
     return out
 
 
-def main():
-    args = parse()
+# --------------------------------------------------------------------------------------------------------------------------
+# the stdout line: compact by construction.  BENCH_r03 lost its headline because the ONE line had grown to 22.6 KB (eight
+# other_configs entries with a full roofline block and two prose strings each): the driver keeps an 8 KB tail.  Everything the
+# contract names stays in the line; what explains it lives in the full file.
+# --------------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+
+def _r(x, sig=5):
+    """floats to `sig` significant digits (a bench line is read by people and parsed by the driver: 17 digits help neither)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def short_variant(v: str) -> str:
+    """'k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2' -> 'sfm<0,1,1,64,1,25,1>g2048'"""
+    import re
+
+    if not v:
+        return v
+    m = re.match(r"k_(\w+?)(?:_step)?(_row16)?<([^>]*)>(?:\s+grid=(\d+))?", v)
+    if not m:
+        return v[:40]
+    vals = ",".join(kv.split("=")[-1] for kv in m.group(3).split(","))
+    return f"{m.group(1)}{m.group(2) or ''}<{vals}>" + (f"g{m.group(4)}" if m.group(4) else "")
+
+
+def compact_roofline(rl: dict) -> dict:
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "valu_frac", "kernel", "kernel_avg_ms", "algorithmic_bytes_per_launch",
+            "bytes_per_agent_substep", "frac_vs_copy", "pmc_build_matches")
+    out = {k: rl.get(k) for k in keep}
+    out["variant"] = short_variant(rl.get("variant"))
+    v = rl.get("valu") or {}
+    out["valu_per_wave_substep"] = v.get("valu_insts_per_wave_substep")
+    out["lds_per_wave_substep"] = v.get("lds_insts_per_wave_substep")
+    return out
+
+
+def compact_line(full: dict) -> str:
+    """The ONE stdout line from the full result: headline keys, config, ONE roofline (the headline's), cpu_baseline, ranks, the Gym
+    step figures and other_configs as a table.  Raises if the line would not fit LINE_LIMIT bytes or is not strict JSON."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "timing_repeats", "kernel_us", "kernel_le_wall", "gym_steps_per_s", "finite_fraction", "build_id")
+    out = {k: full.get(k) for k in keys}
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "worlds_per_gpu", "worlds_total", "agents", "substeps_per_step", "parallelism", "launch", "stationary")}
+    out["roofline"] = compact_roofline(full["roofline"])
+    if full.get("cpu_baseline"):
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value")}
+        out["gpu_over_cpu"] = full.get("gpu_over_cpu")
+    out["dist"] = full.get("dist")
+    out["ranks"] = full.get("ranks")
+    if full.get("gym_step"):
+        out["gym_step"] = full["gym_step"]
+    cols = ("name", "ms_per_step", "kernel_us", "frac", "valu_frac", "variant", "pmc_build_matches", "worlds_total", "steps", "warmup")
+    rows = []
+    for o in full.get("other_configs") or []:
+        rl = o.get("roofline") or {}
+        rows.append([o.get("name"), o.get("ms_per_step"), o.get("kernel_us"), o.get("frac"), o.get("valu_frac"), short_variant(rl.get("variant")),
+                     rl.get("pmc_build_matches"), o.get("worlds_total"), o.get("steps"), o.get("warmup")])
+    out["other_configs"] = {"columns": list(cols), "rows": rows, "workloads": "BASELINE.json configs[1],[3],[4] + the shapes around configs[2]; titles in full_json"}
+    out["full_json"] = full.get("full_json")
+    line = json.dumps(_r(out), allow_nan=False, separators=(",", ":"))
+    if len(line.encode()) >= LINE_LIMIT:
+        # never print a line the driver cannot parse: drop the optional blocks, largest first
+        for k in ("other_configs", "gym_step", "ranks"):
+            if k == "ranks" and out.get("ranks"):
+                out["ranks"] = [{kk: r.get(kk) for kk in ("rank", "device", "kernel_us")} for r in out["ranks"]]
+            elif k in out:
+                out[k] = {"dropped": "line limit; see full_json"}
+            line = json.dumps(_r(out), allow_nan=False, separators=(",", ":"))
+            if len(line.encode()) < LINE_LIMIT:
+                break
+    if len(line.encode()) >= LINE_LIMIT:
+        raise RuntimeError(f"bench line is {len(line)} bytes (limit {LINE_LIMIT})")
+    json.loads(line)
+    return line
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# `--gpus N` without a launcher: start the N ranks here
+# --------------------------------------------------------------------------------------------------------------------------
+def visible_gpus() -> int:
+    """Devices a fresh process would see, counted in a CHILD: this process must not initialise HIP before it starts its ranks."""
+    import subprocess
+
+    code = ("import sys; sys.path.insert(0, %r); from social_navigation_pyenvs_amd import _lib; print(_lib.device_count())" % ROOT)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv, worker=None, n_visible=None) -> int:
+    """Start `args.gpus` ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, one GPU each), relay
+    rank 0's line to stdout and return the worst exit code.  Nothing here imports torch or calls HIP.  `worker` / `n_visible`: the CPU
+    test's stub (tests/test_bench_line_cpu.py)."""
+    import subprocess
+
+    n = args.gpus
+    have = visible_gpus() if n_visible is None else n_visible
+    need = 1 if args.same_device else n
+    if have < need:
+        print(f"bench.py: --gpus {n} needs {need} visible GPU(s), this box shows {have}: not measuring fewer ranks than asked for", file=sys.stderr)
+        return 3
+    port = free_port()
+    cmd = [sys.executable, worker or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), CROWDSTEP_BENCH_LAUNCHER="self")
+        # rank 0's stdout is the line; the other ranks print nothing there (and whatever they do print goes to stderr)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    worst = max((abs(c) for c in codes), default=0)
+    if worst != 0:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif worst == 0:
+        worst = 4
+    return worst
+
+
+def gym_step_figures(W, n, steps=150):
+    """us per batched step of the device-resident Gym loop (BatchedSocialNavGym.step_device: swept collision + reward + bookkeeping, 20
+    fused substeps + observation, regeneration of the worlds whose episode ended) at W hybrid worlds x n humans, from inside the
+    library's stream: without resets / same-step auto-reset / NEXT_STEP mode (tools/device_loop_bench.py prints the longer table)."""
+    import configparser
+
+    import torch
+
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    cfg = configparser.RawConfigParser()
+    cfg.read_dict({
+        "env": {"time_limit": 50, "time_step": 0.0125, "robot_time_step": 0.25, "val_size": 100, "test_size": 500, "randomize_attributes": "false"},
+        "reward": {"success_reward": 1, "collision_penalty": -0.25, "discomfort_dist": 0.2, "discomfort_penalty_factor": 0.5},
+        "sim": {"train_val_sim": "hybrid_scenario", "test_sim": "hybrid_scenario", "square_width": 10, "circle_radius": 7, "human_num": n,
+                "traffic_length": 14, "traffic_height": 3},
+        "humans": {"visible": "true", "policy": "hsfm_farina", "radius": 0.3, "v_pref": 1, "sensor": "coordinates"},
+        "robot": {"visible": "false", "policy": "none", "radius": 0.3, "v_pref": 1, "sensor": "coordinates"},
+    })
+    out = {"worlds": W, "humans": n, "unit": "us per batched Gym step", "steps": steps}
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    for key, mode in (("no_reset", False), ("same_step", True), ("next_step", "next_step")):
+        env = BatchedSocialNavGym(cfg, W)
+        env.reset(phase="train", first_case=0, device=True)
+        buf = env.action_buffer()
+        buf.copy_(torch.randn(W, 2, device="cuda", generator=gen) * 0.5)
+        with torch.cuda.stream(env.device_stream()):
+            for _ in range(60):                      # past the first episode ends: resets are part of the steady state
+                env.step_device(buf, auto_reset=mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                env.step_device(buf, auto_reset=mode)
+            torch.cuda.synchronize()
+            out[key] = (time.perf_counter() - t0) / steps * 1e6
+        if mode is not False and hasattr(env, "failed_resets"):
+            try:
+                out[key + "_failed_resets"] = int(env.failed_resets())
+            except Exception:
+                pass
+        del env
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher.  BEFORE torch is imported or HIP touched -- the ranks are fresh processes.
+        sys.exit(launch_ranks(args, argv))
     # stdout carries ONE JSON line and nothing else: native libraries (RCCL prints a version banner from C when NCCL_DEBUG
     # asks for it) write to file descriptor 1 directly, so everything but the final line is sent to stderr
     sys.stdout.flush()
@@ -435,16 +644,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_size:
+        # a line whose n_gpus differs from what was asked for would be read as an N-GPU measurement: refuse
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}: start it as `python bench.py --gpus {args.gpus}` (it launches its own ranks) "
+              f"or under torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     import torch
 
     from social_navigation_pyenvs_amd import _lib
     from social_navigation_pyenvs_amd.batched import HUMAN_MODELS as SFMS
 
     _lib.require_gpu()
+    n_dev = _lib.device_count()
     dev_index = 0 if args.same_device else local_rank
+    if dev_index >= n_dev:
+        print(f"bench.py: rank {rank} wants GPU {dev_index}, {n_dev} visible", file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(dev_index)
     _lib.set_device(dev_index)
     dist = None
+    dist_info = {"backend": None, "world_size": 1, "launcher": os.environ.get("CROWDSTEP_BENCH_LAUNCHER", "none" if world_size == 1 else "external")}
     if world_size > 1 or args.force_dist:
         import torch.distributed as dist
 
@@ -456,8 +675,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo")
-    if args.gpus != world_size and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world_size}", file=sys.stderr)
+        dist_info.update(backend=dist.get_backend(), world_size=dist.get_world_size())
+        if args.dist_backend == "nccl":
+            try:
+                dist_info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                dist_info["rccl_version"] = None
 
     stream = _lib.stream_create()
     run = Runner(torch, dist, stream, reduce_device="cuda" if args.dist_backend == "nccl" else None)
@@ -466,6 +689,9 @@ def main():
     wall, kern = run.measure(cw, spec, args.steps, args.warmup, args.repeats, eager=args.eager, restore=not args.no_restore)
     per_rank_kernel_us = run.gather(float(np.mean(kern)) * 1e3)
     total_worlds = args.total_worlds if args.total_worlds is not None else world_size * args.worlds
+    # which card every rank sat on
+    me = {"rank": rank, "device": dev_index, "pci": _lib.device_pci_bus_id(dev_index), "worlds": W, "kernel_us": float(np.mean(kern)) * 1e3}
+    ranks = run.gather_objects(me)
 
     # sanity: the state is finite and moved
     S_end = cw.get_states()
@@ -537,15 +763,32 @@ def main():
             "kernel_us_median": rl["kernel_median_ms"] * 1e3,
             "kernel_le_wall": bool(rl["kernel_median_ms"] <= med / args.steps * 1e3),
             "per_rank_kernel_us": per_rank_kernel_us,
+            "dist": dist_info,
+            "ranks": ranks,
             "roofline": rl,
             "other_configs": others,
         }
         if not args.no_cpu_baseline and args.model != "orca" and world_size == 1 and host is not None and not args.robot and not args.per_agent_params:
             out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))   # rank 0, N = 1 only
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
+        if not args.no_gym_step and world_size == 1 and args.model != "orca" and not args.robot and not args.per_agent_params and not args.walls:
+            try:
+                out["gym_step"] = gym_step_figures(args.worlds, args.agents)
+            except Exception as e:   # a side figure never costs the headline
+                out["gym_step"] = {"error": f"{type(e).__name__}: {e}"[:160]}
+        try:
+            os.makedirs(os.path.dirname(args.full_json), exist_ok=True)
+            with open(args.full_json, "w") as f:
+                json.dump(out, f, indent=1)
+            out["full_json"] = os.path.relpath(args.full_json, ROOT)
+        except OSError as e:
+            out["full_json"] = None
+            print(f"bench.py: full result not written ({e})", file=sys.stderr)
+        print(json.dumps(out), file=sys.stderr, flush=True)      # the full blocks: stderr + the side file
+        line = compact_line(out)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
+        print(line, flush=True)
         os.dup2(2, 1)
     if dist is not None:
         dist.barrier()

@@ -104,6 +104,9 @@ int cs_abi_version(void);
 int cs_device_count(int* count);
 int cs_set_device(int device);
 int cs_device_name(int device, char* buf, size_t buflen);
+/* PCI address "domain:bus:device.function" of a device: bench.py reports it per rank, so that a multi-GPU line proves which
+ * card every rank sat on (one process per GPU, no collective on the data path) */
+int cs_device_pci_bus_id(int device, char* buf, size_t buflen);
 int cs_malloc(void** d_ptr, size_t bytes);
 int cs_free(void* d_ptr);
 int cs_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);

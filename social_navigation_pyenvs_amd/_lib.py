@@ -28,7 +28,7 @@ CS_SOCIAL_MOMENTUM = 10
 
 # every symbol include/crowdstep.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
-    "cs_last_error", "cs_abi_version", "cs_device_count", "cs_set_device", "cs_device_name", "cs_malloc",
+    "cs_last_error", "cs_abi_version", "cs_device_count", "cs_set_device", "cs_device_name", "cs_device_pci_bus_id", "cs_malloc",
     "cs_free", "cs_memcpy_h2d", "cs_memcpy_d2h", "cs_memcpy_d2d", "cs_memset", "cs_stream_create",
     "cs_stream_destroy", "cs_stream_sync", "cs_event_create", "cs_event_destroy", "cs_event_record",
     "cs_event_elapsed_ms", "cs_stream_wait_event", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
@@ -207,6 +207,12 @@ def set_device(device: int) -> None:
 def device_name(device: int = 0) -> str:
     buf = C.create_string_buffer(256)
     check(load().cs_device_name(C.c_int(device), buf, C.c_size_t(256)))
+    return buf.value.decode()
+
+
+def device_pci_bus_id(device: int = 0) -> str:
+    buf = C.create_string_buffer(64)
+    check(load().cs_device_pci_bus_id(C.c_int(device), buf, C.c_size_t(64)))
     return buf.value.decode()
 
 

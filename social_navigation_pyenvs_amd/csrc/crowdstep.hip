@@ -440,6 +440,13 @@ int cs_device_name(int device, char* buf, size_t buflen)
     return CS_OK;
 }
 
+int cs_device_pci_bus_id(int device, char* buf, size_t buflen)
+{
+    if (!buf || buflen < 16) return fail(CS_ERR_ARG, "buffer of at least 16 bytes needed");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)buflen, device));
+    return CS_OK;
+}
+
 int cs_malloc(void** d_ptr, size_t bytes) { if (!d_ptr) return fail(CS_ERR_ARG, "null out pointer"); HIP_TRY(hipMalloc(d_ptr, bytes)); return CS_OK; }
 int cs_free(void* d_ptr) { HIP_TRY(hipFree(d_ptr)); return CS_OK; }
 int cs_memcpy_h2d(void* d, const void* h, size_t bytes, void* s) { HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); if (!s) HIP_TRY(hipStreamSynchronize(nullptr)); return CS_OK; }

@@ -1,0 +1,133 @@
+"""bench.py's stdout contract on CPU: the ONE line stays under 4 KB and is strict JSON whatever the measurements were, and
+`--gpus N` without a launcher starts N ranks of its own (stub worker: no GPU, no torch)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def canned_full(n_ranks=1):
+    """A full result assembled from committed measurements: profiles/r3r_main_bench.json is the 22.6 KB line of round 3 -- the one
+    the driver could not parse -- with the blocks this round added beside it."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r3r_main_bench.json")))
+    full["n_gpus"] = n_ranks
+    full["dist"] = {"backend": "nccl" if n_ranks > 1 else None, "world_size": n_ranks, "launcher": "self", "rccl_version": "2.26.6"}
+    full["ranks"] = [{"rank": r, "device": r, "pci": f"0000:{0x05 + 0x10 * r:02x}:00.0", "worlds": 4096, "kernel_us": 31.134706640243532 + r} for r in range(n_ranks)]
+    full["gym_step"] = {"worlds": 4096, "humans": 25, "unit": "us per batched Gym step", "steps": 150, "no_reset": 44.41234567, "same_step": 61.2345678,
+                       "next_step": 52.3456789, "same_step_failed_resets": 0, "next_step_failed_resets": 0}
+    full["full_json"] = "gpurun_out/bench_full.json"
+    return full
+
+
+@pytest.mark.parametrize("n_ranks", [1, 8])
+def test_line_is_compact_strict_json_with_everything_the_contract_names(n_ranks):
+    full = canned_full(n_ranks)
+    assert len(json.dumps(full)) > 20000          # the input really is the oversized one
+    line = bench.compact_line(full)
+    assert "\n" not in line and len(line.encode()) < 4096, len(line)
+    d = json.loads(line, parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["config"]["workload"].startswith("4096 worlds/GPU x 25-agent hsfm_farina")
+    rl = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rl, k
+    assert rl["bound"] == "hbm" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-4
+    assert abs(rl["frac"] - full["roofline"]["frac"]) < 1e-4 and rl["valu_frac"] is not None
+    if n_ranks == 1:
+        cb = d["cpu_baseline"]
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "port"
+    assert abs(d["value"] / full["value"] - 1) < 1e-4 and abs(d["ms_per_step"] / full["ms_per_step"] - 1) < 1e-4
+    assert len(d["ranks"]) == n_ranks and d["ranks"][0]["pci"] and d["dist"]["world_size"] == n_ranks
+    oc = d["other_configs"]
+    assert oc["columns"][:5] == ["name", "ms_per_step", "kernel_us", "frac", "valu_frac"]
+    assert [r[0] for r in oc["rows"]] == [o["name"] for o in full["other_configs"]] and len(oc["rows"]) == 8
+    assert d["gym_step"]["no_reset"] and d["full_json"]
+
+
+def test_line_survives_missing_pmc_entries_and_nan():
+    full = canned_full()
+    full["roofline"].update(traffic=None, valu=None, valu_frac=None, pmc_build_matches=None)
+    full["other_configs"][0]["valu_frac"] = float("nan")      # never reaches the line as a bare NaN
+    full["gym_step"] = {"error": "x" * 160}
+    d = json.loads(bench.compact_line(full))
+    assert d["roofline"]["traffic"] is None and d["other_configs"]["rows"][0][4] is None
+
+
+def test_oversized_optional_blocks_are_dropped_not_printed():
+    full = canned_full(8)
+    full["other_configs"] = full["other_configs"] * 6          # 48 rows: would not fit
+    line = bench.compact_line(full)
+    assert len(line.encode()) < 4096
+    d = json.loads(line)
+    assert "dropped" in d["other_configs"] and d["roofline"]["frac"] and d["value"]
+
+
+def test_short_variant():
+    assert bench.short_variant("k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2") == "sfm<0,1,1,64,1,25,1>g2048"
+    assert bench.short_variant("k_sfm_step_row16<SOC=0,HEADED=0,ROWS=10> grid=1024 block=64 wpb=4") == "sfm_row16<0,0,10>g1024"
+    assert bench.short_variant(None) is None
+
+
+STUB = textwrap.dedent("""
+    import json, os, sys
+    # a rank of the launcher: must find the torchrun-style environment, a distinct rank, and the arguments passed through
+    rank, ws = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert int(os.environ["LOCAL_RANK"]) == rank and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    open(os.path.join(os.environ["STUB_DIR"], f"rank{rank}"), "w").write(" ".join(sys.argv[1:]))
+    print(f"noise from rank {rank}")                 # only rank 0's LAST stdout line is relayed
+    if rank == 0:
+        print(json.dumps({"n_gpus": ws, "argv": sys.argv[1:]}))
+    sys.exit(int(os.environ.get("STUB_FAIL_RANK", "-1")) == rank and 7 or 0)
+""")
+
+
+def run_launcher(tmp_path, n, visible, extra_env=None, extra_args=()):
+    stub = tmp_path / "stub_worker.py"
+    stub.write_text(STUB)
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; a = ['--gpus', '{n}', '--steps', '3'] + {list(extra_args)!r}; "
+            f"rc = bench.launch_ranks(bench.parse(a), a, worker={str(stub)!r}, n_visible={visible}); "
+            "assert 'torch' not in sys.modules, 'the launcher must not import torch'; sys.exit(rc)")
+    env = dict(os.environ, STUB_DIR=str(tmp_path), **(extra_env or {}))
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+
+
+def test_launcher_starts_n_ranks_and_relays_rank0(tmp_path):
+    r = run_launcher(tmp_path, 4, visible=8)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # ONE line on stdout: rank 0's last
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["argv"] == ["--gpus", "4", "--steps", "3"]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("rank")) == ["rank0", "rank1", "rank2", "rank3"]
+    assert "noise from rank 1" in r.stderr                  # the other ranks' stdout goes to stderr
+
+
+def test_launcher_refuses_when_fewer_gpus_are_visible(tmp_path):
+    r = run_launcher(tmp_path, 8, visible=1)
+    assert r.returncode == 3 and r.stdout.strip() == "" and "needs 8 visible" in r.stderr
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("rank")]
+    # the one-GPU rehearsal: every rank on GPU 0
+    r = run_launcher(tmp_path, 2, visible=1, extra_args=("--same-device", "--dist-backend", "gloo"))
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["n_gpus"] == 2
+
+
+def test_launcher_reports_a_failed_rank(tmp_path):
+    r = run_launcher(tmp_path, 2, visible=2, extra_env={"STUB_FAIL_RANK": "1"})
+    assert r.returncode == 7 and "exit codes [0, 7]" in r.stderr
+
+
+def test_rank_refuses_a_world_size_it_was_not_asked_for():
+    """`python bench.py --gpus 8` under a launcher that made ONE rank must not print a line that says n_gpus = 1."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 2 and r.stdout.strip() == "" and "WORLD_SIZE=1" in r.stderr
