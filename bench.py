@@ -771,7 +771,7 @@ def main(argv=None):
         if not args.no_cpu_baseline and args.model != "orca" and world_size == 1 and host is not None and not args.robot and not args.per_agent_params:
             out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))   # rank 0, N = 1 only
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
-        if not args.no_gym_step and world_size == 1 and args.model != "orca" and not args.robot and not args.per_agent_params and not args.walls:
+        if not args.no_gym_step and not args.no_other_configs and world_size == 1 and args.model != "orca" and not args.robot and not args.per_agent_params and not args.walls:
             try:
                 out["gym_step"] = gym_step_figures(args.worlds, args.agents)
             except Exception as e:   # a side figure never costs the headline
