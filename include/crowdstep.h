@@ -160,7 +160,7 @@ int cs_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action,
  *   d_trace [n_substeps][W][rows][12] = px, py, theta, vx, vy, bvx, bvy, omega, gx, gy (state columns 10:12), goals[0].x, goals[0].y
  *   (rows = n + 1 with CS_ROBOT_ROW: the robot's record k is the robot as substep k + 1 sees it -- it moves before the humans,
  *   social_nav_gym.py:240-243 -- and as it stands at the end for the last record).
- *   Types 0..8, worlds of up to 1024 rows; other worlds -> CS_ERR_ARG.
+ *   Types 0..8, any world size (worlds beyond one block: the grid path records from HBM after every substep).
  */
 int cs_step_trace(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_trace, void* stream);
 

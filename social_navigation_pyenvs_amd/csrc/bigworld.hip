@@ -376,6 +376,19 @@ __global__ void k_bw_peek_rows(const GArgs a)
     o[0] = s[0]; o[1] = s[a.fs]; o[2] = s[2 * a.fs]; o[3] = s[3 * a.fs]; o[4] = s[4 * a.fs]; o[5] = s[7 * a.fs]; o[6] = g.x; o[7] = g.y;
 }
 
+// cs_step_trace on the grid path: rows [first, end) of every world as they stand in S, in write_trace's record layout (stepcommon.h),
+// into record `rec` = d_trace + sub * W * rows * 12.  A human's record carries the head of its goal list; the robot's its goal columns.
+__global__ void k_bw_trace(const GArgs a, const float* S, float* rec, int first, int end)
+{
+    const int i = first + blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= end) return;
+    const float* s = S + ((long)w * a.rows + i) * a.as;
+    const long fs = a.fs;
+    float g0x = s[10 * fs], g0y = s[11 * fs];
+    if (i < a.n) { const float* gi = a.goals + ((long)w * a.n + i) * a.G * 2; g0x = gi[0]; g0y = gi[1]; }
+    write_trace(rec + ((long)w * a.rows + i) * 12, s[0], s[fs], s[2 * fs], s[3 * fs], s[4 * fs], s[5 * fs], s[6 * fs], s[7 * fs], s[10 * fs], s[11 * fs], g0x, g0y);
+}
+
 // The robot handed over through cs_worlds.d_robot: robot.step(action, dt) (robot_agent.py:114-136) and states[-1] = robot row
 // (motion_model_manager.py:359) before a substep; one lane per world.  S: the rows the substep is about to read.
 __global__ void k_bw_robot(const GArgs a, float* S)
@@ -540,7 +553,7 @@ size_t sfm_big_scratch_bytes(const cs_worlds* w)
 // n_substeps Euler substeps of worlds beyond one block.  d_out: where the result goes (w->d_state for cs_step / the in-place
 // update); mutate_input: reproduce the reference's in-place writes on w->d_state (out-of-place cs_update_humans_parallel).
 int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, int mutate_input, bool robot_from_array, const float* d_action,
-                   float* d_peek, hipStream_t stream)
+                   float* d_peek, hipStream_t stream, float* d_trace)
 {
     const int W = w->W, n = w->n, rows = n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     if (robot_from_array && !(w->flags & CS_ROBOT_ROW)) robot_from_array = false;
@@ -603,6 +616,9 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
             a.action = robot_moves ? d_action : nullptr;
             hipLaunchKernelGGL(k_bw_robot, dim3((W + 63) / 64), dim3(64), 0, stream, a, cur);
         }
+        // cs_step_trace: the robot's record k is the robot as substep k + 1 sees it (it moves before the humans)
+        if (d_trace && rows > n && sub > 0)
+            hipLaunchKernelGGL(k_bw_trace, dim3(1, W), dim3(64), 0, stream, a, cur, d_trace + (size_t)(sub - 1) * W * rows * 12, n, rows);
         if (sub == 0) hipLaunchKernelGGL(k_bw_reach, dim3(W), dim3(256), 0, stream, a);   // radii, parameters and speed limits hold for the launch
         GridView g;
         int rcg = grid_build(cur, a.as, a.fs, W, rows, NB, a.inv_cell, 0.0f, grid_mem, g, stream);
@@ -611,8 +627,12 @@ int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, i
         hipLaunchKernelGGL(step, dim3((rows + 255) / 256, W), dim3(256), 0, stream, a);
         if (a.mutate) hipLaunchKernelGGL(k_bw_mutate, dim3((n + 255) / 256, W), dim3(256), 0, stream, a);
         if (w->flags & CS_RESPAWN) big_respawn_launch(nxt, a.as, a.fs, W, n, rows, w->d_goals, w->G, w->d_safety, 0, a.bx, a.by, w->d_world_flags, stream);
+        if (d_trace)   // every human's row after this substep (respawn rule included): what the LDS kernels record from their registers
+            hipLaunchKernelGGL(k_bw_trace, dim3((n + 255) / 256, W), dim3(256), 0, stream, a, nxt, d_trace + (size_t)sub * W * rows * 12, 0, n);
         cur = nxt;
     }
+    if (d_trace && rows > n && n_substeps > 0)   // ... and the robot as it stands at the end
+        hipLaunchKernelGGL(k_bw_trace, dim3(1, W), dim3(64), 0, stream, a, cur, d_trace + (size_t)(n_substeps - 1) * W * rows * 12, n, rows);
     HIP_TRY(hipGetLastError());
     if (cur != d_out) HIP_TRY(hipMemcpyAsync(d_out, cur, (size_t)W * rows * 13 * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return CS_OK;

@@ -51,7 +51,7 @@ int big_world_buckets(int rows);   // hashed buckets of a world's grid: the powe
 int grid_build(const float* S, long as, long fs, int W, int rows, int NB, const float* d_inv_cell, float inv_cell, void* mem, GridView& g, hipStream_t stream);
 // SFM / HSFM worlds beyond one block (bigworld.hip)
 int sfm_big_launch(const cs_worlds* w, float dt, int n_substeps, float* d_out, int mutate_input, bool robot_from_array, const float* d_action,
-                   float* d_peek, hipStream_t stream);
+                   float* d_peek, hipStream_t stream, float* d_trace = nullptr);
 // small worlds, one per 16-lane DPP row (rowstep.hip)
 bool row16_supports(int rows);
 int row16_launch(const cstep::KArgs& a, hipStream_t stream);

@@ -358,10 +358,9 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     rc = geometry(w, g);
     if (rc) return rc;
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
-    if (rows > csimpl::big_world_min_rows(1024) && d_trace) return fail(CS_ERR_ARG, "cs_step_trace is not built for worlds beyond one block");
     if (rows > csimpl::big_world_min_rows(1024))   // worlds beyond one block: partners through a uniform grid in HBM (bigworld.hip)
         return csimpl::sfm_big_launch(w, dt, nsub, d_out ? d_out : w->d_state, (mode & M_MUTATE_INPUT) ? 1 : 0,
-                                      (mode & M_ROBOT_FROM_ARRAY) != 0, d_action, (mode & M_PEEK) ? d_peek : nullptr, stream);
+                                      (mode & M_ROBOT_FROM_ARRAY) != 0, d_action, (mode & M_PEEK) ? d_peek : nullptr, stream, d_trace);
     KArgs a;
     std::memset(&a, 0, sizeof(a));
     a.W = w->W; a.n = w->n; a.rows = rows; a.G = w->G; a.O = w->O; a.Smax = w->Smax;

@@ -96,6 +96,14 @@ def write_report(root: str) -> None:
 F32_SLACK = 3.0
 
 
+def single_call_bar(ref32, ref64, omega_in, dt, headed, bar=1e-5):
+    """The tolerance of ONE library call against the f64 oracle from the same float32 inputs: north_star's 1e-5, or -- where the float32
+    instantiation of the oracle is itself farther than that from the float64 one -- F32_SLACK times the float32 oracle's own error,
+    measured for this very case (no blanket tolerance).  Returns (tolerance, float32 oracle error)."""
+    e32 = float(row_errors(ref32, ref64, omega_in, dt, headed)[0].max())
+    return max(bar, F32_SLACK * e32), e32
+
+
 def row_errors(got, ref, omega_in, dt, headed):
     """Vectorised column rules of this module for rows [..., >= 8]: returns (err [...], omega_rel [...], lost [...] bool):
     err = worst of |d px|, |d py| (+ |d bvx|, |d bvy|, and theta / vx / vy minus what float32 holds of theta + omega_in dt when
