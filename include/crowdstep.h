@@ -114,6 +114,9 @@ int cs_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int cs_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
 int cs_memset(void* d_ptr, int value, size_t bytes, void* stream);
 int cs_stream_create(void** stream);
+/* priority: 0 = default, < 0 = the device's highest, > 0 = its lowest (background work beside a step stream: the refill passes of
+ * cs_refill_staged_worlds); a stream of another priority also lands on another hardware queue */
+int cs_stream_create_with_priority(void** stream, int priority);
 int cs_stream_destroy(void* stream);
 int cs_stream_sync(void* stream);
 /* HIP events on the launch stream (bench.py times kernels with these) */
@@ -121,6 +124,7 @@ int cs_event_create(void** event);
 int cs_event_destroy(void* event);
 int cs_event_record(void* event, void* stream);
 int cs_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int cs_event_query(void* event, int* done);                  /* *done = 1 when the work recorded before `event` has finished; never blocks */
 int cs_stream_wait_event(void* stream, void* event);         /* later work of `stream` waits for `event` (no host sync) */
 
 /* HIP graphs: capture the launches issued on `stream` between begin and end (e.g. K cs_step calls of a rollout) and
@@ -299,7 +303,8 @@ int cs_imitation_block(const cs_worlds* w, int32_t robot_type, const float* robo
  * Nothing is allocated, grown or freed while `stream` is capturing: an entry point that would have to returns CS_ERR_ARG
  * -- call cs_reserve_scratch(w, n_substeps, stream) (or the entry point itself once) before cs_graph_begin_capture.  A block
  * handed out during a capture is never freed behind a graph's back (growing it later retires the old block); cs_release_scratch
- * synchronises the device and frees every block -- only when no captured graph that used them will be replayed again.
+ * synchronises EVERY device that holds a block and frees them all -- only when no captured graph that used them will be replayed again.
+ * Threads: one host thread per (device, stream) at a time; different streams never share a block.
  */
 int cs_reserve_scratch(const cs_worlds* w, int n_substeps, void* stream);
 int cs_release_scratch(void);
@@ -350,12 +355,12 @@ int cs_robot_model_rk45(const cs_worlds* w, int32_t robot_type, const float* rob
  *   typed copies of cs_collision_reward's rows (d_out [W][7] -> d_reward [W], d_terminated / d_truncated [W] bytes 0 / 1,
  *   d_info [W]); the per-world step counter and global_time = clock[counter] (social_nav_gym.py:244 accumulates time_step in
  *   float32: the caller tabulates those sums in d_clock [clock_len]); with auto_reset, d_mask [W] = episode ended, the counter
- *   of such a world restarts at 0 and its seed moves on by W (the next unused seed of its arithmetic sequence) -- the inputs
+ *   of such a world restarts at 0 and its seed moves on by seed_stride (the next unused seed of its arithmetic sequence) -- the inputs
  *   of the masked cs_generate_worlds that follows.
  */
 int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, float* d_global_time,
                        const float* d_clock, int clock_len, int auto_reset, float* d_reward, uint8_t* d_terminated,
-                       uint8_t* d_truncated, int32_t* d_info, void* stream);
+                       uint8_t* d_truncated, int32_t* d_info, uint32_t seed_stride /* 0 = W */, void* stream);
 
 /*
  * cs_gym_observe  replaces SocialNavGym.compute_humans_observable_state (social_nav_gym.py:100-105: the list of
@@ -393,7 +398,7 @@ int cs_copy_worlds_masked_observe(const cs_worlds* src, const cs_worlds* dst, co
  */
 int cs_gym_bookkeeping_next_step(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, const int32_t* d_prev_mask,
                                  float* d_global_time, const float* d_clock, int clock_len, float* d_reward, uint8_t* d_terminated,
-                                 uint8_t* d_truncated, int32_t* d_info, void* stream);
+                                 uint8_t* d_truncated, int32_t* d_info, uint32_t seed_stride /* 0 = W */, void* stream);
 
 /*
  * cs_collision_reward_gym  cs_collision_reward and the episode bookkeeping behind it in ONE launch (the lane that writes a world's
@@ -404,7 +409,7 @@ int cs_gym_bookkeeping_next_step(int W, const float* d_out, int32_t* d_counter, 
  */
 typedef struct cs_gym_book {
     int32_t* d_counter;          /* [W] steps of the running episode */
-    uint32_t* d_seeds;           /* [W] seed of the running episode: += W when the episode ends */
+    uint32_t* d_seeds;           /* [W] seed of the running episode: += seed_stride when the episode ends */
     int32_t* d_mask;             /* [W] out: episode ended in this step */
     const int32_t* d_prev_mask;  /* [W] NEXT_STEP mode: worlds being reset during this step; NULL: same-step rules */
     const float* d_clock;        /* [clock_len] float32 sums of the time step */
@@ -414,9 +419,46 @@ typedef struct cs_gym_book {
     uint8_t* d_terminated;
     uint8_t* d_truncated;
     int32_t* d_info;
+    uint32_t seed_stride;        /* what a finished world's seed moves on by: the number of worlds of the WHOLE job, so that world w walks
+                                  * s + w + k * total on any rank count (ShardedBatchedSocialNavGym); 0 = W, the single-process batch */
 } cs_gym_book;
 int cs_collision_reward_gym(const cs_worlds* w, const float* d_action, float T, float* d_global_time,
                             const float* reward_cfg /* host, 5 floats */, float* d_out, const cs_gym_book* book, void* stream);
+
+/*
+ * Pre-staged episodes: the reset of a finished world (SocialNavGym.reset, social_nav_gym.py:120-225: seed -> generator -> rows) taken
+ * off the critical path of a vectorised Gym step.  A world's episodes are a function of their seeds, and the seeds are known ahead:
+ * episode e of world w draws d_base_seed[w] + e * seed_stride.  So every world keeps its next `depth` episodes generated ahead in a
+ * staging batch of depth * W worlds (slot j of world w = staging world j * W + w holds the one episode e in (epoch, epoch + depth] with
+ * e = j mod depth); an episode end is then a copy, and the consumed slots are regenerated on a side stream, several steps later, without
+ * anybody waiting for them -- a world that ends a few steps after its reset (a robot driven into its neighbour) finds the following
+ * episodes staged as well.  No event orders the two streams: the slots carry tags.
+ *   d_staged_seed[j][w]  the seed slot j of world w was generated from -- stored LAST by the generator (release, device scope)
+ *   d_epoch[w]           the episode the live world w is in (0 after reset) -- stored LAST by the consumer (release)
+ * cs_refill_staged_worlds   (side stream) regenerates every slot whose tag differs from the seed of the episode that belongs in it now
+ *   (one wavefront per slot; the other blocks leave at once); d_staged_status[j][w] = cs_generate_worlds' status.  Launches of it must
+ *   be ordered among themselves (one stream).  n <= 64.
+ * cs_consume_staged_worlds  (the step's stream, behind the substeps) for every world with d_mask[w] != 0: episode e = epoch + 1; if the
+ *   tag of slot e mod depth (acquire) equals d_seeds[w] -- the seed the bookkeeping just moved the world to -- the staged world is copied
+ *   over the live one, observation rows included (cs_copy_worlds_masked_observe); if the refill has not got to it yet the world is
+ *   generated in place from d_seeds[w] by the same generator code: the same rows either way, a function of the seed.
+ *   A world that cannot be generated (status != 0) keeps its rows and gets d_failed[w] = 1 (0 after a successful reset); it ends again
+ *   on the next step and then tries the following seed of its sequence.
+ */
+typedef struct cs_stage_book {
+    const uint32_t* d_seeds;      /* [W] cs_gym_book.d_seeds: == d_base_seed + d_epoch * seed_stride between two steps */
+    const uint32_t* d_base_seed;  /* [W] seed of episode 0 */
+    uint32_t* d_epoch;            /* [W] */
+    uint32_t* d_staged_seed;      /* [depth][W] */
+    int32_t* d_staged_status;     /* [depth][W] */
+    int32_t* d_failed;            /* [W] */
+    uint32_t seed_stride;         /* 0 = W */
+    int32_t depth;                /* episodes staged ahead per world: a power of two */
+} cs_stage_book;
+/* `staging` describes depth * W worlds of the shape of the live batch (same n, G, layout, robot row) */
+int cs_refill_staged_worlds(const cs_generator* gen, const cs_worlds* staging, const cs_stage_book* book, void* stream);
+int cs_consume_staged_worlds(const cs_generator* gen, const cs_worlds* staging, const cs_worlds* live, const int32_t* d_mask,
+                             const cs_stage_book* book, int theta_and_omega_visible, float* d_obs, void* stream);
 
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);

@@ -29,15 +29,15 @@ CS_SOCIAL_MOMENTUM = 10
 # every symbol include/crowdstep.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "cs_last_error", "cs_abi_version", "cs_device_count", "cs_set_device", "cs_device_name", "cs_device_pci_bus_id", "cs_malloc",
-    "cs_free", "cs_memcpy_h2d", "cs_memcpy_d2h", "cs_memcpy_d2d", "cs_memset", "cs_stream_create",
+    "cs_free", "cs_memcpy_h2d", "cs_memcpy_d2h", "cs_memcpy_d2d", "cs_memset", "cs_stream_create", "cs_stream_create_with_priority",
     "cs_stream_destroy", "cs_stream_sync", "cs_event_create", "cs_event_destroy", "cs_event_record",
-    "cs_event_elapsed_ms", "cs_stream_wait_event", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
+    "cs_event_elapsed_ms", "cs_event_query", "cs_stream_wait_event", "cs_graph_begin_capture", "cs_graph_end_capture", "cs_graph_launch", "cs_graph_destroy",
     "cs_update_humans_parallel", "cs_step", "cs_peek", "cs_collision_reward",
     "cs_state_aos_to_soa", "cs_state_soa_to_aos", "cs_launch_geometry", "cs_lookahead",
     "cs_generate_scratch_bytes", "cs_generate_worlds", "cs_laser_scan", "cs_robot_model_step", "cs_actual_collision_reward",
     "cs_update_humans_rk45", "cs_gym_bookkeeping", "cs_step_variant", "cs_debug_divsqrt_check", "cs_gym_observe", "cs_copy_worlds_masked", "cs_imitation_block", "cs_gym_bookkeeping_next_step", "cs_robot_model_velocities",
     "cs_step_trace", "cs_reserve_scratch", "cs_release_scratch", "cs_complete_rk45_simulation", "cs_robot_model_rk45", "cs_copy_worlds_masked_status",
-    "cs_collision_reward_gym", "cs_step_observe", "cs_copy_worlds_masked_observe",
+    "cs_collision_reward_gym", "cs_step_observe", "cs_copy_worlds_masked_observe", "cs_refill_staged_worlds", "cs_consume_staged_worlds",
 ]
 
 
@@ -50,6 +50,14 @@ class cs_gym_book(C.Structure):   # include/crowdstep.h cs_gym_book: the bookkee
         ("d_counter", C.c_void_p), ("d_seeds", C.c_void_p), ("d_mask", C.c_void_p), ("d_prev_mask", C.c_void_p), ("d_clock", C.c_void_p),
         ("clock_len", C.c_int32), ("auto_reset", C.c_int32),
         ("d_reward", C.c_void_p), ("d_terminated", C.c_void_p), ("d_truncated", C.c_void_p), ("d_info", C.c_void_p),
+        ("seed_stride", C.c_uint32),
+    ]
+
+
+class cs_stage_book(C.Structure):   # include/crowdstep.h cs_stage_book: the tags of the pre-staged episodes
+    _fields_ = [
+        ("d_seeds", C.c_void_p), ("d_base_seed", C.c_void_p), ("d_epoch", C.c_void_p), ("d_staged_seed", C.c_void_p),
+        ("d_staged_status", C.c_void_p), ("d_failed", C.c_void_p), ("seed_stride", C.c_uint32), ("depth", C.c_int32),
     ]
 
 
@@ -291,6 +299,12 @@ class Event:
         """Make later work of `stream` wait for this event (device-side, the host does not block)."""
         check(load().cs_stream_wait_event(C.c_void_p(stream), C.c_void_p(self.ptr)))
 
+    def done(self) -> bool:
+        """True when the work recorded before this event has finished (never blocks)."""
+        d = C.c_int(0)
+        check(load().cs_event_query(C.c_void_p(self.ptr), C.byref(d)))
+        return bool(d.value)
+
     def elapsed_ms(self, stop: "Event") -> float:
         ms = C.c_float(0)
         check(load().cs_event_elapsed_ms(C.c_void_p(self.ptr), C.c_void_p(stop.ptr), C.byref(ms)))
@@ -337,9 +351,13 @@ class Graph:
             pass
 
 
-def stream_create() -> int:
+def stream_create(priority: int = 0) -> int:
+    """A non-blocking HIP stream; priority < 0: the device's highest, > 0: its lowest (background work)."""
     p = C.c_void_p()
-    check(load().cs_stream_create(C.byref(p)))
+    if priority:
+        check(load().cs_stream_create_with_priority(C.byref(p), C.c_int(priority)))
+    else:
+        check(load().cs_stream_create(C.byref(p)))
     return p.value
 
 

@@ -282,9 +282,10 @@ class CrowdWorlds:
                                                       C.c_int(int(n_eval)), C.c_void_p(nfev.ptr), C.c_void_p(self.stream)))
         return out.download(self.stream), nfev.download(self.stream)
 
-    def robot_model_rk45(self, dt: float) -> np.ndarray:
+    def robot_model_rk45(self, dt: float, download: bool = True):
         """update_robot(t, dt) of a robot whose SFM / HSFM model is integrated with RK45 (motion_model_manager.py:631-640), every world,
-        in place on the robot rows.  Returns the number of right-hand-side evaluations [W]."""
+        in place on the robot rows.  Returns the number of right-hand-side evaluations [W] (``download=False``: None, no
+        synchronisation -- the loop of BatchedSocialNavGym.imitation_learning_step)."""
         if getattr(self, "robot_model", None) is None:
             raise ValueError("no robot motion model set")
         d = self.descriptor()
@@ -293,7 +294,7 @@ class CrowdWorlds:
         check(_lib.load().cs_robot_model_rk45(C.byref(d), C.c_int(self.robot_model), pr, C.c_float(self.robot_margin),
                                               C.c_void_p(_ptr(self.d_human_margin)), C.c_void_p(_ptr(self.d_robot_memory)), C.c_float(dt),
                                               C.c_void_p(nfev.ptr), C.c_void_p(self.stream)))
-        return nfev.download(self.stream)
+        return nfev.download(self.stream) if download else None
 
     # ------------------------------------------------------------------ the robot under a human motion model
     def set_robot_model(self, model, params=None, margin=0.0, human_margin=None, orca_vertices=None) -> None:
@@ -417,16 +418,23 @@ class CrowdWorlds:
         check(_lib.load().cs_step_variant(C.byref(d), C.c_int({"step": 0, "update": 1, "peek": 2}[entry]), buf, C.c_size_t(256)))
         return buf.value.decode()
 
-    def staging_copy(self):
-        """A second batch of the same shape whose world-dependent buffers (state, goals, robot rows, world flags) are separate
-        allocations and everything else (parameters, margins, walls) is shared: the target of a masked cs_generate_worlds that
-        runs beside cs_step; cs_copy_worlds_masked moves the regenerated worlds over afterwards."""
+    def staging_copy(self, depth: int = 1):
+        """A second batch of the same shape -- ``depth`` times the worlds (world j * W + w = slot j of world w: the staging batch of
+        the pre-staged episodes, include/crowdstep.h cs_stage_book) -- whose world-dependent buffers (state, goals, robot rows,
+        world flags) are separate allocations and everything else (parameters, margins, walls) is shared: a target of the device
+        generators; cs_copy_worlds_masked / cs_consume_staged_worlds move the generated worlds over afterwards.  (With depth > 1 the
+        shared per-world buffers do not cover it: such a batch is for the generators and the copies only, never stepped.)"""
         import copy
 
         st = copy.copy(self)
         st._scratch = {}
-        st.d_state = DeviceBuffer(self.d_state.shape)
-        st.d_goals = DeviceBuffer(self.d_goals.shape)
-        st.d_robot = None if self.d_robot is None else DeviceBuffer(self.d_robot.shape)
-        st.d_world_flags = None if self.d_world_flags is None else DeviceBuffer(self.d_world_flags.shape, np.int32)
+        st.W = self.W * int(depth)
+        grow = lambda shape: (shape[0] * int(depth),) + tuple(shape[1:])
+        if self.layout == "soa":      # planes [13][W * rows]
+            st.d_state = DeviceBuffer((self.d_state.nbytes // 4 * int(depth),))
+        else:
+            st.d_state = DeviceBuffer(grow(self.d_state.shape))
+        st.d_goals = DeviceBuffer(grow(self.d_goals.shape))
+        st.d_robot = None if self.d_robot is None else DeviceBuffer(grow(self.d_robot.shape))
+        st.d_world_flags = None if self.d_world_flags is None else DeviceBuffer(grow(self.d_world_flags.shape), np.int32)
         return st

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -40,6 +41,8 @@ thread_local std::string g_err;
 // capturing -- a block that would have to be allocated or grown then is refused with CS_ERR_ARG (reserve it first:
 // cs_reserve_scratch, or one call of the entry point outside the capture); a block handed out during a capture is PINNED:
 // a graph holds its address, so growing it later retires the old block instead of freeing it (cs_release_scratch frees all).
+// Threads: ONE host thread per (device, stream) -- the mutex guards the table, not the block: two threads launching on the same
+// stream could grow (free) a block the other is about to launch into.  Different streams never share a block.
 namespace {
 struct ScratchBlock { void* p = nullptr; size_t cap = 0; bool pinned = false; };
 std::mutex g_scratch_mu;
@@ -78,6 +81,12 @@ int scratch_release_all()
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     int dev0 = 0;
     (void)hipGetDevice(&dev0);
+    // every device that holds a block finishes its work first: a kernel or a graph still running THERE may be using one
+    // (cs_release_scratch used to synchronise the calling thread's current device only)
+    std::set<int> devs;
+    for (auto& kv : g_scratch) if (kv.second.p) devs.insert(std::get<0>(kv.first));
+    for (auto& r : g_retired) devs.insert(r.first);
+    for (int d : devs) { (void)hipSetDevice(d); (void)hipDeviceSynchronize(); }
     for (auto& kv : g_scratch)
         if (kv.second.p) { (void)hipSetDevice(std::get<0>(kv.first)); (void)hipFree(kv.second.p); }
     g_scratch.clear();
@@ -161,6 +170,7 @@ __global__ void k_collision_reward(int W, int n, int rows, const float* S, long 
 // world's reward row when cs_collision_reward_gym asks for it (mode 0: none, 1: same-step rules, 2: NEXT_STEP rules)
 struct GymBook {
     int mode, clock_len, auto_reset;
+    unsigned stride;   // what a finished world's seed moves on by (cs_gym_book.seed_stride; the worlds of the whole job)
     int* counter; unsigned* seeds; int* mask; const int* prev; float* gtime; const float* clock;
     float* reward; unsigned char* terminated; unsigned char* truncated; int* info;
 };
@@ -227,10 +237,10 @@ __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int 
     int c = bk.counter[w] + 1;
     if (bk.mode == 2) {
         bk.mask[w] = done ? 1 : 0;
-        if (done) bk.seeds[w] += (unsigned)W;
+        if (done) bk.seeds[w] += bk.stride;
     } else if (bk.auto_reset) {
         bk.mask[w] = done ? 1 : 0;
-        if (done) { bk.seeds[w] += (unsigned)W; c = 0; }
+        if (done) { bk.seeds[w] += bk.stride; c = 0; }
     }
     c = c < bk.clock_len - 1 ? c : bk.clock_len - 1;
     bk.counter[w] = c;
@@ -416,7 +426,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
 extern "C" {
 
 const char* cs_last_error(void) { return g_err.c_str(); }
-int cs_abi_version(void) { return 1; }
+int cs_abi_version(void) { return 2; }   // 2: seed_stride in cs_gym_book / cs_gym_bookkeeping*, cs_stage_book, cs_event_query, cs_device_pci_bus_id
 
 int cs_device_count(int* count)
 {
@@ -453,10 +463,29 @@ int cs_memcpy_d2h(void* h, const void* d, size_t bytes, void* s) { HIP_TRY(hipMe
 int cs_memcpy_d2d(void* dd, const void* ds, size_t bytes, void* s) { HIP_TRY(hipMemcpyAsync(dd, ds, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); return CS_OK; }
 int cs_memset(void* d, int value, size_t bytes, void* s) { HIP_TRY(hipMemsetAsync(d, value, bytes, (hipStream_t)s)); return CS_OK; }
 int cs_stream_create(void** s) { if (!s) return fail(CS_ERR_ARG, "null out pointer"); hipStream_t st; HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); *s = st; return CS_OK; }
+int cs_stream_create_with_priority(void** s, int priority)
+{
+    if (!s) return fail(CS_ERR_ARG, "null out pointer");
+    int least = 0, greatest = 0;   // (numerically: least priority = the larger number)
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int p = priority == 0 ? 0 : (priority < 0 ? greatest : least);
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, p));
+    *s = st;
+    return CS_OK;
+}
 int cs_stream_destroy(void* s) { HIP_TRY(hipStreamDestroy((hipStream_t)s)); return CS_OK; }
 int cs_stream_sync(void* s) { HIP_TRY(hipStreamSynchronize((hipStream_t)s)); return CS_OK; }
 int cs_event_create(void** e) { if (!e) return fail(CS_ERR_ARG, "null out pointer"); hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); *e = ev; return CS_OK; }
 int cs_event_destroy(void* e) { HIP_TRY(hipEventDestroy((hipEvent_t)e)); return CS_OK; }
+int cs_event_query(void* e, int* done)
+{
+    if (!e || !done) return fail(CS_ERR_ARG, "null argument");
+    const hipError_t rc = hipEventQuery((hipEvent_t)e);
+    if (rc != hipSuccess && rc != hipErrorNotReady) HIP_TRY(rc);
+    *done = rc == hipSuccess ? 1 : 0;
+    return CS_OK;
+}
 int cs_event_record(void* e, void* s) { HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return CS_OK; }
 int cs_stream_wait_event(void* s, void* e) { HIP_TRY(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); return CS_OK; }
 int cs_event_elapsed_ms(void* a, void* b, float* ms)
@@ -573,15 +602,16 @@ int cs_collision_reward_gym(const cs_worlds* w, const float* d_action, float T, 
         if (book->d_prev_mask)
             return cs_gym_bookkeeping_next_step(w->W, d_out, book->d_counter, book->d_seeds, book->d_mask, book->d_prev_mask, d_global_time,
                                                 book->d_clock, book->clock_len, book->d_reward, book->d_terminated, book->d_truncated,
-                                                book->d_info, stream);
+                                                book->d_info, book->seed_stride, stream);
         return cs_gym_bookkeeping(w->W, d_out, book->d_counter, book->d_seeds, book->d_mask, d_global_time, book->d_clock, book->clock_len,
-                                  book->auto_reset, book->d_reward, book->d_terminated, book->d_truncated, book->d_info, stream);
+                                  book->auto_reset, book->d_reward, book->d_terminated, book->d_truncated, book->d_info, book->seed_stride, stream);
     }
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     long as, fs;
     strides(w, rows, as, fs);
     GymBook bk;
     bk.mode = book->d_prev_mask ? 2 : 1; bk.clock_len = book->clock_len; bk.auto_reset = book->auto_reset;
+    bk.stride = book->seed_stride ? book->seed_stride : (unsigned)w->W;
     bk.counter = book->d_counter; bk.seeds = book->d_seeds; bk.mask = book->d_mask; bk.prev = book->d_prev_mask; bk.gtime = d_global_time;
     bk.clock = book->d_clock; bk.reward = book->d_reward; bk.terminated = book->d_terminated; bk.truncated = book->d_truncated;
     bk.info = book->d_info;

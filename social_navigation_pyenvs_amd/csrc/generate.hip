@@ -21,10 +21,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <string>
 
 #include "common.h"
 #include "crowdstep.h"
+#include "worldcopy.h"
 
 #pragma clang fp contract(off) // the reference's numpy expressions are not fused
 
@@ -384,20 +386,28 @@ __device__ __forceinline__ bool closer_than(double dx, double dy, double md)
     return c;
 }
 
-__global__ __launch_bounds__(64) void k_generate_wave(const GArgs a)
+// where a generated world goes (the batch being reset, a staging batch, or the live batch of cs_consume_staged_worlds)
+struct GenOut {
+    float* S; long as, fs; float* goals; float* robot; int* world_flags; int rows, G, robot_row;
+};
+
+__device__ __forceinline__ GenOut gen_out(const GArgs& a)
+{
+    return GenOut{a.S, a.as, a.fs, a.goals, a.robot, a.world_flags, a.rows, a.G, a.robot_row};
+}
+
+// One world by one wavefront (the block): the reference's generator for `seed`, rows written to `a` when it succeeds.  Returns the
+// status (0 ok, 1 rejection sampling gave up, 2 traffic too dense); `scenario_out` = the scenario drawn (hybrid batches).
+__device__ int generate_world_wave(const cs_generator& g, const GenOut& a, int w, int lane, uint32_t seed, int& scenario_out)
 {
     __shared__ uint32_t s_mt[2][624];
     __shared__ double s_rad[64], s_spd[64], s_px[64], s_py[64], s_yaw[64];
-    const int w = blockIdx.x, lane = threadIdx.x;
-    if (a.mask != nullptr && a.mask[w] == 0) return; // block-uniform
-    const cs_generator& g = a.g;
     const int n = g.n;
     const double pi = 3.141592653589793;
     WMT m;
     m.cur = s_mt[0];
     m.nxt = s_mt[1];
     m.pos = 624;
-    const uint32_t seed = a.seeds[w];
     wmt_seed(m, seed, lane);
     int scenario = g.scenario;
     if (scenario == CS_SCN_HYBRID) {
@@ -560,11 +570,8 @@ __global__ __launch_bounds__(64) void k_generate_wave(const GArgs a)
             if (!placed) status = 1;
         }
     }
-    if (lane == 0) {
-        if (a.status != nullptr) a.status[w] = status;
-        if (a.scenario_out != nullptr) a.scenario_out[w] = scenario;
-    }
-    if (status != 0) return;
+    scenario_out = scenario;
+    if (status != 0) return status;
 
     const float nanf_ = __builtin_nanf("");
     if (lane < n) {
@@ -599,6 +606,164 @@ __global__ __launch_bounds__(64) void k_generate_wave(const GArgs a)
         if (a.robot_row) robot_row(a.S + ((long)w * a.rows + n) * a.as, a.fs);
         if (a.world_flags != nullptr) a.world_flags[w] = (scenario == CS_SCN_PARALLEL_TRAFFIC) ? 1 : 0;
     }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_generate_wave(const GArgs a)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (a.mask != nullptr && a.mask[w] == 0) return; // block-uniform
+    int scenario = 0;
+    const int status = generate_world_wave(a.g, gen_out(a), w, lane, a.seeds[w], scenario);
+    if (lane == 0) {
+        if (a.status != nullptr) a.status[w] = status;
+        if (a.scenario_out != nullptr) a.scenario_out[w] = scenario;
+    }
+}
+
+// ---- pre-staged episodes (include/crowdstep.h cs_stage_book) -----------------------------------------------------------------
+struct StageArgs {
+    cs_generator g;
+    GenOut staging, live;
+    csimpl::CopyArgs copy;          // staging -> live (mask / status unused here)
+    const uint32_t* seeds; const uint32_t* base_seed; uint32_t* epoch; uint32_t* staged_seed; int32_t* staged_status; int32_t* failed;
+    const int32_t* mask;
+    uint32_t stride;
+    int W, depth;
+};
+
+__device__ __forceinline__ uint32_t load_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// side stream.  Slot s = j * W + w holds the episode of world w that belongs in ring position j now: the one e in (epoch, epoch + depth]
+// with e = j mod depth; it is regenerated when its tag is not that episode's seed.  The grid is SMALL (<= 1024 blocks of one wavefront,
+// every lane checking one slot per trip, two relaxed device-scope loads): a block per slot -- 65536 workgroups at depth 16 x 4096 worlds,
+// nearly all of which leave at once -- kept the workgroup dispatcher busy for ~45 us per pass and the step stream's next launch waited
+// behind it.  The slots a wavefront finds stale are generated one after the other by the whole wavefront; only those pay for a release
+// (a cache-maintenance operation per checked slot would disturb the step kernel).
+__global__ __launch_bounds__(64) void k_refill_staged(const StageArgs a)
+{
+    const int lane = threadIdx.x;
+    const long total = (long)a.W * a.depth;
+    for (long s0 = (long)blockIdx.x * 64; s0 < total; s0 += (long)gridDim.x * 64) {
+        const long s = s0 + lane;
+        uint32_t want = 0;
+        bool stale = false;
+        if (s < total) {
+            const int w = (int)(s % a.W), j = (int)(s / a.W);
+            const uint32_t epoch = load_relaxed(a.epoch + w);
+            const uint32_t ahead = ((uint32_t)j - epoch - 1u) & (uint32_t)(a.depth - 1);      // 0 .. depth-1
+            want = a.base_seed[w] + (epoch + 1u + ahead) * a.stride;
+            stale = load_relaxed(a.staged_seed + s) != want;
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(stale);                  // wave-uniform from here on
+        while (todo != 0) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const long slot = s0 + l;
+            const uint32_t seed = (uint32_t)__builtin_amdgcn_readlane((int)want, l);
+            int scenario = 0;
+            const int status = generate_world_wave(a.g, a.staging, (int)slot, lane, seed, scenario);
+            if (lane == 0) a.staged_status[slot] = status;
+            __syncthreads();
+            // the tag goes LAST: a consumer that reads `seed` in it (acquire) sees the rows, goal lists, robot row, flag and status above
+            if (lane == 0) store_release(a.staged_seed + slot, seed);
+            __syncthreads();                                                           // (the generator's LDS is reused by the next slot)
+        }
+    }
+}
+
+// the step's stream: a finished world takes over its staged episode -- or, if the refill has not got to it yet, is generated in place
+__global__ __launch_bounds__(64) void k_consume_staged(const StageArgs a)
+{
+    const int w = blockIdx.x, lane = threadIdx.x;
+    if (!a.mask[w]) return;                                                    // block-uniform
+    const uint32_t want = a.seeds[w];                                          // the seed the bookkeeping moved this world to
+    const uint32_t e = a.epoch[w] + 1u;                                        // (only this kernel writes the epochs)
+    const long slot = (long)(e & (uint32_t)(a.depth - 1)) * a.W + w;
+    int status;
+    if (load_acquire(a.staged_seed + slot) == want) {
+        status = a.staged_status[slot];
+        if (status == 0) csimpl::copy_world(a.copy, slot, w, lane);
+    } else {
+        int scenario = 0;
+        status = generate_world_wave(a.g, a.live, w, lane, want, scenario);
+        if (status == 0 && a.copy.obs != nullptr) {
+            __syncthreads();                                                   // the rows this block just wrote
+            for (int k = lane; k < a.copy.n * a.copy.C; k += 64) {
+                const int i = k / a.copy.C, c = k - i * a.copy.C;
+                a.copy.obs[((long)w * a.copy.n + i) * a.copy.C + c] = a.live.S[((long)w * a.live.rows + i) * a.live.as + csimpl::obs_state_column(c) * a.live.fs];
+            }
+        }
+    }
+    if (lane == 0) a.failed[w] = status != 0 ? 1 : 0;
+    __syncthreads();
+    // LAST: from here on the refill may overwrite the slot (it now belongs to episode e + depth)
+    if (lane == 0) store_release(a.epoch + w, e);
+}
+
+int fill_gen_out(const cs_worlds* w, GenOut& o)
+{
+    o.robot_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0;
+    o.rows = w->n + o.robot_row;
+    o.G = w->G;
+    o.S = w->d_state;
+    if (w->layout == CS_LAYOUT_AOS) { o.as = 13; o.fs = 1; }
+    else if (w->layout == CS_LAYOUT_SOA) { o.as = 1; o.fs = (long)w->W * o.rows; }
+    else return fail(CS_ERR_ARG, "bad layout");
+    o.goals = w->d_goals;
+    o.robot = w->d_robot;
+    o.world_flags = const_cast<int*>(w->d_world_flags);
+    return CS_OK;
+}
+
+int check_generator(const cs_generator* gen, const cs_worlds* w)
+{
+    if (!w->d_state || !w->d_goals) return fail(CS_ERR_ARG, "null device buffer in cs_worlds");
+    if (w->W <= 0 || w->n <= 0 || w->G <= 0) return fail(CS_ERR_ARG, "W, n, G must be positive");
+    if (gen->n != w->n) return fail(CS_ERR_ARG, "cs_generator.n differs from cs_worlds.n");
+    if (gen->n > GEN_MAXN) return fail(CS_ERR_ARG, "the device generators place at most 128 humans per world");
+    if (gen->scenario < CS_SCN_CIRCULAR_CROSSING || gen->scenario > CS_SCN_HYBRID) return fail(CS_ERR_ARG, "unknown scenario");
+    if (gen->scenario != CS_SCN_PARALLEL_TRAFFIC && w->G < 2) return fail(CS_ERR_ARG, "circular scenarios need G >= 2 goal slots");
+    if (gen->scenario == CS_SCN_CIRCULAR_CROSSING_STATIC_OBSTACLES) {
+        if (!(gen->circle_radius > 5.0)) return fail(CS_ERR_ARG, "Radius must be greater than 5 for this scenario"); // :375
+        if (gen->n < 2) return fail(CS_ERR_ARG, "static-obstacle scenario needs at least 2 humans (sector = pi / (n // 2))");
+    }
+    if (gen->max_tries <= 0) return fail(CS_ERR_ARG, "max_tries must be positive (the reference's loops are unbounded)");
+    return CS_OK;
+}
+
+int stage_args(const cs_generator* gen, const cs_worlds* staging, const cs_worlds* live, const cs_stage_book* book, StageArgs& a)
+{
+    if (!gen || !staging || !book) return fail(CS_ERR_ARG, "null argument");
+    if (!book->d_staged_seed || !book->d_epoch || !book->d_base_seed || !book->d_staged_status) return fail(CS_ERR_ARG, "null buffer in cs_stage_book");
+    const int K = book->depth;
+    if (K <= 0 || (K & (K - 1)) != 0) return fail(CS_ERR_ARG, "cs_stage_book.depth must be a power of two");
+    if (staging->W % K != 0) return fail(CS_ERR_ARG, "the staging batch must hold depth * W worlds");
+    int rc = check_generator(gen, staging);
+    if (rc) return rc;
+    if (gen->n > 64) return fail(CS_ERR_ARG, "pre-staged episodes are built for worlds of up to 64 humans (one wavefront per world)");
+    std::memset(&a, 0, sizeof(a));
+    a.g = *gen;
+    if ((rc = fill_gen_out(staging, a.staging))) return rc;
+    a.W = staging->W / K; a.depth = K;
+    a.seeds = book->d_seeds; a.base_seed = book->d_base_seed; a.epoch = book->d_epoch; a.staged_seed = book->d_staged_seed;
+    a.staged_status = book->d_staged_status; a.failed = book->d_failed;
+    a.stride = book->seed_stride ? book->seed_stride : (uint32_t)a.W;
+    if (live) {
+        if (a.W != live->W || staging->n != live->n || staging->G != live->G || staging->layout != live->layout ||
+            ((staging->flags ^ live->flags) & CS_ROBOT_ROW) || (!staging->d_robot) != (!live->d_robot) || (!staging->d_world_flags) != (!live->d_world_flags))
+            return fail(CS_ERR_ARG, "staging and live worlds differ in shape");
+        if ((rc = check_generator(gen, live))) return rc;
+        if ((rc = fill_gen_out(live, a.live))) return rc;
+        csimpl::CopyArgs& c = a.copy;
+        c.W = live->W; c.n = live->n; c.rows = a.live.rows; c.G = live->G;
+        c.Ss = staging->d_state; c.Sd = live->d_state; c.as = a.live.as; c.fs = a.live.fs; c.sas = a.staging.as; c.sfs = a.staging.fs;
+        c.gs = staging->d_goals; c.gd = live->d_goals; c.rs = staging->d_robot; c.rd = live->d_robot;
+        c.fsrc = staging->d_world_flags; c.fdst = const_cast<int*>(live->d_world_flags);
+    }
+    return CS_OK;
 }
 
 } // namespace
@@ -611,17 +776,10 @@ int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32
                        int32_t* d_status, int32_t* d_scenario, void* d_scratch, void* stream)
 {
     if (!gen || !w || !d_seeds || !d_scratch) return fail(CS_ERR_ARG, "null argument");
-    if (!w->d_state || !w->d_goals) return fail(CS_ERR_ARG, "null device buffer in cs_worlds");
-    if (w->W <= 0 || w->n <= 0 || w->G <= 0) return fail(CS_ERR_ARG, "W, n, G must be positive");
-    if (gen->n != w->n) return fail(CS_ERR_ARG, "cs_generator.n differs from cs_worlds.n");
-    if (gen->n > GEN_MAXN) return fail(CS_ERR_ARG, "the device generators place at most 128 humans per world");
-    if (gen->scenario < CS_SCN_CIRCULAR_CROSSING || gen->scenario > CS_SCN_HYBRID) return fail(CS_ERR_ARG, "unknown scenario");
-    if (gen->scenario != CS_SCN_PARALLEL_TRAFFIC && w->G < 2) return fail(CS_ERR_ARG, "circular scenarios need G >= 2 goal slots");
-    if (gen->scenario == CS_SCN_CIRCULAR_CROSSING_STATIC_OBSTACLES) {
-        if (!(gen->circle_radius > 5.0)) return fail(CS_ERR_ARG, "Radius must be greater than 5 for this scenario"); // :375
-        if (gen->n < 2) return fail(CS_ERR_ARG, "static-obstacle scenario needs at least 2 humans (sector = pi / (n // 2))");
+    {
+        const int rc = check_generator(gen, w);
+        if (rc) return rc;
     }
-    if (gen->max_tries <= 0) return fail(CS_ERR_ARG, "max_tries must be positive (the reference's loops are unbounded)");
     GArgs a;
     a.g = *gen;
     a.W = w->W;
@@ -646,6 +804,32 @@ int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32
         const int block = 64, grid = (w->W + block - 1) / block;
         hipLaunchKernelGGL(k_generate, dim3(grid), dim3(block), 0, (hipStream_t)stream, a);
     }
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_refill_staged_worlds(const cs_generator* gen, const cs_worlds* staging, const cs_stage_book* book, void* stream)
+{
+    StageArgs a;
+    const int rc = stage_args(gen, staging, nullptr, book, a);
+    if (rc) return rc;
+    const long slots = (long)a.W * a.depth;
+    const int grid = (int)((slots + 63) / 64 < 1024 ? (slots + 63) / 64 : 1024);
+    hipLaunchKernelGGL(k_refill_staged, dim3(grid), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CS_OK;
+}
+
+int cs_consume_staged_worlds(const cs_generator* gen, const cs_worlds* staging, const cs_worlds* live, const int32_t* d_mask,
+                             const cs_stage_book* book, int theta_and_omega_visible, float* d_obs, void* stream)
+{
+    if (!live || !d_mask || !book || !book->d_seeds || !book->d_failed) return fail(CS_ERR_ARG, "null argument");
+    StageArgs a;
+    const int rc = stage_args(gen, staging, live, book, a);
+    if (rc) return rc;
+    a.mask = d_mask;
+    a.copy.obs = d_obs; a.copy.C = theta_and_omega_visible ? 7 : 5;
+    hipLaunchKernelGGL(k_consume_staged, dim3(live->W), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "crowdstep.h"
+#include "worldcopy.h"
 
 namespace {
 
@@ -21,43 +22,17 @@ __global__ void k_gym_observe(int W, int n, int rows, int C, const float* S, lon
     const long wi = k / C;
     const int i = (int)(wi % n);
     const long w = wi / n;
-    const int col = c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 3 : c == 3 ? 4 : c == 4 ? 8 : c == 5 ? 2 : 7;   // px, py, vx, vy, radius (, theta, omega)
-    obs[k] = S[(w * rows + i) * as + col * fs];
+    obs[k] = S[(w * rows + i) * as + csimpl::obs_state_column(c) * fs];   // px, py, vx, vy, radius (, theta, omega)
 }
 
-struct CopyArgs {
-    int W, n, rows, G;
-    const float* Ss; float* Sd; long as, fs;
-    const float* gs; float* gd;
-    const float* rs; float* rd;
-    const int* fsrc; int* fdst;
-    const int* mask;
-    const int* status;   // optional: cs_generate_worlds' per-world status; a world that could not be generated (non-zero) is NOT copied
-    float* obs; int C;   // optional: the Gym's observation rows [W][n][C] of the copied worlds are rewritten from the new rows
-};
+using csimpl::CopyArgs;
 
 __global__ __launch_bounds__(64) void k_copy_worlds_masked(const CopyArgs a)
 {
     const int w = blockIdx.x;
     if (!a.mask[w]) return;
     if (a.status != nullptr && a.status[w] != 0) return;   // a half-built world never replaces a live one
-    const int t = threadIdx.x;
-    for (int k = t; k < a.rows * 13; k += 64) {
-        const int row = k / 13, f = k - row * 13;
-        const long idx = ((long)w * a.rows + row) * a.as + f * a.fs;
-        a.Sd[idx] = a.Ss[idx];
-    }
-    const long g0 = (long)w * a.n * a.G * 2;
-    for (int k = t; k < a.n * a.G * 2; k += 64) a.gd[g0 + k] = a.gs[g0 + k];
-    if (a.rs && a.rd && t < 13) a.rd[(long)w * 13 + t] = a.rs[(long)w * 13 + t];
-    if (a.fsrc && a.fdst && t == 0) a.fdst[w] = a.fsrc[w];
-    if (a.obs != nullptr) {   // same columns as k_gym_observe, read from the source rows
-        for (int k = t; k < a.n * a.C; k += 64) {
-            const int i = k / a.C, c = k - i * a.C;
-            const int col = c == 0 ? 0 : c == 1 ? 1 : c == 2 ? 3 : c == 3 ? 4 : c == 4 ? 8 : c == 5 ? 2 : 7;
-            a.obs[((long)w * a.n + i) * a.C + c] = a.Ss[((long)w * a.rows + i) * a.as + col * a.fs];
-        }
-    }
+    csimpl::copy_world(a, w, w, threadIdx.x);
 }
 
 } // namespace
@@ -99,6 +74,7 @@ int cs_copy_worlds_masked_observe(const cs_worlds* src, const cs_worlds* dst, co
     a.W = src->W; a.n = src->n; a.rows = src->n + ((src->flags & CS_ROBOT_ROW) ? 1 : 0); a.G = src->G;
     a.Ss = src->d_state; a.Sd = dst->d_state;
     a.as = src->layout == CS_LAYOUT_AOS ? 13 : 1; a.fs = src->layout == CS_LAYOUT_AOS ? 1 : (long)src->W * a.rows;
+    a.sas = a.as; a.sfs = a.fs;
     a.gs = src->d_goals; a.gd = dst->d_goals; a.rs = src->d_robot; a.rd = dst->d_robot;
     a.fsrc = src->d_world_flags; a.fdst = const_cast<int*>(dst->d_world_flags); a.mask = d_mask; a.status = d_status;
     a.obs = d_obs; a.C = theta_and_omega_visible ? 7 : 5;

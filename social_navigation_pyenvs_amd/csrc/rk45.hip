@@ -574,7 +574,8 @@ int cs_robot_model_rk45(const cs_worlds* w, int32_t robot_type, const float* rob
     KArgsRobotRk a;
     std::memset(&a, 0, sizeof(a));
     a.W = w->W; a.n = w->n; a.rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
-    a.write_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0;
+    // as robot_step_impl (robot_model.hip): an ORCA crowd's simulator sees the moved robot only after its own doStep (motion_model_manager.py:389)
+    a.write_row = ((w->flags & CS_ROBOT_ROW) && w->type != CS_ORCA) ? 1 : 0;
     a.O = w->O; a.Smax = w->Smax; a.type = robot_type; a.obstacles_shared = (w->flags & CS_OBSTACLES_SHARED) ? 1 : 0;
     a.dt = dt; a.robot_margin = robot_margin;
     std::memcpy(a.P, robot_params, sizeof(a.P));

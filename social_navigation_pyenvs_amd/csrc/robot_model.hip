@@ -206,7 +206,7 @@ __global__ void k_actual_collision_reward(int W, int n, int rows, const float* S
 // output row, so that a step of BatchedSocialNavGym.step_device needs no element-wise torch op.
 __global__ void k_gym_bookkeeping(int W, const float* out7, int* counter, unsigned* seeds, int* mask, float* gtime, const float* clock,
                                   int clock_len, int auto_reset, float* reward, unsigned char* terminated, unsigned char* truncated,
-                                  int* info)
+                                  int* info, unsigned stride)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
@@ -217,7 +217,7 @@ __global__ void k_gym_bookkeeping(int W, const float* out7, int* counter, unsign
     if (auto_reset) {
         const bool done = term || trunc;
         mask[w] = done ? 1 : 0;
-        if (done) { seeds[w] += (unsigned)W; c = 0; }   // every world walks its own arithmetic sequence of seeds
+        if (done) { seeds[w] += stride; c = 0; }   // every world walks its own arithmetic sequence of seeds (stride = worlds of the whole job)
     }
     c = c < clock_len - 1 ? c : clock_len - 1;
     counter[w] = c;
@@ -229,7 +229,7 @@ __global__ void k_gym_bookkeeping(int W, const float* out7, int* counter, unsign
 // that ends now is only flagged (mask) and takes the next seed of its sequence; its replacement is generated beside the next step.
 __global__ void k_gym_bookkeeping_next_step(int W, const float* out7, int* counter, unsigned* seeds, int* mask, const int* prev, float* gtime,
                                             const float* clock, int clock_len, float* reward, unsigned char* terminated,
-                                            unsigned char* truncated, int* info)
+                                            unsigned char* truncated, int* info, unsigned stride)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
@@ -243,7 +243,7 @@ __global__ void k_gym_bookkeeping_next_step(int W, const float* out7, int* count
     reward[w] = o[3]; terminated[w] = term ? 1 : 0; truncated[w] = trunc ? 1 : 0; info[w] = (int)o[6];
     const bool done = term || trunc;
     mask[w] = done ? 1 : 0;
-    if (done) seeds[w] += (unsigned)W;
+    if (done) seeds[w] += stride;
     int c = counter[w] + 1;
     c = c < clock_len - 1 ? c : clock_len - 1;
     counter[w] = c;
@@ -256,14 +256,15 @@ extern "C" {
 
 int cs_gym_bookkeeping_next_step(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, const int32_t* d_prev_mask,
                                  float* d_global_time, const float* d_clock, int clock_len, float* d_reward, uint8_t* d_terminated,
-                                 uint8_t* d_truncated, int32_t* d_info, void* stream)
+                                 uint8_t* d_truncated, int32_t* d_info, uint32_t seed_stride, void* stream)
 {
     if (W <= 0 || clock_len <= 0) return fail(CS_ERR_ARG, "W and clock_len must be positive");
     if (!d_out || !d_counter || !d_seeds || !d_mask || !d_prev_mask || !d_global_time || !d_clock || !d_reward || !d_terminated || !d_truncated || !d_info)
         return fail(CS_ERR_ARG, "null argument");
     const int block = 64;
     hipLaunchKernelGGL(k_gym_bookkeeping_next_step, dim3((W + block - 1) / block), dim3(block), 0, (hipStream_t)stream, W, d_out, d_counter,
-                       d_seeds, d_mask, d_prev_mask, d_global_time, d_clock, clock_len, d_reward, d_terminated, d_truncated, d_info);
+                       d_seeds, d_mask, d_prev_mask, d_global_time, d_clock, clock_len, d_reward, d_terminated, d_truncated, d_info,
+                       seed_stride ? seed_stride : (unsigned)W);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
@@ -333,7 +334,7 @@ int cs_actual_collision_reward(const cs_worlds* w, float T, const float* d_globa
 
 int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* d_seeds, int32_t* d_mask, float* d_global_time,
                        const float* d_clock, int clock_len, int auto_reset, float* d_reward, uint8_t* d_terminated,
-                       uint8_t* d_truncated, int32_t* d_info, void* stream)
+                       uint8_t* d_truncated, int32_t* d_info, uint32_t seed_stride, void* stream)
 {
     if (W <= 0 || clock_len <= 0) return fail(CS_ERR_ARG, "W and clock_len must be positive");
     if (!d_out || !d_counter || !d_global_time || !d_clock || !d_reward || !d_terminated || !d_truncated || !d_info)
@@ -341,7 +342,8 @@ int cs_gym_bookkeeping(int W, const float* d_out, int32_t* d_counter, uint32_t* 
     if (auto_reset && (!d_seeds || !d_mask)) return fail(CS_ERR_ARG, "auto_reset needs the seeds and the mask");
     const int block = 64;
     hipLaunchKernelGGL(k_gym_bookkeeping, dim3((W + block - 1) / block), dim3(block), 0, (hipStream_t)stream, W, d_out, d_counter,
-                       d_seeds, d_mask, d_global_time, d_clock, clock_len, auto_reset, d_reward, d_terminated, d_truncated, d_info);
+                       d_seeds, d_mask, d_global_time, d_clock, clock_len, auto_reset, d_reward, d_terminated, d_truncated, d_info,
+                       seed_stride ? seed_stride : (unsigned)W);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

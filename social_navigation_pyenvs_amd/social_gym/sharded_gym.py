@@ -3,7 +3,8 @@ job -- one process per GPU (``torchrun``), SURVEY.md §8(e).
 
 Worlds are independent units: rank r of R owns the contiguous block of global world ids ``sharding.world_shard`` gives it and
 steps them in its own ``BatchedSocialNavGym`` on its own GPU.  World w of the job is test case ``first_case + w`` of the phase
-whatever R is, so the union of the shards IS the single-process batch, world for world.  **The step has no collective**: reset,
+whatever R is -- and its k-th auto-reset draws seed ``s + w + k * total_worlds`` whatever R is (``seed_stride``) -- so the union of
+the shards IS the single-process batch, world for world, episode after episode.  **The step has no collective**: reset,
 step, step_device, imitation_learning_step and lookahead_device act on the local shard only.  The one optional exchange is
 ``gather`` -- an ``all_gather`` (RCCL on the GPU box: backend "nccl"; gloo in the CPU tests) of per-world tensors such as the
 observations ``[W/R, N, 5]``, once per Gym step, for a learner that wants the whole batch on one rank; ``scatter_actions`` is
@@ -36,6 +37,10 @@ class ShardedBatchedSocialNavGym:
         if env_factory is None:
             from .social_nav_gym import BatchedSocialNavGym as env_factory
         self.env = env_factory(config, self.W, **env_kw)
+        # a finished world's seed moves on by the worlds of the WHOLE job (cs_gym_book.seed_stride): global world w walks
+        # s + w + k * total_worlds whatever the number of ranks, so the union of the shards stays the single-process batch across
+        # auto-resets too (with the local W as the stride, rank 0's second episodes would be rank 1's first ones)
+        self.env.seed_stride = self.total_worlds
 
     # ------------------------------------------------------------------ the local shard: no communication
     def reset(self, phase="test", first_case=0, **kw):

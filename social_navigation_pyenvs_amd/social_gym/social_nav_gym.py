@@ -369,8 +369,31 @@ class BatchedSocialNavGym:
         return self.observe()
 
     # ------------------------------------------------------------------ device-resident loop (torch tensors in HBM)
+    # Every world keeps its next STAGE_DEPTH episodes staged ahead (a power of two; capped so that the staging batch stays below
+    # STAGE_BYTES), and every REFILL_EVERY steps one pass of cs_refill_staged_worlds regenerates the consumed slots on a side stream.
+    # Measured at 4096 x 25 hybrid worlds with a random policy (tools/gym_step_variants.py; 1 % of the worlds end per step, some of them
+    # every five steps -- a robot driven into its neighbour again and again), us per batched step with every finished episode regenerated:
+    #   depth 16, pass every 4 steps 95.5 | depth 32, every 16: 65.6 | depth 64, every 32 or 64: 56.6 | depth 128, every 128: 56.1
+    #   (no resets at all: 45.5; round 3: 144 same-step, 88 NEXT_STEP).  A pass disturbs the step stream for about its own duration
+    #   (~0.2 ms: the generator's wavefronts share SIMDs and the instruction cache with the step kernel), so passes are made rare and
+    #   the ring deep; 4096 x 25 worlds take 5.4 MB per level.
+    REFILL_EVERY = 32
+    STAGE_DEPTH = 64
+    STAGE_BYTES = 1 << 30
+    REFILL_PRIORITY = 0      # stream priority of the refill passes (1 = the device's lowest: no measurable difference)
+
+    def _stage_depth(self):
+        rows = self.cw.rows
+        level = self.W * (rows * 13 + self.n * self.cw.G * 2 + 13 + 1) * 4
+        d = max(1, int(self.STAGE_DEPTH))
+        while d > 2 and d * level > self.STAGE_BYTES:
+            d //= 2
+        return 1 << (d.bit_length() - 1)
+
     def _device_loop_state(self):
-        """Per-world step counters, seeds and the float32 clock table, resident on the GPU."""
+        """Per-world step counters, seeds, the float32 clock table and the pre-staged next episodes, resident on the GPU."""
+        import ctypes as C
+
         import torch
 
         from .. import generators as gen
@@ -379,6 +402,8 @@ class BatchedSocialNavGym:
             return self._dl
         if getattr(self, "_gen_scenario", None) is None:
             raise RuntimeError("step_device needs a world batch generated on the device: reset(..., device=True)")
+        if getattr(self, "_dl", None) is not None:       # a new batch: the old one's refill pass may still be writing its staging worlds
+            _lib.stream_sync(self._dl["stream_b"])
         try:
             torch.zeros(1, device="cuda")
         except RuntimeError as e:  # _lib.load() maps torch's bundled HIP runtime for both, whatever the import order
@@ -394,99 +419,120 @@ class BatchedSocialNavGym:
             for _ in range(self.time_step_factor):
                 t = t + np.float32(self.time_step)
             clock[k] = t
-        dl = dict(cw=self.cw, clock=torch.as_tensor(clock, device="cuda"),
+        seeds = torch.as_tensor(self._seeds_host.astype(np.int64), device="cuda").to(torch.int32)
+        depth = self._stage_depth()
+        dl = dict(depth=depth, cw=self.cw, clock=torch.as_tensor(clock, device="cuda"),
                   counter=torch.zeros(W, dtype=torch.int32, device="cuda"),
                   parity=0,
                   results=[(torch.zeros(W, dtype=torch.float32, device="cuda"), torch.zeros(W, dtype=torch.bool, device="cuda"),
                             torch.zeros(W, dtype=torch.bool, device="cuda"), torch.zeros(W, dtype=torch.int32, device="cuda"))
                            for _ in range(2)],
                   gtime=torch.zeros(W, dtype=torch.float32, device="cuda"),
-                  seeds=torch.as_tensor(self._seeds_host.astype(np.int64), device="cuda").to(torch.int32),
+                  seeds=seeds,
+                  # a world's seed moves on by the worlds of the WHOLE job when its episode ends: world w walks s + w + k * stride on
+                  # any rank count (ShardedBatchedSocialNavGym sets seed_stride = total_worlds; a single process: W)
+                  stride=int(getattr(self, "seed_stride", None) or W),
                   mask=torch.zeros(W, dtype=torch.int32, device="cuda"),
-                  gen_status=torch.zeros(W, dtype=torch.int32, device="cuda"),   # cs_generate_worlds' status of the masked auto-reset
+                  # pre-staged episodes (include/crowdstep.h cs_stage_book): episode e of world w draws base_seed[w] + e * stride; no slot's
+                  # tag is the seed of the episode that belongs in it, so the first refill pass generates every slot
+                  base_seed=seeds.clone(), epoch=torch.zeros(W, dtype=torch.int32, device="cuda"),
+                  staged_seed=seeds.repeat(depth).contiguous(),
+                  staged_status=torch.zeros(W * depth, dtype=torch.int32, device="cuda"),
+                  failed=torch.zeros(W, dtype=torch.int32, device="cuda"),
                   out=self.cw._buffer("reward_out", (W, 7)).torch(),
                   state=self.cw.d_state.torch().view(W, self.cw.rows, 13),
                   gen=gen.make_generator(self.cw, self._gen_scenario, **self._gen_kw),
                   cols=torch.as_tensor([0, 1, 3, 4, 8] + ([2, 7] if self.headed_obs else []), device="cuda"))
-        # the step graph: a torch side stream carries it (ordered against the caller's stream with wait_stream), a library stream
-        # carries the concurrent regeneration; persistent action / observation tensors; a staging batch for regenerated worlds
+        # the step runs on a torch side stream (ordered against the caller's stream with wait_stream); a library stream carries the
+        # refill passes of the staging batch; persistent action / observation tensors
         dl["stream"] = torch.cuda.Stream()
-        dl["stream_b"] = _lib.stream_create()
-        dl["fork"], dl["join"] = _lib.Event(), _lib.Event()
+        dl["stream_b"] = _lib.stream_create(priority=self.REFILL_PRIORITY)
         dl["act"] = torch.zeros((W, 2), dtype=torch.float32, device="cuda")
         dl["obs"] = torch.zeros((W, self.n, 7 if self.headed_obs else 5), dtype=torch.float32, device="cuda")
-        dl["staging"] = self.cw.staging_copy()
+        dl["staging"] = self.cw.staging_copy(depth)
         dl["staging"].stream = dl["stream_b"]
-        import ctypes as C
-        nbytes = int(_lib.load().cs_generate_scratch_bytes(C.c_int(W)))      # (no hipMalloc inside the graph capture)
-        dl["staging"]._buffer("gen_mt19937", (nbytes // 4,), np.uint32)
+        P = lambda t: t.data_ptr()
+        dl["stage_book"] = _lib.cs_stage_book(d_seeds=P(dl["seeds"]), d_base_seed=P(dl["base_seed"]), d_epoch=P(dl["epoch"]),
+                                              d_staged_seed=P(dl["staged_seed"]), d_staged_status=P(dl["staged_status"]), d_failed=P(dl["failed"]),
+                                              seed_stride=dl["stride"], depth=depth)
+        dl["staging_desc"] = dl["staging"].descriptor()
+        dl["refill_args"] = (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), C.byref(dl["stage_book"]), C.c_void_p(dl["stream_b"]))
+        dl["refill_ev"] = _lib.Event()
+        dl["since_refill"] = 0
         self.cw.stream = dl["stream"].cuda_stream
         torch.cuda.synchronize()
+        # every world's next STAGE_DEPTH episodes, generated once up front; from here on a pass only regenerates the consumed slots
+        _lib.check(_lib.load().cs_refill_staged_worlds(*dl["refill_args"]))
+        dl["refill_ev"].record(dl["stream_b"])
+        _lib.stream_sync(dl["stream_b"])
         self._dl = dl
         return dl
+
+    def _maybe_refill(self, dl):
+        """Every REFILL_EVERY steps: one pass of cs_refill_staged_worlds on the side stream (at most one in flight).  Nothing orders it
+        against the step's stream -- the staging slots carry tags (cs_stage_book) -- so it costs the step no wait and no event."""
+        dl["since_refill"] += 1
+        if dl["since_refill"] < self.REFILL_EVERY or not dl["refill_ev"].done():
+            return
+        _lib.check(_lib.load().cs_refill_staged_worlds(*dl["refill_args"]))
+        dl["refill_ev"].record(dl["stream_b"])
+        dl["since_refill"] = 0
 
     def observe_device(self):
         """Observations [W, N, 5|7] as a torch CUDA tensor gathered from the resident state (no host copy)."""
         dl = self._device_loop_state()
         return dl["state"][:, :self.n].index_select(2, dl["cols"])
 
+    def _gym_book(self, dl, parity, mask, prev_mask, auto_reset):
+        reward, terminated, truncated, info = dl["results"][parity]
+        return _lib.cs_gym_book(d_counter=dl["counter"].data_ptr(), d_seeds=dl["seeds"].data_ptr(), d_mask=mask.data_ptr(),
+                                d_prev_mask=None if prev_mask is None else prev_mask.data_ptr(), d_clock=dl["clock"].data_ptr(),
+                                clock_len=dl["clock"].numel(), auto_reset=int(bool(auto_reset)), d_reward=reward.data_ptr(),
+                                d_terminated=terminated.data_ptr(), d_truncated=truncated.data_ptr(), d_info=info.data_ptr(),
+                                seed_stride=dl["stride"])
+
     def _step_graph(self, dl, parity, auto_reset):
-        r"""One vectorised Gym step as ONE HIP graph of library launches (captured once per result set):
+        r"""One vectorised Gym step as ONE HIP graph of library launches on ONE stream (captured once per result set):
 
-            stream A:  cs_collision_reward_gym (reward + bookkeeping) --fork--> cs_step_observe --------join--> cs_copy_worlds_masked_observe
-            stream B:                                              \--> masked cs_generate_worlds (into a staging batch) --/
+            cs_collision_reward_gym (reward + bookkeeping)  ->  cs_step_observe (substeps + observation)  ->  cs_consume_staged_worlds
 
-        Which worlds end is known from the reward of the state BEFORE the substeps (social_nav_gym.py:229-233), so their
-        regeneration (one wavefront per world, latency-bound: ~100 us for the slowest of the ~1 % that end per step) runs
-        beside the 20 fused substeps instead of behind them."""
+        Which worlds end is known from the reward of the state BEFORE the substeps (social_nav_gym.py:229-233); their next episode
+        was generated ahead (its seed is the live one + stride), so the reset is a masked copy.  The regeneration of the consumed
+        staging slots (one latency-bound wavefront per world, ~0.15 ms) runs on a side stream with a whole episode to finish
+        (_maybe_refill) -- round 3 had it on the critical path (144 us per step) or beside the next step (NEXT_STEP mode, 88 us)."""
         import ctypes as C
-
-        from .. import generators as gen
 
         key = ("graph", parity, bool(auto_reset))
         if key in dl:
             return dl[key]
         cw, lib = self.cw, _lib.load()
-        A, B = dl["stream"].cuda_stream, dl["stream_b"]
+        A = dl["stream"].cuda_stream
         d = cw.descriptor()
         cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
-        reward, terminated, truncated, info = dl["results"][parity]
         act = dl["act"]
         with _lib.Graph.capture(A) as graph:
             # reward of the state before the substeps + typed results, step counter, float32 clock, reset mask and next seeds: ONE launch
             # (cs_collision_reward_gym = cs_collision_reward ; cs_gym_bookkeeping without the graph node between them)
-            book = _lib.cs_gym_book(d_counter=dl["counter"].data_ptr(), d_seeds=dl["seeds"].data_ptr(), d_mask=dl["mask"].data_ptr(),
-                                    d_prev_mask=None, d_clock=dl["clock"].data_ptr(), clock_len=dl["clock"].numel(),
-                                    auto_reset=int(bool(auto_reset)), d_reward=reward.data_ptr(), d_terminated=terminated.data_ptr(),
-                                    d_truncated=truncated.data_ptr(), d_info=info.data_ptr())
+            book = self._gym_book(dl, parity, dl["mask"], None, auto_reset)
             _lib.check(lib.cs_collision_reward_gym(C.byref(d), C.c_void_p(act.data_ptr()), C.c_float(self.robot_time_step),
                                                    C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()), C.byref(book),
                                                    C.c_void_p(A)))
-            if auto_reset:
-                dl["fork"].record(A)
-                dl["fork"].wait(B)
-                # (the staging batch launches on stream B; a world whose bounded rejection sampling fails keeps status != 0 and is
-                #  not copied over the live one: failed_resets() counts them)
-                gen.generate_worlds_device(dl["staging"], dl["gen"], dl["seeds"], dl["mask"], d_status=dl["gen_status"])
             # the substeps, and the observation of the stepped crowd from the step kernel's registers (cs_step_observe) ...
             _lib.check(lib.cs_step_observe(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
                                            C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
             if auto_reset:
-                dl["join"].record(B)
-                dl["join"].wait(A)
-                ds = dl["staging"].descriptor()
-                # ... rewritten for the regenerated worlds by the masked copy itself: no separate observation launch
-                _lib.check(lib.cs_copy_worlds_masked_observe(C.byref(ds), C.byref(d), C.c_void_p(dl["mask"].data_ptr()),
-                                                             C.c_void_p(dl["gen_status"].data_ptr()), C.c_int(int(self.headed_obs)),
-                                                             C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
+                # ... rewritten for the worlds that take over their staged episode (a world whose generation failed keeps its rows
+                # and is flagged in reset_failed_mask())
+                _lib.check(lib.cs_consume_staged_worlds(C.byref(dl["gen"]), C.byref(dl["staging_desc"]), C.byref(d), C.c_void_p(dl["mask"].data_ptr()),
+                                                        C.byref(dl["stage_book"]), C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()),
+                                                        C.c_void_p(A)))
         dl[key] = graph
         return graph
 
     def _next_step_pieces(self, dl, parity):
-        """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's launches with every ctypes argument bound once
-        (four direct launches cost less host time than three graph replays with event calls between them).
-        head = cs_collision_reward_gym (reward + the NEXT_STEP bookkeeping: mask_p, prev = mask_{1-p});  gen = masked cs_generate_worlds into
-        staging_p on stream B_p;  body = cs_step_observe;  tail = cs_copy_worlds_masked_observe(staging_{1-p} -> live, mask_{1-p})"""
+        """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's three launches with every ctypes argument bound once.
+        head = cs_collision_reward_gym (reward + the NEXT_STEP bookkeeping: mask_p, prev = mask_{1-p});  body = cs_step_observe;
+        tail = cs_consume_staged_worlds(mask_{1-p}): the worlds that ended in the PREVIOUS step take over their staged episode."""
         import ctypes as C
 
         key = ("ns", parity)
@@ -497,69 +543,42 @@ class BatchedSocialNavGym:
         d = cw.descriptor()
         dref = C.byref(d)
         cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
-        reward, terminated, truncated, info = dl["results"][parity]
         act, masks = dl["act"], dl["ns_masks"]
         P = lambda t: C.c_void_p(t.data_ptr())
-        book = _lib.cs_gym_book(d_counter=dl["counter"].data_ptr(), d_seeds=dl["seeds"].data_ptr(), d_mask=masks[parity].data_ptr(),
-                                d_prev_mask=masks[parity ^ 1].data_ptr(), d_clock=dl["clock"].data_ptr(), clock_len=dl["clock"].numel(),
-                                auto_reset=1, d_reward=reward.data_ptr(), d_terminated=terminated.data_ptr(),
-                                d_truncated=truncated.data_ptr(), d_info=info.data_ptr())
+        book = self._gym_book(dl, parity, masks[parity], masks[parity ^ 1], True)
         a_rew = (dref, P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg, P(dl["out"]), C.byref(book), A)
         a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
-        st = dl["ns_staging"][parity]
-        dg = st.descriptor()
-        nbytes = int(lib.cs_generate_scratch_bytes(C.c_int(self.W)))
-        scratch = st._buffer("gen_mt19937", (nbytes // 4,), np.uint32)
-        a_gen = (C.byref(dl["gen"]), C.byref(dg), P(dl["seeds"]), P(masks[parity]), P(dl["ns_status"][parity]), C.c_void_p(None), C.c_void_p(scratch.ptr),
-                 C.c_void_p(dl["ns_streams"][parity]))
-        ds = dl["ns_staging"][parity ^ 1].descriptor()
-        a_copy = (C.byref(ds), dref, P(masks[parity ^ 1]), P(dl["ns_status"][parity ^ 1]), C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
-        keep = (d, dg, ds, cfg, book)              # the structs the byref arguments point into
-        dl[key] = dict(rew=a_rew, step=a_step, gen=a_gen, copy=a_copy, keep=keep)
+        a_tail = (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), dref, P(masks[parity ^ 1]), C.byref(dl["stage_book"]),
+                  C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
+        keep = (d, cfg, book)              # the structs the byref arguments point into
+        dl[key] = dict(rew=a_rew, step=a_step, tail=a_tail, keep=keep)
         return dl[key]
 
     def _step_device_next_step(self, dl, actions):
-        """One step in NEXT_STEP autoreset mode.  A world that ended at step t returns its terminal observation at t, is regenerated
-        BESIDE step t + 1 (stream B_p, into staging batch p) and returns the new episode's first observation -- with reward 0 and no
-        termination -- at t + 1: the regeneration (one wavefront per world, ~120 us for the slowest) never sits on the critical path."""
+        """One step in NEXT_STEP autoreset mode.  A world that ended at step t returns its terminal observation at t and the first
+        observation of its next episode -- with reward 0 and no termination -- at t + 1, taken over from the staging batch at the end
+        of step t + 1."""
         import torch
 
         if "ns_masks" not in dl:
             W = self.W
             dl["ns_masks"] = [torch.zeros(W, dtype=torch.int32, device="cuda") for _ in range(2)]
-            dl["ns_status"] = [torch.zeros(W, dtype=torch.int32, device="cuda") for _ in range(2)]
-            dl["ns_staging"] = [dl["staging"], self.cw.staging_copy()]
-            dl["ns_streams"] = [dl["stream_b"], _lib.stream_create()]
-            for st, sb in zip(dl["ns_staging"], dl["ns_streams"]):
-                st.stream = sb
-            dl["ns_mask_ev"] = [_lib.Event(), _lib.Event()]
-            dl["ns_gen_ev"] = [_lib.Event(), _lib.Event()]
-            for e, sb in zip(dl["ns_gen_ev"], dl["ns_streams"]):
-                e.record(sb)                      # "nothing pending" for the very first tail
-            for p in (0, 1):
-                self._next_step_pieces(dl, p)     # (allocates the generators' scratch once)
             torch.cuda.synchronize()
         parity = dl["parity"]
         dl["parity"] ^= 1
         c = self._next_step_pieces(dl, parity)
         lib, chk = _lib.load(), _lib.check
         side, cur = dl["stream"], torch.cuda.current_stream()
-        A = side.cuda_stream
-        same = cur.cuda_stream == A
+        same = cur.cuda_stream == side.cuda_stream
         if not same:
             side.wait_stream(cur)
         if actions is not dl["act"]:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
         chk(lib.cs_collision_reward_gym(*c["rew"]))                 # reward of the state before the substeps; who ends now, who is being reset
-        dl["ns_mask_ev"][parity].record(A)
-        B = dl["ns_streams"][parity]
-        dl["ns_mask_ev"][parity].wait(B)
-        chk(lib.cs_generate_worlds(*c["gen"]))                       # beside this step's substeps and the next step
-        dl["ns_gen_ev"][parity].record(B)
         chk(lib.cs_step_observe(*c["step"]))                         # the 20 fused substeps + the observation of the stepped crowd
-        dl["ns_gen_ev"][parity ^ 1].wait(A)                          # the worlds that ended in the PREVIOUS step are ready by now
-        chk(lib.cs_copy_worlds_masked_observe(*c["copy"]))           # ... copied in (unless their generation failed: failed_resets()), observation rows included
+        chk(lib.cs_consume_staged_worlds(*c["tail"]))                # the worlds that ended in the PREVIOUS step: their next episode, observation rows included
+        self._maybe_refill(dl)
         if not same:
             cur.wait_stream(side)
         reward, terminated, truncated, info = dl["results"][parity]
@@ -570,10 +589,10 @@ class BatchedSocialNavGym:
         ``env.action_buffer()`` itself, filled in place (no copy).  Returns torch CUDA tensors (obs [W, N, 5|7], reward [W],
         terminated [W], truncated [W], info_code [W]); obs is a persistent buffer rewritten by the next call, the other four
         alternate between two sets (those of the previous step stay valid for one more call).
-        With ``auto_reset=True`` the worlds whose episode ended are regenerated on the device from the next unused seeds before the
-        observation is taken (same-step autoreset); the whole step is one replay of a HIP graph (``_step_graph``).
-        ``auto_reset="next_step"`` is Gymnasium's NEXT_STEP mode: a finished world returns its terminal observation, spends the next
-        step being reset (reward 0, not terminated) and its regeneration runs beside that step instead of on the critical path."""
+        With ``auto_reset=True`` the worlds whose episode ended take over their next episode -- generated ahead on the device from
+        the next unused seed -- before the observation is taken (same-step autoreset); the whole step is one replay of a HIP graph
+        (``_step_graph``).  ``auto_reset="next_step"`` is Gymnasium's NEXT_STEP mode: a finished world returns its terminal observation
+        and spends the next step being reset (reward 0, not terminated)."""
         import torch
 
         dl = self._device_loop_state()
@@ -594,20 +613,23 @@ class BatchedSocialNavGym:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
         graph.launch()
+        if auto_reset:
+            self._maybe_refill(dl)
         if not same:
             cur.wait_stream(side)                  # ... and with whoever reads the results
         reward, terminated, truncated, info = dl["results"][parity]
         return dl["obs"], reward, terminated, truncated, info
 
+    def reset_failed_mask(self):
+        """int32 CUDA tensor [W], no synchronisation: 1 where the world's LAST device-side auto-reset could not be generated
+        (cs_generate_worlds status != 0: the bounded rejection sampling gave up, or the traffic is too dense -- the reference loops
+        forever / raises there).  Such a world keeps its finished rows, ends again on the next step and then tries the following
+        seed of its sequence; the flag returns to 0 with the first reset that succeeds."""
+        return self._device_loop_state()["failed"]
+
     def failed_resets(self) -> int:
-        """Worlds whose last device-side auto-reset could not be generated (cs_generate_worlds status != 0: the bounded rejection
-        sampling gave up, or the traffic is too dense -- the reference loops forever / raises there).  Such a world is NOT replaced:
-        it keeps its finished episode's rows.  Synchronises."""
-        dl = self._device_loop_state()
-        n = int((dl["gen_status"] != 0).sum().item())
-        for st in dl.get("ns_status", []):
-            n += int((st != 0).sum().item())
-        return n
+        """Number of worlds flagged in ``reset_failed_mask()``.  Synchronises."""
+        return int((self._device_loop_state()["failed"] != 0).sum().item())
 
     def device_stream(self):
         """The torch stream the device-resident step runs on.  A loop that does its own GPU work inside ``with torch.cuda.stream(env.device_stream())``
@@ -676,8 +698,8 @@ class BatchedSocialNavGym:
         from .. import scenarios as sc
         from ..batched import HUMAN_MODELS
 
-        if runge_kutta:
-            raise NotImplementedError("RK45 integration of the ROBOT is not built (the crowd has it: cs_update_humans_rk45)")
+        if runge_kutta and policy_name == "orca":
+            raise NotImplementedError                              # ORCA is Euler only (motion_model_manager.py:579)
         if policy_name not in HUMAN_MODELS:
             raise Exception(f"The robot motion model '{policy_name}' does not exist")
         if self.cw is None:
@@ -693,6 +715,7 @@ class BatchedSocialNavGym:
                 hm[:, :n] = 0.01 + safety_space
             cw.set_robot_model(policy_name, sc.default_params(policy_name), (0.01 + safety_space) if safety_space > 0 else 0.0, hm)
         self.robot_motion_model_title = policy_name
+        self.robot_runge_kutta = bool(runge_kutta)    # every substep's update_robot is an RK45 solve over dt (cs_robot_model_rk45)
 
     def imitation_learning_step(self):
         """SocialNavGym.imitation_learning_step (social_nav_gym.py:252-274) for every world: time_step_factor x
@@ -700,7 +723,14 @@ class BatchedSocialNavGym:
         Returns (obs, reward [W], terminated [W], truncated [W], info_code [W])."""
         if getattr(self.cw, "robot_model", None) is None:
             raise AttributeError("set_human_motion_model_as_robot_policy has not been called")
-        self.cw.imitation_block(self.time_step, self.time_step_factor)
+        if getattr(self, "robot_runge_kutta", False):
+            # motion_model_manager.py:631-640: the robot's SFM / HSFM model integrated by RK45 over every substep, the humans standing
+            # during the solve; then the crowd's Euler substep -- the reference's alternation, launch by launch
+            for _ in range(self.time_step_factor):
+                self.cw.robot_model_rk45(self.time_step, download=False)
+                self.cw.step(self.time_step, 1, None)
+        else:
+            self.cw.imitation_block(self.time_step, self.time_step_factor)
         for _ in range(self.time_step_factor):
             self.global_time += np.float32(self.time_step)
         out = self.cw.actual_collision_reward(self.robot_time_step, self.global_time, self.reward_cfg)

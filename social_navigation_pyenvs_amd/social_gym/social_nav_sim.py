@@ -328,9 +328,9 @@ class SocialNavSim:
     def set_human_motion_model_as_robot_policy(self, policy_name, runge_kutta):
         """The robot moves towards its goal with a human motion model (:862-873); used by imitation learning."""
         if getattr(self, "motion_model_manager", None) is None:   # no world yet (the Gym builds it at the first reset)
-            if runge_kutta:
-                raise NotImplementedError("RK45 integration of the ROBOT is not built (the crowd has it: cs_update_humans_rk45)")
-            self._pending_robot_model = (policy_name, runge_kutta)
+            if runge_kutta and policy_name == "orca":
+                raise NotImplementedError                          # the reference's own (:579)
+            self._pending_robot_model = (policy_name, bool(runge_kutta))
             return
         self.motion_model_manager.set_robot_motion_model(policy_name, runge_kutta)
 

@@ -436,7 +436,16 @@ class MotionModelManager:
         """``n_substeps`` x { update_robot(t, dt) ; update_humans(t, dt) } without leaving the device -- the loop of
         SocialNavGym.imitation_learning_step (social_nav_gym.py:259-263)."""
         cw = self._device_with_robot_model()
-        cw.imitation_block(dt, n_substeps)
+        if getattr(self, "robot_runge_kutta", False) and not self.robot_orca:
+            # the robot under RK45 (:631-640): one solve over dt per substep with the humans standing, then the crowd's Euler substep --
+            # the reference's strict alternation, 2 x n_substeps launches, one read-back
+            nfev = 0
+            for _ in range(int(n_substeps)):
+                nfev += int(cw.robot_model_rk45(dt)[0])
+                cw.step(dt, 1, None)
+            self.robot_rk45_nfev = nfev
+        else:
+            cw.imitation_block(dt, n_substeps)
         self._readback(cw)
         self._readback_robot(cw)
         if self.orca and self.consider_robot:  # set_state_orca(robot) after the last doStep (:389)

@@ -21,6 +21,7 @@ reference produced) is written to the ``.npz`` fixtures.  Groups (SURVEY.md §8c
   g9_laser    LaserSensor.get_laser_measurements (social_gym/src/sensors.py:51-66)
   g13_block_sizes  20-substep blocks at the row counts of the BASELINE.json configurations (10, 25 traffic, 50, 50 + walls +
               immobile humans), all nine models: the shapes the shape-specialised kernel builds run on
+  g15_imitation_rk45  SocialNavGym.imitation_learning_step with the robot's motion model integrated by RK45 (runge_kutta=True)
   g10_social_momentum  MotionModelManager("social_momentum").update_humans single steps (motion_model_manager.py:395-404,
               social_gym/src/social_momentum.py)
 """
@@ -985,11 +986,54 @@ def gen_g13_block_sizes():
     print("g13_block_sizes:", len(cases), "cases ->", save_cases("g13_block_sizes", cases))
 
 
+def gen_g15_imitation_rk45():
+    """The Gym seam with the ROBOT integrated by RK45: set_human_motion_model_as_robot_policy(model, runge_kutta=True)
+    (social_nav_sim.py:862-873 -> motion_model_manager.py:552-563) + imitation_learning_step (social_nav_gym.py:252-274): every one of
+    the 20 substeps of a Gym step is update_robot (solve_ivp RK45 over dt around compute_robot_forces, motion_model_manager.py:631-640,
+    :661-687) followed by the crowd's Euler update_humans.  Six SFM / HSFM robot models, robot visible or not, three scenarios."""
+    cases = []
+    seed = 0
+    human_models = ["sfm_helbing", "hsfm_farina", "sfm_guo", "hsfm_new_guo"]
+    scenarios = ["circle_crossing", "parallel_traffic", "hybrid_scenario"]
+    for rmodel in ("sfm_helbing", "sfm_guo", "hsfm_farina", "hsfm_guo", "hsfm_new", "hsfm_new_guo"):
+        for robot_visible in (False, True):
+            seed += 1
+            rng = np.random.default_rng(150_000 + seed)
+            hmodel = human_models[seed % len(human_models)]
+            scen = scenarios[seed % len(scenarios)]
+            env, _ = make_env(hmodel, scen, 5, robot_visible)
+            env.set_human_motion_model_as_robot_policy(rmodel, True)
+            if seed % 4 == 0:
+                env.set_safety_space(0.1)
+            phase = ("test", "val", "train")[seed % 3]
+            test_case = int(rng.integers(0, 90))
+            ob, info = env.reset(phase=phase, test_case=test_case)
+            mm = env.motion_model_manager
+            assert mm.robot_runge_kutta is True
+            obs, rewards, terms, truncs, infos = [ob_to_array(ob)], [], [], [], []
+            robots = [robot_row(env.robot)]
+            mm_states, mm_goals = [mm.states.copy()], [mm.goals.copy()]
+            for k in range(10):
+                ob, r, term, trunc, info = env.imitation_learning_step()
+                obs.append(ob_to_array(ob)); rewards.append(float(r)); terms.append(bool(term)); truncs.append(bool(trunc))
+                infos.append(type(info[0]).__name__)
+                robots.append(robot_row(env.robot))
+                mm_states.append(mm.states.copy()); mm_goals.append(mm.goals.copy())
+            cases.append(dict(robot_model=rmodel, model=hmodel, scenario=scen, robot_visible=robot_visible, phase=phase, test_case=test_case,
+                              human_num=5, safety_space=float(env.safety_space), respawn=bool(mm.parallel_traffic_humans_respawn),
+                              obs=np.array(obs), rewards=np.array(rewards), terminated=np.array(terms), truncated=np.array(truncs), infos=infos,
+                              robots=np.array(robots), mm_states=np.array(mm_states), mm_goals=np.array(mm_goals), mm_safety=mm.safety_space.copy(),
+                              human_safety=np.array([h.safety_space for h in mm.humans], dtype=float),
+                              robot_params=env.robot.get_parameters(rmodel), global_time=float(env.global_time)))
+            env.parallel_traffic_humans_respawn = False
+    print("g15_imitation_rk45:", len(cases), "cases ->", save_cases("g15_imitation_rk45", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
               g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
               g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45, g14_rk45_more=gen_g14_rk45_more,
-              g13_block_sizes=gen_g13_block_sizes)
+              g13_block_sizes=gen_g13_block_sizes, g15_imitation_rk45=gen_g15_imitation_rk45)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -75,13 +75,14 @@ def test_header_is_plain_c_and_generator_struct_matches():
     import subprocess
     import tempfile
 
-    from social_navigation_pyenvs_amd._lib import cs_gym_book, cs_worlds
+    from social_navigation_pyenvs_amd._lib import cs_gym_book, cs_stage_book, cs_worlds
     from social_navigation_pyenvs_amd.generators import cs_generator
 
     src = ('#include "crowdstep.h"\n#include <stdio.h>\n#include <stddef.h>\n'
-           'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cs_worlds), sizeof(cs_generator), '
+           'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cs_worlds), sizeof(cs_generator), '
            'offsetof(cs_generator, circle_radius), offsetof(cs_generator, robot_desired_speed), offsetof(cs_worlds, d_world_flags), offsetof(cs_worlds, d_orca_vertices), '
-           'sizeof(cs_gym_book), offsetof(cs_gym_book, clock_len), offsetof(cs_gym_book, d_reward));return 0;}\n')
+           'sizeof(cs_gym_book), offsetof(cs_gym_book, clock_len), offsetof(cs_gym_book, d_reward), offsetof(cs_gym_book, seed_stride), '
+           'sizeof(cs_stage_book), offsetof(cs_stage_book, d_failed), offsetof(cs_stage_book, depth));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
@@ -95,6 +96,8 @@ def test_header_is_plain_c_and_generator_struct_matches():
     assert sizes[4] == cs_worlds.d_world_flags.offset
     assert sizes[5] == cs_worlds.d_orca_vertices.offset
     assert sizes[6] == C.sizeof(cs_gym_book) and sizes[7] == cs_gym_book.clock_len.offset and sizes[8] == cs_gym_book.d_reward.offset
+    assert sizes[9] == cs_gym_book.seed_stride.offset
+    assert sizes[10] == C.sizeof(cs_stage_book) and sizes[11] == cs_stage_book.d_failed.offset and sizes[12] == cs_stage_book.depth.offset
 
 
 def test_integration_doc_stub_matches_the_struct():

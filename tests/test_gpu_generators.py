@@ -252,7 +252,7 @@ def test_device_resident_step_equals_host_step_and_auto_resets():
 
 
 def test_device_step_next_step_autoreset_mode():
-    """step_device(auto_reset="next_step") (Gymnasium's NEXT_STEP mode; the regeneration runs beside the following step): until a
+    """step_device(auto_reset="next_step") (Gymnasium's NEXT_STEP mode; the next episode comes from the staging batch one step later): until a
     world's first termination it is bit-identical to the same-step mode; a world that ends at step t returns at t + 1 reward 0, not
     terminated, Nothing, a restarted clock, and the first observation of the world its next seed generates."""
     torch = pytest.importorskip("torch")
@@ -459,10 +459,10 @@ def test_fused_reward_and_bookkeeping_equals_the_two_launches(next_step):
             _lib.check(lib.cs_collision_reward(C.byref(d), P("act"), C.c_float(0.25), P("gtime"), cfg, P("out"), C.c_void_p(cw.stream)))
             if next_step:
                 _lib.check(lib.cs_gym_bookkeeping_next_step(C.c_int(W), P("out"), P("counter"), P("seeds"), P("mask"), P("prev"), P("gtime"), P("clock"),
-                                                            C.c_int(len(clock)), P("reward"), P("term"), P("trunc"), P("info"), C.c_void_p(cw.stream)))
+                                                            C.c_int(len(clock)), P("reward"), P("term"), P("trunc"), P("info"), C.c_uint32(0), C.c_void_p(cw.stream)))
             else:
                 _lib.check(lib.cs_gym_bookkeeping(C.c_int(W), P("out"), P("counter"), P("seeds"), P("mask"), P("gtime"), P("clock"), C.c_int(len(clock)),
-                                                  C.c_int(1), P("reward"), P("term"), P("trunc"), P("info"), C.c_void_p(cw.stream)))
+                                                  C.c_int(1), P("reward"), P("term"), P("trunc"), P("info"), C.c_uint32(0), C.c_void_p(cw.stream)))
         cw.sync()
         res.append({k: b[k].download() for k in ("out", "counter", "seeds", "mask", "gtime", "reward", "term", "trunc", "info")})
     for k in res[0]:
@@ -557,3 +557,122 @@ def test_step_device_from_the_library_stream_equals_the_cross_stream_call():
             assert torch.equal(tx, ty)
         ended += int((x[2] | x[3]).sum())
     assert ended > 0   # some episodes did end and were regenerated on the way
+
+
+def test_prestaged_episodes_consume_refill_and_the_in_place_fallback():
+    """cs_refill_staged_worlds / cs_consume_staged_worlds at the C ABI (include/crowdstep.h cs_stage_book, depth 2): a finished world
+    takes over the episode staged for its next seed -- twice in a row without a refill pass in between; the third time its slot is
+    stale and the world is generated in place by the same generator code: the same rows either way, a function of the seed.  A world
+    whose generation fails keeps its rows, is flagged, and its sequence moves on; a refill pass regenerates exactly the consumed slots."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd import _lib
+    from social_navigation_pyenvs_amd import generators as gen
+
+    W, n, stride, K = 48, 10, 1000, 2
+    lib = _lib.load()
+    live, ref = _blank(W, n, 2), _blank(W, n, 2)
+    staging = live.staging_copy(K)
+    assert staging.W == K * W
+    base = (100 + np.arange(W)).astype(np.uint32)
+    gen.generate_worlds(live, "circle_crossing", base)
+    g = gen.make_generator(live, "circle_crossing", max_tries=3)                      # ten humans, three attempts each: some seeds fail
+    B = lambda a, t: _lib.DeviceBuffer.from_numpy(np.ascontiguousarray(a), dtype=t)
+    b = dict(seeds=B(base, np.uint32), base=B(base, np.uint32), epoch=B(np.zeros(W), np.uint32), staged=B(np.tile(base, K), np.uint32),
+             status=B(np.zeros(K * W), np.int32), failed=B(np.full(W, 9), np.int32), obs=_lib.DeviceBuffer((W, n, 5)))
+    book = _lib.cs_stage_book(d_seeds=b["seeds"].ptr, d_base_seed=b["base"].ptr, d_epoch=b["epoch"].ptr, d_staged_seed=b["staged"].ptr,
+                              d_staged_status=b["status"].ptr, d_failed=b["failed"].ptr, seed_stride=stride, depth=K)
+    ds, dd = staging.descriptor(), live.descriptor()
+    refill = lambda: (_lib.check(lib.cs_refill_staged_worlds(C.byref(g), C.byref(ds), C.byref(book), C.c_void_p(None))), _lib.stream_sync(None))
+
+    def consume(mask):
+        d_mask = B(mask, np.int32)
+        _lib.check(lib.cs_consume_staged_worlds(C.byref(g), C.byref(ds), C.byref(dd), C.c_void_p(d_mask.ptr), C.byref(book), C.c_int(0),
+                                                C.c_void_p(b["obs"].ptr), C.c_void_p(None)))
+        _lib.stream_sync(None)
+
+    def expected(seeds):   # what cs_generate_worlds makes of these seeds with the same generator settings
+        st = B(np.zeros(W), np.int32)
+        d_seeds = B(seeds, np.uint32)
+        dr = ref.descriptor()
+        scratch = _lib.DeviceBuffer((int(lib.cs_generate_scratch_bytes(C.c_int(W))) // 4,), np.uint32)
+        _lib.check(lib.cs_generate_worlds(C.byref(g), C.byref(dr), C.c_void_p(d_seeds.ptr), C.c_void_p(None), C.c_void_p(st.ptr), C.c_void_p(None),
+                                          C.c_void_p(scratch.ptr), C.c_void_p(None)))
+        _lib.stream_sync(None)
+        return ref.get_states().copy(), ref.get_goals().copy(), ref.get_robot().copy(), st.download()
+
+    E = {e: expected(base + e * stride) for e in (1, 2, 3, 4, 5)}
+    assert (E[1][3] != 0).sum() >= 2 and (E[1][3] == 0).sum() >= W // 2, E[1][3]
+    refill()                                                                           # first pass: slot 1 <- episode 1, slot 0 <- episode 2
+    tags = b["staged"].download().reshape(K, W)
+    np.testing.assert_array_equal(tags[1], base + stride); np.testing.assert_array_equal(tags[0], base + 2 * stride)
+    st = b["status"].download().reshape(K, W)
+    np.testing.assert_array_equal(st[1], E[1][3]); np.testing.assert_array_equal(st[0], E[2][3])
+    sS = staging.get_states().reshape(K, W, n, 13)
+    np.testing.assert_array_equal(sS[1][E[1][3] == 0], E[1][0][E[1][3] == 0]); np.testing.assert_array_equal(sS[0][E[2][3] == 0], E[2][0][E[2][3] == 0])
+    mask = np.zeros(W, np.int32); mask[::3] = 1
+    m = mask == 1
+    staged_before = staging.get_states().copy()
+    for e in (1, 2, 3):            # three ends in a row of every third world, NO refill pass in between: staged, staged, generated in place
+        before = live.get_states().copy()
+        b["seeds"].upload(base + (e * stride) * mask.astype(np.uint32))              # the bookkeeping has moved the seeds on
+        consume(mask)
+        S, G, R, stat = E[e]
+        ok = stat == 0
+        took, kept = m & ok, ~m | ~ok
+        assert took.sum() >= 4
+        after = live.get_states()
+        np.testing.assert_array_equal(after[took], S[took]); np.testing.assert_array_equal(live.get_goals()[took], G[took])
+        np.testing.assert_array_equal(live.get_robot()[took], R[took])
+        np.testing.assert_array_equal(b["obs"].download()[took], S[took][:, :, [0, 1, 3, 4, 8]])
+        np.testing.assert_array_equal(after[kept], before[kept])                       # a failed generation never replaces a live world
+        failed = b["failed"].download()
+        np.testing.assert_array_equal(failed[m], (~ok[m]).astype(np.int32)); np.testing.assert_array_equal(failed[~m], 9)
+        np.testing.assert_array_equal(b["epoch"].download(), e * mask.astype(np.uint32))
+        np.testing.assert_array_equal(staging.get_states(), staged_before)             # consuming never writes the staging batch
+    # the refill pass regenerates exactly the consumed slots: episodes 4 (slot 0) and 5 (slot 1) of the worlds that ended
+    refill()
+    tags = b["staged"].download().reshape(K, W)
+    np.testing.assert_array_equal(tags[0], base + np.where(m, 4, 2).astype(np.uint32) * stride)
+    np.testing.assert_array_equal(tags[1], base + np.where(m, 5, 1).astype(np.uint32) * stride)
+    sS = staging.get_states().reshape(K, W, n, 13)
+    for slot, e_new, e_old in ((0, 4, 2), (1, 5, 1)):
+        redo, left = m & (E[e_new][3] == 0), ~m & (E[e_old][3] == 0)
+        np.testing.assert_array_equal(sS[slot][redo], E[e_new][0][redo])
+        np.testing.assert_array_equal(sS[slot][left], E[e_old][0][left])              # slots nobody consumed are left alone
+    before = b["staged"].download()
+    refill()                                                                           # nothing to do: every block leaves at once
+    np.testing.assert_array_equal(b["staged"].download(), before)
+
+
+def test_step_device_is_the_same_whatever_the_refill_cadence():
+    """The staging batch is an optimisation, not a semantics: a loop whose refill pass never runs again after the first one (every later
+    episode end takes the in-place path) returns what the default cadence returns, bit for bit -- episodes of a few steps included
+    (the robots are driven into the nearest human: a world ends, and ends again soon after its reset)."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W = 80
+    cfg = _config("circle_crossing", human_num=6)
+    envs = [BatchedSocialNavGym(cfg, W) for _ in range(3)]
+    envs[1].REFILL_EVERY, envs[1].STAGE_DEPTH = 10 ** 9, 2
+    envs[2].REFILL_EVERY, envs[2].STAGE_DEPTH = 1, 1
+    for e in envs:
+        e.reset(phase="train", first_case=7, device=True)
+    ended = np.zeros(W, int)
+    for k in range(90):
+        rb = envs[0].cw.d_robot.torch().view(W, 13)
+        hum = envs[0].observe_device()[:, :, 0:2]
+        d = hum - rb[:, None, 0:2]
+        near = d[torch.arange(W), d.norm(dim=2).argmin(dim=1)]
+        a = (near / near.norm(dim=1, keepdim=True).clamp(min=1e-6)).contiguous()      # straight at the nearest human
+        outs = [[t.clone() for t in e.step_device(a)] for e in envs]
+        for other in outs[1:]:
+            for x, y in zip(outs[0], other):
+                assert torch.equal(x, y), k
+        ended += (outs[0][2] | outs[0][3]).cpu().numpy().astype(int)
+    assert (ended >= 3).sum() >= W // 4, ended                   # many worlds went through several episodes
+    for e in envs[1:]:
+        np.testing.assert_array_equal(e.cw.get_states(), envs[0].cw.get_states())
+        assert e.failed_resets() == 0
+    assert envs[1]._dl["depth"] == 2 and int(envs[1]._dl["epoch"].max()) > 2                   # (its staging batch really ran dry)

@@ -77,3 +77,37 @@ def test_two_ranks_equal_the_single_process_batch():
             for a, b in zip(got[k], ref[k]):
                 np.testing.assert_array_equal(a, b)
     assert np.any(ref[-1][0] != ref[0])
+
+
+def test_shards_stay_the_single_process_batch_across_auto_resets():
+    """Past the episode ends: a finished world's seed moves on by the worlds of the WHOLE job (cs_gym_book.seed_stride), so the ragged
+    shards of a 37-world batch (19 + 18 worlds, stepped here one after the other on one GPU -- no communication is involved) keep
+    returning what the single-process batch returns, world for world, through every world's second and third episode.  With the local
+    shard size as the stride, rank 0's second episodes would be rank 1's first ones."""
+    import torch
+
+    from social_navigation_pyenvs_amd.social_gym.sharded_gym import ShardedBatchedSocialNavGym
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    full = BatchedSocialNavGym(_config(), TOTAL)
+    full.reset(phase="val", first_case=5, device=True)
+    shards = [ShardedBatchedSocialNavGym(_config(), TOTAL, rank=r, world_size=2) for r in range(2)]
+    for s in shards:
+        s.reset(phase="val", first_case=5, device=True)
+    assert [(s.first, s.W) for s in shards] == [(0, 19), (19, 18)] and all(s.env.seed_stride == TOTAL for s in shards)
+    seeds0 = full._device_loop_state()["seeds"].cpu().numpy().copy()
+    ended = np.zeros(TOTAL, int)
+    for k in range(90):
+        rb = full.cw.d_robot.torch().view(TOTAL, 13)
+        to_goal = rb[:, 10:12] - rb[:, 0:2]
+        a = (to_goal / to_goal.norm(dim=1, keepdim=True).clamp(min=1e-6)).contiguous().clone()   # ReachGoal ends the episodes
+        ref = [t.clone() for t in full.step_device(a)]
+        got = [[t.clone() for t in s.step_device(a)] for s in shards]                     # every shard slices its rows out of the full array
+        for j, r in enumerate(ref):
+            assert torch.equal(torch.cat([g[j] for g in got], 0), r), (k, j)
+        ended += (ref[2] | ref[3]).cpu().numpy().astype(int)
+    assert (ended >= 2).all(), ended
+    seeds = np.concatenate([s._dl["seeds"].cpu().numpy() for s in shards])
+    np.testing.assert_array_equal(seeds, full._dl["seeds"].cpu().numpy())
+    np.testing.assert_array_equal(seeds, seeds0 + TOTAL * ended)                       # world w walks s + w + k * total_worlds
+    np.testing.assert_array_equal(np.concatenate([s.cw.get_states() for s in shards]), full.cw.get_states())
