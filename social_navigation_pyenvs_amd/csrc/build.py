@@ -20,7 +20,7 @@ ROOT = os.path.dirname(PKG)
 LIB_PATH = os.path.join(PKG, "libcrowdstep.so")
 MANIFEST_PATH = LIB_PATH + ".manifest.json"
 OBJ_DIR = os.path.join(CSRC, ".build")
-SOURCES = ["crowdstep.hip", "sfmstep_generic.hip", "sfmstep_leanrt.hip", "sfmstep_lean25.hip", "sfmstep_lean30.hip", "sfmstep_small.hip", "sfmstep_lean50.hip", "sfmstep_robot26.hip", "sfmstep_robotx.hip", "sfmstep_imit.hip", "orca.hip", "lookahead.hip", "generate.hip", "laser.hip", "social_momentum.hip", "robot_model.hip",
+SOURCES = ["crowdstep.hip", "sfmstep_generic.hip", "sfmstep_leanrt.hip", "sfmstep_lean25.hip", "sfmstep_lean30.hip", "sfmstep_small.hip", "sfmstep_lean50.hip", "sfmstep_robot26.hip", "sfmstep_robotx.hip", "sfmstep_imit.hip", "sfmstep_peragent.hip", "orca.hip", "lookahead.hip", "generate.hip", "laser.hip", "social_momentum.hip", "robot_model.hip",
            "rk45.hip", "rowstep.hip", "gymstep.hip", "bigworld.hip"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: v_pk_*_f32 has no throughput advantage over two scalar ops on gfx950 (measured,

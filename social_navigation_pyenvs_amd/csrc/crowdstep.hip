@@ -328,6 +328,9 @@ Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool nee
         if (kind != 3) return Variant{0, 0, 0, 0, peq};
         return Variant{64, rows == 26 ? 1 : 3, rows == 26 ? 26 : 0, 4, true};
     }
+    // per-agent parameters, 25 rows, Helbing / Guo: the compile-time pair-once build with the partners' parameter rows in registers
+    // (sfmstep_peragent.hip; one spill-free register budget for every grid)
+    if (kind == 0 && !peq && rows == 25 && w->type % 3 != 2 && !need_snap) return Variant{64, 1, 25, 0, false};
     if (kind == 0) return Variant{64, 3, 0, 0, peq};
     // small plain worlds (10 humans: BASELINE.json configs[1]; 5: the reference's default environment): one world per 16-lane
     // DPP row, partners exchanged with row shifts instead of LDS (rowstep.hip).  CROWDSTEP_ROW16=0 keeps them on the LDS kernel.
@@ -353,7 +356,7 @@ Variant select_variant(const cs_worlds* w, int mode, const Geometry& g, bool nee
 
 kfn variant_kernel(const Variant& v, int type)
 {
-    for (auto lookup : {sfm_builds_generic, sfm_builds_leanrt, sfm_builds_lean25, sfm_builds_lean30, sfm_builds_small, sfm_builds_lean50, sfm_builds_robot26, sfm_builds_robotx, sfm_builds_imit})
+    for (auto lookup : {sfm_builds_generic, sfm_builds_leanrt, sfm_builds_lean25, sfm_builds_lean30, sfm_builds_small, sfm_builds_lean50, sfm_builds_robot26, sfm_builds_robotx, sfm_builds_imit, sfm_builds_peragent})
         if (kfn fn = lookup(v, type)) return fn;
     return nullptr;
 }
@@ -407,6 +410,9 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
                    2 * PADR * (sizeof(float4) + sizeof(float2)) +
                    ((peq && g.block == 64) ? (size_t)UA * ACC_PITCH * sizeof(float2) : 0);
+    // per-agent parameters on the pair-once loop (Helbing / Guo, block of one wavefront): reaction accumulators + the partners' parameter rows
+    if (!peq && g.block == 64 && w->type % 3 != 2)
+        shmem += (size_t)UA * ACC_PITCH * sizeof(float2) + (size_t)(2 * g.block + PADR) * sizeof(float4);
     // wall segment table (x1, y1, e, 1/|e|^2), shared or one per world of the block, when it is small enough
     const long seg_tab = (long)w->O * w->Smax * ((w->flags & CS_OBSTACLES_SHARED) ? 1 : g.wpb);
     a.seg_tab = (seg_tab > 0 && seg_tab * 20 <= 16 * 1024) ? (int)seg_tab : 0;

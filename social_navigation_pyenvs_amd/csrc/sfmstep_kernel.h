@@ -62,7 +62,12 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // all_params_equal, whole worlds inside one wavefront: every unordered pair is evaluated ONCE (as the reference
     // does, forces_parallel.py:100-131: F[i,j] = f, F[j,i] = -f) and the reaction handed over through LDS.
-    constexpr bool N3L = PEQ && MAXT == 64;
+    // Per-agent parameters (forces_parallel.py:43-84, :261: F_i = sum_j f(P_i; i, j), no antisymmetry) take the same loop for the Helbing /
+    // Guo laws (PP): the lane that visits the pair (i, j) evaluates BOTH directions -- d, 1/d and the overlap are shared, each side's
+    // A e^{./B} (+ C e^{./D}) comes from its own parameters, the partner's read from an LDS row beside its position -- 12 VALU + 3
+    // transcendentals per unordered pair instead of 2 x (12 + 2) (the peragent bench entry: 443 -> 35x VALU per wavefront-substep).
+    constexpr bool N3L = MAXT == 64 && (PEQ || SOC != 2);
+    constexpr bool PP = N3L && !PEQ;
     const int T = blockDim.x;
     // Every world's rows are stored TWICE, back to back ([w][2][rows]): lane i then reads its partners
     // i+1 .. i+rows-1 at constant offsets from one base address -- no own-row slot, no modulo, no
@@ -74,7 +79,9 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     float* lds_g0x = reinterpret_cast<float*>(lds_vr + 2 * T);     // [T] respawn scratch
     int* lds_flag = reinterpret_cast<int*>(lds_g0x + T);           // [T] respawn scratch
     float2* lds_acc = reinterpret_cast<float2*>(lds_flag + T);     // [UA][2T] reaction accumulators (N3L only)
-    float4* lds_seg = reinterpret_cast<float4*>(lds_acc + (N3L ? UA * ACC_PITCH : 0)); // [seg_tab] x1, y1, ex, ey
+    float4* lds_pp = reinterpret_cast<float4*>(lds_acc + (N3L ? UA * ACC_PITCH : 0));   // [2T + PADR] (PP only) partner parameters, doubled rows like lds_p:
+                                                                                        // lA + cB rs, cB, lC + cD rs, cD  (its own radius + safety space folded in)
+    float4* lds_seg = lds_pp + (PP ? 2 * T + PADR : 0);            // [seg_tab] x1, y1, ex, ey
     float* lds_sinv = reinterpret_cast<float*>(lds_seg + a.seg_tab);                   // [seg_tab] 1 / |e|^2, 0 = NaN slot
     float4* lds_poly = reinterpret_cast<float4*>(lds_sinv + ((a.seg_tab + 3) & ~3));   // [seg_tab / Smax] bounding circle cx, cy, R of every polygon
 
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     int gk = 0;          // length of the non-NaN prefix of my goal list
     bool gdirty = false; // a two-goal list rotated in registers, to be written back in the epilogue
     float* gi = nullptr;
-    if (N3L && valid) sp = load_socp(a.params + ((a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20));
+    if (N3L && PEQ && valid) sp = load_socp(a.params + ((a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20));
     if (human) {
         const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20;
         const float* P = a.params + pw + (long)row * 20;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         inv_alpha = 1.0f / alpha;
         inertia = 0.5f * m * r * r;             // :265
         dt_inertia = a.dt / inertia;            // (torque / I) * dt        (:279)
-        if constexpr (!N3L) sp = load_socp(PEQ ? (a.params + pw) : P);
+        if constexpr (!N3L || PP) sp = load_socp(PEQ ? (a.params + pw) : P);
         gi = a.goals + ((long)w * n + row) * a.G * 2;
         g0x = gi[0]; g0y = gi[1];
         // goal lists of <= 2 entries (every Gym scenario) rotate in registers; longer ones go through memory
@@ -217,6 +224,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         lds_p[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         lds_v[i] = make_float2(0.0f, 0.0f);
     }
+    if constexpr (PP)
+        for (int i = tid; i < TP; i += T) lds_pp[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
     // bounding circle of every staged polygon (centre = mean of its segments' midpoints, radius = farthest endpoint)
     for (int q = tid; q < (NO_WALLS || a.Smax <= 0 ? 0 : a.seg_tab / a.Smax); q += T) {
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         *reinterpret_cast<float2*>(&lds_p[buf * TP + pbase + rows + row]) = me;
     };
     // Helbing / Guo pair-once builds read partner velocities only in the (rare) contact pass, which publishes them itself
-    constexpr bool VEL_ON_DEMAND = N3L && SOC != 2;
+    constexpr bool VEL_ON_DEMAND = N3L && SOC != 2 && PEQ;
     auto publish_v = [&](int buf) {    // stored linear velocity; second copy only where the rotated loop reads it
         if constexpr (!VEL_ON_DEMAND) {
             lds_v[buf * TP + pbase + row] = make_float2(vx, vy);
@@ -253,10 +262,18 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         }
     };
     if (valid) {
-        const float4 me = make_float4(px, py, my_rs, 0.0f);
+        // (PP: the sign of my C / A goes along in the free fourth slot: the partner that evaluates my side needs it)
+        const float4 me = make_float4(px, py, my_rs, PP ? sp.sAC : 0.0f);
         for (int buf = 0; buf < 2; ++buf) {
             lds_p[buf * TP + pbase + row] = me;
             lds_p[buf * TP + pbase + rows + row] = me;
+        }
+        if constexpr (PP) {
+            // my side of a pair as my partner will evaluate it: exponent (rs_partner - dist) cB + (lA + cB rs_me); a row without
+            // parameters (the robot: a source only, its own sum is never used) publishes finite zeros
+            const float4 mine = make_float4(fmaf(sp.cB, my_rs, sp.lA), sp.cB, fmaf(sp.cD, my_rs, sp.lC), sp.cD);
+            lds_pp[pbase + row] = mine;
+            lds_pp[pbase + rows + row] = mine;
         }
         publish_v(0);
         float rvx = vx, rvy = vy;
@@ -288,11 +305,19 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     int aoff[RSN];
 #pragma unroll
     for (int k = 0; k < RSN; ++k) aoff[k] = 0;
+    // ... and, with per-agent parameters (PP), its parameter row and the sign of its C / A: nothing but (x, y) is read per pair
+    constexpr int PPN = (ROWS_CT > 0 && PP) ? RSN : 1;
+    float4 ppj[PPN];
+    float sacj[PPN];
+#pragma unroll
+    for (int k = 0; k < PPN; ++k) { ppj[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); sacj[k] = 0.0f; }
     if constexpr (ROWS_CT > 0 && N3L) {
         if (valid) {
 #pragma unroll
             for (int k = 0; k < RSN; ++k) {
-                rsj[k] = lds_p[pbase + row + 1 + k].z;
+                const float4 pk = lds_p[pbase + row + 1 + k];
+                rsj[k] = pk.z;
+                if constexpr (PP) { sacj[k] = pk.w; ppj[k] = lds_pp[pbase + row + 1 + k]; }
                 const int t = row + 1 + k;
                 aoff[k] = t >= ROWS_CT ? t - ROWS_CT : t;
             }
@@ -311,14 +336,24 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         const int Hf = (rows - 1) >> 1;
         const float4* rp = lds_p + cur * TP + pbase + row + 1;   // rp[k]: partner at ring distance k + 1
         const float2* rv = lds_v + cur * TP + pbase + row + 1;
-        float4 qa[UA];
+        const float4* rpp = lds_pp + pbase + row + 1;            // (PP) ... and its parameter row
+        float4 qa[UA], pa[PP ? UA : 1];
         float2 va[UA];
+        auto fetch_pp = [&](float4 (&pq)[PP ? UA : 1], int kk) {
+            if constexpr (PP) {
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    if constexpr (ROWS_CT > 0) pq[u] = ppj[kk + u];   // (kk is a compile-time constant at every call of these builds)
+                    else pq[u] = rpp[kk + u];
+                }
+            }
+        };
         auto fetch = [&](float4 (&q)[UA], float2 (&vq)[UA], int kk) {
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
                 if constexpr (ROWS_CT > 0 && N3L) {   // (kk is a compile-time constant at every call of these builds)
                     const float2 xy = *reinterpret_cast<const float2*>(&rp[kk + u]);
-                    q[u] = make_float4(xy.x, xy.y, rsj[kk + u], 0.0f);
+                    q[u] = make_float4(xy.x, xy.y, rsj[kk + u], PP ? sacj[kk + u] : 0.0f);
                 } else {
                     q[u] = rp[kk + u];
                 }
@@ -534,11 +569,14 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 float2* acc = lds_acc + pbase + row + 1;                 // acc[u * 2T + k]: that partner's slot in row u
                 float2* accw = lds_acc + pbase;                          // compile-time row builds: slot aoff[k] of the world
                 float ex = 0.0f, ey = 0.0f, rdmax = -1.0e30f;   // max over my partners of rs_j - dist
-                if constexpr (!(LEAN && NO_WALLS)) { if (Hf >= UA) fetch(qa, va, 0); }
-                auto pair_once = [&](const float4 q, const float2 vq, float& fx, float& fy) {
+                if constexpr (!(LEAN && NO_WALLS)) { if (Hf >= UA) { fetch(qa, va, 0); fetch_pp(pa, 0); } }
+                // (fx, fy): the force on me, in units of sign(A_me); (gx, gy): what goes to the partner's reaction slot -- the same force
+                // when all parameters are equal (exact antisymmetry), the partner's OWN law on the shared geometry otherwise (PP)
+                auto pair_once = [&](const float4 q, const float2 vq, const float4 pj, float& fx, float& fy, float& gx, float& gy) {
                     const float dx = px - q.x, dy = py - q.y;
                     if constexpr (SOC == 2) {
                         pair_force_moussaid_once(sp, dx, dy, vx - vq.x, vy - vq.y, my_rs + q.z, fx, fy);
+                        gx = fx; gy = fy;
                     } else {
                         // [A e^{rd/B}] n + [C e^{rd/D}] t, in units of sign(A); the k1 / k2 contact parts are exact
                         // zeros unless rd > 0 and are added by the contact pass below
@@ -551,6 +589,17 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             const float gc = exp2_fast(fmaf(rd, sp.cD, lCi)) * (inv * sp.sAC); // +-|C| e^{(rij - dist)/D} / dist
                             fx = fmaf(-gc, dy, fx); fy = fmaf(gc, dx, fy);                       // along t = (-ny, nx)
                         }
+                        if constexpr (PP) {
+                            const float rdi = fmaf(-d2, inv, my_rs);                  // rs_me - dist: the partner's exponent offset holds its own rs
+                            const float gb = exp2_fast(fmaf(rdi, pj.y, pj.x)) * inv;
+                            gx = gb * dx; gy = gb * dy;
+                            if constexpr (SOC == 1) {
+                                const float gd = exp2_fast(fmaf(rdi, pj.w, pj.z)) * (inv * q.w);   // q.w: sign(C_j) sign(A_j)
+                                gx = fmaf(-gd, dy, gx); gy = fmaf(gd, dx, gy);
+                            }
+                        } else {
+                            gx = fx; gy = fy;
+                        }
                         rdmax = fmaxf(rdmax, rd);
                     }
                 };
@@ -560,20 +609,20 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 // accumulator row pitch: 2 KiB, out of reach of the ds_read2_b64 / ds_write2_b64 offset fields on purpose:
                 // the paired forms take 8 / 13 LDS cycles, two single b64 accesses 4 / 12 (MI355X_MICROARCH.md, LDS table)
                 constexpr int AR = ACC_PITCH;
-                auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], float2 (&ac)[UA], const int (&so)[UA]) {
+                auto group = [&](const float4 (&q)[UA], const float2 (&vq)[UA], const float4 (&pq)[PP ? UA : 1], float2 (&ac)[UA], const int (&so)[UA]) {
                     if constexpr (SOC == 2) {
 #pragma unroll
                         for (int u = 0; u < UA; ++u) {
-                            float fx, fy;
-                            pair_once(q[u], vq[u], fx, fy);
+                            float fx, fy, gx, gy;
+                            pair_once(q[u], vq[u], make_float4(0.0f, 0.0f, 0.0f, 0.0f), fx, fy, gx, gy);
                             ex += fx; ey += fy;
-                            ac[u].x += fx; ac[u].y += fy;
+                            ac[u].x += gx; ac[u].y += gy;
                         }
                     } else {
                         // Helbing / Guo: the UA partners advance stage by stage (scheduling barriers between the
                         // stages), so the UA v_rsq_f32 and the UA v_exp_f32 issue back to back and each result is
                         // consumed ~UA instructions later instead of right behind its transcendental
-                        float dx[UA], dy[UA], d2[UA], inv[UA], rd[UA], ea[UA], ec[UA];
+                        float dx[UA], dy[UA], d2[UA], inv[UA], rd[UA], ea[UA], ec[UA], eb[UA], ed[UA];
 #pragma unroll
                         for (int u = 0; u < UA; ++u) {
                             dx[u] = px - q[u].x; dy[u] = py - q[u].y;
@@ -588,18 +637,37 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             rd[u] = fmaf(-d2[u], inv[u], q[u].z);
                             ea[u] = fmaf(rd[u], sp.cB, lAi);
                             if constexpr (SOC == 1) ec[u] = fmaf(rd[u], sp.cD, lCi);
+                            if constexpr (PP) {   // the partner's side of the same pair, from its parameter row
+                                const float rdi = fmaf(-d2[u], inv[u], my_rs);
+                                eb[u] = fmaf(rdi, pq[u].y, pq[u].x);
+                                if constexpr (SOC == 1) ed[u] = fmaf(rdi, pq[u].w, pq[u].z);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < UA; ++u) {
                             ea[u] = exp2_fast(ea[u]);
                             if constexpr (SOC == 1) ec[u] = exp2_fast(ec[u]);
+                            if constexpr (PP) {
+                                eb[u] = exp2_fast(eb[u]);
+                                if constexpr (SOC == 1) ed[u] = exp2_fast(ed[u]);
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < UA; ++u) {
                             const float ga = ea[u] * inv[u];
-                            if constexpr (SOC == 1) {
+                            if constexpr (PP) {
+                                const float gb = eb[u] * inv[u];
+                                if constexpr (SOC == 1) {
+                                    const float gc = ec[u] * (inv[u] * sp.sAC), gd = ed[u] * (inv[u] * q[u].w);
+                                    ex += fmaf(-gc, dy[u], ga * dx[u]); ey += fmaf(gc, dx[u], ga * dy[u]);
+                                    ac[u].x += fmaf(-gd, dy[u], gb * dx[u]); ac[u].y += fmaf(gd, dx[u], gb * dy[u]);
+                                } else {
+                                    ex = fmaf(ga, dx[u], ex); ey = fmaf(ga, dy[u], ey);
+                                    ac[u].x = fmaf(gb, dx[u], ac[u].x); ac[u].y = fmaf(gb, dy[u], ac[u].y);
+                                }
+                            } else if constexpr (SOC == 1) {
                                 const float gc = ec[u] * (inv[u] * sp.sAC);
                                 const float fx = fmaf(-gc, dy[u], ga * dx[u]), fy = fmaf(gc, dx[u], ga * dy[u]);
                                 ex += fx; ey += fy;
@@ -624,7 +692,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 if constexpr (ROWS_CT > 0) {
                     // rows known at compile time: the groups are laid out one after the other, no loop, no scalar branches
                     constexpr int NG = ((ROWS_CT - 1) / 2) / UA;
-                    float4 qb[UA];
+                    float4 qb[UA], pb[PP ? UA : 1];
                     float2 vb[UA], ac[UA];
                     for_each_index([&](auto gtag) {
                         constexpr int g = decltype(gtag)::value;
@@ -635,14 +703,14 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             ac[u] = g == 0 ? make_float2(0.0f, 0.0f) : accw[u * AR + so[u]];   // the first group stores: no zeroing pass
                         }
                         if constexpr (g + 1 < NG) {
-                            if constexpr (g & 1) fetch(qa, va, (g + 1) * UA); else fetch(qb, vb, (g + 1) * UA);
+                            if constexpr (g & 1) { fetch(qa, va, (g + 1) * UA); fetch_pp(pa, (g + 1) * UA); } else { fetch(qb, vb, (g + 1) * UA); fetch_pp(pb, (g + 1) * UA); }
                         }
                         asm volatile("" ::: "memory");
-                        if constexpr (g & 1) group(qb, vb, ac, so); else group(qa, va, ac, so);
+                        if constexpr (g & 1) group(qb, vb, pb, ac, so); else group(qa, va, pa, ac, so);
                     }, std::make_integer_sequence<int, NG>{});
                     k0 = NG * UA;
                 } else if (Hf >= UA) {
-                    float4 qb[UA];
+                    float4 qb[UA], pb[PP ? UA : 1];
                     float2 vb[UA], ac[UA];
                     int so[UA];
                     bool first = true;
@@ -654,17 +722,17 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         }
                         first = false;
                         const bool more_b = k0 + 2 * UA <= Hf;
-                        if (more_b) fetch(qb, vb, k0 + UA);
+                        if (more_b) { fetch(qb, vb, k0 + UA); fetch_pp(pb, k0 + UA); }
                         asm volatile("" ::: "memory");
-                        group(qa, va, ac, so);
+                        group(qa, va, pa, ac, so);
                         k0 += UA;
                         if (!more_b) break;
 #pragma unroll
                         for (int u = 0; u < UA; ++u) { so[u] = slot_rt(k0 + u); ac[u] = accw[u * AR + so[u]]; }
                         const bool more_a = k0 + 2 * UA <= Hf;
-                        if (more_a) fetch(qa, va, k0 + UA);
+                        if (more_a) { fetch(qa, va, k0 + UA); fetch_pp(pa, k0 + UA); }
                         asm volatile("" ::: "memory");
-                        group(qb, vb, ac, so);
+                        group(qb, vb, pb, ac, so);
                         k0 += UA;
                         if (!more_a) break;
                     }
@@ -675,28 +743,30 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         static_assert(HC % UA == 1 || UA > 2, "remainder of the compile-time group layout");
 #pragma unroll
                         for (int k = (HC / UA) * UA; k < HC; ++k) {
-                            float fx, fy;
+                            float fx, fy, gx, gy;
                             float2 vq = make_float2(0.0f, 0.0f);
                             if constexpr (SOC == 2) vq = rv[k];
-                            const float2 xy = *reinterpret_cast<const float2*>(&rp[k]);
-                            pair_once(make_float4(xy.x, xy.y, rsj[k], 0.0f), vq, fx, fy);
+                            float4 qk;
+                            if constexpr (PP) qk = rp[k];
+                            else { const float2 xy = *reinterpret_cast<const float2*>(&rp[k]); qk = make_float4(xy.x, xy.y, rsj[k], 0.0f); }
+                            pair_once(qk, vq, PP ? rpp[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f), fx, fy, gx, gy);
                             ex += fx; ey += fy;
                             float2 ac = (k == 0) ? make_float2(0.0f, 0.0f) : accw[aoff[k]];   // (partner 0 without a full group: first writer of row 0)
-                            ac.x += fx; ac.y += fy;
+                            ac.x += gx; ac.y += gy;
                             accw[aoff[k]] = ac;
                             LDS_ORDER_FENCE();
                         }
                     }
                 } else
                 for (int k = k0; k < Hf; ++k) {   // (fewer than UA partners left; k - k0 is the accumulator row they go to when no group ran)
-                    float fx, fy;
+                    float fx, fy, gx, gy;
                     float2 vq = make_float2(0.0f, 0.0f);
                     if constexpr (SOC == 2) vq = rv[k];
-                    pair_once(rp[k], vq, fx, fy);
+                    pair_once(rp[k], vq, PP ? rpp[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f), fx, fy, gx, gy);
                     ex += fx; ey += fy;
                     const int so = slot_rt(k);
                     float2 ac = (k == 0) ? make_float2(0.0f, 0.0f) : accw[so];   // partner 0 of a world without a full group: first writer of row 0
-                    ac.x += fx; ac.y += fy;
+                    ac.x += gx; ac.y += gy;
                     accw[so] = ac;
                     LDS_ORDER_FENCE();
                 }
@@ -707,7 +777,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         else qz = rp[Hf];
                         if constexpr (SOC == 2) vz = rv[Hf];
                     }
-                    pair_once(qz, vz, fx, fy);
+                    float gx, gy;   // (each end evaluates its own side: nothing handed over)
+                    pair_once(qz, vz, make_float4(0.0f, 0.0f, 0.0f, 0.0f), fx, fy, gx, gy);
                     ex += fx; ey += fy;
                 }
                 STAMP(9);
@@ -728,18 +799,24 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     if (__builtin_amdgcn_ballot_w64(rdmax > -my_rs) != 0) { // contact somewhere in this wavefront
                         const float4* pp = lds_p + cur * TP + pbase;
                         float2* pvel = lds_v + cur * TP + pbase;
-                        pvel[row] = make_float2(vx, vy); // every lane of the wavefront is here: publish the velocities now
-                        LDS_ORDER_FENCE();
+                        if constexpr (VEL_ON_DEMAND) {
+                            pvel[row] = make_float2(vx, vy); // every lane of the wavefront is here: publish the velocities now
+                            LDS_ORDER_FENCE();
+                        }
+                        // per-agent parameters: my refreshed velocity, partner j < i refreshed, j > i stored (prange == range order)
+                        const float vix = PP ? cvx : vx, viy = PP ? cvy : vy;
+                        const float2* vr = lds_vr + cur * T + base;
 #pragma nounroll
                         for (int j = 0; j < rows; ++j) { // rare path: keep it small in the instruction cache
                             const float4 q = pp[j];
-                            const float2 vj = pvel[j];
+                            float2 vj = pvel[j];
+                            if constexpr (PP && HEADED > 0) { if (j < row) vj = vr[j]; }
                             const float dx = px - q.x, dy = py - q.y;
                             const float d2 = (j == row) ? 1.0e30f : fmaf(dx, dx, dy * dy);
                             const float inv = rsq_fast(d2);
                             const float m0 = fmaxf(0.0f, (my_rs + q.z) - dist_refined(d2, inv));
                             const float nx = dx * inv, ny = dy * inv;
-                            const float dv = (vj.y - vy) * nx - (vj.x - vx) * ny;     // (v_j - v_i) . t
+                            const float dv = (vj.y - viy) * nx - (vj.x - vix) * ny;     // (v_j - v_i) . t
                             const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;
                             fsx += fn * nx - ft * ny;
                             fsy += fn * ny + ft * nx;
@@ -1083,5 +1160,6 @@ kfn sfm_builds_lean50(const Variant& v, int type);   // sfmstep_lean50.hip: 50 r
 kfn sfm_builds_robot26(const Variant& v, int type);   // sfmstep_robot26.hip: 25 humans + a visible robot
 kfn sfm_builds_robotx(const Variant& v, int type);   // sfmstep_robotx.hip: 5 / 10 / 50 humans + a visible robot
 kfn sfm_builds_imit(const Variant& v, int type);     // sfmstep_imit.hip: a visible robot under its own human motion model (imitation learning)
+kfn sfm_builds_peragent(const Variant& v, int type); // sfmstep_peragent.hip: 25 rows per world, per-agent parameters (Helbing / Guo laws)
 
 } // namespace cstep

@@ -508,3 +508,47 @@ def test_row16_kernel_respawn_rule_and_goal_switch(n, model):
         assert np.array_equal(moved, np.abs(got[w][:, 0] - S32[w][:, 0]) > 1.0)
         moved_any |= bool(moved.any())
     assert moved_any
+
+
+@pytest.mark.parametrize("n,robot,walls", [(25, False, False), (25, False, True), (25, True, True), (17, True, False), (5, False, True), (2, False, False), (32, False, False), (50, True, False)])
+def test_per_agent_parameters_every_substep(n, robot, walls):
+    """all_params_equal = False (forces_parallel.py:43-84, :261: every human its own parameter row).  The Helbing / Guo laws run the
+    pair-once loop with BOTH directions of a pair evaluated by the lane that visits it (shared geometry, each side's own parameters);
+    Moussaid keeps the all-partners loop.  Hybrid worlds (goal switches, respawns), a visible robot moved by an action, walls; 20 fused
+    substeps checked substep by substep at 1e-5 against the oracle's per-agent path."""
+    from social_navigation_pyenvs_amd import scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds, SFMS
+
+    W = 2 * (64 // (n + int(robot))) + 1
+    rng = np.random.default_rng(100 * n + int(robot))
+    wl = sc.polygon_walls().astype(np.float32) if walls else None
+    # (50 humans in a 14 m x 3 m traffic world: the hsfm_new* torque law diverges in the float64 reference itself there)
+    for model in (("hsfm_farina", "sfm_guo", "hsfm_new_guo", "sfm_helbing", "hsfm_moussaid") if n < 40 else ("hsfm_farina", "sfm_guo", "sfm_helbing")):
+        S, goals, P, rb = sc.hybrid_worlds(W, n, model, seed0=57 + n)
+        rw = (np.arange(W) % 2 == 1).astype(np.int32)
+        # every human its own parameters: +-10 % on the force scales and ranges, a few with a NEGATIVE C (sign handling of the Guo term)
+        Pw = np.repeat(np.asarray(P, np.float64)[None], W, 0) * rng.uniform(0.9, 1.1, (W, n, 20))
+        flip = rng.uniform(size=(W, n)) < 0.15
+        Pw[..., 5] = np.where(flip, -Pw[..., 5], Pw[..., 5])
+        R = A = None
+        if robot:
+            R = np.zeros((W, 13), np.float32)
+            R[:, 0:2] = rng.uniform(-3, 3, (W, 2)); R[:, 8] = 0.3; R[:, 9] = 80; R[:, 10:12] = -R[:, 0:2]; R[:, 12] = 1.0
+            A = rng.uniform(-0.8, 0.8, (W, 2)).astype(np.float32)
+            S = np.concatenate([S, R[:, None, :]], axis=1)
+        S32, g32, P32 = f32(S), f32(goals), f32(Pw)
+        cw = CrowdWorlds(S32, g32, P32, None, wl, type=model, all_params_equal=False, respawn_bounds=rb, respawn_worlds=rw,
+                         robot_row=robot, robot=R)
+        assert "PEQ=0,MAXT=64" in cw.step_variant(), cw.step_variant()
+        for _ in range(2):      # two Gym steps in: distinct velocities, some contacts
+            cw.step(0.0125, 20, A)
+        S_k, g_k, R_k = cw.get_states(), cw.get_goals(), (cw.get_robot() if robot else None)
+        fam = "Moussaid" if model.endswith("moussaid") else "Helbing / Guo"
+        res = fused_substeps_vs_oracle(cw, SFMS.index(model), S_k, g_k, P32, None, wl, 0.0125, 20, False, respawn=rw, respawn_bounds=rb,
+                                       robot_row=robot, robot=R_k, action=A,
+                                       group=f"per-agent parameters per substep inside the fused launch ({fam})", what=f"per-agent {model} n={n}")
+        if fam != "Moussaid":
+            assert res["within"] >= res["substeps"] - res["ill_conditioned"], (model, n, res)
+        ref = CrowdWorlds(S_k, g_k, P32, None, wl, type=model, all_params_equal=False, respawn_bounds=rb, respawn_worlds=rw, robot_row=robot, robot=R_k)
+        ref.step(0.0125, 20, A)
+        np.testing.assert_array_equal(cw.get_states(), ref.get_states())       # the traced launch IS cs_step's
