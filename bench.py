@@ -107,7 +107,9 @@ def spec_key(spec) -> str:
 
 
 def workload_spec(args) -> dict:
-    return dict(name="main", device_generator=bool(args.device_generator), model=args.model, agents=args.agents, scenario=args.scenario, walls=bool(args.walls),
+    # ORCA's cost follows the crossing: the two named phases of other_configs keep their PMC entries when they are run on their own
+    phase = {(0, 20): "first20", (25, 20): "dense"}.get((args.warmup, args.steps)) if (args.model == "orca" and args.scenario == "circle") else None
+    return dict(phase_key=phase, name="main", device_generator=bool(args.device_generator), model=args.model, agents=args.agents, scenario=args.scenario, walls=bool(args.walls),
                 static=int(args.static), substeps=args.substeps, dt=args.dt, layout=args.layout, robot=bool(args.robot),
                 per_agent=bool(args.per_agent_params), worlds=args.worlds, total_worlds=args.total_worlds)
 

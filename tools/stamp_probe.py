@@ -32,15 +32,23 @@ if model == "orca":
     gg, b, wpb = cw.launch_geometry() if False else ((W + (64 // n) - 1) // (64 // n), 64, 64 // n)
     buf = _lib.DeviceBuffer((gg, 8), np.uint64)
     _lib.load().cs_debug_set_stamp_buffer(C.c_void_p(buf.ptr))
-    for _ in range(int(os.environ.get("STAMP_STEPS", "3"))):   # 24: the dense phase of the crossing
+    # STAMP_WARMUP Gym steps first (not counted), then STAMP_STEPS counted ones: bench.py's two named phases of the crossing are
+    # (0, 20) "first20" and (25, 20) "dense"
+    warm, steps = int(os.environ.get("STAMP_WARMUP", "0")), int(os.environ.get("STAMP_STEPS", "3"))
+    for _ in range(warm):
+        cw.step(0.0125, 20)
+    cw.sync()
+    _lib.check(_lib.load().cs_memset(C.c_void_p(buf.ptr), C.c_int(0), C.c_size_t(buf.nbytes), C.c_void_p(cw.stream)))
+    for _ in range(steps):
         cw.step(0.0125, 20)
     cw.sync()
     st = buf.download().astype(np.float64)
     names = ["pre (robot/loads)", "neighbour selection", "ORCA lines", "LP2 (+LP1)", "LP3", "update+goal+respawn", "-", "-"]
     tot = st.sum(1).mean()
-    print(f"ORCA N={n}: mean wave cycles = {tot:.0f} (per substep {tot / 20:.0f})")
+    sub = 20 * steps
+    print(f"ORCA N={n} W={W}, Gym steps {warm}..{warm + steps}: mean wave cycles per substep {tot / sub:.0f} (s_memtime ticks; the stamps drain the pipes: shares, not absolute costs)")
     for k, nm in enumerate(names):
-        print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
+        print(f"  {nm:28s} {st[:, k].mean() / sub:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
     sys.exit(0)
 if len(sys.argv) > 4 and sys.argv[4] in ("circle", "walls"):   # cfg2-style: circular crossing only, no respawn rule; "walls": cfg5-style
     pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
