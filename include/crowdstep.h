@@ -426,6 +426,18 @@ int cs_collision_reward_gym(const cs_worlds* w, const float* d_action, float T, 
                             const float* reward_cfg /* host, 5 floats */, float* d_out, const cs_gym_book* book, void* stream);
 
 /*
+ * cs_gym_step  cs_collision_reward_gym followed by cs_step_observe -- the head and the body of SocialNavGym.step (social_nav_gym.py:
+ *   227-250: reward / termination of the CURRENT state, then the substeps, then the observation) -- in ONE launch: the step kernel's
+ *   prologue computes the swept robot-human distances of the incoming rows, writes the reward row and does the episode bookkeeping
+ *   (the very code of cs_collision_reward_gym, bit for bit), then runs the fused substeps and writes the observation from its registers.
+ *   One launch and one graph node less on the critical path of a vectorised Gym step.  SFM / HSFM worlds of up to 64 rows on the LDS
+ *   kernel; every other world: the two launches, internally.  Arguments as the two calls'.
+ */
+int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float T, float* d_global_time,
+                const float* reward_cfg /* host, 5 floats */, float* d_out, const cs_gym_book* book, int theta_and_omega_visible,
+                float* d_obs, void* stream);
+
+/*
  * Pre-staged episodes: the reset of a finished world (SocialNavGym.reset, social_nav_gym.py:120-225: seed -> generator -> rows) taken
  * off the critical path of a vectorised Gym step.  A world's episodes are a function of their seeds, and the seeds are known ahead:
  * episode e of world w draws d_base_seed[w] + e * seed_stride.  So every world keeps its next `depth` episodes generated ahead in a

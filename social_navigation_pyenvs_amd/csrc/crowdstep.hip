@@ -138,17 +138,7 @@ __global__ void k_collision_reward(int W, int n, int rows, const float* S, long 
     int collision = 0;
     for (int i = 0; i < n; ++i) {
         const float* s = S + ((long)w * rows + i) * as;
-        const float x1 = s[0] - rpx, y1 = s[fs] - rpy;
-        const float x2 = x1 + (s[3 * fs] - ax) * T, y2 = y1 + (s[4 * fs] - ay) * T;
-        const float dx = x2 - x1, dy = y2 - y1;
-        float d;
-        if (dx == 0.0f && dy == 0.0f) d = norm2(0.0f - x1, 0.0f - y1);
-        else {
-            float u = ((0.0f - x1) * dx + (0.0f - y1) * dy) / (dx * dx + dy * dy);
-            if (u > 1.0f) u = 1.0f; else if (u < 0.0f) u = 0.0f;
-            d = norm2(x1 + u * dx, y1 + u * dy);
-        }
-        const float closest = d - s[8 * fs] - rr;
+        const float closest = gym_swept_closest(s[0], s[fs], s[3 * fs], s[4 * fs], s[8 * fs], rpx, rpy, rr, ax, ay, T);
         if (closest < 0.0f) { collision = 1; break; }
         else if (closest < dmin) dmin = closest;
     }
@@ -168,18 +158,8 @@ __global__ void k_collision_reward(int W, int n, int rows, const float* S, long 
 // read once, coalesced), then one lane per world walks them in index order with the reference's early `break`.
 // episode bookkeeping of a vectorised Gym step (cs_gym_bookkeeping / _next_step, robot_model.hip), done by the lane that wrote the
 // world's reward row when cs_collision_reward_gym asks for it (mode 0: none, 1: same-step rules, 2: NEXT_STEP rules)
-struct GymBook {
-    int mode, clock_len, auto_reset;
-    unsigned stride;   // what a finished world's seed moves on by (cs_gym_book.seed_stride; the worlds of the whole job)
-    int* counter; unsigned* seeds; int* mask; const int* prev; float* gtime; const float* clock;
-    float* reward; unsigned char* terminated; unsigned char* truncated; int* info;
-};
-
 __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int rows, int wpb, const float* S, long as, long fs,
-                                                              const float* robot, const float* action, float T,
-                                                              const float* gtime, float time_limit, float success_reward,
-                                                              float collision_penalty, float discomfort_dist,
-                                                              float discomfort_factor, float* out, const GymBook bk)
+                                                              const float* robot, const float* action, const GymHead g)
 {
     __shared__ float s_closest[64];
     const int tid = threadIdx.x;
@@ -193,58 +173,12 @@ __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int 
         rpx = rb[0]; rpy = rb[1]; rr = rb[8]; rgx = rb[10]; rgy = rb[11];
         ax = action[(long)w * 2]; ay = action[(long)w * 2 + 1];
         const float* s = S + ((long)w * rows + i) * as;
-        const float x1 = s[0] - rpx, y1 = s[fs] - rpy;
-        const float x2 = x1 + (s[3 * fs] - ax) * T, y2 = y1 + (s[4 * fs] - ay) * T;
-        const float dx = x2 - x1, dy = y2 - y1;
-        float d;
-        if (dx == 0.0f && dy == 0.0f) d = norm2(0.0f - x1, 0.0f - y1);
-        else {
-            float u = ((0.0f - x1) * dx + (0.0f - y1) * dy) / (dx * dx + dy * dy);
-            if (u > 1.0f) u = 1.0f; else if (u < 0.0f) u = 0.0f;
-            d = norm2(x1 + u * dx, y1 + u * dy);
-        }
-        closest = d - s[8 * fs] - rr;
+        closest = gym_swept_closest(s[0], s[fs], s[3 * fs], s[4 * fs], s[8 * fs], rpx, rpy, rr, ax, ay, g.T);
     }
     s_closest[tid] = closest;
     __syncthreads();
     if (!valid || i != 0) return;
-    float dmin = INFINITY;
-    int collision = 0;
-    for (int j = 0; j < n; ++j) {
-        const float c = s_closest[lw * n + j];
-        if (c < 0.0f) { collision = 1; break; }
-        else if (c < dmin) dmin = c;
-    }
-    const float ex = rpx + ax * T, ey = rpy + ay * T;
-    const int reaching = norm2(ex - rgx, ey - rgy) < rr;
-    float reward = 0.0f; int term = 0, trunc = 0, info = 0;
-    if (gtime[w] >= time_limit - 1.0f) { trunc = 1; info = 4; }
-    else if (collision) { reward = collision_penalty; term = 1; info = 3; }
-    else if (reaching) { reward = success_reward; term = 1; info = 2; }
-    else if (dmin < discomfort_dist) { reward = (dmin - discomfort_dist) * discomfort_factor * T; info = 1; }
-    float* o = out + (long)w * 7;
-    o[0] = (float)collision; o[1] = dmin; o[2] = (float)reaching; o[3] = reward;
-    o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
-    if (bk.mode == 0) return;
-    // the same statements as k_gym_bookkeeping / k_gym_bookkeeping_next_step, on the values just written
-    if (bk.mode == 2 && bk.prev[w]) {
-        bk.reward[w] = 0.0f; bk.terminated[w] = 0; bk.truncated[w] = 0; bk.info[w] = 0;
-        bk.mask[w] = 0; bk.counter[w] = 0; bk.gtime[w] = bk.clock[0];
-        return;
-    }
-    bk.reward[w] = reward; bk.terminated[w] = term ? 1 : 0; bk.truncated[w] = trunc ? 1 : 0; bk.info[w] = info;
-    const bool done = term || trunc;
-    int c = bk.counter[w] + 1;
-    if (bk.mode == 2) {
-        bk.mask[w] = done ? 1 : 0;
-        if (done) bk.seeds[w] += bk.stride;
-    } else if (bk.auto_reset) {
-        bk.mask[w] = done ? 1 : 0;
-        if (done) { bk.seeds[w] += bk.stride; c = 0; }
-    }
-    c = c < bk.clock_len - 1 ? c : bk.clock_len - 1;
-    bk.counter[w] = c;
-    bk.gtime[w] = bk.clock[c];
+    gym_head_world(g, w, n, s_closest + lw * n, rpx, rpy, rr, rgx, rgy, ax, ay);
 }
 
 __global__ void k_transpose_state(const float* src, float* dst, long total_rows, int to_soa)
@@ -361,9 +295,28 @@ kfn variant_kernel(const Variant& v, int type)
     return nullptr;
 }
 
+// the Gym head's arguments from the C ABI's (book == nullptr: reward row only)
+GymHead gym_head(float* d_out, const float* d_global_time, float T, const float* reward_cfg, const cs_gym_book* book, int W)
+{
+    GymHead g;
+    std::memset(&g, 0, sizeof(g));
+    g.out = d_out; g.gtime = d_global_time; g.T = T;
+    g.time_limit = reward_cfg[0]; g.success_reward = reward_cfg[1]; g.collision_penalty = reward_cfg[2];
+    g.discomfort_dist = reward_cfg[3]; g.discomfort_factor = reward_cfg[4];
+    if (book) {
+        GymBook& bk = g.bk;
+        bk.mode = book->d_prev_mask ? 2 : 1; bk.clock_len = book->clock_len; bk.auto_reset = book->auto_reset;
+        bk.stride = book->seed_stride ? book->seed_stride : (unsigned)W;
+        bk.counter = book->d_counter; bk.seeds = book->d_seeds; bk.mask = book->d_mask; bk.prev = book->d_prev_mask; bk.gtime = const_cast<float*>(d_global_time);   // (with a book the caller's buffer is writable: cs_collision_reward_gym)
+        bk.clock = book->d_clock; bk.reward = book->d_reward; bk.terminated = book->d_terminated; bk.truncated = book->d_truncated;
+        bk.info = book->d_info;
+    }
+    return g;
+}
+
 int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, const float* d_action,
                 float* d_peek, hipStream_t stream, float4* d_snap = nullptr, float* d_trace = nullptr, const RobotModel* rm = nullptr,
-                float* d_obs = nullptr, int obs_cols = 0)
+                float* d_obs = nullptr, int obs_cols = 0, const GymHead* gym = nullptr)
 {
     int rc = check_worlds(w);
     if (rc) return rc;
@@ -396,6 +349,10 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.trace = d_trace;
     a.obs = d_obs; a.obs_cols = obs_cols;
     const Variant v = select_variant(w, mode, g, d_snap != nullptr, rm != nullptr);
+    if (gym) {
+        if (v.maxt != 64) return fail(CS_ERR_ARG, "the Gym head runs inside the step launch of blocks of one wavefront only");
+        a.gym = *gym;
+    }
     if (rm) {
         if (v.lean != 4) return fail(CS_ERR_ARG, "the robot's motion model runs inside the crowd's launch only for the plain crowd batch with a robot row");
         a.rm_type = rm->type; a.rm_margin = rm->margin; a.rm_hmargin = rm->d_human_margin; a.rm_memory = rm->d_memory;
@@ -543,6 +500,42 @@ int cs_step_observe(const cs_worlds* w, float dt, int n_substeps, const float* d
                        theta_and_omega_visible ? 7 : 5);
 }
 
+int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float T, float* d_global_time, const float* reward_cfg,
+                float* d_out, const cs_gym_book* book, int theta_and_omega_visible, float* d_obs, void* stream)
+{
+    if (!w || !book || !d_obs) return fail(CS_ERR_ARG, "null argument");
+    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
+    // ONE launch where the step kernel is the LDS kernel of one wavefront per block (SFM / HSFM worlds of up to 64 rows); the two
+    // launches everywhere else (ORCA, social momentum, the DPP-row kernel's small worlds keep their own launch: same results)
+    bool fused = w->type >= 0 && w->type <= 8 && rows <= 64 && w->W > 0 && w->n > 0;
+    if (fused) {
+        if (check_worlds(w)) fused = false;
+        else {
+            Geometry g;
+            if (geometry(w, g)) fused = false;
+            else {
+                int mode = M_COMMIT_GOALS;
+                if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
+                fused = select_variant(w, mode, g).maxt == 64;   // (small plain worlds keep the DPP-row kernel and its own reward launch)
+            }
+        }
+    }
+    if (!fused) {
+        const int rc = cs_collision_reward_gym(w, d_action, T, d_global_time, reward_cfg, d_out, book, stream);
+        return rc ? rc : cs_step_observe(w, dt, n_substeps, d_action, theta_and_omega_visible, d_obs, stream);
+    }
+    if (!d_action || !d_global_time || !reward_cfg || !d_out || !w->d_robot) return fail(CS_ERR_ARG, "null argument");
+    if (book->clock_len <= 0 || !book->d_counter || !book->d_seeds || !book->d_mask || !book->d_clock || !book->d_reward ||
+        !book->d_terminated || !book->d_truncated || !book->d_info)
+        return fail(CS_ERR_ARG, "null buffer in cs_gym_book");
+    int mode = M_COMMIT_GOALS;
+    if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
+    const GymHead gh = gym_head(d_out, d_global_time, T, reward_cfg, book, w->W);
+    return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, d_obs,
+                       theta_and_omega_visible ? 7 : 5, &gh);
+}
+
 int cs_step_trace(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_trace, void* stream)
 {
     if (!w || !d_trace) return fail(CS_ERR_ARG, "null argument");
@@ -580,8 +573,8 @@ int cs_collision_reward(const cs_worlds* w, const float* d_action, float T, cons
     if (w->n <= 64) {
         const int wpb = 64 / w->n, grid = (w->W + wpb - 1) / wpb;
         hipLaunchKernelGGL(k_collision_reward_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w->W, w->n, rows, wpb,
-                           (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, d_global_time,
-                           reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out, GymBook{});
+                           (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action,
+                           gym_head(d_out, d_global_time, T, reward_cfg, nullptr, w->W));
     } else {
         const int block = 64, grid = (w->W + block - 1) / block;
         hipLaunchKernelGGL(k_collision_reward, dim3(grid), dim3(block), 0, (hipStream_t)stream, w->W, w->n, rows,
@@ -615,16 +608,10 @@ int cs_collision_reward_gym(const cs_worlds* w, const float* d_action, float T, 
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     long as, fs;
     strides(w, rows, as, fs);
-    GymBook bk;
-    bk.mode = book->d_prev_mask ? 2 : 1; bk.clock_len = book->clock_len; bk.auto_reset = book->auto_reset;
-    bk.stride = book->seed_stride ? book->seed_stride : (unsigned)w->W;
-    bk.counter = book->d_counter; bk.seeds = book->d_seeds; bk.mask = book->d_mask; bk.prev = book->d_prev_mask; bk.gtime = d_global_time;
-    bk.clock = book->d_clock; bk.reward = book->d_reward; bk.terminated = book->d_terminated; bk.truncated = book->d_truncated;
-    bk.info = book->d_info;
     const int wpb = 64 / w->n, grid = (w->W + wpb - 1) / wpb;
     hipLaunchKernelGGL(k_collision_reward_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w->W, w->n, rows, wpb,
-                       (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, (const float*)d_global_time,
-                       reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out, bk);
+                       (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action,
+                       gym_head(d_out, d_global_time, T, reward_cfg, book, w->W));
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

@@ -1,0 +1,94 @@
+// gymhead.h -- the head of a vectorised Gym step: reward / termination of the state BEFORE the substeps and the episode bookkeeping
+// behind it, shared by k_collision_reward_wave (crowdstep.hip: cs_collision_reward_gym, a launch of its own) and by the step kernel
+// (sfmstep_kernel.h: cs_gym_step runs it in the prologue of the fused substeps -- one launch and one graph node less per Gym step).
+//   collision_detection_and_reaching_goal   /root/reference/social_gym/social_nav_sim.py:949-984  (swept test: utils.py:22-36)
+//   compute_reward_and_infos                social_nav_sim.py:986-1029
+//   SocialNavGym.step                       social_nav_gym.py:227-250  (the reward belongs to the state before the substeps, :229-233)
+// The arithmetic is written without contraction: the two call sites must give the same bits whatever surrounds them.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cstep {
+
+// episode bookkeeping of a vectorised Gym step (cs_gym_bookkeeping / _next_step, robot_model.hip), done by the lane that wrote the
+// world's reward row (mode 0: none, 1: same-step rules, 2: NEXT_STEP rules)
+struct GymBook {
+    int mode, clock_len, auto_reset;
+    unsigned stride;   // what a finished world's seed moves on by (cs_gym_book.seed_stride; the worlds of the whole job)
+    int* counter; unsigned* seeds; int* mask; const int* prev; float* gtime; const float* clock;
+    float* reward; unsigned char* terminated; unsigned char* truncated; int* info;
+};
+
+struct GymHead {
+    float* out;              // [W][7] collision, dmin, reaching_goal, reward, terminated, truncated, info; nullptr: no head in this launch
+    const float* gtime;      // [W] global time read for the time limit (== bk.gtime when the bookkeeping runs)
+    float T, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
+    GymBook bk;
+};
+
+// closest approach of one human to the robot over [0, T] with both velocities held (utils.py:22-36), minus the two radii
+__device__ __forceinline__ float gym_swept_closest(float hx, float hy, float hvx, float hvy, float hr, float rpx, float rpy, float rr,
+                                                   float ax, float ay, float T)
+{
+#pragma clang fp contract(off)
+    const float x1 = hx - rpx, y1 = hy - rpy;
+    const float x2 = x1 + (hvx - ax) * T, y2 = y1 + (hvy - ay) * T;
+    const float dx = x2 - x1, dy = y2 - y1;
+    float qx, qy;
+    if (dx == 0.0f && dy == 0.0f) { qx = 0.0f - x1; qy = 0.0f - y1; }
+    else {
+        float u = ((0.0f - x1) * dx + (0.0f - y1) * dy) / (dx * dx + dy * dy);
+        if (u > 1.0f) u = 1.0f; else if (u < 0.0f) u = 0.0f;
+        qx = x1 + u * dx; qy = y1 + u * dy;
+    }
+    return __builtin_amdgcn_sqrtf(qx * qx + qy * qy) - hr - rr;
+}
+
+// One lane per world: walks the humans' swept distances closest[0 .. n) in index order with the reference's early `break`, writes the
+// reward row and -- bk.mode != 0 -- does the world's bookkeeping.  Returns whether the episode ended (with auto-reset rules: the mask).
+__device__ __forceinline__ void gym_head_world(const GymHead& g, int w, int n, const float* closest, float rpx, float rpy, float rr,
+                                               float rgx, float rgy, float ax, float ay)
+{
+#pragma clang fp contract(off)
+    float dmin = INFINITY;
+    int collision = 0;
+    for (int j = 0; j < n; ++j) {
+        const float c = closest[j];
+        if (c < 0.0f) { collision = 1; break; }
+        else if (c < dmin) dmin = c;
+    }
+    const float ex = rpx + ax * g.T, ey = rpy + ay * g.T;
+    const float gx = ex - rgx, gy = ey - rgy;
+    const int reaching = __builtin_amdgcn_sqrtf(gx * gx + gy * gy) < rr;
+    float reward = 0.0f; int term = 0, trunc = 0, info = 0;
+    if (g.gtime[w] >= g.time_limit - 1.0f) { trunc = 1; info = 4; }
+    else if (collision) { reward = g.collision_penalty; term = 1; info = 3; }
+    else if (reaching) { reward = g.success_reward; term = 1; info = 2; }
+    else if (dmin < g.discomfort_dist) { reward = (dmin - g.discomfort_dist) * g.discomfort_factor * g.T; info = 1; }
+    float* o = g.out + (long)w * 7;
+    o[0] = (float)collision; o[1] = dmin; o[2] = (float)reaching; o[3] = reward;
+    o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
+    const GymBook& bk = g.bk;
+    if (bk.mode == 0) return;
+    // the same statements as k_gym_bookkeeping / k_gym_bookkeeping_next_step (robot_model.hip), on the values just written
+    if (bk.mode == 2 && bk.prev[w]) {
+        bk.reward[w] = 0.0f; bk.terminated[w] = 0; bk.truncated[w] = 0; bk.info[w] = 0;
+        bk.mask[w] = 0; bk.counter[w] = 0; bk.gtime[w] = bk.clock[0];
+        return;
+    }
+    bk.reward[w] = reward; bk.terminated[w] = term ? 1 : 0; bk.truncated[w] = trunc ? 1 : 0; bk.info[w] = info;
+    const bool done = term || trunc;
+    int c = bk.counter[w] + 1;
+    if (bk.mode == 2) {
+        bk.mask[w] = done ? 1 : 0;
+        if (done) bk.seeds[w] += bk.stride;
+    } else if (bk.auto_reset) {
+        bk.mask[w] = done ? 1 : 0;
+        if (done) { bk.seeds[w] += bk.stride; c = 0; }
+    }
+    c = c < bk.clock_len - 1 ? c : bk.clock_len - 1;
+    bk.counter[w] = c;
+    bk.gtime[w] = bk.clock[c];
+}
+
+} // namespace cstep

@@ -214,6 +214,25 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         if (is_robot) { rm_fdx = a.rm_memory[(long)w * 2]; rm_fdy = a.rm_memory[(long)w * 2 + 1]; }
     }
 
+    // ---- cs_gym_step: the head of the Gym step, on the rows as they came in (social_nav_gym.py:229-233) -- the swept robot-human
+    //      distances by the humans' lanes, then the lane of row 0 walks its world's in index order and does the episode bookkeeping
+    //      (gymhead.h: the very code of k_collision_reward_wave).  One scalar branch in a plain cs_step.
+    if constexpr (MAXT == 64) {
+        if (a.gym.out != nullptr) {
+            float* clo = lds_g0x;                              // [T] (the block-respawn scratch: unused by a block of one wavefront)
+            float rpx = 0, rpy = 0, rr = 0, rgx = 0, rgy = 0, gax = 0, gay = 0;
+            if (valid) {
+                const float* rb = a.robot + (long)w * 13;      // the robot BEFORE its move of substep 1
+                rpx = rb[0]; rpy = rb[1]; rr = rb[8]; rgx = rb[10]; rgy = rb[11];
+                gax = a.action[(long)w * 2]; gay = a.action[(long)w * 2 + 1];
+            }
+            clo[tid] = human ? gym_swept_closest(px, py, vx, vy, r, rpx, rpy, rr, gax, gay, a.gym.T) : INFINITY;
+            LDS_ORDER_FENCE();
+            if (valid && row == 0) gym_head_world(a.gym, w, n, clo + base, rpx, rpy, rr, rgx, rgy, gax, gay);
+            LDS_ORDER_FENCE();
+        }
+    }
+
     // ---- prologue: publish substep-0 rows ----------------------------------------------
     if (is_robot && robot_moves) robot_step();
     const float my_rs = r + safety;

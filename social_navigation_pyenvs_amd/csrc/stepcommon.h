@@ -7,6 +7,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "gymhead.h"
 
 namespace cstep {
 
@@ -52,6 +53,7 @@ struct KArgs {
     float rm_P[20];        // the robot's parameters
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     unsigned long long* stamps; // diagnostic build only
+    GymHead gym;           // cs_gym_step: reward / termination of the incoming state + episode bookkeeping in the prologue (gym.out == nullptr: none)
 };
 
 // ---- math: gfx950 single-instruction transcendentals (1 ulp each) ---------------------------

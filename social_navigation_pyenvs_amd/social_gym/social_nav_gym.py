@@ -494,7 +494,7 @@ class BatchedSocialNavGym:
     def _step_graph(self, dl, parity, auto_reset):
         r"""One vectorised Gym step as ONE HIP graph of library launches on ONE stream (captured once per result set):
 
-            cs_collision_reward_gym (reward + bookkeeping)  ->  cs_step_observe (substeps + observation)  ->  cs_consume_staged_worlds
+            cs_gym_step (reward + bookkeeping in the step kernel's prologue, substeps, observation)  ->  cs_consume_staged_worlds
 
         Which worlds end is known from the reward of the state BEFORE the substeps (social_nav_gym.py:229-233); their next episode
         was generated ahead (its seed is the live one + stride), so the reset is a masked copy.  The regeneration of the consumed
@@ -511,15 +511,13 @@ class BatchedSocialNavGym:
         cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
         act = dl["act"]
         with _lib.Graph.capture(A) as graph:
-            # reward of the state before the substeps + typed results, step counter, float32 clock, reset mask and next seeds: ONE launch
-            # (cs_collision_reward_gym = cs_collision_reward ; cs_gym_bookkeeping without the graph node between them)
+            # cs_gym_step: reward of the state before the substeps + typed results, step counter, float32 clock, reset mask and next seeds
+            # (the head: the step kernel's prologue), the substeps, and the observation of the stepped crowd from the kernel's
+            # registers -- ONE launch (round 3: cs_collision_reward_gym ; cs_step_observe, a graph node more on the critical path) ...
             book = self._gym_book(dl, parity, dl["mask"], None, auto_reset)
-            _lib.check(lib.cs_collision_reward_gym(C.byref(d), C.c_void_p(act.data_ptr()), C.c_float(self.robot_time_step),
-                                                   C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()), C.byref(book),
-                                                   C.c_void_p(A)))
-            # the substeps, and the observation of the stepped crowd from the step kernel's registers (cs_step_observe) ...
-            _lib.check(lib.cs_step_observe(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
-                                           C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
+            _lib.check(lib.cs_gym_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
+                                       C.c_float(self.robot_time_step), C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()),
+                                       C.byref(book), C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
             if auto_reset:
                 # ... rewritten for the worlds that take over their staged episode (a world whose generation failed keeps its rows
                 # and is flagged in reset_failed_mask())
@@ -530,8 +528,8 @@ class BatchedSocialNavGym:
         return graph
 
     def _next_step_pieces(self, dl, parity):
-        """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's three launches with every ctypes argument bound once.
-        head = cs_collision_reward_gym (reward + the NEXT_STEP bookkeeping: mask_p, prev = mask_{1-p});  body = cs_step_observe;
+        """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's two launches with every ctypes argument bound once.
+        step = cs_gym_step (reward + the NEXT_STEP bookkeeping: mask_p, prev = mask_{1-p}; the substeps; the observation);
         tail = cs_consume_staged_worlds(mask_{1-p}): the worlds that ended in the PREVIOUS step take over their staged episode."""
         import ctypes as C
 
@@ -546,12 +544,12 @@ class BatchedSocialNavGym:
         act, masks = dl["act"], dl["ns_masks"]
         P = lambda t: C.c_void_p(t.data_ptr())
         book = self._gym_book(dl, parity, masks[parity], masks[parity ^ 1], True)
-        a_rew = (dref, P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg, P(dl["out"]), C.byref(book), A)
-        a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
+        a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg,
+                  P(dl["out"]), C.byref(book), C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
         a_tail = (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), dref, P(masks[parity ^ 1]), C.byref(dl["stage_book"]),
                   C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
         keep = (d, cfg, book)              # the structs the byref arguments point into
-        dl[key] = dict(rew=a_rew, step=a_step, tail=a_tail, keep=keep)
+        dl[key] = dict(step=a_step, tail=a_tail, keep=keep)
         return dl[key]
 
     def _step_device_next_step(self, dl, actions):
@@ -575,8 +573,7 @@ class BatchedSocialNavGym:
         if actions is not dl["act"]:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
-        chk(lib.cs_collision_reward_gym(*c["rew"]))                 # reward of the state before the substeps; who ends now, who is being reset
-        chk(lib.cs_step_observe(*c["step"]))                         # the 20 fused substeps + the observation of the stepped crowd
+        chk(lib.cs_gym_step(*c["step"]))                             # reward of the state before the substeps, who ends now / who is being reset; the 20 fused substeps + the observation
         chk(lib.cs_consume_staged_worlds(*c["tail"]))                # the worlds that ended in the PREVIOUS step: their next episode, observation rows included
         self._maybe_refill(dl)
         if not same:

@@ -676,3 +676,73 @@ def test_step_device_is_the_same_whatever_the_refill_cadence():
         np.testing.assert_array_equal(e.cw.get_states(), envs[0].cw.get_states())
         assert e.failed_resets() == 0
     assert envs[1]._dl["depth"] == 2 and int(envs[1]._dl["epoch"].max()) > 2                   # (its staging batch really ran dry)
+
+
+@pytest.mark.parametrize("n,model,robot_row,next_step", [(25, "hsfm_farina", False, False), (25, "hsfm_farina", True, True), (17, "sfm_guo", False, True),
+                                                         (10, "sfm_helbing", False, False), (50, "hsfm_new_guo", True, False), (7, "orca", False, False)])
+def test_gym_step_is_the_head_and_the_body_in_one_launch(n, model, robot_row, next_step):
+    """cs_gym_step (the step kernel's prologue does the reward / termination of the incoming state and the episode bookkeeping, then the
+    fused substeps, then the observation) == cs_collision_reward_gym ; cs_step_observe -- reward rows, typed results, counters, clocks,
+    masks, seeds, state rows, goal lists, robot rows and observations, bit for bit, over several steps (so that robots collide, reach
+    goals and time out on the way); worlds the LDS kernel does not step (10-row worlds on the DPP-row kernel, ORCA) take the two launches."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd import _lib, scenarios as sc
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    W = 301
+    rng = np.random.default_rng(n + int(next_step))
+    R = np.zeros((W, 13), np.float32)
+    R[:, 0:2] = rng.uniform(-3, 3, (W, 2)); R[:, 8] = 0.3; R[:, 9] = 80; R[:, 10:12] = -R[:, 0:2]; R[:, 12] = 1.0
+    if model == "orca":
+        pos, yaw, g = sc.circular_crossing(W, n, 4.0, 77)
+        S = sc.make_states(pos, yaw, g).astype(np.float32)
+        dd = g[:, :, 0] - S[:, :, 0:2]
+        S[:, :, 5:7] = dd / np.linalg.norm(dd, axis=-1, keepdims=True)
+        mk = lambda: CrowdWorlds(S, g, None, np.full((W, n), 0.01, np.float32), None, type="orca", robot=R)
+    else:
+        S, g, P, rb = sc.hybrid_worlds(W, n, model, seed0=3)
+        R[: W // 5, 0:2] = S[: W // 5, 1, 0:2] + 0.1                                   # some robots on top of a human
+        R[W // 5: 2 * W // 5, 0:2] = R[W // 5: 2 * W // 5, 10:12] - 0.01                # some next to their goal
+        St = np.concatenate([S, R[:, None, :]], axis=1) if robot_row else S
+        mk = lambda: CrowdWorlds(St, g, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
+                                 respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), robot_row=robot_row, robot=R)
+    act = rng.uniform(-0.5, 0.5, (W, 2)).astype(np.float32)
+    clock = np.concatenate([[np.float32(0)], np.cumsum(np.full(240, 0.25, np.float32), dtype=np.float32)]).astype(np.float32)
+    counter0 = rng.integers(0, 190, W).astype(np.int32); counter0[::9] = 197
+    cfg = (C.c_float * 5)(50.0, 1.0, -0.25, 0.2, 0.5)
+    lib, Ccols = _lib.load(), 5
+    res = []
+    for fused in (False, True):
+        cw = mk()
+        if fused and model != "orca" and n != 10:
+            assert "MAXT=64" in cw.step_variant(), cw.step_variant()
+        B = lambda a, t: _lib.DeviceBuffer.from_numpy(np.ascontiguousarray(a), dtype=t)
+        b = dict(act=B(act, np.float32), gtime=B(clock[counter0], np.float32), out=_lib.DeviceBuffer((W, 7)), counter=B(counter0, np.int32),
+                 seeds=B(np.arange(W) + 1000, np.uint32), masks=[B(np.zeros(W), np.int32), B(np.zeros(W), np.int32)], clock=B(clock, np.float32),
+                 reward=_lib.DeviceBuffer((W,)), term=_lib.DeviceBuffer((W,), np.uint8), trunc=_lib.DeviceBuffer((W,), np.uint8),
+                 info=_lib.DeviceBuffer((W,), np.int32), obs=_lib.DeviceBuffer((W, n, Ccols)))
+        P_ = lambda k: C.c_void_p(b[k].ptr)
+        hist = []
+        for k in range(4):
+            d = cw.descriptor()
+            p = k & 1
+            book = _lib.cs_gym_book(d_counter=b["counter"].ptr, d_seeds=b["seeds"].ptr, d_mask=b["masks"][p].ptr,
+                                    d_prev_mask=b["masks"][p ^ 1].ptr if next_step else None, d_clock=b["clock"].ptr, clock_len=len(clock), auto_reset=1,
+                                    d_reward=b["reward"].ptr, d_terminated=b["term"].ptr, d_truncated=b["trunc"].ptr, d_info=b["info"].ptr, seed_stride=777)
+            if fused:
+                _lib.check(lib.cs_gym_step(C.byref(d), C.c_float(0.0125), C.c_int(20), P_("act"), C.c_float(0.25), P_("gtime"), cfg, P_("out"), C.byref(book),
+                                           C.c_int(0), P_("obs"), C.c_void_p(cw.stream)))
+            else:
+                _lib.check(lib.cs_collision_reward_gym(C.byref(d), P_("act"), C.c_float(0.25), P_("gtime"), cfg, P_("out"), C.byref(book), C.c_void_p(cw.stream)))
+                _lib.check(lib.cs_step_observe(C.byref(d), C.c_float(0.0125), C.c_int(20), P_("act"), C.c_int(0), P_("obs"), C.c_void_p(cw.stream)))
+            cw.sync()
+            hist.append({**{kk: b[kk].download() for kk in ("out", "counter", "seeds", "gtime", "reward", "term", "trunc", "info", "obs")},
+                         "mask": b["masks"][p].download(), "S": cw.get_states(), "G": cw.get_goals(), "R": cw.get_robot()})
+        res.append(hist)
+    for k, (x, y) in enumerate(zip(*res)):
+        for kk in x:
+            np.testing.assert_array_equal(x[kk], y[kk], err_msg=f"step {k}: {kk}")
+    infos = np.concatenate([h["out"][:, 6] for h in res[1]]).astype(int)
+    assert set(np.unique(infos)) >= ({0, 4} if model == "orca" else {0, 2, 3, 4}), np.unique(infos)
+    assert sum(int(h["mask"].sum()) for h in res[1]) > 20
