@@ -22,6 +22,33 @@ def _resync(env, c, k):
     env.global_time = 0.25 * k
 
 
+def _block_bar(env, action, floor=5e-5):
+    """The tolerance of ONE Gym step (20 fused float32 substeps) from the re-synchronised state: `floor`, or -- where 20 stiff substeps
+    amplify float32 rounding beyond it (a respawned human at contact distance, Moussaid's sign(theta ~ 0)) -- F32_SLACK times what the
+    float32 instantiation of the ORACLE itself is off its float64 instantiation over the same block.  Measured per step, no blanket
+    3e-4 / 2e-2 classes.  Returns (tolerance, float32 oracle error)."""
+    from oracle import crowd_oracle as orc
+    from parity_util import F32_SLACK, f32
+
+    mm = env.motion_model_manager
+    n = len(mm.humans)
+    up = lambda x: None if x is None else f32(x).astype(np.float64)
+    S = np.array(mm.states, dtype=np.float64)
+    rb = np.asarray(env.robot.get_safe_state(), dtype=np.float64)
+    if mm.consider_robot:
+        S[-1] = rb
+    respawn = bool(mm.parallel_traffic_humans_respawn)
+    rp = (float(mm.respawn_bounds[0]), float(mm.respawn_bounds[1]), 0.0) if respawn else (0.0, 0.0, 0.0)
+    args = (int(mm.sfm_type), up(S), up(mm.goals), up(mm.obstacles), up(mm.params), env.time_step, env.time_step_factor, up(mm.safety_space),
+            bool(mm.all_equal_humans))
+    kw = dict(robot_visible=bool(mm.consider_robot), robot=up(rb), action=up(np.asarray(action, dtype=np.float64)), respawn=respawn, respawn_par=rp)
+    r64 = orc.step_block(*args, **kw)[0]
+    with np.errstate(over="ignore", invalid="ignore"):
+        r32 = orc.step_block(*args, dtype=np.float32, **kw)[0]
+    e32 = float(np.max(np.abs(r32[:n][:, [0, 1, 3, 4]] - r64[:n][:, [0, 1, 3, 4]])))
+    return max(floor, F32_SLACK * e32), e32
+
+
 def _obs_array(ob, headed):
     return np.array([[o.px, o.py, o.vx, o.vy, o.radius] + ([o.theta, o.omega] if headed else []) for o in ob])
 
@@ -29,7 +56,7 @@ def _obs_array(ob, headed):
 def test_gym_step_loop_g3_per_step():
     from social_navigation_pyenvs_amd.crowd_nav.utils.action import ActionXY
 
-    worst = 0.0
+    worst = worst_ratio = 0.0
     for ci, c in enumerate(load_cases("g3_gym")):
         assert np.max(np.abs(c["mm_states"][..., 7])) < 1e3   # no Gym fixture is in the diverged-omega regime: none is skipped
         env = make_env(c["model"], c["scenario"], c["human_num"], c["robot_visible"], c["headed_obs"])
@@ -40,26 +67,27 @@ def test_gym_step_loop_g3_per_step():
         for k in range(len(c["actions"])):
             _resync(env, c, k)
             a = c["actions"][k]
+            tol, e32 = _block_bar(env, a)
             ob, reward, term, trunc, info = env.step(ActionXY(float(a[0]), float(a[1])))
             # reward / flags come from the state BEFORE the substeps: exact
             assert abs(reward - c["rewards"][k]) < 1e-12 and (term, trunc) == (bool(c["terminated"][k]), bool(c["truncated"][k]))
             assert type(info[0]).__name__ == c["infos"][k]
             got = _obs_array(ob, c["headed_obs"])
             ref = c["obs"][k + 1]
-            # 20 fused f32 substeps vs the f64 reference; respawned humans sit at contact distance (stiff), Moussaid
-            # has its sign() discontinuity -> looser
-            tol = 2e-2 if moussaid else (3e-4 if c["respawn"] else 5e-5)  # Moussaid at rest: sign(theta ~ 0) flips on rounding
+            # 20 fused f32 substeps vs the f64 reference: 5e-5 (the end-of-step bound of the per-substep 1e-5 rule, tests/test_gpu_parity.py),
+            # or 3 x the float32 oracle's own error over this very block where float32 cannot do better (_block_bar)
             err = np.max(np.abs(got[:, :4] - ref[:, :4]))
             if moussaid and k == 0:
                 # everybody at rest: theta_ij = wrap(atan2(n) - atan2(-n) + pi) is +-1e-16 rounding noise in the reference
                 # and its sign() picks a side at random; parity is only defined away from rest
                 continue
-            assert err < tol, (ci, c["model"], c["scenario"], k, err)
+            assert err < tol, (ci, c["model"], c["scenario"], k, err, e32)
+            worst_ratio = max(worst_ratio, err / tol)
             if not moussaid and not c["respawn"]:
                 worst = max(worst, err)
             np.testing.assert_allclose([*env.robot.position, *env.robot.linear_velocity], c["robot_states"][k + 1][[0, 1, 3, 4]], atol=1e-5)  # 20 float32 position increments
         assert abs(env.global_time - 0.25 * len(c["actions"])) < 1e-9
-    print("g3 worst per-step |err|", worst)
+    print("g3 worst per-step |err|", worst, "worst err / tolerance", worst_ratio)
 
 
 def test_gym_free_running_first_steps_g3():

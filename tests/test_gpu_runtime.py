@@ -40,3 +40,32 @@ def test_crowdstep_first_then_torch_share_one_hip_runtime():
     r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.strip().splitlines()[-1].startswith("OK")
+
+
+def test_bench_launches_its_own_ranks_and_prints_one_parsable_line():
+    """`python bench.py --gpus 2` with no launcher around it (the rehearsal form for a one-GPU box: both ranks on GPU 0, gloo for the
+    barrier): the parent starts two fresh rank processes before touching HIP, relays rank 0's line -- ONE line on stdout, strict JSON
+    under 4 KB, n_gpus = 2, one record per rank with its device and PCI address, value = the worlds of BOTH ranks over the slowest
+    rank's time -- and `--gpus 2` on a box that shows one GPU (no --same-device) refuses instead of measuring one rank."""
+    import json
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--steps", "4", "--warmup", "2",
+           "--repeats", "3", "--worlds", "512", "--no-other-configs", "--no-cpu-baseline", "--full-json", os.path.join(ROOT, "gpurun_out", "bench_full_test.json")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist"]["world_size"] == 2 and d["dist"]["backend"] == "gloo" and d["dist"]["launcher"] == "self"
+    assert [x["rank"] for x in d["ranks"]] == [0, 1] and all(x["pci"] and x["worlds"] == 512 for x in d["ranks"])
+    assert d["config"]["worlds_total"] == 1024 and d["scaling"] == "weak"
+    assert abs(d["value"] - 1024 * 25 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+    from social_navigation_pyenvs_amd import _lib
+    if _lib.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert r.returncode == 3 and r.stdout.strip() == "" and "needs 2 visible" in r.stderr
