@@ -359,12 +359,20 @@ class Runner:
         return [float(x.item()) for x in out]
 
     def gather_objects(self, obj) -> list:
-        """every rank's record, in rank order"""
+        """every rank's (small, JSON-able) record, in rank order: one all_gather of fixed-size byte tensors on the device the
+        backend reduces on -- the collective the timing path already uses, no object (pickle) collective on RCCL"""
         if self.dist is None or self.dist.get_world_size() == 1:
             return [obj]
-        out = [None] * self.dist.get_world_size()
-        self.dist.all_gather_object(out, obj)
-        return out
+        raw = json.dumps(obj).encode()
+        size = 512
+        if len(raw) > size:
+            raise ValueError("rank record too large")
+        dev = self.reduce_device or "cpu"
+        t = self.torch.zeros(size, dtype=self.torch.uint8, device=dev)
+        t[:len(raw)] = self.torch.tensor(list(raw), dtype=self.torch.uint8, device=dev)
+        out = [self.torch.zeros_like(t) for _ in range(self.dist.get_world_size())]
+        self.dist.all_gather(out, t)
+        return [json.loads(bytes(x.cpu().tolist()).rstrip(b"\0").decode()) for x in out]
 
     def copy_bandwidth(self, nbytes=1 << 30, reps=10):
         """Device-to-device copy bandwidth measured in this run (read + written bytes / time): the practical HBM ceiling

@@ -674,7 +674,9 @@ __global__ __launch_bounds__(64) void k_refill_staged(const StageArgs a)
     }
 }
 
-// the step's stream: a finished world takes over its staged episode -- or, if the refill has not got to it yet, is generated in place
+// the step's stream: a finished world takes over its staged episode -- or, if the refill has not got to it yet, is generated in place.
+// One block per world (4096 workgroups, most of which read one integer and leave: 8 us): the refill's small grid was tried here too -- 64
+// masks per wavefront, its finished worlds copied one after the other -- and cost 13 us more per Gym step (a wavefront with three ends copies serially).
 __global__ __launch_bounds__(64) void k_consume_staged(const StageArgs a)
 {
     const int w = blockIdx.x, lane = threadIdx.x;
