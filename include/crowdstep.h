@@ -96,6 +96,11 @@ typedef struct cs_worlds {
      * the order given, counter-clockwise; next / prev = vertex indices), shared by all worlds.  NULL / 0 = no obstacles. */
     const float* d_orca_vertices;
     int32_t orca_n_vertices;
+    /* ORCA only: RVO2 keeps neighborDist, maxNeighbors, timeHorizon, timeHorizonObst PER AGENT (RVOSimulator::addAgent(position,
+     * neighborDist, maxNeighbors, timeHorizon, timeHorizonObst, radius, maxSpeed, velocity): the call at motion_model_manager.py:241,
+     * where the reference passes ORCA_DEFAULTS for everyone).  [W][rows][4] floats in that order, or NULL = the four scalars above for
+     * every agent.  With it, orca_max_neighbors must be the LARGEST maxNeighbors and orca_neighbor_dist the largest neighborDist. */
+    const float* d_orca_agent_params;
 } cs_worlds;
 
 /* ---------------------------------------------------------------- runtime / memory helpers */

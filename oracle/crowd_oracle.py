@@ -278,9 +278,10 @@ def orca_new_velocities(pos, vel, pref, radius, maxspeed, neighbor_dist=10.0, ma
 
 def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot=None, action=None,
                     neighbor_dist=10.0, max_nb=10, time_horizon=5.0, respawn=False, bounds=(0.0, 0.0), threads=0,
-                    verts=None, time_horizon_obst=5.0):
+                    verts=None, time_horizon_obst=5.0, agent_params=None):
     """Batched ([W, rows, 13]) or single-world block of ORCA substeps on the shared row layout
-    (cols 5:7 = preferred velocity).  Returns (S, goals, robot)."""
+    (cols 5:7 = preferred velocity).  Returns (S, goals, robot).  ``agent_params`` [W, rows, 4] (or [rows, 4]): RVO2's per-agent
+    neighborDist, maxNeighbors, timeHorizon, timeHorizonObst (``max_nb`` must then be the largest maxNeighbors)."""
     f = np.float32
     S = np.ascontiguousarray(S, dtype=f).copy()
     single = S.ndim == 2
@@ -296,13 +297,14 @@ def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot
     if action is not None:
         action = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=f), (W, 2)))
     vt = None if verts is None else np.ascontiguousarray(verts, dtype=f).reshape(-1, 8)
-    fn = lib().orc_orca_step_block_batched_obst
+    ap = None if agent_params is None else np.ascontiguousarray(np.broadcast_to(np.asarray(agent_params, dtype=f), (W, rows, 4)))
+    fn = lib().orc_orca_step_block_batched_pa
     fn.restype = None
     fn(C.c_int(W), _ptr(S, C.c_float), _ptr(goals, C.c_float), C.c_int(G), C.c_int(rows), C.c_int(int(robot_visible)),
        _ptr(margin, C.c_float), _ptr(robot, C.c_float), _ptr(action, C.c_float), C.c_float(dt), C.c_int(n_substeps),
        C.c_float(neighbor_dist), C.c_int(max_nb), C.c_float(time_horizon), C.c_int(int(respawn)),
        C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_int(threads), C.c_float(time_horizon_obst), _ptr(vt, C.c_float),
-       C.c_int(0 if vt is None else len(vt)))
+       C.c_int(0 if vt is None else len(vt)), _ptr(ap, C.c_float))
     if single:
         return S[0], goals[0], (robot[0] if robot is not None else None)
     return S, goals, robot

@@ -301,14 +301,25 @@ static int obstacle_lines(const orca_vertex* V, const int* oi, int no, float px,
  */
 /* with static obstacles: verts [nv] orca_vertex records (or nv = 0); lines_out rows hold max_nb + ORCA_MAX_OBST lines,
  * nobst_out [na] = how many of them are obstacle lines (they come first) */
-void orc_orca_new_velocities_obst(int na, const float* pos, const float* vel, const float* pref, const float* radius,
-                                  const float* maxspeed, float neighbor_dist, int max_nb, float time_horizon,
-                                  float time_horizon_obst, float time_step, const float* verts, int nv, float* out_vel,
-                                  orca_line* lines_out, int* nlines_out, int* nobst_out)
+/* agent_params (optional): [na][4] = neighborDist, maxNeighbors, timeHorizon, timeHorizonObst of every agent -- RVO2 keeps the four per
+ * agent (RVOSimulator::addAgent(position, neighborDist, maxNeighbors, timeHorizon, timeHorizonObst, radius, maxSpeed, velocity), the
+ * signature the reference calls at motion_model_manager.py:241); NULL = the scalar arguments for everyone (what the reference passes:
+ * ORCA_DEFAULTS).  lines_out rows are sized by the scalar max_nb, which must then be the largest per-agent value. */
+void orc_orca_new_velocities_pa(int na, const float* pos, const float* vel, const float* pref, const float* radius,
+                                const float* maxspeed, float neighbor_dist_all, int max_nb_all, float time_horizon_all,
+                                float time_horizon_obst_all, float time_step, const float* verts, int nv, float* out_vel,
+                                orca_line* lines_out, int* nlines_out, int* nobst_out, const float* agent_params)
 {
     const orca_vertex* V = (const orca_vertex*)verts;
-    if (max_nb > ORCA_MAX_NEIGHBORS) max_nb = ORCA_MAX_NEIGHBORS;
+    if (max_nb_all > ORCA_MAX_NEIGHBORS) max_nb_all = ORCA_MAX_NEIGHBORS;
     for (int a = 0; a < na; ++a) {
+        float neighbor_dist = neighbor_dist_all, time_horizon = time_horizon_all, time_horizon_obst = time_horizon_obst_all;
+        int max_nb = max_nb_all;
+        if (agent_params) {
+            const float* ap = agent_params + 4 * (size_t)a;
+            neighbor_dist = ap[0]; max_nb = (int)ap[1]; time_horizon = ap[2]; time_horizon_obst = ap[3];
+            if (max_nb > max_nb_all) max_nb = max_nb_all;
+        }
         orca_line L[ORCA_MAX_LINES];
         int numObst = 0;
         if (nv > 0) { /* rangeSq = sqr(timeHorizonObst * maxSpeed + radius) */
@@ -395,6 +406,15 @@ void orc_orca_new_velocities_obst(int na, const float* pos, const float* vel, co
     }
 }
 
+void orc_orca_new_velocities_obst(int na, const float* pos, const float* vel, const float* pref, const float* radius,
+                                  const float* maxspeed, float neighbor_dist, int max_nb, float time_horizon,
+                                  float time_horizon_obst, float time_step, const float* verts, int nv, float* out_vel,
+                                  orca_line* lines_out, int* nlines_out, int* nobst_out)
+{
+    orc_orca_new_velocities_pa(na, pos, vel, pref, radius, maxspeed, neighbor_dist, max_nb, time_horizon, time_horizon_obst, time_step,
+                               verts, nv, out_vel, lines_out, nlines_out, nobst_out, NULL);
+}
+
 void orc_orca_new_velocities(int na, const float* pos, const float* vel, const float* pref, const float* radius,
                              const float* maxspeed, float neighbor_dist, int max_nb, float time_horizon,
                              float time_step, float* out_vel, orca_line* lines_out, int* nlines_out)
@@ -412,10 +432,10 @@ void orc_orca_new_velocities(int na, const float* pos, const float* vel, const f
  * overwritten AFTER doStep (motion_model_manager.py:389), so humans see the robot one substep late.
  * margin[rows]: what is added to the radius (0.01 or 0.01 + safety_space).
  */
-void orc_orca_step_block_obst(float* S, float* goals, int G, int rows, int robot_visible, const float* margin,
-                              float* robot, const float* action, float dt, int n_substeps, float neighbor_dist,
-                              int max_nb, float time_horizon, int respawn, float bound_x, float bound_y,
-                              float time_horizon_obst, const float* verts, int nv)
+void orc_orca_step_block_pa(float* S, float* goals, int G, int rows, int robot_visible, const float* margin,
+                            float* robot, const float* action, float dt, int n_substeps, float neighbor_dist,
+                            int max_nb, float time_horizon, int respawn, float bound_x, float bound_y,
+                            float time_horizon_obst, const float* verts, int nv, const float* agent_params /* [rows][4] or NULL */)
 {
     const int n = rows - (robot_visible ? 1 : 0);
     float* pos = (float*)malloc(sizeof(float) * rows * 9);
@@ -428,8 +448,8 @@ void orc_orca_step_block_obst(float* S, float* goals, int G, int rows, int robot
             pos[2 * i] = r[0]; pos[2 * i + 1] = r[1]; vel[2 * i] = r[3]; vel[2 * i + 1] = r[4];
             pref[2 * i] = r[5]; pref[2 * i + 1] = r[6]; rad[i] = r[8] + margin[i]; vmax[i] = r[12];
         }
-        orc_orca_new_velocities_obst(rows, pos, vel, pref, rad, vmax, neighbor_dist, max_nb, time_horizon, time_horizon_obst, dt,
-                                     verts, nv, nvv, NULL, NULL, NULL);
+        orc_orca_new_velocities_pa(rows, pos, vel, pref, rad, vmax, neighbor_dist, max_nb, time_horizon, time_horizon_obst, dt,
+                                   verts, nv, nvv, NULL, NULL, NULL, agent_params);
         for (int i = 0; i < n; ++i) {
             float* r = S + 13 * i;
             float* gi = goals + (size_t)i * G * 2;
@@ -484,6 +504,15 @@ void orc_orca_step_block_obst(float* S, float* goals, int G, int rows, int robot
     free(nvv);
 }
 
+void orc_orca_step_block_obst(float* S, float* goals, int G, int rows, int robot_visible, const float* margin,
+                              float* robot, const float* action, float dt, int n_substeps, float neighbor_dist,
+                              int max_nb, float time_horizon, int respawn, float bound_x, float bound_y,
+                              float time_horizon_obst, const float* verts, int nv)
+{
+    orc_orca_step_block_pa(S, goals, G, rows, robot_visible, margin, robot, action, dt, n_substeps, neighbor_dist, max_nb, time_horizon,
+                           respawn, bound_x, bound_y, time_horizon_obst, verts, nv, NULL);
+}
+
 void orc_orca_step_block(float* S, float* goals, int G, int rows, int robot_visible, const float* margin,
                          float* robot, const float* action, float dt, int n_substeps, float neighbor_dist,
                          int max_nb, float time_horizon, int respawn, float bound_x, float bound_y)
@@ -492,10 +521,11 @@ void orc_orca_step_block(float* S, float* goals, int G, int rows, int robot_visi
                              time_horizon, respawn, bound_x, bound_y, 5.0f, NULL, 0);
 }
 
-void orc_orca_step_block_batched_obst(int W, float* S, float* goals, int G, int rows, int robot_visible,
-                                      const float* margin, float* robot, const float* action, float dt, int n_substeps,
-                                      float neighbor_dist, int max_nb, float time_horizon, int respawn, float bound_x,
-                                      float bound_y, int threads, float time_horizon_obst, const float* verts, int nv)
+void orc_orca_step_block_batched_pa(int W, float* S, float* goals, int G, int rows, int robot_visible,
+                                    const float* margin, float* robot, const float* action, float dt, int n_substeps,
+                                    float neighbor_dist, int max_nb, float time_horizon, int respawn, float bound_x,
+                                    float bound_y, int threads, float time_horizon_obst, const float* verts, int nv,
+                                    const float* agent_params /* [W][rows][4] or NULL */)
 {
     const int n = rows - (robot_visible ? 1 : 0);
 #ifdef _OPENMP
@@ -503,10 +533,20 @@ void orc_orca_step_block_batched_obst(int W, float* S, float* goals, int G, int 
 #pragma omp parallel for schedule(static)
 #endif
     for (int w = 0; w < W; ++w)
-        orc_orca_step_block_obst(S + (size_t)w * rows * 13, goals + (size_t)w * n * G * 2, G, rows, robot_visible,
-                                 margin + (size_t)w * rows, robot ? robot + (size_t)w * 13 : NULL,
-                                 action ? action + (size_t)w * 2 : NULL, dt, n_substeps, neighbor_dist, max_nb,
-                                 time_horizon, respawn, bound_x, bound_y, time_horizon_obst, verts, nv);
+        orc_orca_step_block_pa(S + (size_t)w * rows * 13, goals + (size_t)w * n * G * 2, G, rows, robot_visible,
+                               margin + (size_t)w * rows, robot ? robot + (size_t)w * 13 : NULL,
+                               action ? action + (size_t)w * 2 : NULL, dt, n_substeps, neighbor_dist, max_nb,
+                               time_horizon, respawn, bound_x, bound_y, time_horizon_obst, verts, nv,
+                               agent_params ? agent_params + (size_t)w * rows * 4 : NULL);
+}
+
+void orc_orca_step_block_batched_obst(int W, float* S, float* goals, int G, int rows, int robot_visible,
+                                      const float* margin, float* robot, const float* action, float dt, int n_substeps,
+                                      float neighbor_dist, int max_nb, float time_horizon, int respawn, float bound_x,
+                                      float bound_y, int threads, float time_horizon_obst, const float* verts, int nv)
+{
+    orc_orca_step_block_batched_pa(W, S, goals, G, rows, robot_visible, margin, robot, action, dt, n_substeps, neighbor_dist, max_nb,
+                                   time_horizon, respawn, bound_x, bound_y, threads, time_horizon_obst, verts, nv, NULL);
 }
 
 void orc_orca_step_block_batched(int W, float* S, float* goals, int G, int rows, int robot_visible,

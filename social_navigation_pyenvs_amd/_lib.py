@@ -71,6 +71,7 @@ class cs_worlds(C.Structure):
         ("orca_neighbor_dist", C.c_float), ("orca_time_horizon", C.c_float), ("orca_time_horizon_obst", C.c_float),
         ("orca_max_neighbors", C.c_int32), ("sm_n_actions", C.c_int32),
         ("d_orca_vertices", C.c_void_p), ("orca_n_vertices", C.c_int32),
+        ("d_orca_agent_params", C.c_void_p),
     ]
 
 

@@ -46,7 +46,7 @@ class CrowdWorlds:
 
     def __init__(self, states, goals, params, safety=None, obstacles=None, *, type, all_params_equal=False,
                  robot_row=False, robot=None, respawn_bounds=None, respawn_worlds=None, layout="aos", device=None,
-                 stream=None, orca_vertices=None):
+                 stream=None, orca_vertices=None, orca_agent_params=None):
         _lib.require_gpu()
         if device is not None:
             _lib.set_device(device)
@@ -120,6 +120,26 @@ class CrowdWorlds:
                 raise ValueError("orca_vertices only apply to ORCA worlds (SFM / HSFM worlds take `obstacles` segments)")
             ov = np.ascontiguousarray(orca_vertices, dtype=np.float32).reshape(-1, 8)
             self.d_orca_vertices, self.orca_n_vertices = DeviceBuffer.from_numpy(ov), len(ov)
+        self.d_orca_agent_params = None
+        if orca_agent_params is not None:
+            self.set_orca_agent_params(orca_agent_params)
+
+    def set_orca_agent_params(self, agent_params) -> None:
+        """RVO2's per-agent neighborDist, maxNeighbors, timeHorizon, timeHorizonObst (RVOSimulator::addAgent's arguments; the reference
+        passes ORCA_DEFAULTS for everyone, motion_model_manager.py:241): [W, rows, 4] / [rows, 4], or None = ``orca_params`` for every
+        agent.  ``orca_params['max_neighbors']`` / ``['neighbor_dist']`` are raised to the largest per-agent values (the kernel's
+        neighbour columns and the grid's cell edge are laid out for them)."""
+        if agent_params is None:
+            self.d_orca_agent_params = None
+            return
+        if not self.orca:
+            raise ValueError("per-agent RVO2 parameters only apply to ORCA worlds")
+        ap = np.ascontiguousarray(np.broadcast_to(np.asarray(agent_params, dtype=np.float32), (self.W, self.rows, 4)))
+        if np.any(ap[..., 1] < 0) or np.any(ap[..., 1] > 16) or np.any(ap[..., 2] <= 0) or np.any(ap[..., 0] < 0):
+            raise ValueError("per-agent RVO2 parameters: 0 <= maxNeighbors <= 16, timeHorizon > 0, neighborDist >= 0")
+        self.orca_params = dict(self.orca_params, max_neighbors=int(max(self.orca_params["max_neighbors"], ap[..., 1].max())),
+                                neighbor_dist=float(max(self.orca_params["neighbor_dist"], ap[..., 0].max())))
+        self.d_orca_agent_params = DeviceBuffer.from_numpy(ap)
 
     # ------------------------------------------------------------------ descriptor
     def _flags(self, respawn=None) -> int:
@@ -160,6 +180,7 @@ class CrowdWorlds:
         d.sm_n_actions = int(self.sm_n_actions)
         d.d_orca_vertices = _ptr(self.d_orca_vertices)
         d.orca_n_vertices = int(self.orca_n_vertices)
+        d.d_orca_agent_params = _ptr(getattr(self, "d_orca_agent_params", None))
         return d
 
     # ------------------------------------------------------------------ hot path

@@ -65,6 +65,10 @@ struct OArgs {
     int nv, KO;
     float time_horizon_obst;
     int lp3_static;        // diagnostic A/B switch: linearProgram3 as the statically unrolled walk (lp3_fast10) instead of lp3_rows
+    // RVO2 keeps neighborDist, maxNeighbors, timeHorizon, timeHorizonObst PER AGENT (RVOSimulator::addAgent, the call at
+    // motion_model_manager.py:241): [W][rows][4] or null = the four scalars for everyone (what the reference passes: ORCA_DEFAULTS).
+    // K above is then the largest maxNeighbors (the LDS columns are laid out for it); such worlds take the generic solve.
+    const float* agent_params;
 };
 
 __device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
@@ -899,17 +903,25 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
             const float4* pv = lds_pv + cur * T + base;
             const float* rr = lds_r + base;
             if constexpr (!FAST10) {
+                // this agent's own RVO2 parameters, where the caller gave some (constant over the launch)
+                float nbd = a.neighbor_dist, thz = a.time_horizon, tho = a.time_horizon_obst;
+                int Kme = K;
+                if (a.agent_params != nullptr) {
+                    const float* ap = a.agent_params + ((long)w * rows + row) * 4;
+                    nbd = ap[0]; thz = ap[2]; tho = ap[3];
+                    Kme = (int)ap[1] < K ? (int)ap[1] : K;
+                }
                 // ---- Agent::computeNeighbors / insertAgentNeighbor (index order; strict <, ties keep order)
                 int cnt = 0;
-                float rangeSq = a.neighbor_dist * a.neighbor_dist;
-                if (K > 0) {
+                float rangeSq = nbd * nbd;
+                if (Kme > 0) {
                     for (int b = 0; b < rows; ++b) {
                         if (b == row) continue;
                         const float4 q = pv[b];
                         const float ddx = px - q.x, ddy = py - q.y;
                         const float dsq = ddx * ddx + ddy * ddy;
                         if (dsq < rangeSq) {
-                            if (cnt < K) ++cnt;
+                            if (cnt < Kme) ++cnt;
                             int i = cnt - 1;
                             while (i != 0 && dsq < lds_nd[(i - 1) * TL + tid]) {
                                 lds_nd[i * TL + tid] = lds_nd[(i - 1) * TL + tid];
@@ -918,18 +930,18 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
                             }
                             lds_nd[i * TL + tid] = dsq;
                             lds_ni[i * TL + tid] = b;
-                            if (cnt == K) rangeSq = lds_nd[(cnt - 1) * TL + tid];
+                            if (cnt == Kme) rangeSq = lds_nd[(cnt - 1) * TL + tid];
                         }
                     }
                 }
                 // ---- Agent::computeNewVelocity: obstacle half-planes first (static-obstacle worlds), then one per neighbour
                 int nobst = 0;
                 if (a.nv > 0) {
-                    const float rng = a.time_horizon_obst * vmax + (r + margin);   // rangeSq = sqr(timeHorizonObst * maxSpeed + radius)
+                    const float rng = tho * vmax + (r + margin);   // rangeSq = sqr(timeHorizonObst * maxSpeed + radius)
                     const int no = obstacle_neighbors(a.verts, a.nv, a.KO, px, py, rng * rng, lds_od, lds_oi, TL, tid);
-                    nobst = obstacle_lines(a.verts, lds_oi, no, TL, tid, px, py, vx, vy, r + margin, 1.0f / a.time_horizon_obst, L);
+                    nobst = obstacle_lines(a.verts, lds_oi, no, TL, tid, px, py, vx, vy, r + margin, 1.0f / tho, L);
                 }
-                const float invT = 1.0f / a.time_horizon;
+                const float invT = 1.0f / thz;
                 const float invDt = 1.0f / dt;
                 for (int k = 0; k < cnt; ++k) {
                     const int b = lds_ni[k * TL + tid];
@@ -1190,6 +1202,7 @@ struct BigArgs {
     float* robot;          // [W][13] cs_worlds.d_robot: the true robot (moved by the action), copied into its state row AFTER the step
     const float* action;   // [W][2] or null
     const float* verts;    // RVO2 obstacle vertex records (generic build)
+    const float* agent_params;   // [W][rows][4] per-agent neighborDist, maxNeighbors, timeHorizon, timeHorizonObst, or null (see OArgs)
 };
 
 // FAST10: maxNeighbors = 10 without static obstacles, the register-resident solve of the crowd kernel.  Otherwise the generic
@@ -1225,7 +1238,15 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
     const int* st = a.start + (long)w * a.NB;          // positions in the job-wide sorted list
     const int* so = a.sorted;
     const float* mg = a.margin + (long)w * rows;
-    const float range2 = a.neighbor_dist * a.neighbor_dist;
+    // this agent's own RVO2 parameters, where the caller gave some (the grid's cell edge is the scalar neighborDist: the largest one)
+    float nbd = a.neighbor_dist, thz = a.time_horizon, tho = a.time_horizon_obst;
+    int Kme = a.K;
+    if (a.agent_params != nullptr && human) {
+        const float* ap = a.agent_params + ((long)w * rows + i) * 4;
+        nbd = ap[0]; thz = ap[2]; tho = ap[3];
+        Kme = (int)ap[1] < a.K ? (int)ap[1] : a.K;
+    }
+    const float range2 = nbd * nbd;
     // Agent::computeNeighbors through the grid: the 3 x 3 cells around mine hold every agent closer than neighborDist
     auto walk = [&](auto&& visit) {
         const int2 mc = cxy[i];
@@ -1261,7 +1282,7 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
                           },
                           px, py, vx, vy, r + margin, vmax, pvx, pvy, a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
     } else if (human) {
-        const int K = a.K;
+        const int K = Kme;
         int cnt = 0;
         if (K > 0)
             walk([&](float dsq, int b) {
@@ -1283,11 +1304,11 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
         const Lines L{lds_ln, 64, tid}, P{lds_pr, 64, tid};
         int nobst = 0;
         if (a.nv > 0) {
-            const float rng = a.time_horizon_obst * vmax + (r + margin);   // rangeSq = sqr(timeHorizonObst * maxSpeed + radius)
+            const float rng = tho * vmax + (r + margin);   // rangeSq = sqr(timeHorizonObst * maxSpeed + radius)
             const int no = obstacle_neighbors(a.verts, a.nv, a.KO, px, py, rng * rng, lds_od, lds_oi, 64, tid);
-            nobst = obstacle_lines(a.verts, lds_oi, no, 64, tid, px, py, vx, vy, r + margin, 1.0f / a.time_horizon_obst, L);
+            nobst = obstacle_lines(a.verts, lds_oi, no, 64, tid, px, py, vx, vy, r + margin, 1.0f / tho, L);
         }
-        const float invT = 1.0f / a.time_horizon;
+        const float invT = 1.0f / thz;
         const float invDt = 1.0f / a.dt;
         for (int k = 0; k < cnt; ++k) {
             const int b = lds_ni[k * 64 + tid];
@@ -1401,7 +1422,7 @@ static size_t orca_block_shmem(const cs_worlds* w, bool lp3_static)
     const int TL = wpb * rows;
     const int K = w->orca_max_neighbors, nv = w->orca_n_vertices;
     const int KO = nv > 0 ? (nv < KOBST ? nv : KOBST) : 0;
-    const bool fast10 = K == 10 && nv == 0;
+    const bool fast10 = K == 10 && nv == 0 && w->d_orca_agent_params == nullptr;
     return (size_t)T * (2 * sizeof(float4) + 4 * sizeof(float)) +
            (fast10 ? (size_t)10 * TL * sizeof(float4) + (lp3_static ? 0 : 72 * (sizeof(float4) + sizeof(float2))) + (size_t)T * (sizeof(float4) + sizeof(int))
                    : (size_t)(K + KO) * TL * (2 * sizeof(float4) + 2 * sizeof(float)));
@@ -1446,7 +1467,8 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     a.robot = w->d_robot; a.action = d_action;
     a.K = w->orca_max_neighbors; a.nv = w->orca_n_vertices; a.verts = w->d_orca_vertices; a.time_horizon_obst = w->orca_time_horizon_obst;
     a.KO = a.nv > 0 ? (a.nv < KOBST ? a.nv : KOBST) : 0;
-    const bool fast10 = a.K == 10 && a.nv == 0;   // the register-resident solve has no obstacle lines
+    a.agent_params = w->d_orca_agent_params;
+    const bool fast10 = a.K == 10 && a.nv == 0 && a.agent_params == nullptr;   // the register-resident solve: no obstacle lines, one parameter set
     float* S2 = (float*)base;
     void* grid_mem = base + state_pad;
     const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
@@ -1509,7 +1531,8 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     if (d_peek) a.flags &= ~CS_RESPAWN;
     const int T = rows <= 64 ? 64 : (rows <= 256 ? 256 : 512);   // worlds of more than 64 rows: one world per block
     const int grid = (w->W + a.wpb - 1) / a.wpb;
-    const bool fast10 = a.K == 10 && a.nv == 0; // the register-resident solve has no obstacle lines
+    a.agent_params = w->d_orca_agent_params;
+    const bool fast10 = a.K == 10 && a.nv == 0 && a.agent_params == nullptr; // the register-resident solve: no obstacle lines, one parameter set
     const int TL = a.wpb * rows;                // lanes that hold an agent: the width of the per-lane LDS columns
     // linearProgram3 of the register-resident build: one 16-lane row per (agent, violated line) (lp3_rows) in one-wavefront blocks;
     // worlds of more than 64 rows keep the statically unrolled walk (their blocks have no LDS left for the projected lines)
@@ -1535,7 +1558,7 @@ int orca_variant(const cs_worlds* w, char* buf, size_t buflen)
 {
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     const int T = rows <= 64 ? 64 : (rows <= 256 ? 256 : 512);
-    const bool fast10 = w->orca_max_neighbors == 10 && w->orca_n_vertices == 0;
+    const bool fast10 = w->orca_max_neighbors == 10 && w->orca_n_vertices == 0 && w->d_orca_agent_params == nullptr;
     const int wpb = rows <= 64 ? 64 / rows : 1;
     if (orca_uses_grid(w)) {
         std::snprintf(buf, buflen, "k_bw_orca_step<FAST10=%d> grid=(%d,%d) block=64 (one launch per substep)", fast10 ? 1 : 0, (rows + 63) / 64, w->W);

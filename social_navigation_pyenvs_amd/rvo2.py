@@ -12,9 +12,10 @@ programmes and ``position += velocity * timeStep`` (RVO2 ``Agent::computeNeighbo
 restated in csrc/orca.hip; parity with the third-party library itself is unpinned).
 
 Supported: any number of agents (above 512, or when a world's obstacle / neighbour columns outgrow a block's LDS, the neighbours come
-from a uniform grid in HBM: csrc/orca.hip k_bw_orca_step), per-agent radius / maxSpeed / position / velocity / preferred velocity;
-``neighborDist``, ``maxNeighbors``, ``timeHorizon`` must be the same for every agent (the reference never varies
-them: ORCA_DEFAULTS, motion_model_manager.py:14).  Static obstacles: ``addObstacle(vertices)`` (counter-clockwise
+from a uniform grid in HBM: csrc/orca.hip k_bw_orca_step), per-agent radius / maxSpeed / position / velocity / preferred velocity,
+and per-agent ``neighborDist`` / ``maxNeighbors`` (<= 16) / ``timeHorizon`` / ``timeHorizonObst`` as RVO2 keeps them
+(``addAgent``'s arguments, ``setAgent*``; ``cs_worlds.d_orca_agent_params``) -- the reference itself passes ORCA_DEFAULTS for every
+agent (motion_model_manager.py:14, :241), which keeps the register-resident ten-neighbour solve.  Static obstacles: ``addObstacle(vertices)`` (counter-clockwise
 polygons, or two vertices for a one-sided wall) + ``processObstacles()`` build RVO2's vertex records (point, unit direction
 to the next vertex, convexity, links); the kernel restates the obstacle ORCA lines and the hard-constraint form of
 linearProgram3.  The obstacle kd-tree's edge splitting is not modelled and each agent keeps its 16
@@ -69,15 +70,14 @@ class PyRVOSimulator:
                               timeHorizonObst=float(timeHorizonObst), radius=float(radius), maxSpeed=float(maxSpeed),
                               velocity=(float(velocity[0]), float(velocity[1])))
         self._pos, self._vel, self._pref, self._radius, self._maxspeed = [], [], [], [], []
+        self._agent = []     # per agent: [neighborDist, maxNeighbors, timeHorizon, timeHorizonObst] (RVO2 keeps the four per agent)
         self._time = 0.0
         self._cw = None
         self._polygons, self._vertices = [], None
 
     # ------------------------------------------------------------------ building the scene
     def setAgentDefaults(self, neighborDist, maxNeighbors, timeHorizon, timeHorizonObst, radius, maxSpeed, velocity=(0, 0)):
-        if self._pos and (float(neighborDist), int(maxNeighbors), float(timeHorizon)) != (
-                self._defaults["neighborDist"], self._defaults["maxNeighbors"], self._defaults["timeHorizon"]):
-            raise NotImplementedError("per-agent neighborDist / maxNeighbors / timeHorizon are not supported")
+        # (the defaults of agents added from now on: agents already in the simulator keep theirs, as in RVO2)
         self._defaults.update(neighborDist=float(neighborDist), maxNeighbors=int(maxNeighbors), timeHorizon=float(timeHorizon),
                               timeHorizonObst=float(timeHorizonObst), radius=float(radius), maxSpeed=float(maxSpeed),
                               velocity=(float(velocity[0]), float(velocity[1])))
@@ -85,9 +85,11 @@ class PyRVOSimulator:
     def addAgent(self, pos, neighborDist=None, maxNeighbors=None, timeHorizon=None, timeHorizonObst=None, radius=None,
                  maxSpeed=None, velocity=None):
         d = self._defaults
-        for name, val in (("neighborDist", neighborDist), ("maxNeighbors", maxNeighbors), ("timeHorizon", timeHorizon)):
-            if val is not None and float(val) != float(d[name]):
-                raise NotImplementedError(f"per-agent {name} is not supported (the reference uses ORCA_DEFAULTS for every agent)")
+        pick = lambda val, name: float(d[name] if val is None else val)
+        mn = int(pick(maxNeighbors, "maxNeighbors"))
+        if not 0 <= mn <= 16:
+            raise ValueError("maxNeighbors must be in 0..16")
+        self._agent.append([pick(neighborDist, "neighborDist"), float(mn), pick(timeHorizon, "timeHorizon"), pick(timeHorizonObst, "timeHorizonObst")])
         self._pos.append([float(pos[0]), float(pos[1])])
         v = d["velocity"] if velocity is None else velocity
         self._vel.append([float(v[0]), float(v[1])])
@@ -137,10 +139,18 @@ class PyRVOSimulator:
                 raise RuntimeError("processObstacles() has to be called after addObstacle() (RVO2 ignores unprocessed obstacles)")
             self._cw = CrowdWorlds(S, np.full((1, n, 1, 2), _FAR, np.float32), None, None, None, type="orca",
                                    orca_vertices=self._vertices)
-            self._cw.orca_params = dict(neighbor_dist=self._defaults["neighborDist"], max_neighbors=self._defaults["maxNeighbors"],
-                                        time_horizon=self._defaults["timeHorizon"], time_horizon_obst=self._defaults["timeHorizonObst"])
+            self._params_dirty = True
         else:
             self._cw.set_states(S)
+        if getattr(self, "_params_dirty", True):
+            ap = np.asarray(self._agent, np.float32).reshape(1, n, 4)
+            first = ap[0, 0]
+            # one parameter set for everybody (what the reference builds: ORCA_DEFAULTS for every addAgent): the scalar descriptor
+            # fields and the register-resident solve; otherwise the per-agent array (cs_worlds.d_orca_agent_params)
+            self._cw.orca_params = dict(neighbor_dist=float(ap[0, :, 0].max()), max_neighbors=int(ap[0, :, 1].max()),
+                                        time_horizon=float(first[2]), time_horizon_obst=float(first[3]))
+            self._cw.set_orca_agent_params(None if np.all(ap[0] == first) else ap)
+            self._params_dirty = False
         self._cw.step(self._dt, 1, None)
         out = self._cw.get_states()[0]
         self._pos = out[:, 0:2].astype(np.float64).tolist()
@@ -167,16 +177,16 @@ class PyRVOSimulator:
         return self._maxspeed[i]
 
     def getAgentNeighborDist(self, i):
-        return self._defaults["neighborDist"]
+        return self._agent[i][0]
 
     def getAgentMaxNeighbors(self, i):
-        return self._defaults["maxNeighbors"]
+        return int(self._agent[i][1])
 
     def getAgentTimeHorizon(self, i):
-        return self._defaults["timeHorizon"]
+        return self._agent[i][2]
 
     def getAgentTimeHorizonObst(self, i):
-        return self._defaults["timeHorizonObst"]
+        return self._agent[i][3]
 
     def getNumObstacleVertices(self):
         return sum(len(p) for p in self._polygons)
@@ -200,18 +210,20 @@ class PyRVOSimulator:
     def setAgentMaxSpeed(self, i, maxSpeed):
         self._maxspeed[i] = float(maxSpeed)
 
-    def _uniform_only(self, name, value):
-        if float(value) != float(self._defaults[name]):
-            raise NotImplementedError(f"per-agent {name} is not supported")
+    def _set_agent(self, i, col, v):
+        self._agent[i][col] = float(v)
+        self._params_dirty = True
 
     def setAgentNeighborDist(self, i, v):
-        self._uniform_only("neighborDist", v)
+        self._set_agent(i, 0, v)
 
     def setAgentMaxNeighbors(self, i, v):
-        self._uniform_only("maxNeighbors", v)
+        if not 0 <= int(v) <= 16:
+            raise ValueError("maxNeighbors must be in 0..16")
+        self._set_agent(i, 1, int(v))
 
     def setAgentTimeHorizon(self, i, v):
-        self._uniform_only("timeHorizon", v)
+        self._set_agent(i, 2, v)
 
     def setAgentTimeHorizonObst(self, i, v):
-        self._defaults["timeHorizonObst"] = float(v)
+        self._set_agent(i, 3, v)

@@ -50,8 +50,8 @@ def test_struct_layout_matches_header():
 
     from social_navigation_pyenvs_amd._lib import cs_worlds
 
-    # 8 int32 + 7 pointers + 5 floats + 2 int32 (+4 padding) + 1 pointer + 1 int32 (+4 tail padding)
-    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 2 * 4 + 4 + 8 + 4 + 4
+    # 8 int32 + 7 pointers + 5 floats + 2 int32 (+4 padding) + 1 pointer + 1 int32 (+4 padding) + 1 pointer
+    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 2 * 4 + 4 + 8 + 4 + 4 + 8
     assert cs_worlds.d_state.offset == 32
 
 
@@ -80,7 +80,7 @@ def test_header_is_plain_c_and_generator_struct_matches():
 
     src = ('#include "crowdstep.h"\n#include <stdio.h>\n#include <stddef.h>\n'
            'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cs_worlds), sizeof(cs_generator), '
-           'offsetof(cs_generator, circle_radius), offsetof(cs_generator, robot_desired_speed), offsetof(cs_worlds, d_world_flags), offsetof(cs_worlds, d_orca_vertices), '
+           'offsetof(cs_generator, circle_radius), offsetof(cs_generator, robot_desired_speed), offsetof(cs_worlds, d_world_flags), offsetof(cs_worlds, d_orca_agent_params), '
            'sizeof(cs_gym_book), offsetof(cs_gym_book, clock_len), offsetof(cs_gym_book, d_reward), offsetof(cs_gym_book, seed_stride), '
            'sizeof(cs_stage_book), offsetof(cs_stage_book, d_failed), offsetof(cs_stage_book, depth));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
@@ -94,7 +94,7 @@ def test_header_is_plain_c_and_generator_struct_matches():
     assert sizes[2] == cs_generator.circle_radius.offset
     assert sizes[3] == cs_generator.robot_desired_speed.offset
     assert sizes[4] == cs_worlds.d_world_flags.offset
-    assert sizes[5] == cs_worlds.d_orca_vertices.offset
+    assert sizes[5] == cs_worlds.d_orca_agent_params.offset
     assert sizes[6] == C.sizeof(cs_gym_book) and sizes[7] == cs_gym_book.clock_len.offset and sizes[8] == cs_gym_book.d_reward.offset
     assert sizes[9] == cs_gym_book.seed_stride.offset
     assert sizes[10] == C.sizeof(cs_stage_book) and sizes[11] == cs_stage_book.d_failed.offset and sizes[12] == cs_stage_book.depth.offset

@@ -217,8 +217,10 @@ def test_rvo2_module_drop_in():
     assert abs(sim.getGlobalTime() - 5 * 0.25) < 1e-12
     sim.setAgentPosition(0, (9.0, 9.0)); sim.setAgentVelocity(0, (0.0, 0.0)); sim.setAgentRadius(0, 0.5)
     assert sim.getAgentPosition(0) == (9.0, 9.0) and sim.getAgentRadius(0) == 0.5
-    with pytest.raises(NotImplementedError):
-        sim.addAgent((0, 0), 5.0)   # a per-agent neighborDist
+    # per-agent neighborDist / maxNeighbors / timeHorizon, as RVO2 keeps them: see test_rvo2_module_per_agent_parameters
+    k = sim.addAgent((0, 0), 5.0, 3, 2.0, 1.0)
+    assert (sim.getAgentNeighborDist(k), sim.getAgentMaxNeighbors(k), sim.getAgentTimeHorizon(k), sim.getAgentTimeHorizonObst(k)) == (5.0, 3, 2.0, 1.0)
+    assert sim.getAgentMaxNeighbors(0) == 10 and sim.getAgentTimeHorizon(0) == 5.0
 
 
 def _scene_with_polygons(rng, W, n):
@@ -664,3 +666,109 @@ def test_rvo2_module_with_a_thousand_agents():
     got_p = np.array([sim.getAgentPosition(i) for i in range(n)], dtype=np.float32)
     np.testing.assert_array_equal(got_v, nv)
     np.testing.assert_array_equal(got_p, pos + nv * np.float32(0.0125))
+
+
+def _agent_params(rng, W, rows):
+    ap = np.zeros((W, rows, 4), np.float32)
+    ap[..., 0] = rng.choice([1.5, 3.0, 6.0, 10.0], (W, rows))          # neighborDist
+    ap[..., 1] = rng.choice([0, 1, 3, 7, 10, 13], (W, rows))           # maxNeighbors (0: the agent ignores everybody)
+    ap[..., 2] = rng.choice([0.5, 2.0, 5.0, 8.0], (W, rows))           # timeHorizon
+    ap[..., 3] = rng.choice([0.5, 2.0, 5.0], (W, rows))                # timeHorizonObst
+    return ap
+
+
+@pytest.mark.parametrize("case", ["block", "obstacles_robot", "grid", "big_block"])
+def test_orca_per_agent_rvo2_parameters_match_the_restatement(case):
+    """RVO2 keeps neighborDist, maxNeighbors, timeHorizon, timeHorizonObst per agent (addAgent's arguments, motion_model_manager.py:241;
+    the reference passes ORCA_DEFAULTS for everyone): cs_worlds.d_orca_agent_params on every ORCA path that can hold them -- the LDS-column
+    kernel (one wavefront per block and one world per 256-lane block, with static obstacles and a robot row) and the grid path -- bit
+    for bit against the C restatement with the same per-agent array, over fused substeps; and the parameters really matter (the
+    trajectories differ from the uniform ones)."""
+    import os
+
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rng = np.random.default_rng(len(case))
+    W, n = (5, 20) if case != "big_block" else (2, 120)
+    robot = case == "obstacles_robot"
+    verts = None
+    if case == "obstacles_robot":
+        S, goals, verts, _ = _scene_with_polygons(rng, W, n)
+        R = np.zeros((W, 13), np.float32); R[:, 0:2] = (4.5, 4.5); R[:, 8] = 0.3; R[:, 12] = 1.0
+        S = np.concatenate([S, R[:, None, :]], axis=1)
+    else:
+        from social_navigation_pyenvs_amd import scenarios as sc
+        pos, yaw, g = sc.circular_crossing(W, n, 4.0 if n <= 20 else 14.0, 31)
+        S = sc.make_states(pos, yaw, g).astype(np.float32)
+        d = g[:, :, 0] - S[:, :, 0:2]
+        S[:, :, 5:7] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+        S[:, :, 3:5] = rng.normal(0, 0.3, (W, n, 2))
+        goals = g.astype(np.float32)
+    rows = n + int(robot)
+    margin = np.full((W, rows), 0.01, np.float32)
+    ap = _agent_params(rng, W, rows)
+    res = {}
+    if case == "grid":
+        os.environ["CROWDSTEP_BIGWORLD_MIN_ROWS"] = "1"
+    try:
+        for key, params in (("per_agent", ap), ("uniform", None)):
+            cw = CrowdWorlds(S, goals, None, margin, None, type="orca", robot_row=robot, robot=S[:, n] if robot else None, orca_vertices=verts,
+                             orca_agent_params=params, layout="soa" if case == "grid" else "aos")
+            v = cw.step_variant()
+            assert ("k_bw_orca_step" in v) == (case == "grid"), v
+            if params is not None:
+                assert "FAST10=0" in v, v                                        # the register-resident ten-neighbour solve holds ONE parameter set
+            cw.step(0.0125, 12)
+            res[key] = (cw.get_states(), cw.get_goals())
+    finally:
+        os.environ.pop("CROWDSTEP_BIGWORLD_MIN_ROWS", None)
+    ref, rgoals, _ = orc.orca_step_block(S, goals, margin, 0.0125, 12, robot_visible=robot, robot=S[:, n] if robot else None, verts=verts, max_nb=13,
+                                         agent_params=ap)
+    np.testing.assert_array_equal(res["per_agent"][0][:, :n, [0, 1, 3, 4, 5, 6]], ref[:, :n, [0, 1, 3, 4, 5, 6]])
+    np.testing.assert_array_equal(np.nan_to_num(res["per_agent"][1]), np.nan_to_num(rgoals))
+    assert np.max(np.abs(res["per_agent"][0][:, :n, 0:2] - res["uniform"][0][:, :n, 0:2])) > 1e-4
+    # an agent with maxNeighbors = 0 sees nobody: it walks its preferred velocity (clipped to maxSpeed) whatever stands in its way
+    blind = ap[..., 1] == 0
+    blind[:, n:] = False
+    assert blind.any()
+    one = CrowdWorlds(S, goals, None, margin, None, type="orca", robot_row=robot, robot=S[:, n] if robot else None, orca_vertices=None,
+                      orca_agent_params=ap)
+    one.step(0.0125, 1)
+    v1 = one.get_states()[..., 3:5]
+    pref = S[..., 5:7] * np.minimum(1.0, S[..., 12:13] / np.maximum(np.linalg.norm(S[..., 5:7], axis=-1, keepdims=True), 1e-9))
+    np.testing.assert_allclose(v1[blind], pref[blind], atol=1e-6)
+
+
+def test_rvo2_module_per_agent_parameters():
+    """The rvo2 facade with agents of different neighborDist / maxNeighbors / timeHorizon (addAgent's arguments and the setAgent* calls)
+    == the C restatement with the same per-agent array, step by step; changing a parameter between steps takes effect."""
+    from social_navigation_pyenvs_amd import rvo2
+
+    rng = np.random.default_rng(3)
+    n = 14
+    ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+    pos = 2.8 * np.stack([np.cos(ang), np.sin(ang)], -1) + rng.uniform(-0.2, 0.2, (n, 2))
+    vel = rng.normal(0, 0.3, (n, 2))
+    ap = _agent_params(rng, 1, n)[0]
+    sim = rvo2.PyRVOSimulator(0.25, 10, 10, 5, 5, 0.3, 1)
+    for i in range(n):
+        sim.addAgent((pos[i, 0], pos[i, 1]), float(ap[i, 0]), int(ap[i, 1]), float(ap[i, 2]), float(ap[i, 3]), 0.31, 1.0, (vel[i, 0], vel[i, 1]))
+    p32, v32 = pos.astype(np.float32), vel.astype(np.float32)
+    S = np.zeros((1, n, 13), np.float32); S[0, :, 8] = 0.31; S[0, :, 12] = 1.0
+    goals = np.full((1, n, 1, 2), 1.0e9, np.float32)
+    for step in range(6):
+        if step == 3:                                   # a parameter changed between two steps
+            sim.setAgentMaxNeighbors(2, 0); sim.setAgentTimeHorizon(5, 0.5); sim.setAgentNeighborDist(7, 1.5)
+            ap[2, 1] = 0; ap[5, 2] = 0.5; ap[7, 0] = 1.5
+        pref = -p32 / np.linalg.norm(p32, axis=1, keepdims=True)
+        for i in range(n):
+            sim.setAgentPrefVelocity(i, (float(pref[i, 0]), float(pref[i, 1])))
+        sim.doStep()
+        S[0, :, 0:2], S[0, :, 3:5], S[0, :, 5:7] = p32, v32, pref
+        ref, _, _ = orc.orca_step_block(S, goals, np.zeros((1, n), np.float32), 0.25, 1, max_nb=int(ap[:, 1].max()), neighbor_dist=float(ap[:, 0].max()),
+                                        agent_params=ap[None])
+        got_p = np.array([sim.getAgentPosition(i) for i in range(n)], np.float32)
+        got_v = np.array([sim.getAgentVelocity(i) for i in range(n)], np.float32)
+        np.testing.assert_array_equal(got_v, ref[0, :, 3:5])
+        np.testing.assert_array_equal(got_p, ref[0, :, 0:2])
+        p32, v32 = got_p, got_v

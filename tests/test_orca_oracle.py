@@ -260,3 +260,32 @@ def test_agent_does_not_cross_a_wall_over_many_steps():
             np.testing.assert_allclose(closest, 0.31 + (2.5 - 0.31) * (1 - 0.1 / 5.0) ** 120, rtol=5e-3)
         if x0 > 1.2:   # the path beside the box is free: it gets past
             assert S[0, 0, 1] < -1.0
+
+
+def test_per_agent_rvo2_parameters_in_the_restatement():
+    """RVO2's per-agent neighborDist / maxNeighbors / timeHorizon (RVOSimulator::addAgent's arguments) in the C restatement: the uniform
+    array equals the scalar call bit for bit; maxNeighbors = 0 or a neighborDist shorter than the gap makes an agent blind (it keeps its
+    preferred velocity while its partner, who still sees it, takes the whole avoidance); a longer timeHorizon reacts earlier."""
+    from oracle import crowd_oracle as orc
+
+    def head_on(ap):
+        S = np.zeros((1, 2, 13), np.float32)
+        S[0, 0, 0:2] = (-2.0, 0.02); S[0, 1, 0:2] = (2.0, -0.02)
+        S[0, 0, 3:5] = S[0, 0, 5:7] = (1.0, 0.0); S[0, 1, 3:5] = S[0, 1, 5:7] = (-1.0, 0.0)
+        S[0, :, 8] = 0.3; S[0, :, 12] = 1.0
+        goals = np.full((1, 2, 1, 2), 1.0e9, np.float32)
+        out, _, _ = orc.orca_step_block(S, goals, np.zeros((1, 2), np.float32), 0.25, 1, agent_params=ap)
+        return out[0, :, 3:5]
+
+    uniform = np.tile(np.array([10.0, 10, 5.0, 5.0], np.float32), (1, 2, 1))
+    np.testing.assert_array_equal(head_on(uniform), head_on(None))
+    both = head_on(None)
+    assert abs(both[0, 1]) > 1e-3 and abs(both[1, 1]) > 1e-3                 # reciprocal: both give way
+    for blind in (np.array([10.0, 0, 5.0, 5.0], np.float32), np.array([3.0, 10, 5.0, 5.0], np.float32)):   # no neighbours / too short a range (gap 4 m)
+        ap = uniform.copy(); ap[0, 0] = blind
+        v = head_on(ap)
+        np.testing.assert_array_equal(v[0], np.array([1.0, 0.0], np.float32))  # agent 0 sees nobody: preferred velocity
+        np.testing.assert_array_equal(v[1], both[1])                           # agent 1 still takes its half
+    short, long_ = uniform.copy(), uniform.copy()
+    short[0, :, 2] = 0.5; long_[0, :, 2] = 8.0                                 # time to collision: 1.7 s
+    assert np.max(np.abs(head_on(short)[:, 1])) < 1e-6 < np.min(np.abs(head_on(long_)[:, 1]))
