@@ -415,7 +415,7 @@ def pmc_summary() -> dict:
         return {}
 
 
-def roofline_block(spec, W, kern_ms, copy_gbs, cw):
+def roofline_block(spec, W, kern_ms, copy_gbs, cw, window=None):
     n, n_sub = spec["agents"], spec["substeps"]
     fam = family_of(spec["model"])
     alg = ALG_BYTES[fam] * W * n * n_sub          # walls are shared by all worlds: 0 B per world-substep
@@ -444,6 +444,12 @@ def roofline_block(spec, W, kern_ms, copy_gbs, cw):
         out["fp32_tflops_equiv"] = pair_flops / (k_avg * 1e-3) / 1e12
         out["fp32_frac"] = out["fp32_tflops_equiv"] / FP32_PEAK_TFLOPS
     out["valu"] = pm.get("valu")          # measured VALU issue figures (the true bound of this kernel), tagged with their source
+    # a kernel's instruction count follows the crowd's state (cfg5: how many polygons the wave vote skips): where the counters were
+    # also taken over THIS timed window (warmup, steps), those are the ones paired with this kernel time
+    pmw = summary.get(f"{spec_key(spec)}@w{window[0]}s{window[1]}") if window else None
+    if pmw and pmw.get("valu"):
+        out["valu"] = pmw["valu"]
+        out["valu_window"] = f"Gym steps {window[0]}..{window[0] + window[1]} (the timed window)"
     out["valu_frac"] = None
     if out["valu"] and out["valu"].get("valu_insts_per_wave_substep"):
         insts = out["valu"]["valu_insts_per_wave_substep"] * out["valu"]["waves_per_launch"] * n_sub * (W / float(pm.get("worlds", W)))
@@ -719,7 +725,7 @@ def main(argv=None):
             if rank == 0:
                 tot = ospec["total_worlds"] if ospec["total_worlds"] is not None else world_size * ospec["worlds"]
                 med = float(np.median(owall))
-                rl = roofline_block(ospec, oW, okern, copy_gbs, ocw)
+                rl = roofline_block(ospec, oW, okern, copy_gbs, ocw, window=(ospec["warmup"], k_o))
                 others.append({"name": ospec["name"], "workload": ospec["title"], "scaling": "strong" if ospec["total_worlds"] else "weak",
                                "worlds_this_rank": oW, "worlds_total": tot, "warmup": ospec["warmup"], "steps": k_o, "timing_repeats": r_o,
                                "ms_per_step": med / k_o * 1e3,
@@ -735,7 +741,7 @@ def main(argv=None):
         agent_substeps = total_worlds * args.agents * n_sub * args.steps
         value = agent_substeps / med
         g, b, wpb = cw.launch_geometry()
-        rl = roofline_block(spec, W, kern, copy_gbs, cw)
+        rl = roofline_block(spec, W, kern, copy_gbs, cw, window=(args.warmup, args.steps))
         out = {
             "metric": "env-steps/sec (worlds x agents) for HSFM 25-agent crowd",
             "value": value,

@@ -13,7 +13,11 @@ SHAPES = {"cfg3": (4096, 25, "hsfm_farina_25_hybrid"), "cfg2": (4096, 10, "sfm_h
           "cfg5": (8192, 50, "hsfm_farina_50_circle_walls_static"), "cfg3x4": (16384, 25, "hsfm_farina_25_hybrid_16384"),
           "moussaid": (4096, 25, "hsfm_new_moussaid_25_hybrid"), "cfg3_new_guo": (4096, 25, "hsfm_new_guo_25_hybrid"),
           "robot26": (4096, 25, "hsfm_farina_25_hybrid_robot"), "n30": (4096, 30, "hsfm_farina_30_hybrid"),
-          "peragent": (4096, 25, "hsfm_farina_25_hybrid_peragent"), "cfg5_nowalls": (8192, 50, "hsfm_farina_50_circle_static")}
+          "peragent": (4096, 25, "hsfm_farina_25_hybrid_peragent"), "cfg5_nowalls": (8192, 50, "hsfm_farina_50_circle_static"),
+          # the windows of the DRIVER's protocol (--steps 20 --warmup 5): the headline over Gym steps 5-25, cfg5 over steps 20-40.  A kernel's
+          # instruction count follows the crowd's state (cfg5: how many polygons the wave vote skips), so valu_frac pairs counters and
+          # time of the SAME window: bench.py looks "<key>@w<warmup>s<steps>" up before "<key>"
+          "cfg3_w5s20": (4096, 25, "hsfm_farina_25_hybrid@w5s20"), "cfg5_w20s20": (8192, 50, "hsfm_farina_50_circle_walls_static@w20s20")}
 SUBSTEPS = 20
 SIMDS = 256 * 4
 
@@ -41,7 +45,7 @@ def main(d, out, tag):
             nd = max(nd, k)
         e = {"dispatches_averaged": nd, "worlds": W, "source": f"profiles/{tag}_{name}_pmc_*.csv (rocprofv3 --pmc, separate passes)"}
         try:   # the library build the counters were collected on (bench.py: roofline.pmc_build_matches)
-            e["build_id"] = json.load(open(os.path.join(d, f"{name}_bench.json")))["build_id"]
+            e["build_id"] = json.load(open(os.path.join(d, f"{name.split('_w')[0] if '_w' in name and name.split('_w')[-1][0].isdigit() else name}_bench.json")))["build_id"]
         except Exception:
             e["build_id"] = None
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:

@@ -48,6 +48,14 @@ for name in $NAMES; do
   done
   rm -rf $O/${name}_stats
 done
+# the SQ counters once more over the driver protocol's windows (instruction counts follow the crowd's state)
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+for pair in "cfg3_w5s20|--steps 20 --warmup 5" "cfg5_w20s20|${CFG[cfg5]} --steps 20 --warmup 20"; do
+  name=${pair%%|*}; A="${pair#*|} --no-cpu-baseline --no-other-configs"
+  rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/${name}_pmc_SQ_WAVES -- python3 bench.py $A --repeats 1 > /dev/null 2> $O/${name}_pmc_SQ_WAVES.log || { echo "pmc $name failed"; tail -5 $O/${name}_pmc_SQ_WAVES.log; exit 1; }
+  cp $(find $O/${name}_pmc_SQ_WAVES -name "*counter_collection.csv" | head -1) $O/${name}_pmc_SQ_WAVES.csv
+  rm -rf $O/${name}_pmc_SQ_WAVES
+done
 python3 tools/pmc_summary.py $O $O/pmc_summary.json && python3 -c "
 import json; d=json.load(open('$O/pmc_summary.json'))
 for k,v in d.items(): print(k, v.get('build_id'), 'B/agent/launch', v.get('hbm_bytes_per_agent_launch'), 'VALU/wave-substep', (v.get('valu') or {}).get('valu_insts_per_wave_substep'))"
