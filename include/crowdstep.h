@@ -240,6 +240,8 @@ typedef struct cs_generator {
     double  human_mass;           /* 75 (reset_sim, :167)                                                    */
     double  robot_mass, robot_desired_speed; /* RobotAgent defaults (agent.py)                               */
 } cs_generator;
+/* (an ORCA batch -- w->type == CS_ORCA -- also gets RVO2's preferred velocity in columns 5:7 of every generated row: update_goals_orca,
+ * motion_model_manager.py:125-133, as the reference sets it when it builds the simulator) */
 size_t cs_generate_scratch_bytes(int W);
 int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32_t* d_seeds, const int32_t* d_mask,
                        int32_t* d_status, int32_t* d_scenario, void* d_scratch, void* stream);

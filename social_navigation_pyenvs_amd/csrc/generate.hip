@@ -39,6 +39,7 @@ constexpr int GEN_MAXN = 128; // humans per world the per-lane placement arrays 
 struct GArgs {
     cs_generator g;
     int W, rows, G, robot_row;
+    int orca;     // the batch is an ORCA crowd: columns 5:7 carry RVO2's preferred velocity (orca_pref below)
     float* S;
     long as, fs;
     float* goals;
@@ -119,6 +120,19 @@ __device__ double bound_angle_d(double a)
 }
 
 __device__ double norm2d(double x, double y) { return sqrt(x * x + y * y); } // np.linalg.norm of a 2-vector
+
+// An ORCA crowd keeps RVO2's preferred velocity in columns 5:7 of its rows (set_state_orca / update_goals_orca,
+// motion_model_manager.py:105-133: (g - p) / |g - p| if |g - p| > desired_speed else (g - p)), set when the simulator is built -- so
+// a world generated on the device must carry it from its first substep on.  float32 on the stored (rounded) columns, as the host
+// form of the same reset computes it (BatchedSocialNavGym._reset_on_device).
+__device__ __forceinline__ void orca_pref(float* s, long fs, float px, float py, float gx, float gy, float vd)
+{
+    const float dx = gx - px, dy = gy - py;
+    const float dn = sqrtf(dx * dx + dy * dy);
+    const float dd = dn > 1e-30f ? dn : 1e-30f;
+    s[5 * fs] = dn > vd ? dx / dd : dx;
+    s[6 * fs] = dn > vd ? dy / dd : dy;
+}
 
 __global__ __launch_bounds__(64) void k_generate(const GArgs a)
 {
@@ -266,6 +280,7 @@ __global__ __launch_bounds__(64) void k_generate(const GArgs a)
         for (int c = 3; c < 8; ++c) s[c * fs] = 0.0f;
         s[8 * fs] = (float)rad[i]; s[9 * fs] = (float)g.human_mass; s[10 * fs] = (float)g0x; s[11 * fs] = (float)g0y;
         s[12 * fs] = (float)spd[i];
+        if (a.orca) orca_pref(s, fs, (float)px[i], (float)py[i], (float)g0x, (float)g0y, (float)spd[i]);
         float* gl = a.goals + ((long)w * n + i) * a.G * 2;
         for (int k = 0; k < a.G; ++k) {
             float gx = nanf_, gy = nanf_;
@@ -388,12 +403,12 @@ __device__ __forceinline__ bool closer_than(double dx, double dy, double md)
 
 // where a generated world goes (the batch being reset, a staging batch, or the live batch of cs_consume_staged_worlds)
 struct GenOut {
-    float* S; long as, fs; float* goals; float* robot; int* world_flags; int rows, G, robot_row;
+    float* S; long as, fs; float* goals; float* robot; int* world_flags; int rows, G, robot_row, orca;
 };
 
 __device__ __forceinline__ GenOut gen_out(const GArgs& a)
 {
-    return GenOut{a.S, a.as, a.fs, a.goals, a.robot, a.world_flags, a.rows, a.G, a.robot_row};
+    return GenOut{a.S, a.as, a.fs, a.goals, a.robot, a.world_flags, a.rows, a.G, a.robot_row, a.orca};
 }
 
 // One world by one wavefront (the block): the reference's generator for `seed`, rows written to `a` when it succeeds.  Returns the
@@ -587,6 +602,7 @@ __device__ int generate_world_wave(const cs_generator& g, const GenOut& a, int w
         for (int c = 3; c < 8; ++c) s[c * fs] = 0.0f;
         s[8 * fs] = (float)myrad; s[9 * fs] = (float)g.human_mass; s[10 * fs] = (float)g0x; s[11 * fs] = (float)g0y;
         s[12 * fs] = (float)s_spd[i];
+        if (a.orca) orca_pref(s, fs, (float)mx, (float)my, (float)g0x, (float)g0y, (float)s_spd[i]);
         float* gl = a.goals + ((long)w * n + i) * a.G * 2;
         for (int k = 0; k < a.G; ++k) {
             float gx = nanf_, gy = nanf_;
@@ -708,6 +724,7 @@ __global__ __launch_bounds__(64) void k_consume_staged(const StageArgs a)
 int fill_gen_out(const cs_worlds* w, GenOut& o)
 {
     o.robot_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0;
+    o.orca = w->type == CS_ORCA ? 1 : 0;
     o.rows = w->n + o.robot_row;
     o.G = w->G;
     o.S = w->d_state;
@@ -786,6 +803,7 @@ int cs_generate_worlds(const cs_generator* gen, const cs_worlds* w, const uint32
     a.g = *gen;
     a.W = w->W;
     a.robot_row = (w->flags & CS_ROBOT_ROW) ? 1 : 0;
+    a.orca = w->type == CS_ORCA ? 1 : 0;
     a.rows = w->n + a.robot_row;
     a.G = w->G;
     a.S = w->d_state;

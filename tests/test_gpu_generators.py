@@ -746,3 +746,45 @@ def test_gym_step_is_the_head_and_the_body_in_one_launch(n, model, robot_row, ne
     infos = np.concatenate([h["out"][:, 6] for h in res[1]]).astype(int)
     assert set(np.unique(infos)) >= ({0, 4} if model == "orca" else {0, 2, 3, 4}), np.unique(infos)
     assert sum(int(h["mask"].sum()) for h in res[1]) > 20
+
+
+def test_orca_worlds_generated_on_the_device_carry_the_preferred_velocity():
+    """An ORCA crowd keeps RVO2's preferred velocity in columns 5:7 (update_goals_orca, motion_model_manager.py:125-133: the unit vector to
+    the goal, or the goal offset itself within desired_speed of it), set when the reference builds its simulator.  cs_generate_worlds
+    writes it for an ORCA batch -- in the device-resident loop a regenerated world therefore starts its first substep with it, like the
+    worlds of reset(): checked on a fresh batch and on worlds the auto-reset regenerated."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    def pref_of(S, n):
+        d = S[:, :n, 10:12] - S[:, :n, 0:2]
+        dn = np.linalg.norm(d, axis=-1, keepdims=True)
+        return np.where(dn > S[:, :n, 12:13], d / np.maximum(dn, np.float32(1e-30)), d).astype(np.float32)
+
+    W, n = 48, 6
+    env = BatchedSocialNavGym(_config("hybrid_scenario", human_num=n, policy="orca"), W)
+    env.reset(phase="test", first_case=2, device=True)
+    assert env.cw.orca
+    S0 = env.cw.get_states()
+    raw = BatchedSocialNavGym(_config("hybrid_scenario", human_num=n, policy="orca"), W)
+    raw.reset(phase="test", first_case=2, device=True)
+    generate_worlds(raw.cw, "hybrid_scenario", raw._seeds_host, **raw._gen_kw)          # the generator's own rows, no host fix-up behind them
+    Sg = raw.cw.get_states()
+    np.testing.assert_array_equal(Sg[:, :n, 5:7], pref_of(Sg, n))
+    np.testing.assert_array_equal(Sg, S0)
+    assert np.abs(Sg[:, :n, 5:7]).max() > 0.5
+    # the device-resident loop: drive the robots to their goals, compare every freshly regenerated world
+    seen = 0
+    for k in range(60):
+        rb = env.cw.d_robot.torch().view(W, 13)
+        to_goal = rb[:, 10:12] - rb[:, 0:2]
+        a = (to_goal / to_goal.norm(dim=1, keepdim=True).clamp(min=1e-6)).contiguous()
+        obs, rew, term, trunc, info = env.step_device(a)
+        fresh = (term | trunc).cpu().numpy()
+        if fresh.any():
+            S = env.cw.get_states()
+            np.testing.assert_array_equal(S[fresh][:, :n, 5:7], pref_of(S[fresh], n))
+            assert np.all(S[fresh][:, :n, 3:5] == 0)
+            seen += int(fresh.sum())
+    assert seen >= W // 2, seen
