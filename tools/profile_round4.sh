@@ -24,7 +24,7 @@ NAMES=${@:-cfg3 cfg2 cfg4_first20 cfg4_dense cfg5 cfg5_nowalls cfg3_new_guo robo
 # the DRIVER's command (BENCH_rNN.json): python3 bench.py --gpus 1 --steps 20 --warmup 5 -- its line is the one quoted first in README / DESIGN
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_protocol_bench.json 2> $O/driver_protocol_bench.log || { echo "driver-protocol bench failed"; tail -5 $O/driver_protocol_bench.log; exit 1; }
 cp gpurun_out/bench_full.json $O/driver_protocol_bench_full.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/driver_stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/driver_stats.log || { echo "driver stats run failed"; tail -5 $O/driver_stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/driver_stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-gym-step > /dev/null 2> $O/driver_stats.log || { echo "driver stats run failed"; tail -5 $O/driver_stats.log; exit 1; }
 cp $(find $O/driver_stats -name "*kernel_stats.csv" | head -1) $O/driver_protocol_kernel_stats.csv && head -4 $O/driver_protocol_kernel_stats.csv | cut -c1-160
 rm -rf $O/driver_stats
 # the default bench command itself under the kernel trace: its k_sfm_step<..., 25, 1> row is the kernel behind `value`
