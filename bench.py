@@ -589,7 +589,25 @@ def launch_ranks(args, argv, worker=None, n_visible=None) -> int:
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), CROWDSTEP_BENCH_LAUNCHER="self")
         # rank 0's stdout is the line; the other ranks print nothing there (and whatever they do print goes to stderr)
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0, _ = procs[0].communicate()
+    # a rank that dies (no GPU left, a fault) would leave the others waiting in the rendezvous: when one exits non-zero the rest of
+    # OUR ranks (the exact processes started above) are ended instead of hanging until a collective times out
+    out0 = None
+    while out0 is None:
+        try:
+            out0, _ = procs[0].communicate(timeout=1.0)
+        except subprocess.TimeoutExpired:
+            if any(p.poll() not in (None, 0) for p in procs[1:]):
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                out0, _ = procs[0].communicate()
+    if procs[0].returncode != 0:
+        for p in procs[1:]:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    p.kill()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     worst = max((abs(c) for c in codes), default=0)

@@ -131,3 +131,18 @@ def test_rank_refuses_a_world_size_it_was_not_asked_for():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 2 and r.stdout.strip() == "" and "WORLD_SIZE=1" in r.stderr
+
+
+def test_launcher_ends_the_other_ranks_when_one_dies(tmp_path):
+    """A rank that exits non-zero while the others wait (here: sleep) must not leave the launcher hanging in a rendezvous."""
+    import time
+
+    stub = tmp_path / "stub_hang.py"
+    stub.write_text("import os, sys, time\nr = int(os.environ['RANK'])\nif r == 1:\n    sys.exit(9)\ntime.sleep(120)\n")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; a = ['--gpus', '3']; "
+            f"sys.exit(bench.launch_ranks(bench.parse(a), a, worker={str(stub)!r}, n_visible=3))")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
+    assert time.time() - t0 < 30 and r.returncode == 9 and r.stdout.strip() == ""
