@@ -142,3 +142,38 @@ def test_hip_runtime_preload_checks_the_soname_and_maps_one_runtime(tmp_path, mo
             "assert _lib.hip_runtime_path is None and any('not preloading' in str(x.message) for x in w), (_lib.hip_runtime_path, [str(x.message) for x in w])\n"
             "assert len(_lib.mapped_hip_runtimes()) == 1\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_new_entry_points_reject_bad_arguments_before_touching_a_device():
+    """Argument checks of the round-4 entry points come first: null pointers, a staging depth that is not a power of two, a staging
+    batch of the wrong size, a generator that does not fit the worlds -- all CS_ERR_ARG (ValueError through the binding) with no GPU."""
+    import ctypes as C
+
+    from social_navigation_pyenvs_amd import _lib
+    from social_navigation_pyenvs_amd.generators import cs_generator
+
+    lib = _lib.load()
+    null = C.c_void_p(None)
+    assert lib.cs_gym_step(null, C.c_float(0.0125), C.c_int(20), null, C.c_float(0.25), null, null, null, null, C.c_int(0), null, null) == _lib.CS_ERR_ARG
+    assert lib.cs_refill_staged_worlds(null, null, null, null) == _lib.CS_ERR_ARG
+    assert lib.cs_consume_staged_worlds(null, null, null, null, null, C.c_int(0), null, null) == _lib.CS_ERR_ARG
+    buf = C.create_string_buffer(8)
+    assert lib.cs_device_pci_bus_id(C.c_int(0), buf, C.c_size_t(8)) == _lib.CS_ERR_ARG          # buffer too small for "0000:00:00.0"
+    done = C.c_int(0)
+    assert lib.cs_event_query(null, C.byref(done)) == _lib.CS_ERR_ARG
+    # a well-formed descriptor pair with a bad stage book
+    w = _lib.cs_worlds(W=8, n=5, G=2, type=3, layout=_lib.CS_LAYOUT_AOS, d_state=1, d_goals=1)
+    st = _lib.cs_worlds(W=24, n=5, G=2, type=3, layout=_lib.CS_LAYOUT_AOS, d_state=1, d_goals=1)
+    g = cs_generator(scenario=0, n=5, insert_robot=1, randomize_attributes=0, randomize_positions=1, max_tries=100, circle_radius=7.0,
+                     traffic_length=14.0, traffic_height=3.0, robot_radius=0.3, human_mass=75.0, robot_mass=80.0, robot_desired_speed=1.0)
+    book = _lib.cs_stage_book(d_seeds=1, d_base_seed=1, d_epoch=1, d_staged_seed=1, d_staged_status=1, d_failed=1, seed_stride=0, depth=3)
+    assert lib.cs_refill_staged_worlds(C.byref(g), C.byref(st), C.byref(book), null) == _lib.CS_ERR_ARG   # depth 3: not a power of two
+    assert "power of two" in lib.cs_last_error().decode()
+    book.depth = 4
+    mask = C.c_void_p(1)
+    assert lib.cs_consume_staged_worlds(C.byref(g), C.byref(st), C.byref(w), mask, C.byref(book), C.c_int(0), null, null) == _lib.CS_ERR_ARG
+    assert "differ in shape" in lib.cs_last_error().decode()                                             # 24 / 4 = 6 worlds staged per level, 8 live
+    g.n = 7
+    st.W = 32
+    assert lib.cs_refill_staged_worlds(C.byref(g), C.byref(st), C.byref(book), null) == _lib.CS_ERR_ARG
+    assert "cs_generator.n differs" in lib.cs_last_error().decode()
