@@ -788,3 +788,52 @@ def test_orca_worlds_generated_on_the_device_carry_the_preferred_velocity():
             assert np.all(S[fresh][:, :n, 3:5] == 0)
             seen += int(fresh.sum())
     assert seen >= W // 2, seen
+
+
+@pytest.mark.parametrize("headed_obs", [False, True])
+def test_device_resident_step_with_a_visible_robot_equals_the_host_step(headed_obs):
+    """step_device for a Gym whose robot is VISIBLE to the crowd (26th state row, LEAN = 3 build with the Gym head in its prologue) and,
+    with headed_obs, 7-column observations: equal to the host-array step of the same batch step by step, and the worlds the auto-reset
+    takes over from the staging batch equal the host generator's (robot row included)."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W, n = 70, 25
+    cfg = _config("hybrid_scenario", human_num=n)
+    host = BatchedSocialNavGym(cfg, W, robot_visible=True, headed_obs=headed_obs)
+    host.reset(phase="test", first_case=3, device=True)
+    dev = BatchedSocialNavGym(cfg, W, robot_visible=True, headed_obs=headed_obs)
+    dev.reset(phase="test", first_case=3, device=True)
+    assert dev.cw.rows == n + 1 and "LEAN=3" in dev.cw.step_variant()
+    rng = np.random.default_rng(1)
+    same = np.ones(W, bool)   # worlds no auto-reset has touched yet: there the two paths must agree exactly
+    for k in range(5):
+        a = rng.uniform(-0.4, 0.4, (W, 2)).astype(np.float32)
+        oh, rh, th, uh, ih = host.step(a)
+        od, rd, td, ud, idv = dev.step_device(torch.as_tensor(a, device="cuda"))
+        assert od.shape == (W, n, 7 if headed_obs else 5)
+        np.testing.assert_array_equal(rd.cpu().numpy()[same], rh[same])
+        np.testing.assert_array_equal(td.cpu().numpy()[same], th[same])
+        np.testing.assert_array_equal(idv.cpu().numpy()[same], ih[same])
+        same &= ~(th | uh)
+        np.testing.assert_array_equal(od.cpu().numpy()[same], oh[same])
+    assert same.sum() > W // 2
+    np.testing.assert_array_equal(dev.cw.get_states()[same], host.cw.get_states()[same])
+    seen = 0
+    for k in range(70):
+        rb = dev.cw.d_robot.torch().view(W, 13)
+        to_goal = rb[:, 10:12] - rb[:, 0:2]
+        a = (to_goal / to_goal.norm(dim=1, keepdim=True).clamp(min=1e-6)).contiguous()
+        od, rd, td, ud, idv = dev.step_device(a)
+        fresh = (td | ud).cpu().numpy()
+        if fresh.any():
+            seeds = dev._dl["seeds"].cpu().numpy().astype(np.uint32)
+            check = BatchedSocialNavGym(cfg, W, robot_visible=True, headed_obs=headed_obs)
+            check.reset(phase="test", first_case=3, device=True)
+            generate_worlds(check.cw, "hybrid_scenario", seeds, **check._gen_kw)
+            np.testing.assert_array_equal(dev.cw.get_states()[fresh], check.cw.get_states()[fresh])
+            np.testing.assert_array_equal(dev.cw.get_robot()[fresh], check.cw.get_robot()[fresh])
+            np.testing.assert_array_equal(od.cpu().numpy()[fresh], check.observe()[fresh])
+            seen += int(fresh.sum())
+    assert seen >= W // 3 and dev.failed_resets() == 0, seen
