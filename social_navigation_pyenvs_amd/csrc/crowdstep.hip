@@ -168,7 +168,9 @@ __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int 
     const bool valid = lw < wpb && w < W;
     float rpx = 0, rpy = 0, rr = 0, rgx = 0, rgy = 0, ax = 0, ay = 0;
     float closest = INFINITY;
+    cstep::GymPre pre = {0.0f, 0, 0};
     if (valid) {
+        if (i == 0) pre = gym_head_preload(g, w);
         const float* rb = robot + (long)w * 13;
         rpx = rb[0]; rpy = rb[1]; rr = rb[8]; rgx = rb[10]; rgy = rb[11];
         ax = action[(long)w * 2]; ay = action[(long)w * 2 + 1];
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int 
     s_closest[tid] = closest;
     __syncthreads();
     if (!valid || i != 0) return;
-    gym_head_world(g, w, n, s_closest + lw * n, rpx, rpy, rr, rgx, rgy, ax, ay);
+    gym_head_world(g, w, n, s_closest + lw * n, rpx, rpy, rr, rgx, rgy, ax, ay, pre);
 }
 
 __global__ void k_transpose_state(const float* src, float* dst, long total_rows, int to_soa)

@@ -44,41 +44,63 @@ __device__ __forceinline__ float gym_swept_closest(float hx, float hy, float hvx
     return __builtin_amdgcn_sqrtf(qx * qx + qy * qy) - hr - rr;
 }
 
-// One lane per world: walks the humans' swept distances closest[0 .. n) in index order with the reference's early `break`, writes the
-// reward row and -- bk.mode != 0 -- does the world's bookkeeping.  Returns whether the episode ended (with auto-reset rules: the mask).
+// what the head reads of its world's episode state: loaded by the caller together with its other loads (one memory round trip for all)
+struct GymPre { float gtime; int counter, prev; };
+__device__ __forceinline__ GymPre gym_head_preload(const GymHead& g, int w)
+{
+    GymPre p;
+    p.gtime = g.gtime[w]; p.counter = 0; p.prev = 0;
+    if (g.bk.mode != 0) {
+        p.counter = g.bk.counter[w];
+        if (g.bk.mode == 2) p.prev = g.bk.prev[w];
+    }
+    return p;
+}
+
+// One lane per world: goes over the humans' swept distances closest[0 .. n) in index order -- the reference's loop with its early `break`,
+// written without the break (dmin = the minimum over the humans BEFORE the first collision) so that the n LDS reads are independent of each
+// other: round 4's first version waited for every one of them in turn --, writes the reward row and -- bk.mode != 0 -- does the world's bookkeeping.
 __device__ __forceinline__ void gym_head_world(const GymHead& g, int w, int n, const float* closest, float rpx, float rpy, float rr,
-                                               float rgx, float rgy, float ax, float ay)
+                                               float rgx, float rgy, float ax, float ay, const GymPre pre)
 {
 #pragma clang fp contract(off)
+    const GymBook& bk = g.bk;
+    // the clock entries the bookkeeping may write (the step after this one, or a fresh episode's): requested before the walk
+    float clk0 = 0.0f, clk1 = 0.0f;
+    int c1 = 0;
+    if (bk.mode != 0) {
+        c1 = pre.counter + 1 < bk.clock_len - 1 ? pre.counter + 1 : bk.clock_len - 1;
+        clk0 = bk.clock[0]; clk1 = bk.clock[c1];
+    }
     float dmin = INFINITY;
     int collision = 0;
     for (int j = 0; j < n; ++j) {
         const float c = closest[j];
-        if (c < 0.0f) { collision = 1; break; }
-        else if (c < dmin) dmin = c;
+        const bool hit = c < 0.0f;
+        dmin = (!collision && !hit && c < dmin) ? c : dmin;
+        collision |= hit ? 1 : 0;
     }
     const float ex = rpx + ax * g.T, ey = rpy + ay * g.T;
     const float gx = ex - rgx, gy = ey - rgy;
     const int reaching = __builtin_amdgcn_sqrtf(gx * gx + gy * gy) < rr;
     float reward = 0.0f; int term = 0, trunc = 0, info = 0;
-    if (g.gtime[w] >= g.time_limit - 1.0f) { trunc = 1; info = 4; }
+    if (pre.gtime >= g.time_limit - 1.0f) { trunc = 1; info = 4; }
     else if (collision) { reward = g.collision_penalty; term = 1; info = 3; }
     else if (reaching) { reward = g.success_reward; term = 1; info = 2; }
     else if (dmin < g.discomfort_dist) { reward = (dmin - g.discomfort_dist) * g.discomfort_factor * g.T; info = 1; }
     float* o = g.out + (long)w * 7;
     o[0] = (float)collision; o[1] = dmin; o[2] = (float)reaching; o[3] = reward;
     o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
-    const GymBook& bk = g.bk;
     if (bk.mode == 0) return;
     // the same statements as k_gym_bookkeeping / k_gym_bookkeeping_next_step (robot_model.hip), on the values just written
-    if (bk.mode == 2 && bk.prev[w]) {
+    if (bk.mode == 2 && pre.prev) {
         bk.reward[w] = 0.0f; bk.terminated[w] = 0; bk.truncated[w] = 0; bk.info[w] = 0;
-        bk.mask[w] = 0; bk.counter[w] = 0; bk.gtime[w] = bk.clock[0];
+        bk.mask[w] = 0; bk.counter[w] = 0; bk.gtime[w] = clk0;
         return;
     }
     bk.reward[w] = reward; bk.terminated[w] = term ? 1 : 0; bk.truncated[w] = trunc ? 1 : 0; bk.info[w] = info;
     const bool done = term || trunc;
-    int c = bk.counter[w] + 1;
+    int c = c1;                                      // min(counter + 1, clock_len - 1)
     if (bk.mode == 2) {
         bk.mask[w] = done ? 1 : 0;
         if (done) bk.seeds[w] += bk.stride;
@@ -86,9 +108,8 @@ __device__ __forceinline__ void gym_head_world(const GymHead& g, int w, int n, c
         bk.mask[w] = done ? 1 : 0;
         if (done) { bk.seeds[w] += bk.stride; c = 0; }
     }
-    c = c < bk.clock_len - 1 ? c : bk.clock_len - 1;
     bk.counter[w] = c;
-    bk.gtime[w] = bk.clock[c];
+    bk.gtime[w] = c == 0 ? clk0 : clk1;
 }
 
 } // namespace cstep

@@ -73,8 +73,13 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
     const float dt = a.dt;
     const long sidx = (long)(inw ? w : 0) * ROWS + (r < ROWS ? r : 0);
 
-    float px = 0, py = 0, th = 0, vx = 0, vy = 0, bvx = 0, bvy = 0, om = 0, rad = 0, m = 1, gx = 0, gy = 0, vd = 0, safety = 0;
-    if (human) {
+    // ---- load phase: every global load of the prologue is issued before the first result is used -- ONE memory round trip instead of
+    // six dependent ones (row; pair parameters; my parameter row; the goal list slot by slot; respawn flag; action).  Straight-line on
+    // purpose (sfmstep_kernel.h, load phase): lanes without an agent load row 0 of world 0 / of their world, an absent optional
+    // array is replaced by a readable dummy address.
+    const float* dummy = a.Sin;
+    float px, py, th, vx, vy, bvx, bvy, om, rad, m, gx, gy, vd, safety;
+    {
         const float* s = a.Sin + sidx * a.in_as;
         const long fs = a.in_fs;
         px = s[0]; py = s[fs]; th = s[2 * fs]; vx = s[3 * fs]; vy = s[4 * fs]; bvx = s[5 * fs];
@@ -84,31 +89,49 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
     }
     // parameters: P[0] of my world for the pair forces (all_params_equal, forces_parallel.py:220), my own row for the rest
     const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)(inw ? w : 0) * ROWS * 20;
-    const SocP sp = load_socp(a.params + pw);
+    const SocRaw sraw = load_socraw(a.params + pw);
+    const float* P = a.params + pw + (long)(r < ROWS ? r : 0) * 20;
+    const float P0 = P[0], P16 = P[16], P17 = P[17], P18 = P[18], P19 = P[19];
+    float* gi = a.goals + sidx * a.G * 2;          // my goal list (a lane without an agent: one it never touches)
+    float gl[4];
+    gl[0] = gi[0]; gl[1] = gi[1];
+    {
+        const float* g2 = a.G >= 2 ? gi + 2 : gi;
+        gl[2] = g2[0]; gl[3] = g2[1];
+    }
+    const bool has_wflags = a.world_flags != nullptr;
+    const int wflag_raw = *(has_wflags ? a.world_flags + (inw ? w : 0) : reinterpret_cast<const int*>(dummy));
+    const bool robot_moves = a.action != nullptr;   // only the invisible robot of the epilogue (no robot row in this build)
+    float ax, ay;
+    {
+        const float* ap = robot_moves ? a.action + (long)(inw ? w : 0) * 2 : dummy;
+        ax = ap[0]; ay = ap[1];
+    }
+
+    // ---- compute phase
+    if (!human) { px = 0; py = 0; th = 0; vx = 0; vy = 0; bvx = 0; bvy = 0; om = 0; rad = 0; m = 1; gx = 0; gy = 0; vd = 0; safety = 0; }
+    if (!(inw && robot_moves)) { ax = 0; ay = 0; }
+    const SocP sp = make_socp(sraw);
     float m_tau = 0, ko = 0, kd = 0, alpha = 1, klam = 0, dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0;
     float g0x = gx, g0y = gy, g1x = 0, g1y = 0;
     int gk = 0;
     bool gdirty = false;
-    float* gi = nullptr;
     if (human) {
-        const float* P = a.params + pw + (long)r * 20;
-        m_tau = m / P[0];
-        ko = P[16]; kd = P[17]; alpha = P[18]; klam = P[19];
+        m_tau = m / P0;
+        ko = P16; kd = P17; alpha = P18; klam = P19;
         dt_m = dt / m;
         inv_alpha = 1.0f / alpha;
         inertia = 0.5f * m * rad * rad;
         dt_inertia = dt / inertia;
-        gi = a.goals + ((long)w * ROWS + r) * a.G * 2;
-        g0x = gi[0]; g0y = gi[1];
+        g0x = gl[0]; g0y = gl[1];
         gk = a.G;
-        for (int g = a.G - 1; g >= 0; --g)
+        for (int g = a.G - 1; g >= 2; --g)
             if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) gk = g;
-        if (gk == 2) { g1x = gi[2]; g1y = gi[3]; }
+        if (a.G >= 2 && (isnan(gl[2]) || isnan(gl[3]))) gk = 1;
+        if (isnan(gl[0]) || isnan(gl[1])) gk = 0;
+        if (gk == 2) { g1x = gl[2]; g1y = gl[3]; }
     }
-    const bool respawn_here = human && (a.world_flags == nullptr || (a.world_flags[w] & 1));
-    const bool robot_moves = a.action != nullptr;   // only the invisible robot of the epilogue (no robot row in this build)
-    float ax = 0, ay = 0;
-    if (inw && robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
+    const bool respawn_here = human && (!has_wflags || (wflag_raw & 1));
 
     // mirrored value: lanes ROWS .. 15 take the value of lane - ROWS
     auto ext = [&](float x) { const float up = shr<ROWS, true>(x); return mirror ? up : x; };

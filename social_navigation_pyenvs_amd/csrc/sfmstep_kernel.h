@@ -105,59 +105,76 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     const float dt = a.dt;
     const int obs_type = (a.type == 1 || a.type == 4 || a.type == 7) ? 1 : 0;
 
-    // ---- load my row ------------------------------------------------------------------
-    float px = 0, py = 0, th = 0, vx = 0, vy = 0, bvx = 0, bvy = 0, om = 0, r = 0, m = 1, gx = 0, gy = 0, vd = 0;
-    float safety = 0;
+    // ---- load phase ---------------------------------------------------------------------
+    // Every global load of the prologue is issued before the first result is used: ONE memory round trip.  (Until round 4 the row,
+    // the parameter rows, the goal list -- a NaN scan that loaded and waited slot by slot --, the world's respawn flag and the action
+    // were seven dependent round trips, ~3.2 us of a 33 us launch by the s_memtime stamps of tools/launch_floor.sh's probe.)
+    // Straight-line code on purpose: a load inside a branch whose other arm is a constant gets its first use hoisted into the branch
+    // (and a wait with it), so lanes without a world / a human row load world 0's / row 0's (never used) and an absent optional array is
+    // replaced by a readable dummy address instead of being branched around.
     const long sidx = (long)w * rows + row;
-    if (valid) {
-        const float* s = a.Sin + sidx * a.in_as;
-        if (is_robot && (kmode & M_ROBOT_FROM_ARRAY)) {
-            const float* rb = a.robot + (long)w * 13;
-            px = rb[0]; py = rb[1]; th = rb[2]; vx = rb[3]; vy = rb[4]; bvx = rb[5]; bvy = rb[6]; om = rb[7];
-            r = rb[8]; m = rb[9]; gx = rb[10]; gy = rb[11]; vd = rb[12];
-        } else {
-            const long fs = a.in_fs;
-            px = s[0]; py = s[fs]; th = s[2 * fs]; vx = s[3 * fs]; vy = s[4 * fs]; bvx = s[5 * fs];
-            bvy = s[6 * fs]; om = s[7 * fs]; r = s[8 * fs]; m = s[9 * fs]; gx = s[10 * fs]; gy = s[11 * fs];
-            vd = s[12 * fs];
-        }
-        safety = a.safety[sidx];
+    const int wc = valid ? w : 0, rowh = human ? row : 0;
+    const long sidx_c = valid ? sidx : 0;
+    const float* dummy = a.Sin;
+    float px, py, th, vx, vy, bvx, bvy, om, r, m, gx, gy, vd;
+    {
+        const float* s = a.Sin + sidx_c * a.in_as;
+        const long fs = a.in_fs;
+        px = s[0]; py = s[fs]; th = s[2 * fs]; vx = s[3 * fs]; vy = s[4 * fs]; bvx = s[5 * fs];
+        bvy = s[6 * fs]; om = s[7 * fs]; r = s[8 * fs]; m = s[9 * fs]; gx = s[10 * fs]; gy = s[11 * fs];
+        vd = s[12 * fs];
+    }
+    float safety = a.safety[sidx_c];
+    const bool has_wflags = a.world_flags != nullptr;
+    const int wflag_raw = *(has_wflags ? a.world_flags + wc : reinterpret_cast<const int*>(dummy));   // bit 0: the respawn rule applies to my world
+    const bool robot_moves = a.action != nullptr; // (lean build: only the invisible robot of the epilogue)
+    float ax, ay;                                 // robot action (held for the whole block, social_nav_gym.py:240-243)
+    {
+        const float* ap = robot_moves ? a.action + (long)wc * 2 : dummy;
+        ax = ap[0]; ay = ap[1];
     }
     // parameters: my own row of P for the single-agent forces; P[0] of my world for the pair loop
     // when all_params_equal (forces_parallel.py:220), else my own row (:261)
-    float m_tau = 0, Aw = 0, cBw = 0, Cw = 0, cDw = 0, k1 = 0, k2 = 0, ko = 0, kd = 0, alpha = 1, klam = 0;
-    float dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0, wall_cut = 0;
-    SocP sp = {};
-    float g0x = gx, g0y = gy, g1x = 0, g1y = 0;
-    int gk = 0;          // length of the non-NaN prefix of my goal list
-    bool gdirty = false; // a two-goal list rotated in registers, to be written back in the epilogue
-    float* gi = nullptr;
-    if (N3L && PEQ && valid) sp = load_socp(a.params + ((a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20));
-    if (human) {
-        const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)w * n * 20;
-        const float* P = a.params + pw + (long)row * 20;
-        m_tau = m / P[0];                       // m / relax_t              (:39)
-        Aw = P[2]; cBw = LOG2E / P[4]; Cw = P[6]; cDw = LOG2E / P[8]; k1 = P[10]; k2 = P[11];
-        // beyond this distance a wall's force on me is below |A| e^-36 = 5e-13 N (its contact terms are exact zeros there):
-        // a polygon that every agent of the wavefront is that far from is skipped in the substep loop
-        wall_cut = r + safety + a.wall_efolds * fmaxf(P[4], obs_type == 1 ? P[8] : 0.0f);
-        ko = P[16]; kd = P[17]; alpha = P[18]; klam = P[19];
-        dt_m = a.dt / m;                        // (F / m) * dt             (:277,:282)
-        inv_alpha = 1.0f / alpha;
-        inertia = 0.5f * m * r * r;             // :265
-        dt_inertia = a.dt / inertia;            // (torque / I) * dt        (:279)
-        if constexpr (!N3L || PP) sp = load_socp(PEQ ? (a.params + pw) : P);
-        gi = a.goals + ((long)w * n + row) * a.G * 2;
-        g0x = gi[0]; g0y = gi[1];
-        // goal lists of <= 2 entries (every Gym scenario) rotate in registers; longer ones go through memory
-        gk = a.G;
-        for (int g = a.G - 1; g >= 0; --g)
-            if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) gk = g;
-        if (gk == 2) { g1x = gi[2]; g1y = gi[3]; }
+    const long pw = (a.flags & CS_PARAMS_SHARED) ? 0 : (long)wc * n * 20;
+    const float* Prow = a.params + pw + (long)rowh * 20;
+    float Pm[11];                                 // my P[0], [2], [4], [6], [8], [10], [11], [16], [17], [18], [19]
+    Pm[0] = Prow[0]; Pm[1] = Prow[2]; Pm[2] = Prow[4]; Pm[3] = Prow[6]; Pm[4] = Prow[8]; Pm[5] = Prow[10]; Pm[6] = Prow[11];
+    Pm[7] = Prow[16]; Pm[8] = Prow[17]; Pm[9] = Prow[18]; Pm[10] = Prow[19];
+    const SocRaw sraw = load_socraw(PEQ ? a.params + pw : Prow);
+    float* gi = a.goals + ((long)wc * n + rowh) * a.G * 2;   // my goal list (row 0's for a lane without a human)
+    float gl[4];                                  // its first two slots
+    gl[0] = gi[0]; gl[1] = gi[1];
+    {
+        const float* g2 = a.G >= 2 ? gi + 2 : gi;
+        gl[2] = g2[0]; gl[3] = g2[1];
     }
+    if (valid && is_robot && (kmode & M_ROBOT_FROM_ARRAY)) {   // (divergent: the robot's lane)
+        const float* rb = a.robot + (long)w * 13;
+        px = rb[0]; py = rb[1]; th = rb[2]; vx = rb[3]; vy = rb[4]; bvx = rb[5]; bvy = rb[6]; om = rb[7];
+        r = rb[8]; m = rb[9]; gx = rb[10]; gy = rb[11]; vd = rb[12];
+    }
+    // (cs_gym_step: the robot as the head sees it and the action, see below)
+    float hrb[5] = {0, 0, 0, 0, 0}, hact[2] = {0, 0};
+    GymPre hpre = {0.0f, 0, 0};
+    if constexpr (MAXT == 64) {
+        if (a.gym.out != nullptr && valid) {
+            const float* rb = a.robot + (long)w * 13;      // the robot BEFORE its move of substep 1
+            hrb[0] = rb[0]; hrb[1] = rb[1]; hrb[2] = rb[8]; hrb[3] = rb[10]; hrb[4] = rb[11];
+            hact[0] = a.action[(long)w * 2]; hact[1] = a.action[(long)w * 2 + 1];
+            if (row == 0) hpre = gym_head_preload(a.gym, w);   // (last: the compiler waits for these right here)
+        }
+    }
+    // imitation learning (LEAN = 4)
+    float rm_hm = 0.0f, rm_fdx = 0.0f, rm_fdy = 0.0f;
+    if constexpr (IMIT) {
+        if (human) rm_hm = a.rm_hmargin[sidx];
+        if (is_robot) { rm_fdx = a.rm_memory[(long)w * 2]; rm_fdy = a.rm_memory[(long)w * 2 + 1]; }
+    }
+
     const float inv_O = a.O > 0 ? 1.0f / (float)a.O : 0.0f;
     const float* obst = nullptr;
     if (!NO_WALLS && a.O > 0) obst = a.obstacles + ((a.flags & CS_OBSTACLES_SHARED) ? 0 : (long)w * a.O * a.Smax * 4);
+    // (their loads belong to the load phase: the LDS stores below are the first use of anything loaded so far)
     // wall segments are constant over the launch: stage (x1, y1, e, 1/|e|^2) in LDS once instead of re-loading and
     // re-deriving them in every substep (3 polygons x 5 segments cost as much as the whole 50-agent pair loop otherwise)
     const int nseg = NO_WALLS ? 0 : a.O * a.Smax;
@@ -181,12 +198,42 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         lds_sinv[i] = inv;
     }
 
-    const bool respawn_here = valid && (a.world_flags == nullptr || (a.world_flags[w] & 1));
+    // ---- compute phase --------------------------------------------------------------------
+    if (!valid) {   // (selects: what the rows of a lane without a world have always been)
+        px = 0; py = 0; th = 0; vx = 0; vy = 0; bvx = 0; bvy = 0; om = 0; r = 0; m = 1; gx = 0; gy = 0; vd = 0;
+        safety = 0; ax = 0; ay = 0;
+    }
+    if (!robot_moves) { ax = 0; ay = 0; }
+    float m_tau = 0, Aw = 0, cBw = 0, Cw = 0, cDw = 0, k1 = 0, k2 = 0, ko = 0, kd = 0, alpha = 1, klam = 0;
+    float dt_m = 0, inv_alpha = 1, inertia = 1, dt_inertia = 0, wall_cut = 0;
+    SocP sp = {};
+    float g0x = gx, g0y = gy, g1x = 0, g1y = 0;
+    int gk = 0;          // length of the non-NaN prefix of my goal list
+    bool gdirty = false; // a two-goal list rotated in registers, to be written back in the epilogue
+    if (N3L && PEQ && valid) sp = make_socp(sraw);
+    if (human) {
+        m_tau = m / Pm[0];                      // m / relax_t              (:39)
+        Aw = Pm[1]; cBw = LOG2E / Pm[2]; Cw = Pm[3]; cDw = LOG2E / Pm[4]; k1 = Pm[5]; k2 = Pm[6];
+        // beyond this distance a wall's force on me is below |A| e^-36 = 5e-13 N (its contact terms are exact zeros there):
+        // a polygon that every agent of the wavefront is that far from is skipped in the substep loop
+        wall_cut = r + safety + a.wall_efolds * fmaxf(Pm[2], obs_type == 1 ? Pm[4] : 0.0f);
+        ko = Pm[7]; kd = Pm[8]; alpha = Pm[9]; klam = Pm[10];
+        dt_m = a.dt / m;                        // (F / m) * dt             (:277,:282)
+        inv_alpha = 1.0f / alpha;
+        inertia = 0.5f * m * r * r;             // :265
+        dt_inertia = a.dt / inertia;            // (torque / I) * dt        (:279)
+        if constexpr (!N3L || PP) sp = make_socp(sraw);
+        g0x = gl[0]; g0y = gl[1];
+        // goal lists of <= 2 entries (every Gym scenario) rotate in registers; longer ones go through memory
+        gk = a.G;
+        for (int g = a.G - 1; g >= 2; --g)
+            if (isnan(gi[2 * g]) || isnan(gi[2 * g + 1])) gk = g;
+        if (a.G >= 2 && (isnan(gl[2]) || isnan(gl[3]))) gk = 1;
+        if (isnan(gl[0]) || isnan(gl[1])) gk = 0;
+        if (gk == 2) { g1x = gl[2]; g1y = gl[3]; }
+    }
+    const bool respawn_here = valid && (!has_wflags || (wflag_raw & 1));
 
-    // robot action (held for the whole block, social_nav_gym.py:240-243)
-    const bool robot_moves = a.action != nullptr; // (lean build: only the invisible robot of the epilogue)
-    float ax = 0, ay = 0;
-    if (valid && robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
     auto robot_step = [&]() { // robot_agent.py:114-136
         if (a.flags & CS_ROBOT_UNICYCLE) {
             float c, s;
@@ -208,11 +255,6 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     // and one float2 slot per lane for the terms.
     float4* lds_rob = reinterpret_cast<float4*>(lds_vr);
     float2* lds_rf = reinterpret_cast<float2*>(lds_g0x);
-    float rm_hm = 0.0f, rm_fdx = 0.0f, rm_fdy = 0.0f;
-    if constexpr (IMIT) {
-        if (human) rm_hm = a.rm_hmargin[sidx];
-        if (is_robot) { rm_fdx = a.rm_memory[(long)w * 2]; rm_fdy = a.rm_memory[(long)w * 2 + 1]; }
-    }
 
     // ---- cs_gym_step: the head of the Gym step, on the rows as they came in (social_nav_gym.py:229-233) -- the swept robot-human
     //      distances by the humans' lanes, then the lane of row 0 walks its world's in index order and does the episode bookkeeping
@@ -220,15 +262,10 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     if constexpr (MAXT == 64) {
         if (a.gym.out != nullptr) {
             float* clo = lds_g0x;                              // [T] (the block-respawn scratch: unused by a block of one wavefront)
-            float rpx = 0, rpy = 0, rr = 0, rgx = 0, rgy = 0, gax = 0, gay = 0;
-            if (valid) {
-                const float* rb = a.robot + (long)w * 13;      // the robot BEFORE its move of substep 1
-                rpx = rb[0]; rpy = rb[1]; rr = rb[8]; rgx = rb[10]; rgy = rb[11];
-                gax = a.action[(long)w * 2]; gay = a.action[(long)w * 2 + 1];
-            }
+            const float rpx = hrb[0], rpy = hrb[1], rr = hrb[2], rgx = hrb[3], rgy = hrb[4], gax = hact[0], gay = hact[1];   // (loaded at the top)
             clo[tid] = human ? gym_swept_closest(px, py, vx, vy, r, rpx, rpy, rr, gax, gay, a.gym.T) : INFINITY;
             LDS_ORDER_FENCE();
-            if (valid && row == 0) gym_head_world(a.gym, w, n, clo + base, rpx, rpy, rr, rgx, rgy, gax, gay);
+            if (valid && row == 0) gym_head_world(a.gym, w, n, clo + base, rpx, rpy, rr, rgx, rgy, gax, gay, hpre);
             LDS_ORDER_FENCE();
         }
     }

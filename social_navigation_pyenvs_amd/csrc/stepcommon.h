@@ -177,17 +177,29 @@ struct SocP {
     float cg, c1, c2;     // Moussaid: log2(e) / gamma, -ns1^2 log2(e), -ns^2 log2(e)
 };
 
-__device__ __forceinline__ SocP load_socp(const float* P)
+// the social-force entries of a parameter row as loaded (no arithmetic: a caller issues its other loads before it uses them) ...
+struct SocRaw { float v[11]; };   // P[1], [3], [5], [7], [9], [10] .. [15]
+__device__ __forceinline__ SocRaw load_socraw(const float* P)
+{
+    SocRaw q;
+    q.v[0] = P[1]; q.v[1] = P[3]; q.v[2] = P[5]; q.v[3] = P[7]; q.v[4] = P[9];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) q.v[5 + k] = P[10 + k];
+    return q;
+}
+// ... and the derived constants of the pair loop
+__device__ __forceinline__ SocP make_socp(const SocRaw& q)
 {
     SocP s;
-    s.Ai = P[1]; s.cB = LOG2E / P[3]; s.Ci = P[5]; s.cD = LOG2E / P[7]; s.Ei = P[9];
-    s.k1 = P[10]; s.k2 = P[11]; s.lam = P[12]; s.gam = P[13]; s.ns = P[14]; s.ns1 = P[15];
+    s.Ai = q.v[0]; s.cB = LOG2E / q.v[1]; s.Ci = q.v[2]; s.cD = LOG2E / q.v[3]; s.Ei = q.v[4];
+    s.k1 = q.v[5]; s.k2 = q.v[6]; s.lam = q.v[7]; s.gam = q.v[8]; s.ns = q.v[9]; s.ns1 = q.v[10];
     s.lA = log2f(fabsf(s.Ai)); s.sA = copysignf(1.0f, s.Ai);
     s.lC = log2f(fabsf(s.Ci)); s.sC = copysignf(1.0f, s.Ci);
     s.sAC = s.sA * s.sC;
     s.cg = LOG2E / s.gam; s.c1 = -(s.ns1 * s.ns1) * LOG2E; s.c2 = -(s.ns * s.ns) * LOG2E;
     return s;
 }
+__device__ __forceinline__ SocP load_socp(const float* P) { return make_socp(load_socraw(P)); }
 
 // forces_parallel.py:120-130 / :72-83 -- Moussaid force on (pi, vi) from (pj, vj); `skip` marks the
 // lane's own row / padding.  rij = r_i + r_j + safety_i + safety_j.

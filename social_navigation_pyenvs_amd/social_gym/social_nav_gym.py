@@ -491,95 +491,53 @@ class BatchedSocialNavGym:
                                 d_terminated=terminated.data_ptr(), d_truncated=truncated.data_ptr(), d_info=info.data_ptr(),
                                 seed_stride=dl["stride"])
 
-    def _step_graph(self, dl, parity, auto_reset):
-        r"""One vectorised Gym step as ONE HIP graph of library launches on ONE stream (captured once per result set):
+    def _step_pieces(self, dl, parity, mode):
+        r"""One vectorised Gym step = TWO library launches on ONE stream, every ctypes argument bound once per (result set, mode):
 
             cs_gym_step (reward + bookkeeping in the step kernel's prologue, substeps, observation)  ->  cs_consume_staged_worlds
 
         Which worlds end is known from the reward of the state BEFORE the substeps (social_nav_gym.py:229-233); their next episode
         was generated ahead (its seed is the live one + stride), so the reset is a masked copy.  The regeneration of the consumed
         staging slots (one latency-bound wavefront per world, ~0.15 ms) runs on a side stream with a whole episode to finish
-        (_maybe_refill) -- round 3 had it on the critical path (144 us per step) or beside the next step (NEXT_STEP mode, 88 us)."""
+        (_maybe_refill) -- round 3 had it on the critical path (144 us per step) or beside the next step (NEXT_STEP mode, 88 us).
+
+        mode "same_step": the worlds whose episode ends NOW take over their staged episode before the observation is returned;
+        mode "next_step" (Gymnasium's default since 1.0): the bookkeeping of this parity writes mask_p and reads prev = mask_{1-p};
+        the tail resets the worlds that ended in the PREVIOUS step; mode "none": no tail.
+
+        Plain launches, not a HIP graph: two consecutive replays of a graph leave the stream idle for 8.5 us (rocprofv3 kernel trace,
+        profiles/r4ae_gym_step_timeline.txt: 8.6 us between the consume kernel of one replay and the step kernel of the next, 8.4 us
+        between one-kernel graphs) where two plain launches follow each other within 0.3 us -- with two launches per step the graph
+        saves the host nothing it needs (28 us of host time per step against 44 us on the GPU)."""
         import ctypes as C
 
-        key = ("graph", parity, bool(auto_reset))
+        key = ("pieces", parity, mode)
         if key in dl:
             return dl[key]
-        cw, lib = self.cw, _lib.load()
-        A = dl["stream"].cuda_stream
-        d = cw.descriptor()
-        cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
-        act = dl["act"]
-        with _lib.Graph.capture(A) as graph:
-            # cs_gym_step: reward of the state before the substeps + typed results, step counter, float32 clock, reset mask and next seeds
-            # (the head: the step kernel's prologue), the substeps, and the observation of the stepped crowd from the kernel's
-            # registers -- ONE launch (round 3: cs_collision_reward_gym ; cs_step_observe, a graph node more on the critical path) ...
-            book = self._gym_book(dl, parity, dl["mask"], None, auto_reset)
-            _lib.check(lib.cs_gym_step(C.byref(d), C.c_float(self.time_step), C.c_int(self.time_step_factor), C.c_void_p(act.data_ptr()),
-                                       C.c_float(self.robot_time_step), C.c_void_p(dl["gtime"].data_ptr()), cfg, C.c_void_p(dl["out"].data_ptr()),
-                                       C.byref(book), C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()), C.c_void_p(A)))
-            if auto_reset:
-                # ... rewritten for the worlds that take over their staged episode (a world whose generation failed keeps its rows
-                # and is flagged in reset_failed_mask())
-                _lib.check(lib.cs_consume_staged_worlds(C.byref(dl["gen"]), C.byref(dl["staging_desc"]), C.byref(d), C.c_void_p(dl["mask"].data_ptr()),
-                                                        C.byref(dl["stage_book"]), C.c_int(int(self.headed_obs)), C.c_void_p(dl["obs"].data_ptr()),
-                                                        C.c_void_p(A)))
-        dl[key] = graph
-        return graph
-
-    def _next_step_pieces(self, dl, parity):
-        """NEXT_STEP autoreset (Gymnasium's default since 1.0): this parity's two launches with every ctypes argument bound once.
-        step = cs_gym_step (reward + the NEXT_STEP bookkeeping: mask_p, prev = mask_{1-p}; the substeps; the observation);
-        tail = cs_consume_staged_worlds(mask_{1-p}): the worlds that ended in the PREVIOUS step take over their staged episode."""
-        import ctypes as C
-
-        key = ("ns", parity)
-        if key in dl:
-            return dl[key]
-        cw, lib = self.cw, _lib.load()
+        cw = self.cw
         A = C.c_void_p(dl["stream"].cuda_stream)
         d = cw.descriptor()
         dref = C.byref(d)
         cfg = (C.c_float * 5)(*[float(x) for x in self.reward_cfg])
-        act, masks = dl["act"], dl["ns_masks"]
         P = lambda t: C.c_void_p(t.data_ptr())
-        book = self._gym_book(dl, parity, masks[parity], masks[parity ^ 1], True)
-        a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(act), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg,
+        if mode == "next_step":
+            masks = dl["ns_masks"]
+            book = self._gym_book(dl, parity, masks[parity], masks[parity ^ 1], True)
+            tail_mask = masks[parity ^ 1]
+        else:
+            book = self._gym_book(dl, parity, dl["mask"], None, mode == "same_step")
+            tail_mask = dl["mask"] if mode == "same_step" else None
+        # cs_gym_step: reward of the state before the substeps + typed results, step counter, float32 clock, reset mask and next seeds
+        # (the head: the step kernel's prologue), the substeps, and the observation of the stepped crowd from the kernel's registers
+        a_step = (dref, C.c_float(self.time_step), C.c_int(self.time_step_factor), P(dl["act"]), C.c_float(self.robot_time_step), P(dl["gtime"]), cfg,
                   P(dl["out"]), C.byref(book), C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
-        a_tail = (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), dref, P(masks[parity ^ 1]), C.byref(dl["stage_book"]),
-                  C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
+        # ... rewritten for the worlds that take over their staged episode (a world whose generation failed keeps its rows and is
+        # flagged in reset_failed_mask())
+        a_tail = None if tail_mask is None else (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), dref, P(tail_mask), C.byref(dl["stage_book"]),
+                                                 C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
         keep = (d, cfg, book)              # the structs the byref arguments point into
         dl[key] = dict(step=a_step, tail=a_tail, keep=keep)
         return dl[key]
-
-    def _step_device_next_step(self, dl, actions):
-        """One step in NEXT_STEP autoreset mode.  A world that ended at step t returns its terminal observation at t and the first
-        observation of its next episode -- with reward 0 and no termination -- at t + 1, taken over from the staging batch at the end
-        of step t + 1."""
-        import torch
-
-        if "ns_masks" not in dl:
-            W = self.W
-            dl["ns_masks"] = [torch.zeros(W, dtype=torch.int32, device="cuda") for _ in range(2)]
-            torch.cuda.synchronize()
-        parity = dl["parity"]
-        dl["parity"] ^= 1
-        c = self._next_step_pieces(dl, parity)
-        lib, chk = _lib.load(), _lib.check
-        side, cur = dl["stream"], torch.cuda.current_stream()
-        same = cur.cuda_stream == side.cuda_stream
-        if not same:
-            side.wait_stream(cur)
-        if actions is not dl["act"]:
-            with torch.cuda.stream(side):
-                dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
-        chk(lib.cs_gym_step(*c["step"]))                             # reward of the state before the substeps, who ends now / who is being reset; the 20 fused substeps + the observation
-        chk(lib.cs_consume_staged_worlds(*c["tail"]))                # the worlds that ended in the PREVIOUS step: their next episode, observation rows included
-        self._maybe_refill(dl)
-        if not same:
-            cur.wait_stream(side)
-        reward, terminated, truncated, info = dl["results"][parity]
-        return dl["obs"], reward, terminated, truncated, info
 
     def step_device(self, actions, auto_reset=True):
         """``step`` without leaving the GPU: ``actions`` is a float32 torch CUDA tensor [W, 2] (holonomic vx, vy) -- or
@@ -587,21 +545,25 @@ class BatchedSocialNavGym:
         terminated [W], truncated [W], info_code [W]); obs is a persistent buffer rewritten by the next call, the other four
         alternate between two sets (those of the previous step stay valid for one more call).
         With ``auto_reset=True`` the worlds whose episode ended take over their next episode -- generated ahead on the device from
-        the next unused seed -- before the observation is taken (same-step autoreset); the whole step is one replay of a HIP graph
-        (``_step_graph``).  ``auto_reset="next_step"`` is Gymnasium's NEXT_STEP mode: a finished world returns its terminal observation
-        and spends the next step being reset (reward 0, not terminated)."""
+        the next unused seed -- before the observation is taken (same-step autoreset).  ``auto_reset="next_step"`` is Gymnasium's
+        NEXT_STEP mode: a world that ended at step t returns its terminal observation at t and the first observation of its next
+        episode -- with reward 0 and no termination -- at t + 1, taken over from the staging batch at the end of step t + 1.
+        ``auto_reset=False``: no resets (a finished world keeps stepping)."""
         import torch
 
         dl = self._device_loop_state()
-        if auto_reset == "next_step":
-            dl["mode"] = "next_step"
-            return self._step_device_next_step(dl, actions)
-        if dl.get("mode") == "next_step" and "ns_masks" in dl and any(bool(m.any().item()) for m in dl["ns_masks"]):
+        mode = "next_step" if auto_reset == "next_step" else ("same_step" if auto_reset else "none")
+        if mode == "next_step":
+            if "ns_masks" not in dl:
+                dl["ns_masks"] = [torch.zeros(self.W, dtype=torch.int32, device="cuda") for _ in range(2)]
+                torch.cuda.synchronize()
+        elif dl.get("mode") == "next_step" and "ns_masks" in dl and any(bool(m.any().item()) for m in dl["ns_masks"]):
             raise RuntimeError("a NEXT_STEP auto-reset is pending for some world: keep auto_reset=\"next_step\" (or reset()) before changing the mode")
-        dl["mode"] = "same_step" if auto_reset else "none"
+        dl["mode"] = mode
         parity = dl["parity"]
         dl["parity"] ^= 1
-        graph = self._step_graph(dl, parity, auto_reset)
+        c = self._step_pieces(dl, parity, mode)
+        lib, chk = _lib.load(), _lib.check
         side, cur = dl["stream"], torch.cuda.current_stream()
         same = cur.cuda_stream == side.cuda_stream   # the caller already works on the library's stream (`with torch.cuda.stream(env.device_stream())`)
         if not same:
@@ -609,8 +571,9 @@ class BatchedSocialNavGym:
         if actions is not dl["act"]:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
-        graph.launch()
-        if auto_reset:
+        chk(lib.cs_gym_step(*c["step"]))
+        if c["tail"] is not None:
+            chk(lib.cs_consume_staged_worlds(*c["tail"]))
             self._maybe_refill(dl)
         if not same:
             cur.wait_stream(side)                  # ... and with whoever reads the results

@@ -38,15 +38,16 @@ if model == "orca":
     for _ in range(warm):
         cw.step(0.0125, 20)
     cw.sync()
-    _lib.check(_lib.load().cs_memset(C.c_void_p(buf.ptr), C.c_int(0), C.c_size_t(buf.nbytes), C.c_void_p(cw.stream)))
+    # the kernel WRITES its wavefronts' stamps (it does not add to the buffer): one download per launch, summed here
+    st = np.zeros((gg, 8), np.float64)
     for _ in range(steps):
         cw.step(0.0125, 20)
-    cw.sync()
-    st = buf.download().astype(np.float64)
+        cw.sync()
+        st += buf.download().astype(np.float64)
     names = ["pre (robot/loads)", "neighbour selection", "ORCA lines", "LP2 (+LP1)", "LP3", "update+goal+respawn", "-", "-"]
     tot = st.sum(1).mean()
     sub = 20 * steps
-    print(f"ORCA N={n} W={W}, Gym steps {warm}..{warm + steps}: mean wave cycles per substep {tot / sub:.0f} (s_memtime ticks; the stamps drain the pipes: shares, not absolute costs)")
+    print(f"ORCA N={n} W={W}, Gym steps {warm}..{warm + steps}: mean wave cycles per substep {tot / sub:.0f} (s_memtime ticks = shader clocks; the stamps drain the pipes: shares, not absolute costs)")
     for k, nm in enumerate(names):
         print(f"  {nm:28s} {st[:, k].mean() / sub:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
     sys.exit(0)
