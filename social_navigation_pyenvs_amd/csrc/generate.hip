@@ -649,7 +649,6 @@ struct StageArgs {
 };
 
 __device__ __forceinline__ uint32_t load_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t load_acquire(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
 // side stream.  Slot s = j * W + w holds the episode of world w that belongs in ring position j now: the one e in (epoch, epoch + depth]
@@ -691,19 +690,23 @@ __global__ __launch_bounds__(64) void k_refill_staged(const StageArgs a)
 }
 
 // the step's stream: a finished world takes over its staged episode -- or, if the refill has not got to it yet, is generated in place.
-// One block per world (4096 workgroups, most of which read one integer and leave: 8 us): the refill's small grid was tried here too -- 64
-// masks per wavefront, its finished worlds copied one after the other -- and cost 13 us more per Gym step (a wavefront with three ends copies serially).
+// One block per world (4096 workgroups, most of which read one integer and leave: 2.9 us when nobody ends; tools/consume_probe.py): the
+// refill's small grid was tried here too -- 64 masks per wavefront, its finished worlds copied one after the other -- and cost 13 us more
+// per Gym step (a wavefront with three ends copies serially).
+// No acquire / release pair here: an acquire at device scope invalidates this XCD's L2 and a release writes all of it back, each time a
+// world ends, beside the step kernels.  The slot is read with device-scope relaxed loads instead (they miss a stale L2 line by themselves),
+// after the tag -- a control dependency --, and the epoch is stored after the loads have returned (the barrier waits for them): all the
+// refill needs to know before it overwrites the slot is that nobody reads it any more.
 __global__ __launch_bounds__(64) void k_consume_staged(const StageArgs a)
 {
     const int w = blockIdx.x, lane = threadIdx.x;
-    if (!a.mask[w]) return;                                                    // block-uniform
+    if (!a.mask[w]) return;                                                    // block-uniform (seed and epoch requested with the mask: +2 us for the 4000 blocks that leave here)
     const uint32_t want = a.seeds[w];                                          // the seed the bookkeeping moved this world to
     const uint32_t e = a.epoch[w] + 1u;                                        // (only this kernel writes the epochs)
     const long slot = (long)(e & (uint32_t)(a.depth - 1)) * a.W + w;
     int status;
-    if (load_acquire(a.staged_seed + slot) == want) {
-        status = a.staged_status[slot];
-        if (status == 0) csimpl::copy_world(a.copy, slot, w, lane);
+    if (load_relaxed(a.staged_seed + slot) == want) {                          // written LAST by the refill, behind a release of the slot's words
+        status = csimpl::copy_world<true>(a.copy, slot, w, lane, a.staged_status + slot);   // (the status word comes with the first batch)
     } else {
         int scenario = 0;
         status = generate_world_wave(a.g, a.live, w, lane, want, scenario);
@@ -716,9 +719,9 @@ __global__ __launch_bounds__(64) void k_consume_staged(const StageArgs a)
         }
     }
     if (lane == 0) a.failed[w] = status != 0 ? 1 : 0;
-    __syncthreads();
+    __syncthreads();                                                           // every lane's loads of the slot have returned
     // LAST: from here on the refill may overwrite the slot (it now belongs to episode e + depth)
-    if (lane == 0) store_release(a.epoch + w, e);
+    if (lane == 0) __hip_atomic_store(a.epoch + w, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int fill_gen_out(const cs_worlds* w, GenOut& o)
