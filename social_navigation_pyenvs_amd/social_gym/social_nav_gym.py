@@ -597,7 +597,7 @@ class BatchedSocialNavGym:
         return self._device_loop_state()["stream"]
 
     def action_buffer(self):
-        """The persistent [W, 2] action tensor the step graph reads: write actions into it and pass it to ``step_device``."""
+        """The persistent [W, 2] action tensor the step kernel reads: write actions into it and pass it to ``step_device``."""
         return self._device_loop_state()["act"]
 
     def lookahead_device(self, action_space):
