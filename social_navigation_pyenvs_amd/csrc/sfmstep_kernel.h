@@ -595,15 +595,27 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     const float inv = rsq_fast(bcl);
                     const float dist = best * inv;
                     const float nx = bdx * inv, ny = bdy * inv;
-                    const float dv = -(cvy * nx - cvx * ny);                 // -(v . t), t = (-ny, nx)
                     const float rd = r - dist + safety;
-                    const float m0 = fmaxf(0.0f, r - dist_refined(bcl, inv) + safety);
-                    const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
-                    float ft;                                                 // coefficient of t
-                    if (obs_type == 0) ft = -(k2 * m0) * dv;
-                    else ft = (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
-                    fox += fn * nx - ft * ny;
-                    foy += fn * ny + ft * nx;
+                    // Helbing walls: the body-contact terms (k1, k2; the refined distance, the tangential velocity) are exact zeros
+                    // unless somebody overlaps the polygon -- a wave vote, with a millimetre of margin for the unrefined distance; the
+                    // short branch leaves the same bits as the long one with m0 = 0 (fn = A e + k1 0, ft = -(k2 0) dv = -+0: the
+                    // products rounded once, then the sums).  8192 x 50 + 3 polygons: 221.5 -> 215.5 us
+                    if (obs_type != 0 || __builtin_amdgcn_ballot_w64(rd > -1.0e-3f) != 0) {
+                        const float dv = -(cvy * nx - cvx * ny);                 // -(v . t), t = (-ny, nx)
+                        const float m0 = fmaxf(0.0f, r - dist_refined(bcl, inv) + safety);
+                        const float fn = fmaf(Aw, exp2_fast(rd * cBw), k1 * m0);
+                        float ft;                                                 // coefficient of t
+                        if (obs_type == 0) ft = -(k2 * m0) * dv;
+                        else ft = (-Cw * exp2_fast(rd * cDw) - k2 * m0) * dv;
+                        fox += fn * nx - ft * ny;
+                        foy += fn * ny + ft * nx;
+                    } else {
+#pragma clang fp contract(off)
+                        const float fn = Aw * exp2_fast(rd * cBw);
+                        const float tx = fn * nx, ty = fn * ny;   // (not contracted into the sums: the long branch rounds the products too)
+                        fox = fox + tx;
+                        foy = foy + ty;
+                    }
                 }
                 fox *= inv_O; foy *= inv_O;
             }
