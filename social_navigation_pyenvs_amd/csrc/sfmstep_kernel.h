@@ -865,6 +865,42 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 if constexpr (SOC != 2) {
                     fsx *= sp.sA; fsy *= sp.sA;
                     if (__builtin_amdgcn_ballot_w64(rdmax > -my_rs) != 0) { // contact somewhere in this wavefront
+#ifdef CS_STAMPS
+                        st_acc[11] += 1000;   // (diagnostic: how often the contact pass runs, per mille of the substeps)
+#endif
+                        if constexpr (!PP) {
+                            // Equal parameters: every term of the all-partners sum below is an exact zero except those of the rows that
+                            // touch somebody, so only those rows are gone through -- as SOURCES, broadcast from their lane's registers (the
+                            // published position and, here, velocity of a row ARE its lane's registers), every lane of the world adding its
+                            // own term from the source in the order of the loop it replaces (increasing row): the same bits, ~25 instructions
+                            // per touching row instead of 16 x rows.  The launch waits for the wavefront that takes this path.
+                            auto bcast = [](float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); };
+                            // S: the lower ends of the overlapping pairs (they saw it in the pair loop); T: S and whoever overlaps one of S
+                            unsigned long long T2 = __builtin_amdgcn_ballot_w64(rdmax > -my_rs);
+                            for (unsigned long long m2 = T2; m2 != 0; m2 &= m2 - 1) {
+                                const int sa = __builtin_ctzll(m2);
+                                const float ax_ = bcast(px, sa), ay_ = bcast(py, sa), ars = bcast(my_rs, sa);
+                                const float dx = px - ax_, dy = py - ay_, lim = my_rs + ars + 1.0e-3f;
+                                const bool same = sa >= base && sa < base + rows && sa != tid;
+                                T2 |= __builtin_amdgcn_ballot_w64(same && fmaf(dx, dx, dy * dy) < lim * lim);
+                            }
+                            for (unsigned long long m2 = T2; m2 != 0; m2 &= m2 - 1) {
+                                const int sa = __builtin_ctzll(m2);
+                                const float4 q = make_float4(bcast(px, sa), bcast(py, sa), bcast(my_rs, sa), 0.0f);
+                                const float2 vj = make_float2(bcast(vx, sa), bcast(vy, sa));
+                                const bool same = sa >= base && sa < base + rows && sa != tid;
+                                const float dx = px - q.x, dy = py - q.y;
+                                const float d2 = fmaf(dx, dx, dy * dy);
+                                const float inv = rsq_fast(d2);
+                                const float m0 = fmaxf(0.0f, (my_rs + q.z) - dist_refined(d2, inv));
+                                const float nx = dx * inv, ny = dy * inv;
+                                const float dv = (vj.y - vy) * nx - (vj.x - vx) * ny;     // (v_j - v_i) . t
+                                const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;
+                                const float tx = fn * nx - ft * ny, ty = fn * ny + ft * nx;
+                                fsx += same ? tx : 0.0f;
+                                fsy += same ? ty : 0.0f;
+                            }
+                        } else {
                         const float4* pp = lds_p + cur * TP + pbase;
                         float2* pvel = lds_v + cur * TP + pbase;
                         if constexpr (VEL_ON_DEMAND) {
@@ -874,8 +910,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                         // per-agent parameters: my refreshed velocity, partner j < i refreshed, j > i stored (prange == range order)
                         const float vix = PP ? cvx : vx, viy = PP ? cvy : vy;
                         const float2* vr = lds_vr + cur * T + base;
-#pragma nounroll
-                        for (int j = 0; j < rows; ++j) { // rare path: keep it small in the instruction cache
+#pragma unroll 8
+                        for (int j = 0; j < rows; ++j) { // rare path, but the launch waits for the wavefront that takes it: eight partner rows requested per trip
                             const float4 q = pp[j];
                             float2 vj = pvel[j];
                             if constexpr (PP && HEADED > 0) { if (j < row) vj = vr[j]; }
@@ -888,6 +924,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                             const float fn = sp.k1 * m0, ft = (sp.k2 * m0) * dv;
                             fsx += fn * nx - ft * ny;
                             fsy += fn * ny + ft * nx;
+                        }
                         }
                     }
                 }
@@ -1066,10 +1103,19 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                     const int c = __builtin_popcountll(fm & wm & ((1ull << tid) - 1ull));
                     const float4* pvn = lds_p + nxt * TP + pbase;
                     float mx = pvn[0].x, mr = pvn[0].z;
-#pragma nounroll
-                    for (int j = 1; j < n; ++j) {
-                        mx = fmaxf(mx, pvn[j].x);
-                        mr = fmaxf(mr, pvn[j].z);
+                    // (the rows requested together -- all of them when the row count is a compile-time constant, eight per trip otherwise:
+                    // one at a time was 24 dependent LDS round trips per respawn, and the launch waits for its slowest wavefront: 31.1 -> 29.9 us at cfg3)
+                    if constexpr (ROWS_CT > 0 && ROWS_CT <= 32) {
+#pragma unroll
+                        for (int j = 1; j < ROWS_CT; ++j) {
+                            if (j < n) { mx = fmaxf(mx, pvn[j].x); mr = fmaxf(mr, pvn[j].z); }
+                        }
+                    } else {
+#pragma unroll 8
+                        for (int j = 1; j < n; ++j) {
+                            mx = fmaxf(mx, pvn[j].x);
+                            mr = fmaxf(mr, pvn[j].z);
+                        }
                     }
                     if (robot_row) { // consider_robot: the robot where it stands in THIS substep
                         const float4 qr = lds_p[cur * TP + pbase + n];

@@ -63,13 +63,20 @@ g, b, wpb = cw.launch_geometry()
 buf = _lib.DeviceBuffer((g * (b // 64), 12), np.uint64)
 lib = _lib.load()
 lib.cs_debug_set_stamp_buffer(C.c_void_p(buf.ptr))
-for _ in range(5):
+# STAMP_WARMUP Gym steps first, then the stamps of STAMP_STEPS launches summed (the kernel overwrites its buffer: one download per launch)
+warm, steps = int(os.environ.get("STAMP_WARMUP", "0")), int(os.environ.get("STAMP_STEPS", "5"))
+for _ in range(warm):
     cw.step(0.0125, 20)
 cw.sync()
-st = buf.download().astype(np.float64)
+st = np.zeros((g * (b // 64), 12), np.float64)
+for _ in range(steps):
+    cw.step(0.0125, 20)
+    cw.sync()
+    st += buf.download().astype(np.float64)
+st /= steps
 names = ["goal switch", "rot+desired+walls", "pair-once: contact pass/ballot", "torque+euler+lds write", "barrier", "respawn check", "all-partners pair loop (not pair-once)", "loop top",
-         "pair-once: zero accumulators", "pair-once: partner groups", "pair-once: reaction sum", "-"]
+         "pair-once: zero accumulators", "pair-once: partner groups", "pair-once: reaction sum", "contact passes per 1000 wavefront-substeps (a count, not cycles)"]
 tot = st.sum(1).mean()
-print(f"N={n} {model}: mean wave cycles in loop = {tot:.0f} (per substep {tot / 20:.0f})")
+print(f"N={n} {model}, Gym steps {warm}..{warm + steps}: mean wave cycles in loop = {tot:.0f} (per substep {tot / 20:.0f})")
 for k, nm in enumerate(names):
     print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
