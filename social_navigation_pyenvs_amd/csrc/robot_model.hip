@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
     const bool pre = a.snap != nullptr && a.n <= 64;
     float4 qpre = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (pre && lane < a.n) qpre = a.snap[(long)w * a.n + lane];
+    // radius + margins of "my" human never change during the launch (worlds of up to 64 humans: one per lane): loaded once, not in every
+    // substep behind a dependent global load
+    float rij_lane = 0.0f;
+    if (a.n <= 64 && lane < a.n) rij_lane = rme + a.S[((long)w * a.rows + lane) * a.as + 8 * a.fs] + a.hmargin[(long)w * a.rows + lane];
     for (int sub = 0; sub < a.nsub; ++sub) {
     float4 qnext = qpre;
     if (pre && lane < a.n && sub + 1 < a.nsub) qnext = a.snap[((long)(sub + 1) * a.W + w) * a.n + lane];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         if (pre) { hx = qpre.x; hy = qpre.y; hvx = qpre.z; hvy = qpre.w; }
         else if (a.snap != nullptr) { const float4 q = a.snap[((long)sub * a.W + w) * a.n + j]; hx = q.x; hy = q.y; hvx = q.z; hvy = q.w; }
         else { hx = s[0]; hy = s[a.fs]; hvx = s[3 * a.fs]; hvy = s[4 * a.fs]; }
-        const float rij = rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + j];
+        const float rij = a.n <= 64 ? rij_lane : rme + s[8 * a.fs] + a.hmargin[(long)w * a.rows + j];
         float tx, ty;
         rmodel::pair_term(soc, P, r.px, r.py, r.vx, r.vy, hx, hy, hvx, hvy, rij, tx, ty);
         fsx += tx; fsy += ty;
@@ -115,7 +119,8 @@ __global__ __launch_bounds__(256) void k_robot_model_step(const RArgs a)
         s_term[wv][lane] = make_float2(fsx, fsy);        // (lanes >= n hold zeros and are not read)
         asm volatile("" ::: "memory");                    // one wavefront: its LDS operations execute in order
         float sx = 0.0f, sy = 0.0f;
-        for (int j = 0; j < a.n; ++j) { const float2 t = s_term[wv][j]; sx += t.x; sy += t.y; }
+#pragma unroll 8
+        for (int j = 0; j < a.n; ++j) { const float2 t = s_term[wv][j]; sx += t.x; sy += t.y; }   // (eight terms requested per trip; summed in index order)
         asm volatile("" ::: "memory");
         fsx = sx; fsy = sy;
     } else {

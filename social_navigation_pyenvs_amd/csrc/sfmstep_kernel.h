@@ -443,8 +443,8 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             if (is_robot) {
                 float sx = 0.0f, sy = 0.0f;
                 const float2* tf = lds_rf + base;
-#pragma nounroll
-                for (int j = 0; j < n; ++j) { const float2 t = tf[j]; sx += t.x; sy += t.y; }
+#pragma unroll 8
+                for (int j = 0; j < n; ++j) { const float2 t = tf[j]; sx += t.x; sy += t.y; }   // (eight terms requested per trip; summed in index order)
                 rmodel::integrate(rs, a.rm_type, a.rm_P, sx, sy, 0.0f, 0.0f, rsn, rcs, dt, 0);
                 px = rs.px; py = rs.py; th = rs.yaw; vx = rs.vx; vy = rs.vy; bvx = rs.bvx; bvy = rs.bvy; om = rs.om;
                 rm_fdx = rs.fdx; rm_fdy = rs.fdy;
