@@ -378,6 +378,8 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float)) + 16 + (size_t)(a.seg_tab > 0 ? a.seg_tab / w->Smax : 0) * sizeof(float4);
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    // two one-wavefront blocks per SIMD (the benchmark's 4096 x 25): the second half of the grid shares each SIMD with an older wavefront
+    a.young_from = (g.block == 64 && g.grid == 2 * csimpl::device_simds()) ? g.grid / 2 : 0x7fffffff;
     hipLaunchKernelGGL(fn, dim3(g.grid), dim3(g.block), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;

@@ -69,6 +69,7 @@ struct OArgs {
     // motion_model_manager.py:241): [W][rows][4] or null = the four scalars for everyone (what the reference passes: ORCA_DEFAULTS).
     // K above is then the largest maxNeighbors (the LDS columns are laid out for it); such worlds take the generic solve.
     const float* agent_params;
+    int young_from;        // blocks from this index on are the YOUNGER wavefront of their SIMD (a grid of exactly two per SIMD; sfmstep_kernel.h), INT_MAX: no split
 };
 
 __device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
@@ -887,7 +888,9 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(g_ost_last)::"memory");
 #endif
     int cur = 0;
+    const bool prio_young = MAXT == 64 && (int)blockIdx.x >= a.young_from;   // (of two ready wavefronts of equal priority the arbiter issues the older: the younger takes every other substep)
     for (int sub = 0; sub < a.nsub; ++sub) {
+        if constexpr (MAXT == 64) { if (prio_young) { if (sub & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
         const int nxt = cur ^ 1;
         if (valid && robot_moves && (is_robot || (!robot_row && row == 0))) { // robot.step(action, dt) (holonomic)
             rbx += ax * dt; rby += ay * dt; rbvx = ax; rbvy = ay;
@@ -1539,6 +1542,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
     a.lp3_static = (T > 64 || (lp3_env && std::strcmp(lp3_env, "static") == 0)) ? 1 : 0;
     const size_t shmem = orca_block_shmem(w, a.lp3_static != 0);
+    a.young_from = (T == 64 && grid == 2 * csimpl::device_simds()) ? grid / 2 : 0x7fffffff;
     auto launch = [&](auto kernel) -> int {
         if (shmem > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));

@@ -379,7 +379,14 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             }
         }
     }
+    // Two wavefronts share a SIMD at the benchmark's 4096 worlds, and of two ready wavefronts of equal priority the arbiter issues the OLDER:
+    // the first half of the grid finished its 20 substeps 16 % ahead of the second (s_memtime stamps: two classes of exactly 1024
+    // wavefronts), which then ran its last three substeps alone, at a lone wavefront's latency-bound pace.  The younger wavefront of a
+    // SIMD (a.young_from, set by the launcher for a grid of exactly two per SIMD) raises its priority in every other substep: the two
+    // take turns and finish within 3 % of each other (31.1 -> 29.4 us with the short rare paths, -> 28.3 us with this).
+    const bool prio_young = MAXT == 64 && (int)blockIdx.x >= a.young_from;
     for (int sub = 0; sub < a.nsub; ++sub) {
+        if constexpr (MAXT == 64) { if (prio_young) { if (sub & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
         const int nxt = cur ^ 1;
         STAMP(7);
         if (a.snap != nullptr || a.trace != nullptr) {   // (one scalar branch for both recorders: neither is on in a plain cs_step)

@@ -51,6 +51,7 @@ struct KArgs {
     const float* rm_hmargin; // [W][rows] the humans' safety space as the robot's model sees it
     float* rm_memory;      // [W][2] robot.desired_force between substeps
     float rm_P[20];        // the robot's parameters
+    int young_from;        // blocks from this index on are the YOUNGER wavefront of their SIMD (a grid of exactly two wavefronts per SIMD), INT_MAX: no such split
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     unsigned long long* stamps; // diagnostic build only
     GymHead gym;           // cs_gym_step: reward / termination of the incoming state + episode bookkeeping in the prologue (gym.out == nullptr: none)

@@ -50,6 +50,8 @@ if model == "orca":
     print(f"ORCA N={n} W={W}, Gym steps {warm}..{warm + steps}: mean wave cycles per substep {tot / sub:.0f} (s_memtime ticks = shader clocks; the stamps drain the pipes: shares, not absolute costs)")
     for k, nm in enumerate(names):
         print(f"  {nm:28s} {st[:, k].mean() / sub:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
+    per_wave = st.sum(1)
+    print(f"  the launch waits for its slowest wavefront: slowest / mean wavefront = {per_wave.max() / per_wave.mean():.3f}, 99th percentile / mean = {np.percentile(per_wave, 99) / per_wave.mean():.3f}")
     sys.exit(0)
 if len(sys.argv) > 4 and sys.argv[4] in ("circle", "walls"):   # cfg2-style: circular crossing only, no respawn rule; "walls": cfg5-style
     pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
@@ -80,3 +82,7 @@ tot = st.sum(1).mean()
 print(f"N={n} {model}, Gym steps {warm}..{warm + steps}: mean wave cycles in loop = {tot:.0f} (per substep {tot / 20:.0f})")
 for k, nm in enumerate(names):
     print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
+per_wave = st[:, :11].sum(1)
+print(f"  the launch waits for its slowest wavefront: slowest / mean wavefront = {per_wave.max() / per_wave.mean():.3f}, 99th percentile / mean = {np.percentile(per_wave, 99) / per_wave.mean():.3f}")
+if os.environ.get("STAMP_DUMP"):
+    np.save(os.environ["STAMP_DUMP"], st)
