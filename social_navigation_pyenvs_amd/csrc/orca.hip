@@ -889,8 +889,9 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
 #endif
     int cur = 0;
     const bool prio_young = MAXT == 64 && (int)blockIdx.x >= a.young_from;   // (of two ready wavefronts of equal priority the arbiter issues the older: the younger takes every other substep)
+    if constexpr (MAXT == 64) __builtin_amdgcn_s_setprio(1);   // (base priority 1: above the generator's wavefronts of a refill pass, sfmstep_kernel.h)
     for (int sub = 0; sub < a.nsub; ++sub) {
-        if constexpr (MAXT == 64) { if (prio_young) { if (sub & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
+        if constexpr (MAXT == 64) { if (prio_young) { if (sub & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); } }
         const int nxt = cur ^ 1;
         if (valid && robot_moves && (is_robot || (!robot_row && row == 0))) { // robot.step(action, dt) (holonomic)
             rbx += ax * dt; rby += ay * dt; rbvx = ax; rbvy = ay;

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
     constexpr bool EVEN = (ROWS % 2) == 0;        // even worlds: plus the antipodal partner, evaluated by both ends
     constexpr int KMAX = EVEN ? ROWS / 2 : HF;
     const int tid = threadIdx.x, r = tid & 15;
+    __builtin_amdgcn_s_setprio(1);   // (base priority 1: above the generator's wavefronts of a refill pass, sfmstep_kernel.h)
     const int w = blockIdx.x * 4 + (tid >> 4);
     const bool inw = w < a.W;
     const bool human = inw && r < ROWS;

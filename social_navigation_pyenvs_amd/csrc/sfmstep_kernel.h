@@ -383,10 +383,13 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     // the first half of the grid finished its 20 substeps 16 % ahead of the second (s_memtime stamps: two classes of exactly 1024
     // wavefronts), which then ran its last three substeps alone, at a lone wavefront's latency-bound pace.  The younger wavefront of a
     // SIMD (a.young_from, set by the launcher for a grid of exactly two per SIMD) raises its priority in every other substep: the two
-    // take turns and finish within 3 % of each other (31.1 -> 29.4 us with the short rare paths, -> 28.3 us with this).
+    // take turns (priority 2 / 1) and finish within 3 % of each other (31.1 -> 29.4 us with the short rare paths, -> 28.3 us with this).
     const bool prio_young = MAXT == 64 && (int)blockIdx.x >= a.young_from;
+    // base priority 1: above the generator's wavefronts of a refill pass on the side stream (priority 0, and OLDER than any of mine, so a tie
+    // would go to them): the Gym step in NEXT_STEP mode 43.3 -> 41.5 us, a plain launch unchanged
+    if constexpr (MAXT == 64) __builtin_amdgcn_s_setprio(1);
     for (int sub = 0; sub < a.nsub; ++sub) {
-        if constexpr (MAXT == 64) { if (prio_young) { if (sub & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); } }
+        if constexpr (MAXT == 64) { if (prio_young) { if (sub & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); } }
         const int nxt = cur ^ 1;
         STAMP(7);
         if (a.snap != nullptr || a.trace != nullptr) {   // (one scalar branch for both recorders: neither is on in a plain cs_step)
