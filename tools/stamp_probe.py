@@ -52,6 +52,10 @@ if model == "orca":
         print(f"  {nm:28s} {st[:, k].mean() / sub:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
     per_wave = st.sum(1)
     print(f"  the launch waits for its slowest wavefront: slowest / mean wavefront = {per_wave.max() / per_wave.mean():.3f}, 99th percentile / mean = {np.percentile(per_wave, 99) / per_wave.mean():.3f}")
+    h = len(per_wave) // 2
+    print(f"  second half of the grid (the younger wavefront of each SIMD) / first half: {per_wave[h:].mean() / per_wave[:h].mean():.3f}")
+    if os.environ.get("STAMP_DUMP"):
+        np.save(os.environ["STAMP_DUMP"], st)
     sys.exit(0)
 if len(sys.argv) > 4 and sys.argv[4] in ("circle", "walls"):   # cfg2-style: circular crossing only, no respawn rule; "walls": cfg5-style
     pos, yaw, g = sc.circular_crossing(W, n, 7.0, 1000)
@@ -84,5 +88,6 @@ for k, nm in enumerate(names):
     print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
 per_wave = st[:, :11].sum(1)
 print(f"  the launch waits for its slowest wavefront: slowest / mean wavefront = {per_wave.max() / per_wave.mean():.3f}, 99th percentile / mean = {np.percentile(per_wave, 99) / per_wave.mean():.3f}")
+print(f"  second half of the grid (the younger wavefront of each SIMD) / first half: {per_wave[len(per_wave) // 2:].mean() / per_wave[:len(per_wave) // 2].mean():.3f}")
 if os.environ.get("STAMP_DUMP"):
     np.save(os.environ["STAMP_DUMP"], st)
