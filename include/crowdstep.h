@@ -491,6 +491,19 @@ int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_pe
  * with d_out != d_state, 2 = cs_peek.  buf receives e.g. "k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2". */
 int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen);
 
+/* The arithmetic of the register-resident ORCA build (k_orca_step<FAST10>: maxNeighbors = 10, no static obstacles, one RVO2
+ * parameter set -- what motion_model_manager.py:14, 237-246 always creates).  RVO2's linearProgram1 / 2 / 3 (reached through
+ * rvo2.PyRVOSimulator.doStep, motion_model_manager.py:387) divide and take square roots in float32:
+ *   0 "exact": correctly rounded divide / sqrt, no FMA contraction: bit-identical to oracle/orca_oracle.c (the reference build
+ *              of the bit-identity tests);
+ *   1 "fast":  v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp each);
+ *   2 "fma":   fast, and determinants / dot products as mul + fma.
+ * The mode holds for the process from the call on (-1 = back to CROWDSTEP_ORCA_MATH=exact|fast|fma, else the library default;
+ * DESIGN.md 4.2a).  North-star parity for ORCA is 1e-5 per step on positions / velocities, not bits.  The generic ORCA builds
+ * (other maxNeighbors, static obstacles, per-agent parameters, the grid path, the robot's own ORCA model) are always exact. */
+int cs_orca_set_math(int mode);
+int cs_orca_get_math(void);
+
 /* Diagnostic: the ORCA kernels' correctly rounded divide / square root sequences (csrc/orca.hip ieee_div, ieee_sqrt: the
  * compiler's FMA sequences without the exponent-range handling) against the compiler's operators on n_pairs random operand
  * pairs of the linear programmes' range.  h_out[0], h_out[1] = number of quotients / roots that differ in any bit (must be 0),

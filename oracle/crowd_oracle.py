@@ -310,6 +310,26 @@ def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot
     return S, goals, robot
 
 
+def orca_step_block_f64(S, goals, margin, dt, n_substeps, neighbor_dist=10.0, max_nb=10, time_horizon=5.0, threads=0):
+    """orca_step_block with the restatement instantiated in DOUBLE (oracle/orca_oracle_f64.c): the algorithm without float32
+    rounding, from the same (float32-valued) rows.  A classification aid for tests/orca_fast_parity.py, not a second reference:
+    RVO2 itself is float32.  Plain crowd batches only (no robot, no obstacles, no respawn).  Returns (S, goals) as float64."""
+    S = np.ascontiguousarray(S, dtype=np.float64).copy()
+    single = S.ndim == 2
+    if single:
+        S = S[None]
+    W, rows = S.shape[0], S.shape[1]
+    goals = np.ascontiguousarray(goals, dtype=np.float64).copy().reshape(W, rows, -1, 2)
+    G = goals.shape[2]
+    margin = np.ascontiguousarray(np.broadcast_to(np.asarray(margin, dtype=np.float64), (W, rows)))
+    fn = lib().orc64_orca_step_block_batched_pa
+    fn.restype = None
+    fn(C.c_int(W), _ptr(S, C.c_double), _ptr(goals, C.c_double), C.c_int(G), C.c_int(rows), C.c_int(0), _ptr(margin, C.c_double), None, None,
+       C.c_double(dt), C.c_int(n_substeps), C.c_double(neighbor_dist), C.c_int(max_nb), C.c_double(time_horizon), C.c_int(0),
+       C.c_double(0.0), C.c_double(0.0), C.c_int(threads), C.c_double(5.0), None, C.c_int(0), None)
+    return (S[0], goals[0]) if single else (S, goals)
+
+
 def effective_cores() -> int:
     """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows 256 logical CPUs
     and grants 16 through cpu.max: an OpenMP team of 256 only gets throttled, and costs ~0.1 s to spin up per call)."""

@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "cs_update_humans_rk45", "cs_gym_bookkeeping", "cs_step_variant", "cs_debug_divsqrt_check", "cs_gym_observe", "cs_copy_worlds_masked", "cs_imitation_block", "cs_gym_bookkeeping_next_step", "cs_robot_model_velocities",
     "cs_step_trace", "cs_reserve_scratch", "cs_release_scratch", "cs_complete_rk45_simulation", "cs_robot_model_rk45", "cs_copy_worlds_masked_status",
     "cs_collision_reward_gym", "cs_step_observe", "cs_copy_worlds_masked_observe", "cs_refill_staged_worlds", "cs_consume_staged_worlds", "cs_gym_step",
+    "cs_orca_set_math", "cs_orca_get_math",
 ]
 
 

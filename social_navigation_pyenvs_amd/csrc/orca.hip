@@ -69,6 +69,7 @@ struct OArgs {
     // motion_model_manager.py:241): [W][rows][4] or null = the four scalars for everyone (what the reference passes: ORCA_DEFAULTS).
     // K above is then the largest maxNeighbors (the LDS columns are laid out for it); such worlds take the generic solve.
     const float* agent_params;
+    int lp2_walk;          // diagnostic A/B switch: linearProgram2 with linearProgram1 inside the walk (the round-4 form) instead of up front
     int young_from;        // blocks from this index on are the YOUNGER wavefront of their SIMD (a grid of exactly two per SIMD; sfmstep_kernel.h), INT_MAX: no split
 };
 
@@ -104,6 +105,47 @@ __device__ __forceinline__ float ieee_sqrt(float x)
     const float ru = fmaf(-up, s, x);
     const float res = (ru > 0.0f) ? up : t;     // the root was rounded down, step up
     return (x == 0.0f) ? x : res;               // +-0 stay (s - 1 ulp of 0 is not a number to step to)
+}
+
+// ---- the arithmetic the register-resident build is instantiated with (template parameter FM of everything below) -------------
+// FM = 0: "exact": IEEE divide / square root, no FMA contraction -- the restatement's operations on the restatement's operands,
+//         bit-identical to oracle/orca_oracle.c (the bit-identity reference; CROWDSTEP_ORCA_MATH=exact / cs_orca_set_math(0)).
+// FM = 1: "fast": v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp each) instead of the 8- and 9-instruction correctly rounded sequences.
+// FM = 2: "fast + fma": and the 2 x 2 determinants, dot products and point + t * direction as mul + fma (one rounding less).
+// north_star asks for 1e-5 on positions / velocities per step, not for bits, and the restatement cannot be pinned on rvo2 anyway;
+// tests/test_gpu_orca_fast.py measures the fast builds per substep from re-synchronised state against the exact restatement and
+// accounts for every agent-substep beyond 1e-5.
+template <int FM> __device__ __forceinline__ float odiv(float a, float b)
+{
+    if constexpr (FM != 0) return a * __builtin_amdgcn_rcpf(b); else return ieee_div(a, b);
+}
+template <int FM> __device__ __forceinline__ float orcp(float b)
+{
+    if constexpr (FM != 0) return __builtin_amdgcn_rcpf(b); else return ieee_div(1.0f, b);
+}
+template <int FM> __device__ __forceinline__ float osqrt(float x)
+{
+    if constexpr (FM != 0) return __builtin_amdgcn_sqrtf(x); else return ieee_sqrt(x);
+}
+// 1 / sqrt(x): RVO2 normalises a vector by the reciprocal of its length (Vector2 / float)
+template <int FM> __device__ __forceinline__ float orsqrt(float x)
+{
+    if constexpr (FM != 0) return __builtin_amdgcn_rsqf(x); else return ieee_div(1.0f, ieee_sqrt(x));
+}
+// a.x * b.y - a.y * b.x
+template <int FM> __device__ __forceinline__ float odet(float ax, float ay, float bx, float by)
+{
+    if constexpr (FM >= 2) return fmaf(ax, by, -(ay * bx)); else return ax * by - ay * bx;
+}
+// a.x * b.x + a.y * b.y
+template <int FM> __device__ __forceinline__ float odot(float ax, float ay, float bx, float by)
+{
+    if constexpr (FM >= 2) return fmaf(ax, bx, ay * by); else return ax * bx + ay * by;
+}
+// p + t * d
+template <int FM> __device__ __forceinline__ float omad(float t, float d, float p)
+{
+    if constexpr (FM >= 2) return fmaf(t, d, p); else return p + t * d;
 }
 
 // per-lane column views into LDS: element i of lane tid lives at base[i * T + tid]
@@ -355,6 +397,9 @@ __device__ int obstacle_lines(const float* V, const int* oi, int no, int T, int 
 // on a leg, and the collision case (cut-off circle of the time step) -- each take one square root and one reciprocal of
 // different arguments; the arguments are selected first, so a lane pays one IEEE sqrt and one IEEE divide whatever cases the
 // wavefront mixes, with the very same operations on the very same operands as the case it is in.  invDt = 1 / timeStep.
+// (FM: the decisions -- collision, cut-off circle or leg, which leg -- are taken on the same uncontracted quantities in every build;
+//  only the root and the reciprocal differ.)
+template <int FM = 0>
 __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float vy, const float4 q, float R, float invT, float invDt)
 {
     const float rpx = q.x - px, rpy = q.y - py;
@@ -367,9 +412,11 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
     const float wLenSq = wx * wx + wy * wy;
     const float dot1 = wx * rpx + wy * rpy;
     const bool circ = coll || (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq);
-    const float root = ieee_sqrt(circ ? wLenSq : distSq - RSq);   // |w|  or  the leg length
+    const float root = osqrt<FM>(circ ? wLenSq : distSq - RSq);   // |w|  or  the leg length
     const float den = circ ? root : distSq;
-    const float inv = (den == 0.0f) ? INFINITY : ieee_div(1.0f, den);   // (w == 0 exactly: 1 / +0 as the operator gives it)
+    float inv;
+    if constexpr (FM != 0) inv = __builtin_amdgcn_rcpf(den);           // (v_rcp_f32(+0) = +inf)
+    else inv = (den == 0.0f) ? INFINITY : ieee_div(1.0f, den);          // (w == 0 exactly: 1 / +0 as the operator gives it)
     // cut-off circle (of the time horizon, or of the time step when the discs overlap)
     const float uwx = wx * inv, uwy = wy * inv;
     const float sc = R * kT - root;
@@ -388,13 +435,14 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
 // projected lines j < i and linearProgram2 / linearProgram1 over them are statically unrolled and guarded by the uniform j < i.
 // RVO2 drops a projected line whose source line is parallel to line i and points the same way: here it keeps its slot and a
 // cleared bit in `pvalid`, and every loop skips it, which visits the surviving lines in the same order.
+template <int FM>
 __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int failed, float vmax, float& rx, float& ry)
 {
     float distance = 0.0f;
 #pragma nounroll
     for (int i = 0; i < 10; ++i) {
         const float4 li = L.get(i);   // line i by its run-time index: from the LDS copy (a register array indexed at run time goes to scratch memory, ~10x the latency)
-        const bool act = (i >= failed) && (i < cnt) && (det2(li.z, li.w, li.x - rx, li.y - ry) > distance);
+        const bool act = (i >= failed) && (i < cnt) && (odet<FM>(li.z, li.w, li.x - rx, li.y - ry) > distance);
         if (__builtin_amdgcn_ballot_w64(act) == 0) continue;
         float4 Pr[9];
         unsigned pvalid = 0;
@@ -402,16 +450,15 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
         for (int j = 0; j < 9; ++j) {
             if (j < i) {
                 const float4 lj = Lr[j];
-                const float d = det2(li.z, li.w, lj.z, lj.w);
+                const float d = odet<FM>(li.z, li.w, lj.z, lj.w);
                 const bool par = fabsf(d) <= RVO_EPSILON;
-                const bool same = li.z * lj.z + li.w * lj.w > 0.0f;
-                const float s = ieee_div(det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y), d);
+                const bool same = odot<FM>(li.z, li.w, lj.z, lj.w) > 0.0f;
+                const float s = odiv<FM>(odet<FM>(lj.z, lj.w, li.x - lj.x, li.y - lj.y), d);
                 float4 ln;
-                ln.x = par ? 0.5f * (li.x + lj.x) : li.x + s * li.z;
-                ln.y = par ? 0.5f * (li.y + lj.y) : li.y + s * li.w;
+                ln.x = par ? 0.5f * (li.x + lj.x) : omad<FM>(s, li.z, li.x);
+                ln.y = par ? 0.5f * (li.y + lj.y) : omad<FM>(s, li.w, li.y);
                 const float ex = lj.z - li.z, ey = lj.w - li.w;
-                const float en = ieee_sqrt(ex * ex + ey * ey);
-                const float inv = ieee_div(1.0f, en);
+                const float inv = orsqrt<FM>(odot<FM>(ex, ey, ex, ey));
                 ln.z = ex * inv; ln.w = ey * inv;
                 Pr[j] = ln;
                 pvalid |= (par && same) ? 0u : (1u << j);
@@ -425,19 +472,19 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
         for (int k = 0; k < 9; ++k) {
             if (k < i) {
                 const float4 lk = Pr[k];
-                const bool viol = act && !fail2 && ((pvalid >> k) & 1u) && (det2(lk.z, lk.w, lk.x - qx, lk.y - qy) > 0.0f);
+                const bool viol = act && !fail2 && ((pvalid >> k) & 1u) && (odet<FM>(lk.z, lk.w, lk.x - qx, lk.y - qy) > 0.0f);
                 if (__builtin_amdgcn_ballot_w64(viol) != 0) { // linearProgram1(projLines, k, ...)
-                    const float dot = lk.x * lk.z + lk.y * lk.w;
-                    const float disc = dot * dot + vmax * vmax - (lk.x * lk.x + lk.y * lk.y);
+                    const float dot = odot<FM>(lk.x, lk.y, lk.z, lk.w);
+                    const float disc = dot * dot + vmax * vmax - odot<FM>(lk.x, lk.y, lk.x, lk.y);
                     bool ok = !(disc < 0.0f);
-                    const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
+                    const float sq = osqrt<FM>(fmaxf(disc, 0.0f));
                     float tL = -dot - sq, tR = -dot + sq;
 #pragma unroll
                     for (int m = 0; m < k; ++m) {   // branch-free: the divisions of all m are independent and overlap
                         const float4 lm = Pr[m];
-                        const float den = det2(lk.z, lk.w, lm.z, lm.w);
-                        const float num = det2(lm.z, lm.w, lk.x - lm.x, lk.y - lm.y);
-                        const float t = ieee_div(num, den);
+                        const float den = odet<FM>(lk.z, lk.w, lm.z, lm.w);
+                        const float num = odet<FM>(lm.z, lm.w, lk.x - lm.x, lk.y - lm.y);
+                        const float t = odiv<FM>(num, den);
                         const bool live = ((pvalid >> m) & 1u) != 0;
                         const bool par = fabsf(den) <= RVO_EPSILON;
                         const bool upd = live && !par && ok;             // (after a failure RVO2 has already returned)
@@ -445,10 +492,10 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
                         tR = upd ? nR : tR; tL = upd ? nL : tL;
                         ok = ok && !(live && par && num < 0.0f) && !(upd && tL > tR);
                     }
-                    const float t = (ox * lk.z + oy * lk.w > 0.0f) ? tR : tL;
+                    const float t = (odot<FM>(ox, oy, lk.z, lk.w) > 0.0f) ? tR : tL;
                     const bool set = viol && ok;
-                    qx = set ? lk.x + t * lk.z : qx;
-                    qy = set ? lk.y + t * lk.w : qy;
+                    qx = set ? omad<FM>(t, lk.z, lk.x) : qx;
+                    qy = set ? omad<FM>(t, lk.w, lk.y) : qy;
                     fail2 = fail2 || (viol && !ok);
                 }
             }
@@ -456,7 +503,7 @@ __device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int 
         const bool take = act && !fail2;           // a failed linearProgram2 leaves the result where it was
         rx = take ? qx : rx;
         ry = take ? qy : ry;
-        distance = act ? det2(li.z, li.w, li.x - rx, li.y - ry) : distance;
+        distance = act ? odet<FM>(li.z, li.w, li.x - rx, li.y - ry) : distance;
     }
 }
 
@@ -523,7 +570,7 @@ __device__ __forceinline__ void row_minmax8(float& mn, float& mx)
 // (Measured and rejected: a group that keeps its agent for ALL its violated lines instead of one per round -- the wavefront then waits
 //  for the longest chain of the eight agents of a pass while the other groups idle: 512 -> 548 us in the dense phase of cfg4; re-dealing
 //  the agents that still have a violated line every round packs the groups densely.)
-template <int RW>
+template <int RW, int FM>
 __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int npend)
 {
     constexpr int GROUPS = 64 / RW;
@@ -541,23 +588,22 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
         const float4 lj = L.p[jj * TL + a];
         const bool task = rowvalid && j < lv;
         // RVO2 linearProgram3: line j projected on line i
-        const float d = det2(li.z, li.w, lj.z, lj.w);
+        const float d = odet<FM>(li.z, li.w, lj.z, lj.w);
         const bool par = fabsf(d) <= RVO_EPSILON;
-        const bool same = li.z * lj.z + li.w * lj.w > 0.0f;
-        const float sp = ieee_div(det2(lj.z, lj.w, li.x - lj.x, li.y - lj.y), d);
+        const bool same = odot<FM>(li.z, li.w, lj.z, lj.w) > 0.0f;
+        const float sp = odiv<FM>(odet<FM>(lj.z, lj.w, li.x - lj.x, li.y - lj.y), d);
         float4 pr;
-        pr.x = par ? 0.5f * (li.x + lj.x) : li.x + sp * li.z;
-        pr.y = par ? 0.5f * (li.y + lj.y) : li.y + sp * li.w;
+        pr.x = par ? 0.5f * (li.x + lj.x) : omad<FM>(sp, li.z, li.x);
+        pr.y = par ? 0.5f * (li.y + lj.y) : omad<FM>(sp, li.w, li.y);
         const float ex = lj.z - li.z, ey = lj.w - li.w;
-        const float en = ieee_sqrt(ex * ex + ey * ey);
-        const float inv = ieee_div(1.0f, en);
+        const float inv = orsqrt<FM>(odot<FM>(ex, ey, ex, ey));
         pr.z = ex * inv; pr.w = ey * inv;
         const bool live = task && !(par && same);   // RVO2 drops a parallel line that points the same way
         // what linearProgram1 computes from this line alone, should it become the violated one: the circle's chord
         const float vm = qa.z;
-        const float dot = pr.x * pr.z + pr.y * pr.w;
-        const float disc = dot * dot + vm * vm - (pr.x * pr.x + pr.y * pr.y);
-        const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
+        const float dot = odot<FM>(pr.x, pr.y, pr.z, pr.w);
+        const float disc = dot * dot + vm * vm - odot<FM>(pr.x, pr.y, pr.x, pr.y);
+        const float sq = osqrt<FM>(fmaxf(disc, 0.0f));
         const float2 aux = (disc < 0.0f) ? make_float2(INFINITY, -INFINITY) : make_float2(-dot - sq, -dot + sq);
         if (task) { R.P[jj * 8 + slot] = pr; R.A[jj * 8 + slot] = aux; }
         // linearProgram2(projLines, radius, (-dir.y, dir.x), directionOpt = true) starts on the circle
@@ -568,7 +614,7 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
         ORCA_LDS_FENCE();
 #pragma nounroll
         for (int it = 0; it < 9; ++it) {
-            const bool viol = live && !done && (j > k) && (det2(pr.z, pr.w, pr.x - qx, pr.y - qy) > 0.0f);
+            const bool viol = live && !done && (j > k) && (odet<FM>(pr.z, pr.w, pr.x - qx, pr.y - qy) > 0.0f);
             const unsigned long long vmask = __builtin_amdgcn_ballot_w64(viol);
             if (vmask == 0) break;
             const unsigned rb = (unsigned)(vmask >> grp_sh) & ((1u << RW) - 1u);
@@ -579,9 +625,9 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
             const float2 ak = R.A[kk * 8 + slot];
             // linearProgram1(projLines, kk, ...): lane j < kk evaluates line j against line kk
             const bool in = live && (j < kk);
-            const float den = det2(lk.z, lk.w, pr.z, pr.w);
-            const float num = det2(pr.z, pr.w, lk.x - pr.x, lk.y - pr.y);
-            const float t = ieee_div(num, den);
+            const float den = odet<FM>(lk.z, lk.w, pr.z, pr.w);
+            const float num = odet<FM>(pr.z, pr.w, lk.x - pr.x, lk.y - pr.y);
+            const float t = odiv<FM>(num, den);
             const bool parl = fabsf(den) <= RVO_EPSILON;
             // a parallel earlier line with this line on its wrong side fails linearProgram1 outright: it enters the
             // reduction as the empty interval (tR = -inf, tL = +inf), which the tL > tR test below turns into the failure
@@ -591,18 +637,18 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
             if constexpr (RW == 16) row_minmax16(rmin, rmax); else row_minmax8(rmin, rmax);
             const float tR = fminf(ak.y, rmin), tL = fmaxf(ak.x, rmax);
             const bool ok = !(tL > tR);
-            const float tt = (ox * lk.z + oy * lk.w > 0.0f) ? tR : tL;
+            const float tt = (odot<FM>(ox, oy, lk.z, lk.w) > 0.0f) ? tR : tL;
             const bool run = any && !done;
             const bool set = run && ok, bad = run && !ok;
-            qx = set ? lk.x + tt * lk.z : qx;
-            qy = set ? lk.y + tt * lk.w : qy;
+            qx = set ? omad<FM>(tt, lk.z, lk.x) : qx;
+            qy = set ? omad<FM>(tt, lk.w, lk.y) : qy;
             k = set ? kk : k;
             fail2 = fail2 || bad;                               // linearProgram2 failed: LP3 keeps the old result
             done = done || bad;
         }
         const bool take = rowvalid && !fail2;
         const float nrx = take ? qx : qa.x, nry = take ? qy : qa.y;
-        const float ndist = det2(li.z, li.w, li.x - nrx, li.y - nry);
+        const float ndist = odet<FM>(li.z, li.w, li.x - nrx, li.y - nry);
         if (rowvalid && j == 0) R.q[a] = make_float4(nrx, nry, qa.z, ndist);
         ORCA_LDS_FENCE();
     }
@@ -613,6 +659,7 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
 // A round serves every agent's next violated line: those at levels 0 .. 8 (the lines j < 8 fit half a row) eight agents per pass on
 // 8-lane groups, those at level 9 (an agent with ten neighbours whose LAST line is violated: needs nine projected lines) four per
 // pass on whole rows.  Round 3: with rows of 16 for everybody a pass served four agents and nine of its sixteen lanes at most.
+template <int FM>
 __device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R, int cnt, int failed, float vmax, float& rx, float& ry)
 {
     const int me = L.tid;
@@ -626,7 +673,7 @@ __device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R
 #pragma unroll
         for (int i = 9; i >= 0; --i) {
             const float4 li = Lr[i];
-            const bool v = (i >= next_i) && (i < cnt) && (det2(li.z, li.w, li.x - rx, li.y - ry) > distance);
+            const bool v = (i >= next_i) && (i < cnt) && (odet<FM>(li.z, li.w, li.x - rx, li.y - ry) > distance);
             lvl = v ? i : lvl;
         }
         const bool pending = lvl >= 0;
@@ -641,7 +688,7 @@ __device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R
                 R.sel[wbase + rank] = me | (lvl << 16);
             }
             ORCA_LDS_FENCE();
-            lp3_serve<8>(L, R, __builtin_popcountll(ma));
+            lp3_serve<8, FM>(L, R, __builtin_popcountll(ma));
         }
         if (mb != 0) {
             ORCA_LDS_FENCE();
@@ -650,7 +697,7 @@ __device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R
                 R.sel[wbase + rank] = me | (lvl << 16);
             }
             ORCA_LDS_FENCE();
-            lp3_serve<16>(L, R, __builtin_popcountll(mb));
+            lp3_serve<16, FM>(L, R, __builtin_popcountll(mb));
         }
         if (pending) {
             const float4 qo = R.q[me];
@@ -685,8 +732,8 @@ __device__ __forceinline__ double key_sentinel() { return __hiloint2double(0x7F7
 
 // From the ten neighbour keys on: ORCA lines, linearProgram2, linearProgram3.  fetch(b, q, rad): (x, y, vx, vy) and radius +
 // margin of row b (LDS rows of the world in the crowd kernel, global rows found through the grid in the big-world kernel).
-template <class Fetch>
-__device__ void orca_solve_fast10(bool active, bool lp3_static, const double (&key)[10], int row, Fetch&& fetch, float px, float py, float vx,
+template <int FM, class Fetch>
+__device__ void orca_solve_fast10(bool active, bool lp3_static, bool lp2_walk, const double (&key)[10], int row, Fetch&& fetch, float px, float py, float vx,
                                   float vy, float my_r, float vmax, float pvx, float pvy, float time_horizon, float dt, const Lines& L,
                                   const RowLds& R, float& nvx, float& nvy, unsigned long long* g_ost, unsigned long long& g_ost_last)
 {
@@ -705,48 +752,104 @@ __device__ void orca_solve_fast10(bool active, bool lp3_static, const double (&k
         float4 q;
         float rad;
         fetch(b, q, rad);
-        Lr[k] = orca_line(px, py, vx, vy, q, my_r + rad, invT, invDt);
+        Lr[k] = orca_line<FM>(px, py, vx, vy, q, my_r + rad, invT, invDt);
     }
 
     OSTAMP(2);
     // linearProgram2(lines, maxSpeed, prefVelocity, directionOpt = false)
     float rx, ry;
     if (pvx * pvx + pvy * pvy > vmax * vmax) {
-        const float nrm = ieee_sqrt(pvx * pvx + pvy * pvy);
-        const float inv = ieee_div(1.0f, nrm);
+        const float inv = orsqrt<FM>(pvx * pvx + pvy * pvy);
         rx = pvx * inv * vmax; ry = pvy * inv * vmax;
     } else { rx = pvx; ry = pvy; }
     int failed = cnt;
-    bool done = false;
-#pragma unroll
-    for (int i = 0; i < KF; ++i) {
-        const float4 ln = Lr[i];
-        const bool viol = !done && (i < cnt) && (det2(ln.z, ln.w, ln.x - rx, ln.y - ry) > 0.0f);
-        if (__builtin_amdgcn_ballot_w64(viol) != 0) { // linearProgram1(i) for the lanes that violate line i
-            const float dot = ln.x * ln.z + ln.y * ln.w;
-            const float disc = dot * dot + vmax * vmax - (ln.x * ln.x + ln.y * ln.y);
-            bool ok = !(disc < 0.0f);
-            const float sq = ieee_sqrt(fmaxf(disc, 0.0f));
-            float tL = -dot - sq, tR = -dot + sq;
-#pragma unroll
-            for (int j = 0; j < i; ++j) {   // branch-free: the divisions of all j are independent and overlap
-                const float4 lj = Lr[j];
-                const float den = det2(ln.z, ln.w, lj.z, lj.w);
-                const float num = det2(lj.z, lj.w, ln.x - lj.x, ln.y - lj.y);
-                const float t = ieee_div(num, den);
-                const bool par = fabsf(den) <= RVO_EPSILON;
-                const bool upd = !par && ok;                     // (after a failure RVO2 has already returned)
-                const float nR = (den >= 0.0f) ? fminf(tR, t) : tR, nL = (den >= 0.0f) ? tL : fmaxf(tL, t);
-                tR = upd ? nR : tR; tL = upd ? nL : tL;
-                ok = ok && !(par && num < 0.0f) && !(upd && tL > tR);   // parallel and on the wrong side, or an empty interval
+    if (lp2_walk) {
+        // (A/B switch CROWDSTEP_ORCA_LP2=walk: the round-4 form -- linearProgram1(i) evaluated inside the walk, where a lane of the
+        //  wavefront violates line i)
+        bool done = false;
+    #pragma unroll
+        for (int i = 0; i < KF; ++i) {
+            const float4 ln = Lr[i];
+            const bool viol = !done && (i < cnt) && (odet<FM>(ln.z, ln.w, ln.x - rx, ln.y - ry) > 0.0f);
+            if (__builtin_amdgcn_ballot_w64(viol) != 0) { // linearProgram1(i) for the lanes that violate line i
+                const float dot = odot<FM>(ln.x, ln.y, ln.z, ln.w);
+                const float disc = dot * dot + vmax * vmax - odot<FM>(ln.x, ln.y, ln.x, ln.y);
+                bool ok = !(disc < 0.0f);
+                const float sq = osqrt<FM>(fmaxf(disc, 0.0f));
+                float tL = -dot - sq, tR = -dot + sq;
+    #pragma unroll
+                for (int j = 0; j < i; ++j) {   // branch-free: the divisions of all j are independent and overlap
+                    const float4 lj = Lr[j];
+                    const float den = odet<FM>(ln.z, ln.w, lj.z, lj.w);
+                    const float num = odet<FM>(lj.z, lj.w, ln.x - lj.x, ln.y - lj.y);
+                    const float t = odiv<FM>(num, den);
+                    const bool par = fabsf(den) <= RVO_EPSILON;
+                    const bool upd = !par && ok;                     // (after a failure RVO2 has already returned)
+                    const float nR = (den >= 0.0f) ? fminf(tR, t) : tR, nL = (den >= 0.0f) ? tL : fmaxf(tL, t);
+                    tR = upd ? nR : tR; tL = upd ? nL : tL;
+                    ok = ok && !(par && num < 0.0f) && !(upd && tL > tR);   // parallel and on the wrong side, or an empty interval
+                }
+                float t = odot<FM>(ln.z, ln.w, pvx - ln.x, pvy - ln.y);
+                t = (t < tL) ? tL : ((t > tR) ? tR : t);
+                const bool set = viol && ok, bad = viol && !ok;
+                rx = set ? omad<FM>(t, ln.z, ln.x) : rx;
+                ry = set ? omad<FM>(t, ln.w, ln.y) : ry;
+                failed = bad ? i : failed;
+                done = done || bad;
             }
-            float t = ln.z * (pvx - ln.x) + ln.w * (pvy - ln.y);
-            t = (t < tL) ? tL : ((t > tR) ? tR : t);
-            const bool set = viol && ok, bad = viol && !ok;
-            rx = set ? ln.x + t * ln.z : rx;
-            ry = set ? ln.y + t * ln.w : ry;
-            failed = bad ? i : failed;
-            done = done || bad;
+        }
+    } else {
+        // linearProgram1(i) does not depend on the point linearProgram2 has reached -- only on line i, the lines j < i, the speed
+        // circle and the preferred velocity: its interval [tL, tR], its failure and the point it returns are functions of the LINES.
+        // So they are evaluated for every i up front, as one block of independent arithmetic (45 pair bodies + 10 chords with no
+        // branch, vote or select chain between them: the two wavefronts of a SIMD overlap their latencies), and the walk over the
+        // violated lines is ten short steps.  The operations on the path RVO2 takes are the same on the same operands: tL only
+        // grows and tR only shrinks, so RVO2's early exits (an empty interval after some j; a parallel line on the wrong side) equal
+        // the tests on the final interval, and min / max are exact in any order.  In the dense phase of a crossing 99.8 % of the
+        // agents violate a line and a wavefront of 50 agents enters linearProgram1 for nearly every i anyway (round 3).
+        bool anyviol = false;
+#pragma unroll
+        for (int i = 0; i < KF; ++i) anyviol = anyviol || ((i < cnt) && (odet<FM>(Lr[i].z, Lr[i].w, Lr[i].x - rx, Lr[i].y - ry) > 0.0f));
+        if (__builtin_amdgcn_ballot_w64(anyviol) != 0) {   // (nobody violates a line at the preferred velocity: it is everybody's result)
+            float cx[KF], cy[KF];
+            unsigned okbits = 0;
+#pragma unroll
+            for (int i = 0; i < KF; ++i) {
+                const float4 ln = Lr[i];
+                const float dot = odot<FM>(ln.x, ln.y, ln.z, ln.w);
+                const float disc = dot * dot + vmax * vmax - odot<FM>(ln.x, ln.y, ln.x, ln.y);
+                const float sq = osqrt<FM>(fmaxf(disc, 0.0f));
+                float tL = -dot - sq, tR = -dot + sq;
+                bool failp = false;
+#pragma unroll
+                for (int j = 0; j < i; ++j) {
+                    const float4 lj = Lr[j];
+                    const float den = odet<FM>(ln.z, ln.w, lj.z, lj.w);
+                    const float num = odet<FM>(lj.z, lj.w, ln.x - lj.x, ln.y - lj.y);
+                    const float t = odiv<FM>(num, den);
+                    const bool right = den > RVO_EPSILON, left = den < -RVO_EPSILON;      // (neither: parallel, |den| <= RVO_EPSILON)
+                    tR = fminf(tR, right ? t : INFINITY);
+                    tL = fmaxf(tL, left ? t : -INFINITY);
+                    failp = failp || (!right && !left && num < 0.0f);
+                }
+                float t = odot<FM>(ln.z, ln.w, pvx - ln.x, pvy - ln.y);
+                t = (t < tL) ? tL : ((t > tR) ? tR : t);
+                cx[i] = omad<FM>(t, ln.z, ln.x);
+                cy[i] = omad<FM>(t, ln.w, ln.y);
+                okbits |= (!(disc < 0.0f) && !failp && !(tL > tR)) ? (1u << i) : 0u;
+            }
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < KF; ++i) {
+                const float4 ln = Lr[i];
+                const bool viol = !done && (i < cnt) && (odet<FM>(ln.z, ln.w, ln.x - rx, ln.y - ry) > 0.0f);
+                const bool ok = ((okbits >> i) & 1u) != 0;
+                const bool set = viol && ok, bad = viol && !ok;
+                rx = set ? cx[i] : rx;
+                ry = set ? cy[i] : ry;
+                failed = bad ? i : failed;
+                done = done || bad;
+            }
         }
     }
     OSTAMP(3);
@@ -756,8 +859,8 @@ __device__ void orca_solve_fast10(bool active, bool lp3_static, const double (&k
             for (int k = 0; k < KF; ++k) L.set(k, Lr[k]);
         }
         ORCA_LDS_FENCE();
-        if (lp3_static) lp3_fast10(Lr, L, cnt, failed, vmax, rx, ry);   // (A/B switch, CROWDSTEP_ORCA_LP3=static)
-        else lp3_rows(Lr, L, R, cnt, failed, vmax, rx, ry);
+        if (lp3_static) lp3_fast10<FM>(Lr, L, cnt, failed, vmax, rx, ry);   // (A/B switch, CROWDSTEP_ORCA_LP3=static)
+        else lp3_rows<FM>(Lr, L, R, cnt, failed, vmax, rx, ry);
     }
     OSTAMP(4);
     nvx = rx; nvy = ry;
@@ -765,7 +868,8 @@ __device__ void orca_solve_fast10(bool active, bool lp3_static, const double (&k
 
 //  The crowd kernel's form: the world's rows in LDS, brute-force walk in index order.
 //  Called by all 64 lanes of a wavefront (`active` = this lane holds an agent): linearProgram3 re-deals the lanes (lp3_rows).
-__device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
+template <int FM>
+__device__ void orca_velocity_fast10(bool active, bool lp3_static, bool lp2_walk, const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
                                      float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
                                      float time_horizon, float dt, const Lines& L, const RowLds& R, float& nvx, float& nvy,
                                      unsigned long long* g_ost, unsigned long long& g_ost_last)
@@ -804,12 +908,13 @@ __device__ void orca_velocity_fast10(bool active, bool lp3_static, const float4*
         for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
     }
     for (int b = b0; b < rows; ++b) key_insert10(key, candidate(b));
-    orca_solve_fast10(active, lp3_static, key, row, [&](int b, float4& q, float& rad) { q = pv[b]; rad = rr[b]; }, px, py, vx, vy, my_r, vmax,
+    orca_solve_fast10<FM>(active, lp3_static, lp2_walk, key, row, [&](int b, float4& q, float& rad) { q = pv[b]; rad = rr[b]; }, px, py, vx, vy, my_r, vmax,
                       pvx, pvy, time_horizon, dt, L, R, nvx, nvy, g_ost, g_ost_last);
 }
 
 // MAXT = 64: floor(64 / rows) worlds per one-wavefront block; MAXT = 256 / 512: one world of up to MAXT rows per block
-template <bool FAST10, int MAXT>
+// FM: the arithmetic of the register-resident build (0 exact / 1 fast / 2 fast + fma, see odiv above); the generic build is always exact
+template <bool FAST10, int MAXT, int FM = 0>
 __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -900,7 +1005,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
         if constexpr (FAST10) {
             // every lane of the wavefront takes part (linearProgram3 re-deals the lanes); lanes without a human carry no lines
             const int hb = human ? base : 0, hr = human ? row : 0;
-            orca_velocity_fast10(human, a.lp3_static != 0, lds_pv + cur * T + hb, lds_r + hb, rows, hr, px, py, vx, vy, r + margin, vmax, pvx, pvy,
+            orca_velocity_fast10<FM>(human, a.lp3_static != 0, a.lp2_walk != 0, lds_pv + cur * T + hb, lds_r + hb, rows, hr, px, py, vx, vy, r + margin, vmax, pvx, pvy,
                                  a.neighbor_dist, a.time_horizon, dt, L, RL, nvx, nvy, g_ost, g_ost_last);
         }
         if (human) {
@@ -959,7 +1064,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
             vx = nvx; vy = nvy;
             px += vx * dt; py += vy * dt;
             float ddx = g0x - px, ddy = g0y - py;
-            if (ieee_sqrt(ddx * ddx + ddy * ddy) < r) { // update_goals: strict <  (:66-70)
+            if (osqrt<FM>(ddx * ddx + ddy * ddy) < r) { // update_goals: strict <  (:66-70)
                 int k = a.G;
                 for (int g = 0; g < a.G; ++g) if (isnan(gi[2 * g])) { k = g; break; }
                 if (a.peek_out == nullptr) {
@@ -970,8 +1075,14 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
                 } else if (k > 1) { g0x = gi[2]; g0y = gi[3]; }
                 ddx = g0x - px; ddy = g0y - py;
             }
-            const float nrm = ieee_sqrt(ddx * ddx + ddy * ddy);
-            if (nrm > vmax) { pvx = ieee_div(ddx, nrm); pvy = ieee_div(ddy, nrm); } else { pvx = ddx; pvy = ddy; }
+            const float nrm = osqrt<FM>(ddx * ddx + ddy * ddy);
+            if constexpr (FM != 0) {
+                const float inrm = __builtin_amdgcn_rcpf(nrm);
+                const bool far = nrm > vmax;
+                pvx = far ? ddx * inrm : ddx; pvy = far ? ddy * inrm : ddy;
+            } else {
+                if (nrm > vmax) { pvx = ieee_div(ddx, nrm); pvy = ieee_div(ddy, nrm); } else { pvx = ddx; pvy = ddy; }
+            }
             lds_pv[nxt * T + tid] = make_float4(px, py, vx, vy);
         } else if (is_robot) {
             // set_state_orca(robot) AFTER doStep (:389): the simulator's robot agent takes the true state (moved by the
@@ -982,7 +1093,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
         __syncthreads();
         if (a.flags & CS_RESPAWN) { // motion_model_manager.py:407-422, sequential inside a world
             const float rdx = px - g0x, rdy = py - g0y;
-            const int flag = (human && respawn_here && ieee_sqrt(rdx * rdx + rdy * rdy) < 3.0f) ? 1 : 0;
+            const int flag = (human && respawn_here && osqrt<FM>(rdx * rdx + rdy * rdy) < 3.0f) ? 1 : 0;
             bool any_flag;
             if constexpr (MAXT == 64) any_flag = __builtin_amdgcn_ballot_w64(flag != 0) != 0;
             else any_flag = __syncthreads_or(flag) != 0;        // a world spans several wavefronts: block-wide vote
@@ -1173,7 +1284,7 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
     const Lines L{lds_ln, 64, tid};
     const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
     const int mt = mine ? tid : 0;                                    // all 64 lanes take part (lp3_rows re-deals them)
-    orca_velocity_fast10(mine, false, lds_pv + mt * ent, lds_rr + mt * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
+    orca_velocity_fast10<0>(mine, false, false, lds_pv + mt * ent, lds_rr + mt * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
                          a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
     if (!mine) return;
     vx = nvx; vy = nvy;
@@ -1278,7 +1389,7 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
         unsigned long long ost_last = 0;
         const Lines L{lds_ln, 64, tid};
         const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
-        orca_solve_fast10(human, a.lp3_static != 0, key, human ? i : 0,
+        orca_solve_fast10<0>(human, a.lp3_static != 0, false, key, human ? i : 0,
                           [&](int b, float4& q, float& rad) {
                               const float* sb = Sw + (long)b * a.as;
                               q = make_float4(sb[0], sb[fs], sb[3 * fs], sb[4 * fs]);
@@ -1416,6 +1527,28 @@ int big_world_min_rows(int dflt)
     return v < dflt ? (v < 1 ? 1 : v) : dflt;
 }
 
+// The arithmetic of the register-resident build (k_orca_step<FAST10 = true>): 0 exact (bit-identical to the restatement), 1 fast
+// (v_rcp / v_sqrt / v_rsq), 2 fast + fma.  cs_orca_set_math() sets it for the process; CROWDSTEP_ORCA_MATH=exact|fast|fma is read
+// once, at the first ORCA launch, when nobody has set it.  DESIGN.md 4.2a says which one is the default and why.
+static int g_orca_math = -1;
+constexpr int ORCA_MATH_DEFAULT = 0;
+int orca_math()
+{
+    if (g_orca_math < 0) {
+        const char* e = std::getenv("CROWDSTEP_ORCA_MATH");
+        int m = ORCA_MATH_DEFAULT;
+        if (e) m = std::strcmp(e, "exact") == 0 ? 0 : (std::strcmp(e, "fast") == 0 ? 1 : (std::strcmp(e, "fma") == 0 ? 2 : ORCA_MATH_DEFAULT));
+        g_orca_math = m;
+    }
+    return g_orca_math;
+}
+int orca_set_math(int mode)
+{
+    if (mode < -1 || mode > 2) return fail(CS_ERR_ARG, "ORCA arithmetic: 0 exact, 1 fast, 2 fast + fma (-1: back to the environment / default)");
+    g_orca_math = mode;
+    return CS_OK;
+}
+
 // dynamic LDS of the one-block kernel (k_orca_step) for these worlds: [2][T] rows + radii / respawn scratch, and either the
 // register-resident build's line copies (maxNeighbors = 10, no obstacles) or the generic build's per-agent columns
 static size_t orca_block_shmem(const cs_worlds* w, bool lp3_static)
@@ -1542,6 +1675,8 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     // worlds of more than 64 rows keep the statically unrolled walk (their blocks have no LDS left for the projected lines)
     const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
     a.lp3_static = (T > 64 || (lp3_env && std::strcmp(lp3_env, "static") == 0)) ? 1 : 0;
+    const char* lp2_env = std::getenv("CROWDSTEP_ORCA_LP2");
+    a.lp2_walk = (lp2_env && std::strcmp(lp2_env, "walk") == 0) ? 1 : 0;
     const size_t shmem = orca_block_shmem(w, a.lp3_static != 0);
     a.young_from = (T == 64 && grid == 2 * csimpl::device_simds()) ? grid / 2 : 0x7fffffff;
     auto launch = [&](auto kernel) -> int {
@@ -1551,9 +1686,17 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
         return CS_OK;
     };
     int rc;
-    if (T == 64) rc = fast10 ? launch(k_orca_step<true, 64>) : launch(k_orca_step<false, 64>);
-    else if (T == 256) rc = fast10 ? launch(k_orca_step<true, 256>) : launch(k_orca_step<false, 256>);
-    else rc = fast10 ? launch(k_orca_step<true, 512>) : launch(k_orca_step<false, 512>);
+    const int fm = fast10 ? orca_math() : 0;   // the generic build (other maxNeighbors, static obstacles, per-agent parameters) is always exact
+    if (T == 64) {
+        if (!fast10) rc = launch(k_orca_step<false, 64>);
+        else rc = fm == 0 ? launch(k_orca_step<true, 64, 0>) : (fm == 1 ? launch(k_orca_step<true, 64, 1>) : launch(k_orca_step<true, 64, 2>));
+    } else if (T == 256) {
+        if (!fast10) rc = launch(k_orca_step<false, 256>);
+        else rc = fm == 0 ? launch(k_orca_step<true, 256, 0>) : (fm == 1 ? launch(k_orca_step<true, 256, 1>) : launch(k_orca_step<true, 256, 2>));
+    } else {
+        if (!fast10) rc = launch(k_orca_step<false, 512>);
+        else rc = fm == 0 ? launch(k_orca_step<true, 512, 0>) : (fm == 1 ? launch(k_orca_step<true, 512, 1>) : launch(k_orca_step<true, 512, 2>));
+    }
     if (rc != CS_OK) return rc;
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -1569,7 +1712,8 @@ int orca_variant(const cs_worlds* w, char* buf, size_t buflen)
         std::snprintf(buf, buflen, "k_bw_orca_step<FAST10=%d> grid=(%d,%d) block=64 (one launch per substep)", fast10 ? 1 : 0, (rows + 63) / 64, w->W);
         return CS_OK;
     }
-    std::snprintf(buf, buflen, "k_orca_step<FAST10=%d,MAXT=%d> grid=%d block=%d wpb=%d", fast10 ? 1 : 0, T, (w->W + wpb - 1) / wpb, T, wpb);
+    std::snprintf(buf, buflen, "k_orca_step<FAST10=%d,MAXT=%d> grid=%d block=%d wpb=%d math=%s", fast10 ? 1 : 0, T, (w->W + wpb - 1) / wpb, T, wpb,
+                  !fast10 ? "exact" : (orca_math() == 0 ? "exact" : (orca_math() == 1 ? "fast" : "fma")));
     return CS_OK;
 }
 
@@ -1609,6 +1753,9 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
 }
 
 } // namespace csimpl
+
+extern "C" int cs_orca_set_math(int mode) { return csimpl::orca_set_math(mode); }
+extern "C" int cs_orca_get_math(void) { return csimpl::orca_math(); }
 
 extern "C" int cs_debug_divsqrt_check(unsigned long long n_pairs, unsigned seed, unsigned long long* h_out, void* stream)
 {
