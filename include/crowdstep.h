@@ -105,6 +105,9 @@ typedef struct cs_worlds {
 
 /* ---------------------------------------------------------------- runtime / memory helpers */
 const char* cs_last_error(void);
+/* The ABI this header describes.  A host binding must refuse a library whose cs_abi_version() differs: struct layouts (cs_worlds,
+ * cs_gym_book, cs_stage_book) and argument lists change between versions (social_navigation_pyenvs_amd/_lib.py load() does). */
+#define CS_ABI_VERSION 3
 int cs_abi_version(void);
 int cs_device_count(int* count);
 int cs_set_device(int device);

@@ -26,6 +26,8 @@ CS_ROBOT_UNICYCLE = 1 << 5
 CS_ORCA = 9
 CS_SOCIAL_MOMENTUM = 10
 
+ABI_VERSION = 3   # include/crowdstep.h CS_ABI_VERSION
+
 # every symbol include/crowdstep.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "cs_last_error", "cs_abi_version", "cs_device_count", "cs_set_device", "cs_device_name", "cs_device_pci_bus_id", "cs_malloc",
@@ -178,6 +180,10 @@ def load():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the crowd stepper.")
     _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
+    lib.cs_abi_version.restype = C.c_int
+    got = lib.cs_abi_version() if hasattr(lib, "cs_abi_version") else None
+    if got != ABI_VERSION:   # a stale or foreign build (CROWDSTEP_LIB): its structs and argument lists are not the ones bound here
+        raise CrowdstepError(f"{LIB_PATH} speaks ABI {got}, this binding ABI {ABI_VERSION} (include/crowdstep.h CS_ABI_VERSION): rebuild the library")
     lib.cs_last_error.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         if name != "cs_last_error" and hasattr(lib, name):

@@ -69,7 +69,6 @@ struct OArgs {
     // motion_model_manager.py:241): [W][rows][4] or null = the four scalars for everyone (what the reference passes: ORCA_DEFAULTS).
     // K above is then the largest maxNeighbors (the LDS columns are laid out for it); such worlds take the generic solve.
     const float* agent_params;
-    int lp2_walk;          // diagnostic A/B switch: linearProgram2 with linearProgram1 inside the walk (the round-4 form) instead of up front
     int young_from;        // blocks from this index on are the YOUNGER wavefront of their SIMD (a grid of exactly two per SIMD; sfmstep_kernel.h), INT_MAX: no split
 };
 
@@ -422,8 +421,11 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
     const float sc = R * kT - root;
     // legs
     const bool left = det2(rpx, rpy, wx, wy) > 0.0f;
-    const float lx = left ? (rpx * root - rpy * R) * inv : -(rpx * root + rpy * R) * inv;
-    const float ly = left ? (rpx * R + rpy * root) * inv : -(-rpx * R + rpy * root) * inv;
+    // RVO2: left leg (rp.x * leg - rp.y * R, rp.x * R + rp.y * leg) / distSq, right leg -(rp.x * leg + rp.y * R, -rp.x * R + rp.y * leg) / distSq:
+    // the right leg is the left one with -leg for leg, bit for bit (negation commutes with every rounding here)
+    const float sroot = left ? root : -root;
+    const float lx = (rpx * sroot - rpy * R) * inv;
+    const float ly = (rpx * R + rpy * sroot) * inv;
     const float dot2 = rvx * lx + rvy * ly;
     const float dx = circ ? uwy : lx, dy = circ ? -uwx : ly;
     const float ux = circ ? sc * uwx : dot2 * lx - rvx, uy = circ ? sc * uwy : dot2 * ly - rvy;
@@ -436,7 +438,7 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
 // RVO2 drops a projected line whose source line is parallel to line i and points the same way: here it keeps its slot and a
 // cleared bit in `pvalid`, and every loop skips it, which visits the surviving lines in the same order.
 template <int FM>
-__device__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int failed, float vmax, float& rx, float& ry)
+__device__ __forceinline__ void lp3_fast10(const float4 (&Lr)[10], const Lines& L, int cnt, int failed, float vmax, float& rx, float& ry)
 {
     float distance = 0.0f;
 #pragma nounroll
@@ -654,13 +656,17 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
     }
 }
 
+// (Round 5, measured and rejected: the same sub-phase with linearProgram1 evaluated for EVERY line k of the level up front -- one batch of
+//  LDS reads, a DPP reduction per k, then a lane-local walk with no vote or LDS access inside -- as linearProgram2 does below.  Bit-identical,
+//  and slower: 471 vs 404 us in the dense phase of cfg4 (fma arithmetic).  A level needs 3.1 linearProgram1 calls; evaluating all 8 costs more
+//  instructions than the serial chains cost in latency: the kernel is bound by instruction issue, not by those chains.  HISTORY.md.)
 // Called by ALL 64 lanes of a wavefront (lanes without an agent pass cnt = failed = 0).  Lr: the caller's ten lines (also
 // stored in L's column L.tid); on return (rx, ry) is linearProgram3's result for lanes with failed < cnt.
 // A round serves every agent's next violated line: those at levels 0 .. 8 (the lines j < 8 fit half a row) eight agents per pass on
 // 8-lane groups, those at level 9 (an agent with ten neighbours whose LAST line is violated: needs nine projected lines) four per
 // pass on whole rows.  Round 3: with rows of 16 for everybody a pass served four agents and nine of its sixteen lanes at most.
 template <int FM>
-__device__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R, int cnt, int failed, float vmax, float& rx, float& ry)
+__device__ __forceinline__ void lp3_rows(const float4 (&Lr)[10], const Lines& L, const RowLds& R, int cnt, int failed, float vmax, float& rx, float& ry)
 {
     const int me = L.tid;
     const int wbase = threadIdx.x & ~63;
@@ -733,7 +739,7 @@ __device__ __forceinline__ double key_sentinel() { return __hiloint2double(0x7F7
 // From the ten neighbour keys on: ORCA lines, linearProgram2, linearProgram3.  fetch(b, q, rad): (x, y, vx, vy) and radius +
 // margin of row b (LDS rows of the world in the crowd kernel, global rows found through the grid in the big-world kernel).
 template <int FM, class Fetch>
-__device__ void orca_solve_fast10(bool active, bool lp3_static, bool lp2_walk, const double (&key)[10], int row, Fetch&& fetch, float px, float py, float vx,
+__device__ __forceinline__ void orca_solve_fast10(bool active, bool lp3_static, const double (&key)[10], int row, Fetch&& fetch, float px, float py, float vx,
                                   float vy, float my_r, float vmax, float pvx, float pvy, float time_horizon, float dt, const Lines& L,
                                   const RowLds& R, float& nvx, float& nvy, unsigned long long* g_ost, unsigned long long& g_ost_last)
 {
@@ -763,42 +769,7 @@ __device__ void orca_solve_fast10(bool active, bool lp3_static, bool lp2_walk, c
         rx = pvx * inv * vmax; ry = pvy * inv * vmax;
     } else { rx = pvx; ry = pvy; }
     int failed = cnt;
-    if (lp2_walk) {
-        // (A/B switch CROWDSTEP_ORCA_LP2=walk: the round-4 form -- linearProgram1(i) evaluated inside the walk, where a lane of the
-        //  wavefront violates line i)
-        bool done = false;
-    #pragma unroll
-        for (int i = 0; i < KF; ++i) {
-            const float4 ln = Lr[i];
-            const bool viol = !done && (i < cnt) && (odet<FM>(ln.z, ln.w, ln.x - rx, ln.y - ry) > 0.0f);
-            if (__builtin_amdgcn_ballot_w64(viol) != 0) { // linearProgram1(i) for the lanes that violate line i
-                const float dot = odot<FM>(ln.x, ln.y, ln.z, ln.w);
-                const float disc = dot * dot + vmax * vmax - odot<FM>(ln.x, ln.y, ln.x, ln.y);
-                bool ok = !(disc < 0.0f);
-                const float sq = osqrt<FM>(fmaxf(disc, 0.0f));
-                float tL = -dot - sq, tR = -dot + sq;
-    #pragma unroll
-                for (int j = 0; j < i; ++j) {   // branch-free: the divisions of all j are independent and overlap
-                    const float4 lj = Lr[j];
-                    const float den = odet<FM>(ln.z, ln.w, lj.z, lj.w);
-                    const float num = odet<FM>(lj.z, lj.w, ln.x - lj.x, ln.y - lj.y);
-                    const float t = odiv<FM>(num, den);
-                    const bool par = fabsf(den) <= RVO_EPSILON;
-                    const bool upd = !par && ok;                     // (after a failure RVO2 has already returned)
-                    const float nR = (den >= 0.0f) ? fminf(tR, t) : tR, nL = (den >= 0.0f) ? tL : fmaxf(tL, t);
-                    tR = upd ? nR : tR; tL = upd ? nL : tL;
-                    ok = ok && !(par && num < 0.0f) && !(upd && tL > tR);   // parallel and on the wrong side, or an empty interval
-                }
-                float t = odot<FM>(ln.z, ln.w, pvx - ln.x, pvy - ln.y);
-                t = (t < tL) ? tL : ((t > tR) ? tR : t);
-                const bool set = viol && ok, bad = viol && !ok;
-                rx = set ? omad<FM>(t, ln.z, ln.x) : rx;
-                ry = set ? omad<FM>(t, ln.w, ln.y) : ry;
-                failed = bad ? i : failed;
-                done = done || bad;
-            }
-        }
-    } else {
+    {
         // linearProgram1(i) does not depend on the point linearProgram2 has reached -- only on line i, the lines j < i, the speed
         // circle and the preferred velocity: its interval [tL, tR], its failure and the point it returns are functions of the LINES.
         // So they are evaluated for every i up front, as one block of independent arithmetic (45 pair bodies + 10 chords with no
@@ -806,7 +777,9 @@ __device__ void orca_solve_fast10(bool active, bool lp3_static, bool lp2_walk, c
         // violated lines is ten short steps.  The operations on the path RVO2 takes are the same on the same operands: tL only
         // grows and tR only shrinks, so RVO2's early exits (an empty interval after some j; a parallel line on the wrong side) equal
         // the tests on the final interval, and min / max are exact in any order.  In the dense phase of a crossing 99.8 % of the
-        // agents violate a line and a wavefront of 50 agents enters linearProgram1 for nearly every i anyway (round 3).
+        // agents violate a line and a wavefront of 50 agents enters linearProgram1 for nearly every i anyway (round 3).  Against the
+        // round-4 form (linearProgram1(i) inside the walk, behind a vote, with the `ok` chain through its bodies): bit-identical,
+        // 472 -> 450 us exact, 431 -> 406 us fast in the dense phase of cfg4 (profiles/r5a_orca_modes_ab.txt).
         bool anyviol = false;
 #pragma unroll
         for (int i = 0; i < KF; ++i) anyviol = anyviol || ((i < cnt) && (odet<FM>(Lr[i].z, Lr[i].w, Lr[i].x - rx, Lr[i].y - ry) > 0.0f));
@@ -869,7 +842,7 @@ __device__ void orca_solve_fast10(bool active, bool lp3_static, bool lp2_walk, c
 //  The crowd kernel's form: the world's rows in LDS, brute-force walk in index order.
 //  Called by all 64 lanes of a wavefront (`active` = this lane holds an agent): linearProgram3 re-deals the lanes (lp3_rows).
 template <int FM>
-__device__ void orca_velocity_fast10(bool active, bool lp3_static, bool lp2_walk, const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
+__device__ __forceinline__ void orca_velocity_fast10(bool active, bool lp3_static, const float4* pv, const float* rr, int rows, int row, float px, float py, float vx,
                                      float vy, float my_r, float vmax, float pvx, float pvy, float neighbor_dist,
                                      float time_horizon, float dt, const Lines& L, const RowLds& R, float& nvx, float& nvy,
                                      unsigned long long* g_ost, unsigned long long& g_ost_last)
@@ -908,14 +881,17 @@ __device__ void orca_velocity_fast10(bool active, bool lp3_static, bool lp2_walk
         for (int s = 0; s < 10; ++s) key[s] = key_sentinel();
     }
     for (int b = b0; b < rows; ++b) key_insert10(key, candidate(b));
-    orca_solve_fast10<FM>(active, lp3_static, lp2_walk, key, row, [&](int b, float4& q, float& rad) { q = pv[b]; rad = rr[b]; }, px, py, vx, vy, my_r, vmax,
+    orca_solve_fast10<FM>(active, lp3_static, key, row, [&](int b, float4& q, float& rad) { q = pv[b]; rad = rr[b]; }, px, py, vx, vy, my_r, vmax,
                       pvx, pvy, time_horizon, dt, L, R, nvx, nvy, g_ost, g_ost_last);
 }
 
 // MAXT = 64: floor(64 / rows) worlds per one-wavefront block; MAXT = 256 / 512: one world of up to MAXT rows per block
 // FM: the arithmetic of the register-resident build (0 exact / 1 fast / 2 fast + fma, see odiv above); the generic build is always exact
+// at most two wavefronts per SIMD: the register-resident build needs ~220 VGPRs whatever the scheduler is told, and knowing the
+// bound it stops trading instructions for registers it cannot use (-0.7 %, profiles/r5b_ab_scheduler_variants.txt)
+#define ORCA_WPE_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
 template <bool FAST10, int MAXT, int FM = 0>
-__global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
+__global__ __launch_bounds__(MAXT) ORCA_WPE_ATTR void k_orca_step(const OArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int T = blockDim.x;
@@ -1005,7 +981,7 @@ __global__ __launch_bounds__(MAXT) void k_orca_step(const OArgs a)
         if constexpr (FAST10) {
             // every lane of the wavefront takes part (linearProgram3 re-deals the lanes); lanes without a human carry no lines
             const int hb = human ? base : 0, hr = human ? row : 0;
-            orca_velocity_fast10<FM>(human, a.lp3_static != 0, a.lp2_walk != 0, lds_pv + cur * T + hb, lds_r + hb, rows, hr, px, py, vx, vy, r + margin, vmax, pvx, pvy,
+            orca_velocity_fast10<FM>(human, a.lp3_static != 0, lds_pv + cur * T + hb, lds_r + hb, rows, hr, px, py, vx, vy, r + margin, vmax, pvx, pvy,
                                  a.neighbor_dist, a.time_horizon, dt, L, RL, nvx, nvy, g_ost, g_ost_last);
         }
         if (human) {
@@ -1284,7 +1260,7 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
     const Lines L{lds_ln, 64, tid};
     const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
     const int mt = mine ? tid : 0;                                    // all 64 lanes take part (lp3_rows re-deals them)
-    orca_velocity_fast10<0>(mine, false, false, lds_pv + mt * ent, lds_rr + mt * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
+    orca_velocity_fast10<0>(mine, false, lds_pv + mt * ent, lds_rr + mt * ent, ent, a.n, px, py, vx, vy, r, vmax, pvx, pvy, a.neighbor_dist,
                          a.time_horizon, a.dt, L, RL, nvx, nvy, nullptr, ost_last);
     if (!mine) return;
     vx = nvx; vy = nvy;
@@ -1389,7 +1365,7 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
         unsigned long long ost_last = 0;
         const Lines L{lds_ln, 64, tid};
         const RowLds RL{lds_pr, lds_pa, lds_q, lds_sel};
-        orca_solve_fast10<0>(human, a.lp3_static != 0, false, key, human ? i : 0,
+        orca_solve_fast10<0>(human, a.lp3_static != 0, key, human ? i : 0,
                           [&](int b, float4& q, float& rad) {
                               const float* sb = Sw + (long)b * a.as;
                               q = make_float4(sb[0], sb[fs], sb[3 * fs], sb[4 * fs]);
@@ -1531,7 +1507,7 @@ int big_world_min_rows(int dflt)
 // (v_rcp / v_sqrt / v_rsq), 2 fast + fma.  cs_orca_set_math() sets it for the process; CROWDSTEP_ORCA_MATH=exact|fast|fma is read
 // once, at the first ORCA launch, when nobody has set it.  DESIGN.md 4.2a says which one is the default and why.
 static int g_orca_math = -1;
-constexpr int ORCA_MATH_DEFAULT = 0;
+constexpr int ORCA_MATH_DEFAULT = 2;   // "fma": DESIGN.md 4.2a (profiles/r5c_orca_fast_parity.txt)
 int orca_math()
 {
     if (g_orca_math < 0) {
@@ -1675,8 +1651,6 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     // worlds of more than 64 rows keep the statically unrolled walk (their blocks have no LDS left for the projected lines)
     const char* lp3_env = std::getenv("CROWDSTEP_ORCA_LP3");
     a.lp3_static = (T > 64 || (lp3_env && std::strcmp(lp3_env, "static") == 0)) ? 1 : 0;
-    const char* lp2_env = std::getenv("CROWDSTEP_ORCA_LP2");
-    a.lp2_walk = (lp2_env && std::strcmp(lp2_env, "walk") == 0) ? 1 : 0;
     const size_t shmem = orca_block_shmem(w, a.lp3_static != 0);
     a.young_from = (T == 64 && grid == 2 * csimpl::device_simds()) ? grid / 2 : 0x7fffffff;
     auto launch = [&](auto kernel) -> int {

@@ -21,7 +21,9 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libcrowdstep.so does not export {name}"
     assert set(_lib.ABI_SYMBOLS) == declared
-    assert lib.cs_abi_version() >= 1
+    assert lib.cs_abi_version() == _lib.ABI_VERSION == 3
+    hdr = open(os.path.join(ROOT, "include", "crowdstep.h")).read()
+    assert "#define CS_ABI_VERSION 3" in hdr          # header, library and binding name one ABI
 
 
 def test_library_on_disk_was_built_from_the_sources_on_disk():

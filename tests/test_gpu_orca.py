@@ -8,6 +8,19 @@ from oracle import crowd_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def exact_orca_arithmetic():
+    """This module is the BIT-IDENTITY suite: the register-resident ORCA build runs in its exact arithmetic (cs_orca_set_math(0):
+    correctly rounded divide / square root, no FMA contraction) and must equal oracle/orca_oracle.c bit for bit.  The library's
+    default arithmetic ("fma") is measured per substep in tests/test_gpu_orca_fast.py."""
+    from social_navigation_pyenvs_amd import _lib
+
+    lib = _lib.load()
+    _lib.check(lib.cs_orca_set_math(0))
+    yield
+    _lib.check(lib.cs_orca_set_math(-1))
+
+
 def make_worlds(rng, W, n, robot=False, traffic=False):
     rows = n + int(robot)
     S = np.zeros((W, rows, 13), np.float32)
@@ -359,7 +372,7 @@ def test_orca_cfg4_full_size():
 
     def run(sel):
         cw = CrowdWorlds(S[sel], g[sel], None, margin[sel], None, type="orca", layout="soa")
-        assert "k_orca_step<FAST10=1,MAXT=64>" in cw.step_variant(), cw.step_variant()
+        assert "k_orca_step<FAST10=1,MAXT=64>" in cw.step_variant() and "math=exact" in cw.step_variant(), cw.step_variant()
         for _ in range(3):
             cw.step(0.0125, 20)
         return cw.get_states(), cw.get_goals()

@@ -58,7 +58,7 @@ for n, R, Wn, nsub in ((25, 7.0, W, NSUB), (10, 3.0, max(256, W // 4), min(NSUB,
         report["shapes"][key][MODES[mode]] = res
         print(f"[{key}] {MODES[mode]:5s}: {res['agent_substeps']:.3g} agent-substeps, bit-identical {res['bit_identical_agent_substeps'] / res['agent_substeps']:.4f}, "
               f"p50 {res['p50']:.1e} p99 {res['p99']:.1e} p99.99 {res['p9999']:.1e} worst {res['worst']:.2e}; beyond {ofp.BAR:g} vs exact f32: {res['beyond_bar']} "
-              f"({res['beyond_bar_share']:.2e} of all) = f64 {res['class_f64']} + edge1 {res['class_edge1']} + edge4 {res['class_edge4']} + unexplained {res['unexplained']} "
+              f"({res['beyond_bar_share']:.2e} of all) = f64 {res['class_f64']} + edge1 {res['class_edge1']} + edge4 {res['class_edge4']} + edge16 {res['class_edge16']} + unexplained {res['unexplained']} "
               f"(worst {res['worst_unexplained']:.2e}) + not examined {res['not_examined']}; of these closer to f64: build {res['disagree_build_closer_to_f64']} / exact {res['disagree_exact_closer_to_f64']}; "
               f"beyond bar vs f64: build {res['beyond_bar_vs_f64_build_share']:.2e}, exact f32 {res['beyond_bar_vs_f64_exact_share']:.2e}; goal flips {res['goal_column_flips']}; "
               f"pref velocity worst {res['pref_velocity_worst']:.1e}  ({res['seconds']} s)", flush=True)

@@ -13,10 +13,8 @@ sys.path.insert(0, ROOT)
 from social_navigation_pyenvs_amd import _lib, scenarios as sc  # noqa: E402
 from social_navigation_pyenvs_amd.csrc import build as hb  # noqa: E402
 
-so = os.path.join(ROOT, "gpurun_out", "libcrowdstep_stamps.so")
-os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call([hb.hipcc_path()] + hb.FLAGS + ["-shared", "-DCS_STAMPS", "-I", os.path.join(ROOT, "include"), "-o", so
-                      ] + [os.path.join(hb.CSRC, x) for x in hb._sources()])
+# libcrowdstep_stamps.so beside the product library (content-keyed: built in the build container, it travels to the GPU box and is reused there)
+so = hb.build(variant="stamps", extra_flags=["-DCS_STAMPS"])
 _lib.LIB_PATH = so
 _lib._lib = None
 from social_navigation_pyenvs_amd.batched import CrowdWorlds  # noqa: E402
