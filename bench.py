@@ -62,7 +62,14 @@ ALG_BYTES = {"sfm": 52, "hsfm": 76, "orca": 48}
 PAIR_FLOPS = {"helbing": 45, "guo": 60, "moussaid": 120}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32 peak (MI355X_MICROARCH.md)
-SIMDS, CLOCK_HZ, VALU_ISSUE_CYCLES = 256 * 4, 2.4e9, 4.0   # one wave64 VALU instruction holds its SIMD's issue for 4 cycles
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
+# What one SIMD needs per wave64 vector instruction when >= 2 wavefronts share it, MEASURED per instruction class on an MI355X
+# (tools/valu_issue_ceiling.hip, profiles/r5_valu_issue_ceiling.txt: independent streams in inline assembly at 1 / 2 / 4 / 8
+# wavefronts per SIMD, shader cycles by s_memtime; round 4 priced everything at 4): v_fma / v_mul / v_add / v_mov / v_and..xor 2.2;
+# v_min / v_max / v_max3 / v_cmp / v_cndmask (VOP3 or fed by a compare) / DPP / f64 min-max 4.1; v_exp / v_rcp / v_rsq / v_sqrt 8.2.
+# One wavefront ALONE on a SIMD issues no faster than one instruction per 4.4 - 5.6 cycles whatever the class.
+VALU_CLASS_CYCLES = {"fma": 2.2, "other": 4.1, "trans": 8.2}
+CPU_ROWS = ("cfg2", "cfg4_first20", "cfg4_dense", "cfg5_shard", "moussaid")   # other_configs rows that get their own CPU figure
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 
 
@@ -129,6 +136,9 @@ def other_config_specs(args) -> list[dict]:
         dict(base, name="cfg5", agents=50, scenario="circle", walls=True, static=3, worlds=8192, total_worlds=65536, device_generator=True,
              title="65536 worlds (whole job, strong split) x 50-agent HSFM circle crossing R=14 (generators.static_obstacle_crossing: "
                    "the worlds tests/test_gpu_fullsize.py checks), 3 immobile humans + 3 polygon walls"),
+        dict(base, name="cfg5_shard", agents=50, scenario="circle", walls=True, static=3, worlds=8192, device_generator=True,
+             title="8192 worlds/GPU x 50-agent HSFM + 3 immobile humans + 3 polygon walls: ONE GPU's shard of cfg5 (what each of 8 ranks runs), Gym steps 20-70"),
+        dict(base, name="moussaid", model="hsfm_new_moussaid", title="4096 worlds/GPU x 25-agent hsfm_new_moussaid hybrid scenario (the Moussaid pair force: 3 of the 9 model types)"),
         dict(base, name="cfg3_new_guo", model="hsfm_new_guo", title="4096 worlds/GPU x 25-agent hsfm_new_guo hybrid scenario (SURVEY.md §8d cfg3's second model)"),
         dict(base, name="robot26", robot=True, title="4096 worlds/GPU x 25-agent hsfm_farina hybrid scenario + a VISIBLE robot (26 rows per world), constant action"),
         dict(base, name="n30", agents=30, title="4096 worlds/GPU x 30-agent hsfm_farina hybrid scenario"),
@@ -212,44 +222,91 @@ def build_worlds(spec, rank, world_size):
     return cw, h, h["W"]
 
 
-def cpu_baseline(args, host, type_id):
-    """The C oracle (port of the reference's f64 array kernel) on this box's host cores, on a bounded
-    sample of the same workload: the first `sample_worlds` worlds, blocks of `substeps` substeps, stepped in
-    place (no host copies in the timed loop).  Run on all cores (OpenMP over worlds) and on one."""
+_CPU_CORES = None
+
+
+def host_cpu_info() -> dict:
+    """CPU model string and logical CPU count of this box (a CPU figure states both)"""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count()}
+
+
+def cpu_baseline(spec, seconds=12.0, single_seconds=4.0):
+    """The C oracle (port of the reference's array kernel; ORCA: the RVO2 restatement) on this box's host cores, on a bounded sample of
+    the SAME workload: the first `sample` worlds of the configuration's host generator, blocks of `substeps` substeps.  All cores
+    (OpenMP over worlds) and one.  SFM / HSFM: f64 like the reference, stepped in place from the reset (the all-pairs cost does not follow
+    the crowd's state).  ORCA: float32 like RVO2, advanced (untimed) to the Gym step the GPU window starts at -- its cost follows the
+    crossing -- then exactly the window's steps per repetition, every repetition from that state."""
     from oracle import crowd_oracle as orc
+    from social_navigation_pyenvs_amd.batched import HUMAN_MODELS as SFMS
 
     orc.build()
-    cores = min(orc.num_threads(), orc.effective_cores())
-    respawn = host["respawn_bounds"] is not None
-    rp = (host["respawn_bounds"][0], host["respawn_bounds"][1], 0.0) if respawn else (0.0, 0.0, 0.0)
+    global _CPU_CORES
+    if _CPU_CORES is None:   # (a single-core leg sets OpenMP's thread count for the process: ask once, before any)
+        _CPU_CORES = min(orc.num_threads(), orc.effective_cores())
+    cores = _CPU_CORES
+    sample = min(spec["worlds"], 32 * max(1, cores))
+    host = host_worlds(dict(spec, worlds=sample, total_worlds=None, device_generator=False), 0, 1)
+    n, nsub, dt = spec["agents"], spec["substeps"], spec["dt"]
+    info = host_cpu_info()
+    if spec["model"] == "orca":
+        S0, g0, margin = host["S"].astype(np.float32), host["goals"].astype(np.float32), host["margin"].astype(np.float32)
+        for _ in range(int(spec.get("warmup", 0))):
+            S0, g0, _ = orc.orca_step_block(S0, g0, margin, dt, nsub, threads=cores)
+        steps = int(spec.get("steps", 20))
 
-    def timed(sample_worlds, threads, seconds):
-        idx = np.arange(sample_worlds)
-        groups = [(idx, respawn)] if host["respawn_worlds"] is None else \
-            [(idx[host["respawn_worlds"][idx] == 1], True), (idx[host["respawn_worlds"][idx] == 0], False)]
-        runners = [orc.StepBlockRunner(type_id, host["S"][sel], host["goals"][sel], host["walls"], host["P"],
-                                       np.zeros((sel.size, host["S"].shape[1])), True, respawn=rs, respawn_par=rp,
-                                       dtype=np.float64, threads=threads) for sel, rs in groups if sel.size]
-        done, reps = 0, 0
-        t0 = time.perf_counter()
-        while True:
-            for r in runners:
-                r.run(args.dt, args.substeps)
-                done += r.W * args.substeps
-            reps += 1
-            if time.perf_counter() - t0 >= seconds:
-                break
-        el = time.perf_counter() - t0
-        return done * args.agents / el, reps, el
+        def timed(sel, threads, secs):
+            done, reps, t0 = 0, 0, time.perf_counter()
+            while True:
+                s_, g_ = S0[:sel], g0[:sel]
+                for _ in range(steps):
+                    s_, g_, _ = orc.orca_step_block(s_, g_, margin[:sel], dt, nsub, threads=threads)
+                done += sel * nsub * steps
+                reps += 1
+                if time.perf_counter() - t0 >= secs:
+                    break
+            el = time.perf_counter() - t0
+            return done * n / el, reps * steps, el
+        what = f"float32 RVO2 restatement (oracle/orca_oracle.c), Gym steps {spec.get('warmup', 0)}..{spec.get('warmup', 0) + steps}"
+    else:
+        type_id = SFMS.index(spec["model"])
+        respawn = host["respawn_bounds"] is not None
+        rp = (host["respawn_bounds"][0], host["respawn_bounds"][1], 0.0) if respawn else (0.0, 0.0, 0.0)
 
-    sw_all = min(args.worlds, 32 * max(1, cores))
-    v_all, reps, el = timed(sw_all, cores, args.cpu_seconds)
-    v_one, reps1, el1 = timed(min(args.worlds, 64), 1, min(4.0, args.cpu_seconds))
-    return {"value": v_all, "unit": "agent-substeps/s", "cores": cores, "kind": "port",
-            "single_core_value": v_one,
-            "sample": f"{sw_all} worlds x {args.agents} agents x {reps * args.substeps} substeps, f64 C oracle "
-                      f"(oracle/), OpenMP over worlds on {cores} threads, {el:.1f} s; single-core leg: 64 worlds x "
-                      f"{reps1 * args.substeps} substeps, {el1:.1f} s"}
+        def timed(sel, threads, secs):
+            idx = np.arange(sel)
+            groups = [(idx, respawn)] if host["respawn_worlds"] is None else \
+                [(idx[host["respawn_worlds"][idx] == 1], True), (idx[host["respawn_worlds"][idx] == 0], False)]
+            runners = [orc.StepBlockRunner(type_id, host["S"][g_], host["goals"][g_], host["walls"], host["P"],
+                                           np.zeros((g_.size, host["S"].shape[1])), True, respawn=rs, respawn_par=rp,
+                                           dtype=np.float64, threads=threads) for g_, rs in groups if g_.size]
+            done, reps, t0 = 0, 0, time.perf_counter()
+            while True:
+                for r in runners:
+                    r.run(dt, nsub)
+                    done += r.W * nsub
+                reps += 1
+                if time.perf_counter() - t0 >= secs:
+                    break
+            el = time.perf_counter() - t0
+            return done * n / el, reps, el
+        what = "f64 C oracle (oracle/sfm_step.inc)"
+    v_all, reps, el = timed(sample, cores, seconds)
+    out = {"value": v_all, "unit": "agent-substeps/s", "cores": cores, "kind": "port", "cpu_model": info["cpu_model"], "nproc": info["nproc"]}
+    tail = ""
+    if single_seconds > 0:
+        v_one, reps1, el1 = timed(min(sample, 64), 1, single_seconds)
+        out["single_core_value"] = v_one
+        tail = f"; single-core leg: {min(sample, 64)} worlds x {reps1 * nsub} substeps, {el1:.1f} s"
+    out["sample"] = f"{sample} worlds x {n} agents x {reps * nsub} substeps, {what}, OpenMP over worlds on {cores} threads, {el:.1f} s{tail}"
+    return out
 
 
 class Snapshot:
@@ -450,12 +507,27 @@ def roofline_block(spec, W, kern_ms, copy_gbs, cw, window=None):
     if pmw and pmw.get("valu"):
         out["valu"] = pmw["valu"]
         out["valu_window"] = f"Gym steps {window[0]}..{window[0] + window[1]} (the timed window)"
-    out["valu_frac"] = None
+    out["valu_frac"] = out["valu_frac_floor"] = None
     if out["valu"] and out["valu"].get("valu_insts_per_wave_substep"):
-        insts = out["valu"]["valu_insts_per_wave_substep"] * out["valu"]["waves_per_launch"] * n_sub * (W / float(pm.get("worlds", W)))
-        out["valu_frac"] = insts * VALU_ISSUE_CYCLES / (SIMDS * k_avg * 1e-3 * CLOCK_HZ)
-        out["valu_frac_meaning"] = ("VALU instructions per launch (PMC SQ_INSTS_VALU) x 4 issue cycles / (1024 SIMDs x kernel time x 2.4 GHz): "
-                                    "share of the chip's VALU issue slots the kernel fills -- the bound that holds for this kernel")
+        scale = out["valu"]["waves_per_launch"] * n_sub * (W / float(pm.get("worlds", W)))
+        insts = out["valu"]["valu_insts_per_wave_substep"] * scale
+        simd_cycles = SIMDS * k_avg * 1e-3 * CLOCK_HZ
+        mix = out["valu"].get("mix_per_wave_substep")
+        if mix:   # SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 of the same passes: the classes the microbenchmark priced
+            fma = (mix.get("add_f32", 0) + mix.get("mul_f32", 0) + mix.get("fma_f32", 0)) * scale
+            trans = mix.get("trans_f32", 0) * scale
+            other = max(0.0, insts - fma - trans)
+            cyc = fma * VALU_CLASS_CYCLES["fma"] + trans * VALU_CLASS_CYCLES["trans"] + other * VALU_CLASS_CYCLES["other"]
+            out["valu_issue_cycles_per_inst_model"] = cyc / insts
+            out["valu_frac"] = cyc / simd_cycles
+            out["valu_frac_floor"] = ((fma + other) * VALU_CLASS_CYCLES["fma"] + trans * VALU_CLASS_CYCLES["trans"]) / simd_cycles
+        else:     # no class counters for this configuration yet: every instruction at the 4.1 of the compare / select / min-max class
+            out["valu_frac"] = insts * VALU_CLASS_CYCLES["other"] / simd_cycles
+        out["valu_cycles_per_inst_achieved"] = simd_cycles / insts
+        out["valu_frac_meaning"] = ("SIMD issue cycles the launch's vector instructions need (PMC instruction counts by class x the MEASURED cost of the class at >= 2 "
+                                    "wavefronts per SIMD: fma/mul/add 2.2, transcendental 8.2, everything else 4.1; profiles/r5_valu_issue_ceiling.txt) / (1024 SIMDs x kernel "
+                                    "time x 2.4 GHz).  valu_frac_floor prices every non-transcendental instruction at 2.2 (no SIMD can do better).  Without class "
+                                    "counters: all at 4.1")
     return out
 
 
@@ -490,7 +562,8 @@ def short_variant(v: str) -> str:
     if not m:
         return v[:40]
     vals = ",".join(kv.split("=")[-1] for kv in m.group(3).split(","))
-    return f"{m.group(1)}{m.group(2) or ''}<{vals}>" + (f"g{m.group(4)}" if m.group(4) else "")
+    math = re.search(r"math=(\w+)", v)            # the ORCA build's arithmetic (exact / fast / fma)
+    return f"{m.group(1)}{m.group(2) or ''}<{vals}>" + (f"g{m.group(4)}" if m.group(4) else "") + (f":{math.group(1)}" if math else "")
 
 
 def compact_roofline(rl: dict) -> dict:
@@ -515,19 +588,19 @@ def compact_line(full: dict) -> str:
     out["roofline"] = compact_roofline(full["roofline"])
     if full.get("cpu_baseline"):
         cb = full["cpu_baseline"]
-        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value")}
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "single_core_value", "cpu_model", "nproc")}
         out["gpu_over_cpu"] = full.get("gpu_over_cpu")
     out["dist"] = full.get("dist")
     out["ranks"] = full.get("ranks")
     if full.get("gym_step"):
         out["gym_step"] = full["gym_step"]
-    cols = ("name", "ms_per_step", "kernel_us", "frac", "valu_frac", "variant", "pmc_build_matches", "worlds_total", "steps", "warmup")
+    cols = ("name", "ms_per_step", "kernel_us", "frac", "valu_frac", "variant", "pmc_build_matches", "worlds_total", "steps", "warmup", "cpu_value")
     rows = []
     for o in full.get("other_configs") or []:
         rl = o.get("roofline") or {}
-        rows.append([o.get("name"), o.get("ms_per_step"), o.get("kernel_us"), o.get("frac"), o.get("valu_frac"), short_variant(rl.get("variant")),
-                     rl.get("pmc_build_matches"), o.get("worlds_total"), o.get("steps"), o.get("warmup")])
-    out["other_configs"] = {"columns": list(cols), "rows": rows, "workloads": "BASELINE.json configs[1],[3],[4] + the shapes around configs[2]; titles in full_json"}
+        rows.append([o.get("name"), _r(o.get("ms_per_step"), 4), _r(o.get("kernel_us"), 4), _r(o.get("frac"), 3), _r(o.get("valu_frac"), 3), short_variant(rl.get("variant")),
+                     rl.get("pmc_build_matches"), o.get("worlds_total"), o.get("steps"), o.get("warmup"), _r(o.get("cpu_value"), 3)])
+    out["other_configs"] = {"columns": list(cols), "rows": rows, "workloads": "BASELINE.json configs[1],[3],[4] + cfg5's per-GPU shard + the shapes around configs[2]; cpu_value = the C oracle on all host cores (agent-substeps/s); titles in full_json"}
     out["full_json"] = full.get("full_json")
     line = json.dumps(_r(out), allow_nan=False, separators=(",", ":"))
     if len(line.encode()) >= LINE_LIMIT:
@@ -559,6 +632,9 @@ def visible_gpus() -> int:
         return int(out.stdout.strip().splitlines()[-1])
     except Exception:
         return 0
+
+
+RANK_EXIT_TIMEOUT_S = 60.0   # how long the other ranks may take to exit after rank 0 has (teardown, the final barrier)
 
 
 def free_port() -> int:
@@ -601,21 +677,24 @@ def launch_ranks(args, argv, worker=None, n_visible=None) -> int:
                     if p.poll() is None:
                         p.kill()
                 out0, _ = procs[0].communicate()
-    if procs[0].returncode != 0:
-        for p in procs[1:]:
-            if p.poll() is None:
-                try:
-                    p.wait(timeout=30)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0 is through: its line goes out NOW -- a rank that hangs in its teardown must not cost the measurement
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    if lines:
+        print(lines[-1], flush=True)
+    codes = [procs[0].returncode]
+    deadline = time.monotonic() + RANK_EXIT_TIMEOUT_S
+    for p in procs[1:]:      # the exact processes started above, each waited for within ONE overall deadline, then ended
+        try:
+            codes.append(p.wait(timeout=max(0.1, deadline - time.monotonic())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+            codes.append(-9)
+            print(f"bench.py: a rank did not exit within {RANK_EXIT_TIMEOUT_S} s of rank 0 and was ended", file=sys.stderr)
     worst = max((abs(c) for c in codes), default=0)
     if worst != 0:
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-    if lines:
-        print(lines[-1], flush=True)
-    elif worst == 0:
+    if not lines and worst == 0:
         worst = 4
     return worst
 
@@ -664,8 +743,28 @@ def gym_step_figures(W, n, steps=150):
     return out
 
 
+def gym_step_child(W, n, timeout_s=240.0) -> dict:
+    """gym_step_figures in a CHILD process with a deadline: a hang or a GPU fault in the side figure cannot take the headline with it
+    (a process that has initialised the GPU may start children; it must not exec)."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gym-step-child", str(W), str(n)], capture_output=True, text=True, timeout=timeout_s)
+        last = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        if r.returncode != 0 or not last:
+            return {"error": f"child rc={r.returncode}: {(r.stderr or '').strip().splitlines()[-1] if (r.stderr or '').strip() else 'no output'}"[:160]}
+        return json.loads(last[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"gym_step child exceeded {timeout_s:.0f} s and was ended"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:160]}
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
+    if len(argv) == 3 and argv[0] == "--gym-step-child":
+        print(json.dumps(gym_step_figures(int(argv[1]), int(argv[2]))), flush=True)
+        return
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: be the launcher.  BEFORE torch is imported or HIP touched -- the ranks are fresh processes.
@@ -736,7 +835,7 @@ def main(argv=None):
     if not args.no_other_configs:
         for ospec in other_config_specs(args):
             ocw, _, oW = build_worlds(ospec, rank, world_size)
-            k_o = max(5, min(args.steps, ospec["steps"]))
+            k_o = ospec["steps"]   # every row over its OWN window, whatever --steps says: the driver's line and profiles/ show the same figures
             r_o = 7
             owall, okern = run.measure(ocw, ospec, k_o, ospec["warmup"], r_o, restore=not args.no_restore)
             ous = run.gather(float(np.mean(okern)) * 1e3)
@@ -802,22 +901,34 @@ def main(argv=None):
             "roofline": rl,
             "other_configs": others,
         }
-        if not args.no_cpu_baseline and args.model != "orca" and world_size == 1 and host is not None and not args.robot and not args.per_agent_params:
-            out["cpu_baseline"] = cpu_baseline(args, host, SFMS.index(args.model))   # rank 0, N = 1 only
+        if not args.no_cpu_baseline and world_size == 1 and not args.robot and not args.per_agent_params:
+            out["cpu_baseline"] = cpu_baseline(dict(spec, warmup=args.warmup, steps=args.steps), args.cpu_seconds)   # rank 0, N = 1 only
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
-        if not args.no_gym_step and not args.no_other_configs and world_size == 1 and args.model != "orca" and not args.robot and not args.per_agent_params and not args.walls:
+            # the other configurations the oracle covers, each beside its own row (3 s of CPU work per row)
+            for o in others:
+                if o["name"] in CPU_ROWS:
+                    try:
+                        ospec = next(x for x in other_config_specs(args) if x["name"] == o["name"])
+                        cb = cpu_baseline(ospec, seconds=3.0, single_seconds=0.0)
+                        o["cpu_baseline"] = cb
+                        o["cpu_value"] = cb["value"]
+                        o["gpu_over_cpu"] = o["value"] / cb["value"]
+                    except Exception as e:   # a side figure never costs the headline
+                        o["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"[:160]}
+        def write_full():
             try:
-                out["gym_step"] = gym_step_figures(args.worlds, args.agents)
-            except Exception as e:   # a side figure never costs the headline
-                out["gym_step"] = {"error": f"{type(e).__name__}: {e}"[:160]}
-        try:
-            os.makedirs(os.path.dirname(args.full_json), exist_ok=True)
-            with open(args.full_json, "w") as f:
-                json.dump(out, f, indent=1)
-            out["full_json"] = os.path.relpath(args.full_json, ROOT)
-        except OSError as e:
-            out["full_json"] = None
-            print(f"bench.py: full result not written ({e})", file=sys.stderr)
+                os.makedirs(os.path.dirname(args.full_json), exist_ok=True)
+                with open(args.full_json, "w") as f:
+                    json.dump(out, f, indent=1)
+                out["full_json"] = os.path.relpath(args.full_json, ROOT)
+            except OSError as e:
+                out["full_json"] = None
+                print(f"bench.py: full result not written ({e})", file=sys.stderr)
+
+        write_full()   # the measurement is on disk before the side figure below runs
+        if not args.no_gym_step and not args.no_other_configs and world_size == 1 and args.model != "orca" and not args.robot and not args.per_agent_params and not args.walls:
+            out["gym_step"] = gym_step_child(args.worlds, args.agents)
+            write_full()
         print(json.dumps(out), file=sys.stderr, flush=True)      # the full blocks: stderr + the side file
         line = compact_line(out)
         sys.stdout.flush()

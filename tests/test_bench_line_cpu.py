@@ -23,6 +23,14 @@ def canned_full(n_ranks=1):
     full["gym_step"] = {"worlds": 4096, "humans": 25, "unit": "us per batched Gym step", "steps": 150, "no_reset": 44.41234567, "same_step": 61.2345678,
                        "next_step": 52.3456789, "same_step_failed_resets": 0, "next_step_failed_resets": 0}
     full["full_json"] = "gpurun_out/bench_full.json"
+    # round 5: cfg5's per-GPU shard and a Moussaid row, a CPU figure beside the rows the oracle covers, CPU model + nproc in the block
+    for name in ("cfg5_shard", "moussaid"):
+        full["other_configs"].append(dict(full["other_configs"][0], name=name))
+    for o in full["other_configs"]:
+        if o["name"] in bench.CPU_ROWS or o["name"] == "cfg4_dense":
+            o["cpu_value"] = 12345678.912345
+    if full.get("cpu_baseline"):
+        full["cpu_baseline"].update(cpu_model="AMD EPYC 9575F 64-Core Processor", nproc=256)
     return full
 
 
@@ -48,7 +56,10 @@ def test_line_is_compact_strict_json_with_everything_the_contract_names(n_ranks)
     assert len(d["ranks"]) == n_ranks and d["ranks"][0]["pci"] and d["dist"]["world_size"] == n_ranks
     oc = d["other_configs"]
     assert oc["columns"][:5] == ["name", "ms_per_step", "kernel_us", "frac", "valu_frac"]
-    assert [r[0] for r in oc["rows"]] == [o["name"] for o in full["other_configs"]] and len(oc["rows"]) == 8
+    assert [r[0] for r in oc["rows"]] == [o["name"] for o in full["other_configs"]] and len(oc["rows"]) == 10
+    assert oc["columns"][-1] == "cpu_value" and any(r[-1] for r in oc["rows"])
+    if n_ranks == 1:
+        assert d["cpu_baseline"]["cpu_model"] and d["cpu_baseline"]["nproc"]
     assert d["gym_step"]["no_reset"] and d["full_json"]
 
 
@@ -73,6 +84,7 @@ def test_oversized_optional_blocks_are_dropped_not_printed():
 def test_short_variant():
     assert bench.short_variant("k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2") == "sfm<0,1,1,64,1,25,1>g2048"
     assert bench.short_variant("k_sfm_step_row16<SOC=0,HEADED=0,ROWS=10> grid=1024 block=64 wpb=4") == "sfm_row16<0,0,10>g1024"
+    assert bench.short_variant("k_orca_step<FAST10=1,MAXT=64> grid=2048 block=64 wpb=2 math=fma") == "orca<1,64>g2048:fma"
     assert bench.short_variant(None) is None
 
 

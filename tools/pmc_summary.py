@@ -18,6 +18,7 @@ SHAPES = {"cfg3": (4096, 25, "hsfm_farina_25_hybrid"), "cfg2": (4096, 10, "sfm_h
           # instruction count follows the crowd's state (cfg5: how many polygons the wave vote skips), so valu_frac pairs counters and
           # time of the SAME window: bench.py looks "<key>@w<warmup>s<steps>" up before "<key>"
           "cfg3_w5s20": (4096, 25, "hsfm_farina_25_hybrid@w5s20"), "cfg5_w20s20": (8192, 50, "hsfm_farina_50_circle_walls_static@w20s20")}
+# (round 5: every other_configs row runs over its own window whatever --steps says, so only the headline needs its driver-protocol window)
 SUBSTEPS = 20
 SIMDS = 256 * 4
 
@@ -65,6 +66,12 @@ def main(d, out, tag):
                  "wait_inst_any_frac": m.get("SQ_WAIT_INST_ANY", 0) / max(m.get("SQ_WAVE_CYCLES", 1), 1),
                  "waves_per_simd": waves / SIMDS,
                  "source": f"profiles/{tag}_{name}_pmc_SQ_WAVES.csv"}
+            if "SQ_INSTS_VALU_FMA_F32" in m:   # the instruction classes tools/valu_issue_ceiling.hip priced (bench.py VALU_CLASS_CYCLES)
+                v["mix_per_wave_substep"] = {k: m.get(c, 0) / waves / SUBSTEPS for k, c in (
+                    ("add_f32", "SQ_INSTS_VALU_ADD_F32"), ("mul_f32", "SQ_INSTS_VALU_MUL_F32"), ("fma_f32", "SQ_INSTS_VALU_FMA_F32"),
+                    ("trans_f32", "SQ_INSTS_VALU_TRANS_F32"), ("int32", "SQ_INSTS_VALU_INT32"), ("cvt", "SQ_INSTS_VALU_CVT"),
+                    ("add_f64", "SQ_INSTS_VALU_ADD_F64"), ("mul_f64", "SQ_INSTS_VALU_MUL_F64"))}
+                v["mix_source"] = f"profiles/{tag}_{name}_pmc_SQ_INSTS_VALU_ADD_F32.csv"
             # VALU issue occupancy of a SIMD ~ (share of a wave's cycles its VALU instructions are active) x (waves resident per SIMD)
             v["simd_valu_busy_est"] = min(1.0, v["valu_active_frac_of_wave_cycles"] * max(1.0, v["waves_per_simd"]))
             v["bound"] = "VALU issue / single-wave latency (not HBM): see DESIGN.md §4.1"
