@@ -341,6 +341,13 @@ class MotionModelManager:
             bx, by = self.states[:n, 5].copy(), self.states[:n, 6].copy()
             self.states[:n, 3] = c * bx - s * by
             self.states[:n, 4] = s * bx + c * by
+        if not (self.orca or self.sm):
+            # set_human_states(saved) also rewrites the goal columns of every state row from the saved state, whose goal is the head of
+            # the human's goal LIST (:285-297, :333: `*state[i,6:8]`).  Where the row and the list had disagreed (parallel traffic after a
+            # respawn: the row keeps the clamped y, golden g4_peek cases 2 and 6) the row follows the list from the first peek on -- and
+            # the next peek's desired force with it (4e-5 on a velocity in case 6).
+            n = len(self.humans)
+            self.states[:n, 10:12] = np.array([h.goals[0] for h in self.humans], dtype=PRECISION).reshape(n, 2)
         if self.orca:
             self._refresh_orca_pref(range(len(self.humans)))
         return nxt if theta_and_omega_visible else nxt[:, [0, 1, 3, 4]]

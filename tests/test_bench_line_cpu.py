@@ -158,3 +158,31 @@ def test_launcher_ends_the_other_ranks_when_one_dies(tmp_path):
     t0 = time.time()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
     assert time.time() - t0 < 30 and r.returncode == 9 and r.stdout.strip() == ""
+
+
+def test_launcher_with_eight_ranks(tmp_path):
+    """The shape of the driver's 8-GPU run, with stub ranks: eight processes, eight distinct ranks, one port, ONE relayed line."""
+    r = run_launcher(tmp_path, 8, visible=8, extra_args=("--total-worlds", "65536"))
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 8
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("rank")) == [f"rank{k}" for k in range(8)]
+    assert all(open(tmp_path / f"rank{k}").read() == "--gpus 8 --steps 3 --total-worlds 65536" for k in range(8))
+
+
+def test_line_is_relayed_at_once_and_a_rank_hanging_in_its_teardown_is_ended(tmp_path):
+    """Rank 0 prints its line and exits 0; rank 1 hangs (a stuck final barrier).  The line must reach stdout without waiting for rank 1,
+    and the launcher must end rank 1 within its deadline instead of hanging."""
+    import time
+
+    stub = tmp_path / "stub_teardown.py"
+    stub.write_text("import json, os, sys, time\nr = int(os.environ['RANK'])\nif r == 0:\n    print(json.dumps({'n_gpus': 2}))\n    sys.exit(0)\ntime.sleep(300)\n")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.RANK_EXIT_TIMEOUT_S = 3.0; a = ['--gpus', '2']; "
+            f"sys.exit(bench.launch_ranks(bench.parse(a), a, worker={str(stub)!r}, n_visible=2))")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
+    assert time.time() - t0 < 30
+    assert json.loads(r.stdout.strip())["n_gpus"] == 2          # the measurement survived
+    assert r.returncode == 9 and "did not exit within" in r.stderr

@@ -91,7 +91,10 @@ def test_gym_step_loop_g3_per_step():
 
 
 def test_gym_free_running_first_steps_g3():
-    """No re-synchronisation: the first three Gym steps (60 substeps) stay close to the reference."""
+    """No re-synchronisation: the first three Gym steps (60 substeps).  The bound is the SUM of the three steps' own per-step bars
+    (_block_bar: 5e-5 per block of 20 substeps, or 3 x the float32 oracle's own error over that block), each measured on the
+    state the env is in -- an error of step k is carried into step k + 1, where these first steps of an episode (crowds far apart)
+    do not amplify it; not a blanket 1e-3 (round 4).  A secondary check: the per-step test above is the parity claim."""
     from social_navigation_pyenvs_amd.crowd_nav.utils.action import ActionXY
 
     for c in load_cases("g3_gym"):
@@ -101,14 +104,19 @@ def test_gym_free_running_first_steps_g3():
         if c["safety_space"] > 0:
             env.set_safety_space(c["safety_space"])
         env.reset(phase=c["phase"], test_case=c["test_case"])
+        budget = 0.0
         for k in range(3):
             a = c["actions"][k]
+            budget += _block_bar(env, a)[0]
             ob, *_ = env.step(ActionXY(float(a[0]), float(a[1])))
         err = np.max(np.abs(_obs_array(ob, c["headed_obs"])[:, :4] - c["obs"][3][:, :4]))
-        assert err < 1e-3, (c["model"], c["scenario"], err)
+        assert err < budget, (c["model"], c["scenario"], err, budget)
 
 
 def test_motion_model_manager_peek_g4():
+    from oracle import crowd_oracle as orc
+    from parity_util import F32_SLACK
+
     for k, c in enumerate(load_cases("g4_peek")):
         env = make_env(c["model"], c["scenario"], 6, c["robot_visible"])
         env.reset(phase="test", test_case=c["test_case"])
@@ -123,9 +131,21 @@ def test_motion_model_manager_peek_g4():
         nxt8 = mm.get_next_human_observable_states(0.25, theta_and_omega_visible=True)
         assert nxt4.shape == c["next4"].shape and nxt8.shape == c["next8"].shape
         if not c["model"].endswith("moussaid"):
-            assert np.max(np.abs(nxt4 - c["next4"])) < 1e-4, k
-            assert np.max(np.abs(nxt8[:, [0, 1, 3, 4, 6, 7]] - c["next8"][:, [0, 1, 3, 4, 6, 7]])) < 1e-4, k
+            # the bar of ONE library call, measured for this very case (parity_util.single_call_bar, the rule of the kernel-level G4 test in
+            # tests/test_gpu_parity.py): north_star's 1e-5, or 3 x the float32 oracle's own error where one Euler step of 0.25 s with
+            # stiff forces is ill-conditioned in float32 -- not a blanket 1e-4 (round 4).  + 2e-6: the golden rows passed through float32
+            n = nxt4.shape[0]
+            for key, got, want, cols in (("states_before", nxt4, c["next4"], slice(None)), ("states_mid", nxt8, c["next8"], [0, 1, 3, 4, 6, 7])):
+                args = (c["type"], c[key].astype(np.float32).astype(np.float64), c["goals_before"].astype(np.float32).astype(np.float64), None,
+                        c["params"].astype(np.float32).astype(np.float64), c["dt"], c["safety"].astype(np.float32).astype(np.float64), c["all_params_equal"], c["robot_visible"])
+                ref64 = orc.update_humans(*args)[0]
+                with np.errstate(over="ignore", invalid="ignore"):
+                    ref32 = orc.update_humans(*args, dtype=np.float32)[0]
+                tol = max(1e-5, F32_SLACK * float(np.max(np.abs(ref32[:n][:, [0, 1, 3, 4]] - ref64[:n][:, [0, 1, 3, 4]])))) + 2e-6
+                assert np.max(np.abs(got[:, cols] - want[:, cols])) < tol, (k, key, tol)
         np.testing.assert_allclose(mm.states[:, [0, 1, 2, 5, 6, 7]], c["states_after"][:, [0, 1, 2, 5, 6, 7]], atol=1e-12)  # restored
+        nh = c["goals_before"].shape[0]
+        np.testing.assert_allclose(mm.states[:nh, 10:12], c["states_after"][:nh, 10:12], atol=1e-12)   # the rows' goal columns follow the goal lists (set_human_states)
         np.testing.assert_allclose(mm.goals, c["goals_after"], atol=0, equal_nan=True)
 
 

@@ -187,19 +187,20 @@ def test_block_of_20_substeps(group):
             continue
         cw.step(c["dt"], c["n_substeps"])
         got = cw.get_states()[0]
-        # 20 stiff substeps amplify f32 rounding; SURVEY.md G2 allows 5e-5 (Moussaid: from same inputs).
-        # A respawned human is placed exactly at contact distance (max_x + 2 r) of the right-most one,
-        # where dF/dx = A/B = 25 kN/m: f32 rounding of that position grows ~4x per substep -> 3e-4.
+        # SECONDARY bounds on the END state of the block (the parity claim is the per-substep test below: every one of the 20 substeps
+        # inside the fused launch within 1e-5 from re-synchronised rows).  20 stiff substeps amplify f32 rounding; SURVEY.md G2 allows
+        # 5e-5 (Moussaid: from same inputs).  A respawned human is placed exactly at contact distance (max_x + 2 r) of the right-most
+        # one, where dF/dx = A/B = 25 kN/m: f32 rounding of that position grows ~4x per substep -> 3e-4.
         tol = 5e-5 if c["type"] % 3 != 2 else 2e-3
         if c["respawn"]:
             tol = max(tol, 3e-4)
         err = np.max(np.abs(got[:, PV] - ref[:, PV]))
         assert err < tol, f"{what}: {err}"
-        record(f"{group} 20 substeps (GPU vs f64 oracle, same f32 inputs)", err)
+        record(f"{group} 20 substeps, END state -- secondary to the per-substep groups (GPU vs f64 oracle, same f32 inputs)", err)
         if c["type"] % 3 != 2:
             errg = np.max(np.abs(got[:, PV] - c["out_states"][:, PV]))
             assert errg < max(1e-4, 2 * tol), f"{what} vs golden: {errg}"
-            record(f"{group} 20 substeps (GPU vs golden, continuous models)", errg)
+            record(f"{group} 20 substeps, END state -- secondary to the per-substep groups (GPU vs golden, continuous models)", errg)
         g = cw.get_goals()[0]
         assert np.max(np.abs(np.nan_to_num(g) - np.nan_to_num(ref_goals))) < 1e-4
         if c["respawn"]:  # respawned rows land exactly on the bound rule
