@@ -340,9 +340,13 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.robot = w->d_robot; a.action = d_action; a.peek_out = d_peek;
     a.bx = w->respawn_bound_x; a.by = w->respawn_bound_y;
     a.world_flags = w->d_world_flags;
-    {   // |A| e^-36 = 5e-13 N: far below float32 resolution of any force sum (diagnostic override: CROWDSTEP_WALL_EFOLDS)
+    {   // The reach of a wall's force: beyond 22 e-folding lengths it is below |A| e^-22 = 5.6e-7 N for the reference's A = 2000 N -- less than
+        // the float32 ulp of a 10 N force sum (9.5e-7 N; an agent near a wall carries tens of newtons), 9e-11 m/s on a velocity per substep
+        // (dt / m = 1.7e-4 s/kg) against north_star's 1e-5.  Rounds 2 - 4 used 36 (5e-13 N); in cfg5's bench window the crowd stands among
+        // the polygons and 36 lengths = 2.9 m reach two thirds of all (agent, polygon) pairs, 22 = 1.8 m about half
+        // (profiles/r5e_wall_pairs_ab.txt).  CROWDSTEP_WALL_EFOLDS overrides it.
         const char* e = std::getenv("CROWDSTEP_WALL_EFOLDS");
-        a.wall_efolds = e ? (float)std::atof(e) : 36.0f;
+        a.wall_efolds = e ? (float)std::atof(e) : 22.0f;
     }
 #ifdef CS_STAMPS
     a.stamps = g_stamp_buf;
@@ -376,6 +380,14 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     const long seg_tab = (long)w->O * w->Smax * ((w->flags & CS_OBSTACLES_SHARED) ? 1 : g.wpb);
     a.seg_tab = (seg_tab > 0 && seg_tab * 20 <= 16 * 1024) ? (int)seg_tab : 0;
     shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float)) + 16 + (size_t)(a.seg_tab > 0 ? a.seg_tab / w->Smax : 0) * sizeof(float4);
+    shmem += 128 * sizeof(int) + 130 * sizeof(float2) + sizeof(float4);   // wall pairs (sfmstep_kernel.h): the pairs' records and forces, the wall law
+    {
+        // one (agent, polygon) pair per lane: Helbing-type walls (no tangential term outside a contact), at most 4 polygons staged in LDS, no
+        // respawn rule (the only way an agent jumps); CROWDSTEP_WALL_PAIRS=0 keeps every launch on the all-lanes pass (A/B)
+        static const bool wp_env = []{ const char* e = std::getenv("CROWDSTEP_WALL_PAIRS"); return !(e && e[0] == '0'); }();
+        const bool guo_walls = w->type == 1 || w->type == 4 || w->type == 7;
+        a.wall_pairs = (wp_env && peq && a.seg_tab > 0 && a.seg_tab < 4096 && w->O > 0 && w->O <= 4 && !guo_walls && !(w->flags & CS_RESPAWN) && g.block == 64) ? 1 : 0;
+    }
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     // two one-wavefront blocks per SIMD (the benchmark's 4096 x 25): the second half of the grid shares each SIMD with an older wavefront

@@ -84,7 +84,15 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     float4* lds_seg = lds_pp + (PP ? 2 * T + PADR : 0);            // [seg_tab] x1, y1, ex, ey
     float* lds_sinv = reinterpret_cast<float*>(lds_seg + a.seg_tab);                   // [seg_tab] 1 / |e|^2, 0 = NaN slot
     float4* lds_poly = reinterpret_cast<float4*>(lds_sinv + ((a.seg_tab + 3) & ~3));   // [seg_tab / Smax] bounding circle cx, cy, R of every polygon
-
+    // wall pairs (LEAN = 2; all_params_equal, no respawn rule): up to WP_MAX (agent, polygon) pairs per block.  The 50-row wall build runs
+    // twelve blocks per CU at 10.5 KB each: 4 KB more per block cost it one of them (measured: 208 -> 260 us), so the agents' radii live in
+    // lds_vr (written by the per-agent-parameter builds only) and the contact velocities in the respawn scratch (idle without the rule)
+    constexpr int WP_MAX = 128;
+    int* lds_wrec = reinterpret_cast<int*>(lds_poly + (a.Smax > 0 ? a.seg_tab / a.Smax : 0));   // [WP_MAX] pair: agent's row in lds_p | first segment << 8 | agent lane << 20
+    float2* lds_wres = reinterpret_cast<float2*>(lds_wrec + WP_MAX);                             // [WP_MAX + 1] the pairs' forces ([WP_MAX]: the zero of "no pair")
+    float4* lds_wlaw = reinterpret_cast<float4*>(lds_wres + WP_MAX + 2);                         // [1] the wall law A, log2 e / B, k1, k2 (all_params_equal)
+    float2* lds_wrs = lds_vr;                                                                    // [WP_MAX] pair: the agent's radius, safety space
+    float2* lds_wcv = reinterpret_cast<float2*>(lds_g0x);                                        // [T] the agents' refreshed linear velocities (contact terms)
     const int tid = threadIdx.x;
     static_assert(!LEAN || (PEQ && MAXT == 64), "the lean build is a pair-once build");
     constexpr bool LEAN_ROBOT = LEAN == 3 || LEAN == 4 || LEAN == 5;   // the robot is the last row (5: with walls)
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     if (human) {
         m_tau = m / Pm[0];                      // m / relax_t              (:39)
         Aw = Pm[1]; cBw = LOG2E / Pm[2]; Cw = Pm[3]; cDw = LOG2E / Pm[4]; k1 = Pm[5]; k2 = Pm[6];
-        // beyond this distance a wall's force on me is below |A| e^-36 = 5e-13 N (its contact terms are exact zeros there):
+        // beyond this distance a wall's force on me is below |A| e^-wall_efolds (22: 5.6e-7 N, crowdstep.hip; its contact terms are exact zeros there):
         // a polygon that every agent of the wavefront is that far from is skipped in the substep loop
         wall_cut = r + safety + a.wall_efolds * fmaxf(Pm[2], obs_type == 1 ? Pm[4] : 0.0f);
         ko = Pm[7]; kd = Pm[8]; alpha = Pm[9]; klam = Pm[10];
@@ -384,6 +392,47 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     // wavefronts), which then ran its last three substeps alone, at a lone wavefront's latency-bound pace.  The younger wavefront of a
     // SIMD (a.young_from, set by the launcher for a grid of exactly two per SIMD) raises its priority in every other substep: the two
     // take turns (priority 2 / 1) and finish within 3 % of each other (31.1 -> 29.4 us with the short rare paths, -> 28.3 us with this).
+    // ---- wall pairs (LEAN = 2: the 50-row crowd with polygon walls, cfg5's per-GPU shard) --------------------------------------------
+    // Every lane used to walk every polygon some agent of its wavefront is near: with 50 agents somebody is near each of the three
+    // polygons, so the wave vote never skips -- 3 x (vote + 5 segments x 13 + force) = 252 of a substep's 710 vector instructions --
+    // while half to two thirds of the 150 (agent, polygon) pairs are within the reach of the force in that window, none before it
+    // (tools/wall_pairs_stats.py).
+    // Round 4 compacted the pairs inside every substep (votes, prefix counts, rows handed over through LDS): 90 instructions of
+    // bookkeeping per substep and no gain.  Here the pairs are numbered ONCE per launch: an agent that starts farther than
+    // reach + n_substeps dt v_desired from a polygon cannot get within its reach during the launch (speeds are clamped to v_desired and
+    // the respawn rule -- the only jump -- keeps the builds with CS_RESPAWN on the old pass), so the numbering holds for all substeps.
+    // A substep then costs ONE closest-point + force per lane and pass (two passes for 65 .. 128 pairs; more: the old pass for this
+    // launch) and three LDS reads per agent; a lane whose agent touches its polygon adds the k1 / k2 terms from the agent's refreshed
+    // velocity (published by every agent at the head of the substep).  Same operations on the same operands per pair; a polygon beyond
+    // an agent's reach adds an exact zero instead of a force below the reach's bound.  8192 x 50 + 3 polygons, Gym steps 20-70:
+    // 211 -> 197 us at the old reach of 36 e-folding lengths, 205 -> 191 us at 22 (profiles/r5e_wall_pairs_ab.txt).
+    constexpr int WP_O = 4;                    // polygons per world the pair numbers of an agent cover (one byte each)
+    bool wp_on = false;
+    int wp_count = 0;
+    unsigned wp_mine = 0x80808080u;            // my pairs' numbers, one byte per polygon; WP_MAX = none (lds_wres[WP_MAX] stays zero)
+    if constexpr (LEAN == 2 && MAXT == 64) {
+        if (a.wall_pairs != 0) {                                              // (kernel argument: wave-uniform)
+            const float travel = (float)a.nsub * a.dt * vd + 1.0e-3f;
+            int total = 0;
+            for (int o = 0; o < a.O; ++o) {
+                const float4 pc = lds_poly[(sbase / a.Smax) + o];
+                const float dxc = px - pc.x, dyc = py - pc.y, lim = pc.z + wall_cut + travel;
+                const bool reach = human && fmaf(dxc, dxc, dyc * dyc) < lim * lim;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(reach);
+                const int rank = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (reach && rank < WP_MAX) {
+                    lds_wrec[rank] = (pbase + row) | ((sbase + o * a.Smax) << 8) | (tid << 20);
+                    lds_wrs[rank] = make_float2(r, safety);
+                    wp_mine = (wp_mine & ~(0xFFu << (8 * o))) | ((unsigned)rank << (8 * o));
+                }
+                total += __builtin_popcountll(mk);
+            }
+            if (tid == 0) { lds_wres[WP_MAX] = make_float2(0.0f, 0.0f); *lds_wlaw = make_float4(Aw, cBw, k1, k2); }   // (lane 0 is a human of the block's first world)
+            wp_count = total;
+            wp_on = total <= WP_MAX;             // (more: this launch walks the polygons as before)
+            LDS_ORDER_FENCE();
+        }
+    }
     const bool prio_young = MAXT == 64 && (int)blockIdx.x >= a.young_from;
     // base priority 1: above the generator's wavefronts of a refill pass on the side stream (priority 0, and OLDER than any of mine, so a tie
     // would go to them): the Gym step in NEXT_STEP mode 43.3 -> 41.5 us, a plain launch unchanged
@@ -523,6 +572,61 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         float fsx = 0.0f, fsy = 0.0f;
         // (the reaction accumulators need no zeroing: the first partner group of a substep stores into them)
         STAMP(8);
+        // -- wall pairs: one (agent, polygon) pair per lane and pass, numbered in the prologue (two passes for more than 64 pairs)
+        const bool wp_step = wp_on;
+        if constexpr (LEAN == 2 && MAXT == 64) {
+            if (wp_on && wp_count > 0) {
+                {   // every agent's refreshed linear velocity, for the contact terms of a pair whose agent touches its polygon
+                    float wvx = vx, wvy = vy;
+                    if constexpr (HEADED > 0) { wvx = cs * bvx + (-sn) * bvy; wvy = sn * bvx + cs * bvy; }   // (the statements of part A below)
+                    lds_wcv[tid] = make_float2(wvx, wvy);
+                }
+                LDS_ORDER_FENCE();
+                const float4 law = *lds_wlaw;
+                for (int k0 = 0; k0 < wp_count; k0 += 64) {                                             // (wave-uniform trip count)
+                    const int k = k0 + tid;
+                    if (k < wp_count) {
+                        const int wr = lds_wrec[k];
+                        const float2 wq = lds_wrs[k];
+                        const float2 ap = *reinterpret_cast<const float2*>(&lds_p[cur * TP + (wr & 0xFF)]);   // the agent's incoming position
+                        const float4* sgp = lds_seg + ((wr >> 8) & 0xFFF);
+                        const float* sip = lds_sinv + ((wr >> 8) & 0xFFF);
+                        float best = INFINITY, bdx = 0.0f, bdy = 0.0f;
+                        for (int s0 = 0; s0 < a.Smax; ++s0) {                                            // first argmin over the polygon's segments
+                            const float4 e = sgp[s0];
+                            const float iv = sip[s0];
+                            const float qx = ap.x - e.x, qy = ap.y - e.y;
+                            const float t = fmaf(qx, e.z, qy * e.w) * iv;
+                            const float ts = fminf(fmaxf(t, 0.0f), 1.0f);
+                            const float ddx = fmaf(-ts, e.z, qx), ddy = fmaf(-ts, e.w, qy);
+                            const float d = fmaf(ddx, ddx, ddy * ddy);
+                            const bool better = d < best;
+                            best = better ? d : best; bdx = better ? ddx : bdx; bdy = better ? ddy : bdy;
+                        }
+                        const float bcl = fmaxf(best, 1e-30f);
+                        const float inv = rsq_fast(bcl);
+                        const float dist = best * inv;
+                        const float nx = bdx * inv, ny = bdy * inv;
+                        const float rd = wq.x - dist + wq.y;
+                        float2 f;
+                        if (rd > -1.0e-3f) {   // (rare, lane-divergent) body contact: the k1 / k2 terms on the refined distance and the tangential velocity
+                            const float2 cv = lds_wcv[wr >> 20];
+                            const float dv = -(cv.y * nx - cv.x * ny);
+                            const float m0 = fmaxf(0.0f, wq.x - dist_refined(bcl, inv) + wq.y);
+                            const float fn = fmaf(law.x, exp2_fast(rd * law.y), law.z * m0);
+                            const float ft = -(law.w * m0) * dv;
+                            f = make_float2(fn * nx - ft * ny, fn * ny + ft * nx);
+                        } else {
+#pragma clang fp contract(off)
+                            const float fn = law.x * exp2_fast(rd * law.y);
+                            f = make_float2(fn * nx, fn * ny);
+                        }
+                        lds_wres[k] = f;
+                    }
+                }
+                LDS_ORDER_FENCE();
+            }
+        }
         // -- part A of the per-agent update: everything that does not need this substep's social force
         const float c = cs, s = sn;          // rotation matrix of the incoming heading, :254-256
         float cvx = vx, cvy = vy;            // refreshed linear velocity
@@ -544,7 +648,16 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 fdy = far_ ? wy : 0.0f;
             }
             // -- obstacle force: closest point per polygon :236-252, then :136-162
-            if (obst != nullptr) {
+            if (obst != nullptr && wp_step) {
+                // (wall pairs) my pairs' forces in polygon order -- the reference's order of summation; a polygon beyond my reach left its zero
+#pragma clang fp contract(off)
+                for (int o = 0; o < a.O; ++o) {
+                    const float2 f = lds_wres[(wp_mine >> (8 * o)) & 0xFFu];
+                    fox = fox + f.x;
+                    foy = foy + f.y;
+                }
+                fox *= inv_O; foy *= inv_O;
+            } else if (obst != nullptr) {
                 for (int o = 0; o < a.O; ++o) {
                     // first argmin over the polygon's segments, on squared distances (same order)
                     float best = INFINITY, bdx = 0.0f, bdy = 0.0f;   // the first slot always beats +inf: a first argmin

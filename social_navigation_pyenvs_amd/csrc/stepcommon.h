@@ -53,6 +53,8 @@ struct KArgs {
     float rm_P[20];        // the robot's parameters
     int young_from;        // blocks from this index on are the YOUNGER wavefront of their SIMD (a grid of exactly two wavefronts per SIMD), INT_MAX: no such split
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
+    int wall_pairs;        // LEAN = 2 builds: the (agent, polygon) pairs within reach over the whole launch are numbered ONCE in the prologue and a
+                           // substep evaluates one pair per lane (sfmstep_kernel.h, "wall pairs"); 0: every lane walks every polygon its wavefront is near
     unsigned long long* stamps; // diagnostic build only
     GymHead gym;           // cs_gym_step: reward / termination of the incoming state + episode bookkeeping in the prologue (gym.out == nullptr: none)
 };
