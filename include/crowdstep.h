@@ -473,14 +473,31 @@ typedef struct cs_stage_book {
     uint32_t* d_epoch;            /* [W] */
     uint32_t* d_staged_seed;      /* [depth][W] */
     int32_t* d_staged_status;     /* [depth][W] */
-    int32_t* d_failed;            /* [W] */
+    int32_t* d_failed;            /* [W] 0 = the last take-over succeeded, 1 = the staged episode could not be generated, 2 = deferred (cs_gym_step_staged) */
     uint32_t seed_stride;         /* 0 = W */
     int32_t depth;                /* episodes staged ahead per world: a power of two */
+    int32_t* d_pending;           /* [W] cs_gym_step_staged only (may be NULL otherwise): 1 = the world's episode is over and its take-over deferred */
 } cs_stage_book;
 /* `staging` describes depth * W worlds of the shape of the live batch (same n, G, layout, robot row) */
 int cs_refill_staged_worlds(const cs_generator* gen, const cs_worlds* staging, const cs_stage_book* book, void* stream);
 int cs_consume_staged_worlds(const cs_generator* gen, const cs_worlds* staging, const cs_worlds* live, const int32_t* d_mask,
                              const cs_stage_book* book, int theta_and_omega_visible, float* d_obs, void* stream);
+
+/* cs_gym_step followed by cs_consume_staged_worlds in ONE launch (SocialNavGym.step + the reset of the worlds that ended,
+ * social_nav_gym.py:227-250, :120-225): the head of the step kernel decides which worlds take over their staged episode at the end of this
+ * launch -- same-step rules (book->auto_reset): the worlds that end now; NEXT_STEP rules (book->d_prev_mask): those that ended in the
+ * previous step -- and the wavefront that stepped such a world copies the staged episode over it (rows, goal lists, robot row, world
+ * flag, observation rows) instead of writing the stepped rows.  Same results as the two launches, bit for bit, whenever the slot is staged.
+ * A slot the refill has NOT staged yet is not generated in place (cs_consume_staged_worlds does that): the take-over is DEFERRED --
+ * d_pending[w] = 1, d_failed[w] = 2, the world is between two episodes (reward 0, no flags, observation of its finished rows) until a later
+ * cs_gym_step_staged finds the slot.  With the refill cadence of social_gym/social_nav_gym.py (a pass whenever a world may have ended, `depth`
+ * episodes ahead) that does not happen.  Only for worlds cs_gym_step runs as one launch (cs_gym_step_is_one_launch: SFM / HSFM worlds of
+ * up to 64 rows on the one-wavefront builds) and without polygon walls; CS_ERR_ARG otherwise -- take the two launches there.
+ * cs_gym_step_is_one_launch: 0 = cs_gym_step is two launches for these worlds, 1 = one launch, 2 = one launch and cs_gym_step_staged too. */
+int cs_gym_step_is_one_launch(const cs_worlds* w);
+int cs_gym_step_staged(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float T, float* d_global_time, const float* reward_cfg,
+                       float* d_out, const cs_gym_book* book, int theta_and_omega_visible, float* d_obs, const cs_generator* gen,
+                       const cs_worlds* staging, const cs_stage_book* stage_book, void* stream);
 
 /* layout conversion of a state array between the reference's AoS rows and SoA planes */
 int cs_state_aos_to_soa(const float* d_aos, float* d_soa, int W, int rows, void* stream);

@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "cs_update_humans_rk45", "cs_gym_bookkeeping", "cs_step_variant", "cs_debug_divsqrt_check", "cs_gym_observe", "cs_copy_worlds_masked", "cs_imitation_block", "cs_gym_bookkeeping_next_step", "cs_robot_model_velocities",
     "cs_step_trace", "cs_reserve_scratch", "cs_release_scratch", "cs_complete_rk45_simulation", "cs_robot_model_rk45", "cs_copy_worlds_masked_status",
     "cs_collision_reward_gym", "cs_step_observe", "cs_copy_worlds_masked_observe", "cs_refill_staged_worlds", "cs_consume_staged_worlds", "cs_gym_step",
-    "cs_orca_set_math", "cs_orca_get_math",
+    "cs_orca_set_math", "cs_orca_get_math", "cs_gym_step_is_one_launch", "cs_gym_step_staged",
 ]
 
 
@@ -60,7 +60,7 @@ class cs_gym_book(C.Structure):   # include/crowdstep.h cs_gym_book: the bookkee
 class cs_stage_book(C.Structure):   # include/crowdstep.h cs_stage_book: the tags of the pre-staged episodes
     _fields_ = [
         ("d_seeds", C.c_void_p), ("d_base_seed", C.c_void_p), ("d_epoch", C.c_void_p), ("d_staged_seed", C.c_void_p),
-        ("d_staged_status", C.c_void_p), ("d_failed", C.c_void_p), ("seed_stride", C.c_uint32), ("depth", C.c_int32),
+        ("d_staged_status", C.c_void_p), ("d_failed", C.c_void_p), ("seed_stride", C.c_uint32), ("depth", C.c_int32), ("d_pending", C.c_void_p),
     ]
 
 

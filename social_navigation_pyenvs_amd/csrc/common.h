@@ -6,7 +6,7 @@
 
 #include "crowdstep.h"
 
-namespace cstep { struct KArgs; }
+namespace cstep { struct KArgs; struct GymFold; }
 
 namespace csimpl {
 
@@ -21,6 +21,11 @@ inline int fail(int code, const std::string& msg)
 #ifdef CS_STAMPS
 extern unsigned long long* g_stamp_buf; // diagnostic build only (tools/stamp_probe.py)
 #endif
+
+// cs_gym_step_staged (crowdstep.hip): the staged-episode take-over's arguments for the step kernel's epilogue, built and checked where
+// the pre-staged episodes live (generate.hip)
+int stage_fold(const cs_generator* gen, const cs_worlds* staging, const cs_worlds* live, const cs_stage_book* book, int obs_cols, float* d_obs,
+               cstep::GymFold& out);
 
 // ORCA branch (orca.hip)
 int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float* d_peek, hipStream_t stream);

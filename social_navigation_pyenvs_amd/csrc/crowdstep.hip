@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int 
     const bool valid = lw < wpb && w < W;
     float rpx = 0, rpy = 0, rr = 0, rgx = 0, rgy = 0, ax = 0, ay = 0;
     float closest = INFINITY;
-    cstep::GymPre pre = {0.0f, 0, 0};
+    cstep::GymPre pre = {0.0f, 0, 0, 0, 0u, 0u};
     if (valid) {
         if (i == 0) pre = gym_head_preload(g, w);
         const float* rb = robot + (long)w * 13;
@@ -516,14 +516,12 @@ int cs_step_observe(const cs_worlds* w, float dt, int n_substeps, const float* d
                        theta_and_omega_visible ? 7 : 5);
 }
 
-int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float T, float* d_global_time, const float* reward_cfg,
-                float* d_out, const cs_gym_book* book, int theta_and_omega_visible, float* d_obs, void* stream)
+int cs_gym_step_is_one_launch(const cs_worlds* w)
 {
-    if (!w || !book || !d_obs) return fail(CS_ERR_ARG, "null argument");
-    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
-    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     // ONE launch where the step kernel is the LDS kernel of one wavefront per block (SFM / HSFM worlds of up to 64 rows); the two
     // launches everywhere else (ORCA, social momentum, the DPP-row kernel's small worlds keep their own launch: same results)
+    if (!w) return 0;
+    const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     bool fused = w->type >= 0 && w->type <= 8 && rows <= 64 && w->W > 0 && w->n > 0;
     if (fused) {
         if (check_worlds(w)) fused = false;
@@ -537,6 +535,17 @@ int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_act
             }
         }
     }
+    if (!fused) return 0;
+    // 2: cs_gym_step_staged as well (the take-over in the epilogue is compiled into the builds without walls: sfmstep_kernel.h FOLD)
+    return w->O > 0 ? 1 : 2;
+}
+
+int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float T, float* d_global_time, const float* reward_cfg,
+                float* d_out, const cs_gym_book* book, int theta_and_omega_visible, float* d_obs, void* stream)
+{
+    if (!w || !book || !d_obs) return fail(CS_ERR_ARG, "null argument");
+    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
+    const bool fused = cs_gym_step_is_one_launch(w) != 0;
     if (!fused) {
         const int rc = cs_collision_reward_gym(w, d_action, T, d_global_time, reward_cfg, d_out, book, stream);
         return rc ? rc : cs_step_observe(w, dt, n_substeps, d_action, theta_and_omega_visible, d_obs, stream);
@@ -548,6 +557,29 @@ int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     int mode = M_COMMIT_GOALS;
     if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
     const GymHead gh = gym_head(d_out, d_global_time, T, reward_cfg, book, w->W);
+    return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, d_obs,
+                       theta_and_omega_visible ? 7 : 5, &gh);
+}
+
+int cs_gym_step_staged(const cs_worlds* w, float dt, int n_substeps, const float* d_action, float T, float* d_global_time, const float* reward_cfg,
+                       float* d_out, const cs_gym_book* book, int theta_and_omega_visible, float* d_obs, const cs_generator* gen,
+                       const cs_worlds* staging, const cs_stage_book* stage_book, void* stream)
+{
+    if (!w || !book || !d_obs || !gen || !staging || !stage_book) return fail(CS_ERR_ARG, "null argument");
+    if (n_substeps <= 0) return fail(CS_ERR_ARG, "n_substeps must be positive");
+    if (!stage_book->d_pending || !stage_book->d_failed) return fail(CS_ERR_ARG, "cs_gym_step_staged needs cs_stage_book.d_pending and d_failed");
+    if (!book->auto_reset && !book->d_prev_mask) return fail(CS_ERR_ARG, "cs_gym_step_staged is the auto-reset step (cs_gym_book.auto_reset or the NEXT_STEP masks)");
+    if (cs_gym_step_is_one_launch(w) != 2) return fail(CS_ERR_ARG, "cs_gym_step_staged: these worlds take the two launches (cs_gym_step, then cs_consume_staged_worlds)");
+    if (!d_action || !d_global_time || !reward_cfg || !d_out || !w->d_robot) return fail(CS_ERR_ARG, "null argument");
+    if (book->clock_len <= 0 || !book->d_counter || !book->d_seeds || !book->d_mask || !book->d_clock || !book->d_reward ||
+        !book->d_terminated || !book->d_truncated || !book->d_info)
+        return fail(CS_ERR_ARG, "null buffer in cs_gym_book");
+    if (book->d_seeds != stage_book->d_seeds) return fail(CS_ERR_ARG, "cs_gym_book.d_seeds and cs_stage_book.d_seeds must be one buffer");
+    int mode = M_COMMIT_GOALS;
+    if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
+    GymHead gh = gym_head(d_out, d_global_time, T, reward_cfg, book, w->W);
+    const int rc = csimpl::stage_fold(gen, staging, w, stage_book, theta_and_omega_visible ? 7 : 5, d_obs, gh.fold);
+    if (rc) return rc;
     return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, d_obs,
                        theta_and_omega_visible ? 7 : 5, &gh);
 }

@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "crowdstep.h"
+#include "gymhead.h"
 #include "worldcopy.h"
 
 #pragma clang fp contract(off) // the reference's numpy expressions are not fused
@@ -789,6 +790,20 @@ int stage_args(const cs_generator* gen, const cs_worlds* staging, const cs_world
 }
 
 } // namespace
+
+int csimpl::stage_fold(const cs_generator* gen, const cs_worlds* staging, const cs_worlds* live, const cs_stage_book* book, int obs_cols, float* d_obs,
+                       cstep::GymFold& out)
+{
+    StageArgs a;
+    const int rc = stage_args(gen, staging, live, book, a);
+    if (rc) return rc;
+    if (!live || !book->d_pending || !book->d_failed) return fail(CS_ERR_ARG, "null argument");
+    out.on = 1; out.depth = a.depth; out.W = a.W;
+    out.staged_seed = a.staged_seed; out.staged_status = a.staged_status; out.epoch = a.epoch; out.failed = a.failed; out.pending = book->d_pending;
+    out.copy = a.copy;
+    out.copy.obs = d_obs; out.copy.C = obs_cols;
+    return CS_OK;
+}
 
 extern "C" {
 

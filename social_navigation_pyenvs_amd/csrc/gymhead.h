@@ -8,7 +8,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "worldcopy.h"
+
 namespace cstep {
+
+// cs_gym_step_staged: the take-over of the pre-staged episodes (cs_consume_staged_worlds, generate.hip) folded into the step launch.
+// The head (prologue) decides which worlds take over their staged episode at the end of THIS launch, checks the slot's tag and leaves a
+// code in `pending[w]`; the epilogue of the wavefront that stepped the world copies the slot over it instead of writing the stepped rows.
+//   pending[w]  between launches: 1 = the world's episode is over but its slot was not staged yet (the take-over is DEFERRED: the world
+//               is between episodes -- reward 0, no flags, as a NEXT_STEP world after its terminal step -- until a later launch finds
+//               the slot), 0 otherwise.  Inside a launch: 0 = keep stepping, 1 = deferred, 2 + slot = copy that slot.
+// Ordering (no acquire / release pair, as in k_consume_staged): the tag is written LAST by the refill, behind a release of the slot's
+// words; it is read here with a device-scope relaxed load, the words ~30 us later with device-scope relaxed loads under a control
+// dependency on it (a slot whose tag is this world's next seed is not rewritten before the world's epoch moves); the epoch is stored
+// after every load of the slot has returned (s_waitcnt vmcnt(0) behind the copy: program order of one wavefront) -- from then on the
+// refill may overwrite the slot.
+struct GymFold {
+    int on, depth, W;
+    const unsigned* staged_seed; const int* staged_status; unsigned* epoch; int* failed; int* pending;
+    csimpl::CopyArgs copy;   // staging -> live (with the Gym's observation rows)
+};
 
 // episode bookkeeping of a vectorised Gym step (cs_gym_bookkeeping / _next_step, robot_model.hip), done by the lane that wrote the
 // world's reward row (mode 0: none, 1: same-step rules, 2: NEXT_STEP rules)
@@ -24,6 +43,7 @@ struct GymHead {
     const float* gtime;      // [W] global time read for the time limit (== bk.gtime when the bookkeeping runs)
     float T, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     GymBook bk;
+    GymFold fold;
 };
 
 // closest approach of one human to the robot over [0, T] with both velocities held (utils.py:22-36), minus the two radii
@@ -45,14 +65,16 @@ __device__ __forceinline__ float gym_swept_closest(float hx, float hy, float hvx
 }
 
 // what the head reads of its world's episode state: loaded by the caller together with its other loads (one memory round trip for all)
-struct GymPre { float gtime; int counter, prev; };
+struct GymPre { float gtime; int counter, prev, pending; unsigned seed, epoch; };
+template <bool FOLD = true>
 __device__ __forceinline__ GymPre gym_head_preload(const GymHead& g, int w)
 {
     GymPre p;
-    p.gtime = g.gtime[w]; p.counter = 0; p.prev = 0;
+    p.gtime = g.gtime[w]; p.counter = 0; p.prev = 0; p.pending = 0; p.seed = 0; p.epoch = 0;
     if (g.bk.mode != 0) {
         p.counter = g.bk.counter[w];
         if (g.bk.mode == 2) p.prev = g.bk.prev[w];
+        if (FOLD && g.fold.on) { p.pending = g.fold.pending[w]; p.seed = g.bk.seeds[w]; p.epoch = g.fold.epoch[w]; }
     }
     return p;
 }
@@ -60,7 +82,9 @@ __device__ __forceinline__ GymPre gym_head_preload(const GymHead& g, int w)
 // One lane per world: goes over the humans' swept distances closest[0 .. n) in index order -- the reference's loop with its early `break`,
 // written without the break (dmin = the minimum over the humans BEFORE the first collision) so that the n LDS reads are independent of each
 // other: round 4's first version waited for every one of them in turn --, writes the reward row and -- bk.mode != 0 -- does the world's bookkeeping.
-__device__ __forceinline__ void gym_head_world(const GymHead& g, int w, int n, const float* closest, float rpx, float rpy, float rr,
+// Returns true when the world takes over its staged episode at the end of this launch (cs_gym_step_staged; the separate
+// cs_consume_staged_worlds launch reads the same decision from the masks).
+__device__ __forceinline__ bool gym_head_world(const GymHead& g, int w, int n, const float* closest, float rpx, float rpy, float rr,
                                                float rgx, float rgy, float ax, float ay, const GymPre pre)
 {
 #pragma clang fp contract(off)
@@ -91,12 +115,12 @@ __device__ __forceinline__ void gym_head_world(const GymHead& g, int w, int n, c
     float* o = g.out + (long)w * 7;
     o[0] = (float)collision; o[1] = dmin; o[2] = (float)reaching; o[3] = reward;
     o[4] = (float)term; o[5] = (float)trunc; o[6] = (float)info;
-    if (bk.mode == 0) return;
+    if (bk.mode == 0) return false;
     // the same statements as k_gym_bookkeeping / k_gym_bookkeeping_next_step (robot_model.hip), on the values just written
-    if (bk.mode == 2 && pre.prev) {
+    if ((bk.mode == 2 && pre.prev) || pre.pending) {   // between two episodes (NEXT_STEP's step after the terminal one; a deferred take-over)
         bk.reward[w] = 0.0f; bk.terminated[w] = 0; bk.truncated[w] = 0; bk.info[w] = 0;
         bk.mask[w] = 0; bk.counter[w] = 0; bk.gtime[w] = clk0;
-        return;
+        return true;
     }
     bk.reward[w] = reward; bk.terminated[w] = term ? 1 : 0; bk.truncated[w] = trunc ? 1 : 0; bk.info[w] = info;
     const bool done = term || trunc;
@@ -110,6 +134,22 @@ __device__ __forceinline__ void gym_head_world(const GymHead& g, int w, int n, c
     }
     bk.counter[w] = c;
     bk.gtime[w] = c == 0 ? clk0 : clk1;
+    return bk.mode != 2 && bk.auto_reset && done;      // same-step rules: the world that ends NOW is replaced before the observation is returned
+}
+
+// The head's second half under cs_gym_step_staged, by the lane that ran gym_head_world: `take` = its verdict.  Leaves the launch's code in
+// pending[w] (read back by the whole wavefront in the epilogue with a device-scope load).
+__device__ __forceinline__ void gym_fold_decide(const GymHead& g, int w, bool take, bool ended_now, const GymPre pre)
+{
+    const GymFold& f = g.fold;
+    int code = 0;
+    if (take) {
+        const unsigned want = pre.seed + (ended_now ? g.bk.stride : 0u);              // the seed the bookkeeping has moved this world to
+        const long slot = (long)((pre.epoch + 1u) & (unsigned)(f.depth - 1)) * f.W + w;
+        const unsigned tag = __hip_atomic_load(f.staged_seed + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        code = tag == want ? (int)slot + 2 : 1;
+    }
+    if (code != 0 || pre.pending != 0) __hip_atomic_store(f.pending + w, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 } // namespace cstep

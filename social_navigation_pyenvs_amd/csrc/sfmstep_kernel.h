@@ -163,13 +163,16 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     }
     // (cs_gym_step: the robot as the head sees it and the action, see below)
     float hrb[5] = {0, 0, 0, 0, 0}, hact[2] = {0, 0};
-    GymPre hpre = {0.0f, 0, 0};
+    // cs_gym_step_staged's take-over in the epilogue (gymhead.h GymFold): compiled into the builds without walls only -- the 50-row wall build
+    // has no register to spare (its shard went 191 -> 200 us with the fold compiled in), and a Gym with polygon walls keeps the two launches
+    constexpr bool FOLD = MAXT == 64 && !(LEAN == 2 || LEAN == 5);
+    GymPre hpre = {0.0f, 0, 0, 0, 0u, 0u};
     if constexpr (MAXT == 64) {
         if (a.gym.out != nullptr && valid) {
             const float* rb = a.robot + (long)w * 13;      // the robot BEFORE its move of substep 1
             hrb[0] = rb[0]; hrb[1] = rb[1]; hrb[2] = rb[8]; hrb[3] = rb[10]; hrb[4] = rb[11];
             hact[0] = a.action[(long)w * 2]; hact[1] = a.action[(long)w * 2 + 1];
-            if (row == 0) hpre = gym_head_preload(a.gym, w);   // (last: the compiler waits for these right here)
+            if (row == 0) hpre = gym_head_preload<MAXT == 64 && !(LEAN == 2 || LEAN == 5)>(a.gym, w);   // (last: the compiler waits for these right here)
         }
     }
     // imitation learning (LEAN = 4)
@@ -273,7 +276,10 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
             const float rpx = hrb[0], rpy = hrb[1], rr = hrb[2], rgx = hrb[3], rgy = hrb[4], gax = hact[0], gay = hact[1];   // (loaded at the top)
             clo[tid] = human ? gym_swept_closest(px, py, vx, vy, r, rpx, rpy, rr, gax, gay, a.gym.T) : INFINITY;
             LDS_ORDER_FENCE();
-            if (valid && row == 0) gym_head_world(a.gym, w, n, clo + base, rpx, rpy, rr, rgx, rgy, gax, gay, hpre);
+            if (valid && row == 0) {
+                const bool take = gym_head_world(a.gym, w, n, clo + base, rpx, rpy, rr, rgx, rgy, gax, gay, hpre);
+                if constexpr (FOLD) { if (a.gym.fold.on) gym_fold_decide(a.gym, w, take, take && !((a.gym.bk.mode == 2 && hpre.prev) || hpre.pending), hpre); }
+            }
             LDS_ORDER_FENCE();
         }
     }
@@ -1314,8 +1320,16 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         }
         return;
     }
-    if (human && gdirty && (kmode & M_COMMIT_GOALS)) { gi[0] = g0x; gi[1] = g0y; gi[2] = g1x; gi[3] = g1y; }
-    if (valid) {
+    // cs_gym_step_staged: what the head decided for my world (gymhead.h GymFold).  A world that takes over its staged episode writes
+    // nothing of the stepped rows; the wavefront copies the slot over it below.
+    int fold_code = 0;
+    if constexpr (FOLD) {
+        if (a.gym.out != nullptr && a.gym.fold.on && valid)
+            fold_code = __hip_atomic_load(a.gym.fold.pending + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool taken_over = fold_code >= 2;
+    if (human && gdirty && (kmode & M_COMMIT_GOALS) && !taken_over) { gi[0] = g0x; gi[1] = g0y; gi[2] = g1x; gi[3] = g1y; }
+    if (valid && !taken_over) {
         float* o = a.Sout + sidx * a.out_as;
         const long fs = a.out_fs;
         if (human || is_robot) {
@@ -1357,6 +1371,30 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
                 }
             }
             rb[0] = qx; rb[1] = qy; rb[2] = qt; rb[3] = qvx; rb[4] = qvy;
+        }
+    }
+    if constexpr (FOLD) {
+        if (a.gym.out != nullptr && a.gym.fold.on) {
+            const GymFold& f = a.gym.fold;
+            for (int l = 0; l < a.wpb; ++l) {                                   // the worlds of this wavefront, one after the other (wave-uniform)
+                const int wl = blockIdx.x * a.wpb + l;
+                if (wl >= a.W) break;
+                const int code = __builtin_amdgcn_readlane(fold_code, l * rows);  // (the lane of the world's row 0 holds its code like every lane of the world)
+                if (code == 0) continue;
+                if (code >= 2) {
+                    const long slot = code - 2;
+                    const int status = csimpl::copy_world<true>(f.copy, slot, wl, tid, f.staged_status + slot);   // (a world that could not be generated is not copied)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every load of the slot has returned
+                    if (tid == 0) {
+                        f.failed[wl] = status != 0 ? 1 : 0;
+                        __hip_atomic_store(f.pending + wl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // LAST: from here on the refill may overwrite the slot (it now belongs to episode epoch + depth)
+                        __hip_atomic_store(f.epoch + wl, f.epoch[wl] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else if (tid == 0) {
+                    f.failed[wl] = 2;                                             // deferred: the slot was not staged yet (pending[wl] stays 1)
+                }
+            }
         }
     }
 }

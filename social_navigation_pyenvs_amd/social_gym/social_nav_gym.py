@@ -381,6 +381,7 @@ class BatchedSocialNavGym:
     STAGE_DEPTH = 64
     STAGE_BYTES = 1 << 30
     REFILL_PRIORITY = 0      # stream priority of the refill passes (1 = the device's lowest: no measurable difference)
+    FOLD_RESET = True        # the take-over of the staged episodes inside the step's launch (cs_gym_step_staged) where the step kernel allows it
 
     def _stage_depth(self):
         rows = self.cw.rows
@@ -403,7 +404,7 @@ class BatchedSocialNavGym:
         if getattr(self, "_gen_scenario", None) is None:
             raise RuntimeError("step_device needs a world batch generated on the device: reset(..., device=True)")
         if getattr(self, "_dl", None) is not None:       # a new batch: the old one's refill pass may still be writing its staging worlds
-            _lib.stream_sync(self._dl["stream_b"])
+            self._release_device_loop()
         try:
             torch.zeros(1, device="cuda")
         except RuntimeError as e:  # _lib.load() maps torch's bundled HIP runtime for both, whatever the import order
@@ -439,6 +440,7 @@ class BatchedSocialNavGym:
                   staged_seed=seeds.repeat(depth).contiguous(),
                   staged_status=torch.zeros(W * depth, dtype=torch.int32, device="cuda"),
                   failed=torch.zeros(W, dtype=torch.int32, device="cuda"),
+                  pending=torch.zeros(W, dtype=torch.int32, device="cuda"),     # cs_gym_step_staged: take-overs deferred to a later step
                   out=self.cw._buffer("reward_out", (W, 7)).torch(),
                   state=self.cw.d_state.torch().view(W, self.cw.rows, 13),
                   gen=gen.make_generator(self.cw, self._gen_scenario, **self._gen_kw),
@@ -454,7 +456,7 @@ class BatchedSocialNavGym:
         P = lambda t: t.data_ptr()
         dl["stage_book"] = _lib.cs_stage_book(d_seeds=P(dl["seeds"]), d_base_seed=P(dl["base_seed"]), d_epoch=P(dl["epoch"]),
                                               d_staged_seed=P(dl["staged_seed"]), d_staged_status=P(dl["staged_status"]), d_failed=P(dl["failed"]),
-                                              seed_stride=dl["stride"], depth=depth)
+                                              seed_stride=dl["stride"], depth=depth, d_pending=P(dl["pending"]))
         dl["staging_desc"] = dl["staging"].descriptor()
         dl["refill_args"] = (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), C.byref(dl["stage_book"]), C.c_void_p(dl["stream_b"]))
         dl["refill_ev"] = _lib.Event()
@@ -467,6 +469,29 @@ class BatchedSocialNavGym:
         _lib.stream_sync(dl["stream_b"])
         self._dl = dl
         return dl
+
+    def _release_device_loop(self):
+        """The refill passes run on a library stream torch's allocator knows nothing about, on tensors torch owns (epoch, base_seed, the
+        staging tags): before those tensors can go back to the allocator the stream must have drained -- and it is destroyed, not leaked."""
+        dl = getattr(self, "_dl", None)
+        if dl is None:
+            return
+        self._dl = None
+        try:
+            _lib.stream_sync(dl["stream_b"])
+            _lib.stream_destroy(dl["stream_b"])
+        except Exception:
+            pass
+
+    def close(self):
+        """End of the environment's device-resident loop (also run when the object is collected): drains and destroys the refill stream."""
+        self._release_device_loop()
+
+    def __del__(self):
+        try:
+            self._release_device_loop()
+        except Exception:
+            pass
 
     def _maybe_refill(self, dl):
         """Every REFILL_EVERY steps: one pass of cs_refill_staged_worlds on the side stream (at most one in flight).  Nothing orders it
@@ -492,7 +517,8 @@ class BatchedSocialNavGym:
                                 seed_stride=dl["stride"])
 
     def _step_pieces(self, dl, parity, mode):
-        r"""One vectorised Gym step = TWO library launches on ONE stream, every ctypes argument bound once per (result set, mode):
+        r"""One vectorised Gym step = ONE library launch (cs_gym_step_staged; SFM / HSFM crowds on the one-wavefront kernels) or two on one
+        stream, every ctypes argument bound once per (result set, mode):
 
             cs_gym_step (reward + bookkeeping in the step kernel's prologue, substeps, observation)  ->  cs_consume_staged_worlds
 
@@ -535,8 +561,13 @@ class BatchedSocialNavGym:
         # flagged in reset_failed_mask())
         a_tail = None if tail_mask is None else (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), dref, P(tail_mask), C.byref(dl["stage_book"]),
                                                  C.c_int(int(self.headed_obs)), P(dl["obs"]), A)
+        # ... or both in ONE launch (cs_gym_step_staged: the take-over in the step kernel's epilogue) where the step is the one-wavefront
+        # SFM / HSFM kernel; FOLD_RESET = False keeps the two launches (the bit-equality reference of the tests)
+        a_fold = None
+        if tail_mask is not None and self.FOLD_RESET and _lib.load().cs_gym_step_is_one_launch(dref) == 2:
+            a_fold = a_step[:-1] + (C.byref(dl["gen"]), C.byref(dl["staging_desc"]), C.byref(dl["stage_book"]), A)
         keep = (d, cfg, book)              # the structs the byref arguments point into
-        dl[key] = dict(step=a_step, tail=a_tail, keep=keep)
+        dl[key] = dict(step=a_step, tail=a_tail, fold=a_fold, keep=keep)
         return dl[key]
 
     def step_device(self, actions, auto_reset=True):
@@ -571,10 +602,14 @@ class BatchedSocialNavGym:
         if actions is not dl["act"]:
             with torch.cuda.stream(side):
                 dl["act"].copy_(actions.to(device="cuda", dtype=torch.float32), non_blocking=True)
-        chk(lib.cs_gym_step(*c["step"]))
-        if c["tail"] is not None:
-            chk(lib.cs_consume_staged_worlds(*c["tail"]))
+        if c["fold"] is not None:
+            chk(lib.cs_gym_step_staged(*c["fold"]))
             self._maybe_refill(dl)
+        else:
+            chk(lib.cs_gym_step(*c["step"]))
+            if c["tail"] is not None:
+                chk(lib.cs_consume_staged_worlds(*c["tail"]))
+                self._maybe_refill(dl)
         if not same:
             cur.wait_stream(side)                  # ... and with whoever reads the results
         reward, terminated, truncated, info = dl["results"][parity]
@@ -583,8 +618,12 @@ class BatchedSocialNavGym:
     def reset_failed_mask(self):
         """int32 CUDA tensor [W], no synchronisation: 1 where the world's LAST device-side auto-reset could not be generated
         (cs_generate_worlds status != 0: the bounded rejection sampling gave up, or the traffic is too dense -- the reference loops
-        forever / raises there).  Such a world keeps its finished rows, ends again on the next step and then tries the following
-        seed of its sequence; the flag returns to 0 with the first reset that succeeds."""
+        forever / raises there).  Such a world keeps its finished rows and starts a new episode FROM them (its step counter and clock
+        were reset with the others'): after a collision or a reached goal it ends again at once and tries the following seed of its
+        sequence; after a time-limit truncation it runs a further episode from where it stands.  The flag returns to 0 with the first
+        reset that succeeds.  2: the take-over was DEFERRED (one-launch step, cs_gym_step_staged: the staged episode was not ready; the
+        world is between two episodes -- reward 0, no flags -- until a later step finds it; with the refill cadence of this class that does
+        not happen)."""
         return self._device_loop_state()["failed"]
 
     def failed_resets(self) -> int:

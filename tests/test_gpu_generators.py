@@ -657,6 +657,9 @@ def test_step_device_is_the_same_whatever_the_refill_cadence():
     envs = [BatchedSocialNavGym(cfg, W) for _ in range(3)]
     envs[1].REFILL_EVERY, envs[1].STAGE_DEPTH = 10 ** 9, 2
     envs[2].REFILL_EVERY, envs[2].STAGE_DEPTH = 1, 1
+    # envs[0] takes the ONE-launch step (cs_gym_step_staged, the default); the two odd cadences run a staging batch dry on purpose and need
+    # the in-place generation of the separate consume launch: the two-launch path -- which is thereby also the bit-equality reference of the fold
+    envs[1].FOLD_RESET = envs[2].FOLD_RESET = False
     for e in envs:
         e.reset(phase="train", first_case=7, device=True)
     ended = np.zeros(W, int)
@@ -676,6 +679,94 @@ def test_step_device_is_the_same_whatever_the_refill_cadence():
         np.testing.assert_array_equal(e.cw.get_states(), envs[0].cw.get_states())
         assert e.failed_resets() == 0
     assert envs[1]._dl["depth"] == 2 and int(envs[1]._dl["epoch"].max()) > 2                   # (its staging batch really ran dry)
+    assert envs[0]._dl[("pieces", 0, "same_step")]["fold"] is not None and envs[1]._dl[("pieces", 0, "same_step")]["fold"] is None
+    assert int(envs[0]._dl["pending"].sum()) == 0                                                # nothing was ever deferred at the default cadence
+
+
+@pytest.mark.parametrize("mode", [True, "next_step"])
+@pytest.mark.parametrize("W,n,steps", [(96, 6, 90), (4096, 25, 130)])
+def test_one_launch_gym_step_equals_the_two_launches(mode, W, n, steps):
+    """cs_gym_step_staged (reward + bookkeeping, substeps, observation AND the take-over of the staged episodes in one launch) against
+    cs_gym_step + cs_consume_staged_worlds, bit for bit: observations, rewards, flags, info codes of every step, the state rows, goal
+    lists, robot rows, seeds, epochs and clocks at the end -- same-step and NEXT_STEP rules, a small batch of short episodes (the robots
+    run into the nearest human: worlds end again and again) and the benchmark's 4096 x 25 hybrid batch."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    cfg = _config("circle_crossing" if n == 6 else "hybrid_scenario", human_num=n)
+    one, two = BatchedSocialNavGym(cfg, W), BatchedSocialNavGym(cfg, W)
+    two.FOLD_RESET = False
+    for e in (one, two):
+        e.reset(phase="train", first_case=11, device=True)
+    ended = np.zeros(W, int)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    for k in range(steps):
+        if n == 6:
+            rb = one.cw.d_robot.torch().view(W, 13)
+            d = one.observe_device()[:, :, 0:2] - rb[:, None, 0:2]
+            near = d[torch.arange(W), d.norm(dim=2).argmin(dim=1)]
+            a = (near / near.norm(dim=1, keepdim=True).clamp(min=1e-6)).contiguous()
+        else:
+            a = torch.randn(W, 2, device="cuda", generator=gen) * 0.7
+        o1 = [t.clone() for t in one.step_device(a, auto_reset=mode)]
+        o2 = [t.clone() for t in two.step_device(a, auto_reset=mode)]
+        for x, y in zip(o1, o2):
+            assert torch.equal(x, y), k
+        ended += (o1[2] | o1[3]).cpu().numpy().astype(int)
+    assert one._dl[("pieces", 0, "next_step" if mode == "next_step" else "same_step")]["fold"] is not None
+    assert (ended >= 1).sum() >= W // 8, ended.sum()
+    np.testing.assert_array_equal(one.cw.get_states(), two.cw.get_states())
+    np.testing.assert_array_equal(one.cw.get_goals(), two.cw.get_goals())
+    np.testing.assert_array_equal(one.cw.get_robot(), two.cw.get_robot())
+    for key in ("seeds", "epoch", "counter", "gtime", "failed"):
+        assert torch.equal(one._dl[key], two._dl[key]), key
+    assert int(one._dl["pending"].sum()) == 0 and one.failed_resets() == 0
+
+
+def test_one_launch_gym_step_defers_a_take_over_whose_episode_is_not_staged_yet():
+    """A staging batch of ONE episode per world that is refilled only every sixteenth step runs dry when a world ends twice in between.  The
+    one-launch step does not generate in place: the take-over is deferred (reset_failed_mask() == 2, pending), the world is between two
+    episodes -- reward 0, no flags -- and takes over exactly the episode of its next seed once a refill pass has staged it.  No episode
+    is skipped or repeated: every world's epoch equals the number of its episode ends."""
+    torch = pytest.importorskip("torch")
+    from social_navigation_pyenvs_amd.generators import generate_worlds
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
+
+    W = 96
+    cfg = _config("circle_crossing", human_num=6)
+    env = BatchedSocialNavGym(cfg, W)
+    env.REFILL_EVERY, env.STAGE_DEPTH = 16, 1
+    env.reset(phase="train", first_case=3, device=True)
+    ends = np.zeros(W, int)
+    deferred_seen = 0
+    was_pending = np.zeros(W, bool)
+    for k in range(120):
+        rb = env.cw.d_robot.torch().view(W, 13)
+        d = env.observe_device()[:, :, 0:2] - rb[:, None, 0:2]
+        near = d[torch.arange(W), d.norm(dim=2).argmin(dim=1)]
+        a = (near / near.norm(dim=1, keepdim=True).clamp(min=1e-6)).contiguous()
+        obs, rew, term, trunc, info = [t.clone() for t in env.step_device(a)]
+        torch.cuda.synchronize()
+        pend = env._dl["pending"].cpu().numpy().astype(bool)
+        failed = env.reset_failed_mask().cpu().numpy()
+        done = (term | trunc).cpu().numpy()
+        # a world that entered this step pending was between two episodes: nothing is reported for it
+        assert not done[was_pending].any() and np.all(rew.cpu().numpy()[was_pending] == 0) and np.all(info.cpu().numpy()[was_pending] == 0)
+        assert np.all(failed[pend] == 2) and np.all(failed[~pend] == 0)
+        ends += done
+        deferred_seen += int(pend.sum())
+        # a world that took over an episode in this step stands on the first rows of the episode its seed generates
+        took = (done | was_pending) & ~pend
+        if took.any():
+            check = BatchedSocialNavGym(cfg, W); check.reset(phase="train", first_case=3, device=True)
+            generate_worlds(check.cw, "circle_crossing", env._dl["seeds"].cpu().numpy().astype(np.uint32), insert_robot=True)
+            np.testing.assert_array_equal(env.cw.get_states()[took], check.cw.get_states()[took])
+            np.testing.assert_array_equal(obs.cpu().numpy()[took], check.observe()[took])
+        was_pending = pend
+    assert deferred_seen > 0, "the staging batch never ran dry: the test did not exercise a deferral"
+    epoch = env._dl["epoch"].cpu().numpy()
+    assert np.array_equal(epoch + was_pending.astype(int), ends), (epoch, ends)          # every ended episode was followed by exactly one take-over
+    assert np.array_equal(env._dl["seeds"].cpu().numpy().astype(np.int64) - env._dl["base_seed"].cpu().numpy().astype(np.int64), ends * W)
 
 
 @pytest.mark.parametrize("n,model,robot_row,next_step", [(25, "hsfm_farina", False, False), (25, "hsfm_farina", True, True), (17, "sfm_guo", False, True),
