@@ -456,16 +456,20 @@ int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_act
  * anybody waiting for them -- a world that ends a few steps after its reset (a robot driven into its neighbour) finds the following
  * episodes staged as well.  No event orders the two streams: the slots carry tags.
  *   d_staged_seed[j][w]  the seed slot j of world w was generated from -- stored LAST by the generator (release, device scope)
- *   d_epoch[w]           the episode the live world w is in (0 after reset) -- stored LAST by the consumer (release)
+ *   d_epoch[w]           the episode the live world w is in (0 after reset) -- stored LAST by the consumer, once every load of the slot
+ *                        has returned (relaxed, device scope; the obligations of the protocol are listed in csrc/generate.hip)
  * cs_refill_staged_worlds   (side stream) regenerates every slot whose tag differs from the seed of the episode that belongs in it now
  *   (one wavefront per slot; the other blocks leave at once); d_staged_status[j][w] = cs_generate_worlds' status.  Launches of it must
  *   be ordered among themselves (one stream).  n <= 64.
  * cs_consume_staged_worlds  (the step's stream, behind the substeps) for every world with d_mask[w] != 0: episode e = epoch + 1; if the
- *   tag of slot e mod depth (acquire) equals d_seeds[w] -- the seed the bookkeeping just moved the world to -- the staged world is copied
+ *   tag of slot e mod depth (a device-scope relaxed load; the slot's words are read with device-scope loads under a control dependency
+ *   on it) equals d_seeds[w] -- the seed the bookkeeping just moved the world to -- the staged world is copied
  *   over the live one, observation rows included (cs_copy_worlds_masked_observe); if the refill has not got to it yet the world is
  *   generated in place from d_seeds[w] by the same generator code: the same rows either way, a function of the seed.
- *   A world that cannot be generated (status != 0) keeps its rows and gets d_failed[w] = 1 (0 after a successful reset); it ends again
- *   on the next step and then tries the following seed of its sequence.
+ *   A world that cannot be generated (status != 0) keeps its rows and gets d_failed[w] = 1 (0 after a successful reset): it starts a new
+ *   episode FROM its finished rows (step counter and clock were reset by the bookkeeping) -- after a collision or a reached goal it ends
+ *   again at the next step and then tries the following seed of its sequence; after a time-limit truncation it runs a further episode
+ *   from where it stands, flagged in d_failed the whole time.
  */
 typedef struct cs_stage_book {
     const uint32_t* d_seeds;      /* [W] cs_gym_book.d_seeds: == d_base_seed + d_epoch * seed_stride between two steps */

@@ -652,6 +652,33 @@ struct StageArgs {
 __device__ __forceinline__ uint32_t load_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_release(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
 
+// ---- the staging protocol: two kernels on two streams, no event, no acquire ----------------------------------------------------------
+// Writer: k_refill_staged (side stream).  Readers: k_consume_staged (step stream) and the epilogue of k_sfm_step under cs_gym_step_staged
+// (gymhead.h GymFold).  Shared words: the slot's rows / goal lists / robot row / flag / status, its TAG staged_seed[slot], and epoch[w].
+// What makes it correct -- each line is an obligation of the code, checked by the tests named at the end:
+//   W1  the writer regenerates a slot only when its tag differs from the seed of the episode that belongs in it NOW (a function of
+//       epoch[w], base_seed[w], the slot index): a slot a reader may be copying -- tag == the world's next seed, epoch not yet moved --
+//       is never written.
+//   W2  the writer stores the tag LAST, with a device-scope RELEASE (store_release): a reader that sees the new tag sees every word
+//       of the slot the writer stored before it, PROVIDED the reader's loads of those words cannot be served from a line cached before
+//       the release -- R2.
+//   R1  a reader loads the tag first (device-scope relaxed atomic load) and touches the slot only if tag == the world's next seed:
+//       a CONTROL dependency.  No load of a slot word may be issued before the tag has returned and compared equal: the loads sit in the
+//       taken branch and are `__hip_atomic_load`s, which the compiler may not hoist above the branch or merge with earlier loads.
+//   R2  the slot's words are read with device-scope relaxed atomic loads (copy_world<COHERENT = true>: sc1 loads that miss this XCD's
+//       L2 instead of hitting a line from before the refill).  A plain load here would be a silent bug.  Not an acquire on purpose: an
+//       acquire fence at device scope invalidates the whole L2 of the XCD beside the running step kernels, each time a world ends.
+//   R3  the reader stores epoch[w] (device-scope relaxed) only after EVERY load of the slot has returned: behind a barrier of the
+//       block (k_consume_staged) / an s_waitcnt vmcnt(0) of the one wavefront (the step kernel's epilogue).  From that store on W1 lets
+//       the writer take the slot.  It is the linearisation point of the take-over.
+//   R4  only readers write epoch[w], and one world is read by one block per launch; launches of a reader are ordered on the step stream,
+//       launches of the writer on the side stream.
+// This is outside the HIP memory model's guarantees for coarse-grained memory between concurrent kernels (no happens-before without
+// an acquire); it relies on gfx950's device-scope atomics going to the memory side of the L2s.  The net under it: every regenerated
+// episode is compared bit for bit with the in-place generation of the same seed, under three refill cadences, at 96 and at 4096 worlds
+// (tests/test_gpu_generators.py::test_step_device_is_the_same_whatever_the_refill_cadence, ::test_one_launch_gym_step_equals_the_two_launches,
+// tools/device_loop_soak.py: 191k episodes).  A half-written world would differ from its seed's.
+//
 // side stream.  Slot s = j * W + w holds the episode of world w that belongs in ring position j now: the one e in (epoch, epoch + depth]
 // with e = j mod depth; it is regenerated when its tag is not that episode's seed.  The grid is SMALL (<= 1024 blocks of one wavefront,
 // every lane checking one slot per trip, two relaxed device-scope loads): a block per slot -- 65536 workgroups at depth 16 x 4096 worlds,
