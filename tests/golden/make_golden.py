@@ -22,6 +22,9 @@ reference produced) is written to the ``.npz`` fixtures.  Groups (SURVEY.md §8c
   g13_block_sizes  20-substep blocks at the row counts of the BASELINE.json configurations (10, 25 traffic, 50, 50 + walls +
               immobile humans), all nine models: the shapes the shape-specialised kernel builds run on
   g15_imitation_rk45  SocialNavGym.imitation_learning_step with the robot's motion model integrated by RK45 (runge_kutta=True)
+  g16_policy  CADRL.predict / SARL.predict of the reference (crowd_nav/policy/cadrl.py:235-291, multi_human_rl.py:12-88, sarl.py) with
+              seeded weights over Gym episodes of the reference env: weights, joint states, the peeked next human states, the 81 action
+              values and the chosen action of every decision (the policy seam, SURVEY.md §8 rows b + f1)
   g10_social_momentum  MotionModelManager("social_momentum").update_humans single steps (motion_model_manager.py:395-404,
               social_gym/src/social_momentum.py)
 """
@@ -986,6 +989,82 @@ def gen_g13_block_sizes():
     print("g13_block_sizes:", len(cases), "cases ->", save_cases("g13_block_sizes", cases))
 
 
+def gen_g16_policy():
+    """The reference's own value-based policies deciding in the reference's own Gym: CADRL (cadrl.py:235-291) and SARL
+    (multi_human_rl.py:12-88 with sarl.py's attention network), default policy.config, weights drawn from a seeded torch generator,
+    the parallel branch (SocialNavGym.reset sets policy.parallelize, social_nav_gym.py:128: compute_rotated_states_and_reward + one
+    model() call per action).  Recorded per decision: the full crowd rows the env holds (mm.states, goal lists), the robot's full state,
+    the observation, what get_next_human_observable_states returned to the policy, the 81 action values and the arg-max."""
+    import torch
+    import crowd_nav.policy.cadrl as cadrl_mod
+    import crowd_nav.policy.multi_human_rl as mh_mod
+    from crowd_nav.policy.policy_factory import policy_factory
+    from crowd_nav.utils.state import JointState
+
+    pcfg = configparser.RawConfigParser()
+    pcfg.read(os.path.join(_refharness.REFERENCE_ROOT, "crowd_nav", "configs", "policy.config"))
+    cases = []
+    for pname, human_policy, n, scenario in (("cadrl", "sfm_helbing", 5, "circle_crossing"), ("sarl", "hsfm_farina", 5, "circle_crossing"),
+                                             ("sarl", "hsfm_new_guo", 10, "parallel_traffic")):
+        env, cfg = make_env(human_policy, scenario, n, robot_visible=False)
+        policy = policy_factory[pname]()
+        policy.configure(pcfg)
+        torch.manual_seed({"cadrl": 1601, "sarl": 1602}[pname] + n)
+        with torch.no_grad():                       # an untrained network whose 81 values are spread out: weights a few times the default init
+            for prm in policy.model.parameters():
+                prm.copy_(torch.randn_like(prm) * (0.25 if prm.dim() > 1 else 0.1))
+        policy.set_device(torch.device("cpu"))
+        policy.set_phase("test")
+        policy.set_env(env)
+        env.robot.set_policy(policy)
+        # the weights once per policy instance (float32, as torch holds them): a case of its own, the decisions name it by `wkey`
+        wkey = f"{pname}_{human_policy}_{n}"
+        sd = policy.model.state_dict()
+        cases.append(dict(kind="weights", wkey=wkey, policy=pname, weights_keys=np.array(list(sd.keys())),
+                          **{f"w_{i}": v.detach().cpu().numpy().astype(np.float32) for i, v in enumerate(sd.values())}))
+        rec = {}
+        orig_peek = env.motion_model_manager.__class__.get_next_human_observable_states
+        orig_cav_c, orig_cav_m = cadrl_mod.compute_action_value, mh_mod.compute_action_value
+
+        def cav(rewards, outs, dt, gamma, vpref):
+            v = orig_cav_c(rewards, outs, dt, gamma, vpref)
+            rec["values"], rec["rewards"], rec["net"] = np.array(v), np.array(rewards), np.array(outs)
+            return v
+        cadrl_mod.compute_action_value = mh_mod.compute_action_value = cav
+        try:
+            for test_case in range(4):
+                ob, _ = env.reset(phase="test", test_case=test_case)
+                mm = env.motion_model_manager
+
+                def peek(self, dt, theta_and_omega_visible=False, _o=orig_peek):
+                    r = _o(self, dt, theta_and_omega_visible)
+                    rec["next"] = np.array(r)
+                    return r
+                mm.__class__.get_next_human_observable_states = peek
+                for k in range(14):
+                    rec.clear()
+                    snap = mm_snapshot(mm)
+                    robot_full = env.robot.get_full_state()
+                    action = env.robot.act(ob)
+                    if "values" not in rec:      # reach_destination: no decision was taken
+                        break
+                    A = policy.action_space_ndarray
+                    cases.append(dict(kind="decision", wkey=wkey, policy=pname, model=human_policy, type=SFMS.index(human_policy), scenario=scenario, n=n,
+                                      test_case=test_case, step=k, gamma=policy.gamma, dt=env.robot_time_step, substep=env.time_step, action_space=np.array(A),
+                                      mm_states=snap["states"], mm_goals=snap["goals"], mm_params=snap["params"], mm_safety=snap["safety"],
+                                      robot=np.array([robot_full.px, robot_full.py, robot_full.vx, robot_full.vy, robot_full.radius, robot_full.gx,
+                                                      robot_full.gy, robot_full.v_pref, robot_full.theta]),
+                                      obs=ob_to_array(ob), next_humans=rec["next"], rewards=rec["rewards"], net_outputs=rec["net"],
+                                      action_values=rec["values"], chosen=int(np.argmax(rec["values"])), action=np.array([action.vx, action.vy])))
+                    ob, reward, term, trunc, info = env.step(action)
+                    if term or trunc:
+                        break
+        finally:
+            cadrl_mod.compute_action_value, mh_mod.compute_action_value = orig_cav_c, orig_cav_m
+            env.motion_model_manager.__class__.get_next_human_observable_states = orig_peek
+    print("g16_policy:", sum(c["kind"] == "decision" for c in cases), "decisions ->", save_cases("g16_policy", cases))
+
+
 def gen_g15_imitation_rk45():
     """The Gym seam with the ROBOT integrated by RK45: set_human_motion_model_as_robot_policy(model, runge_kutta=True)
     (social_nav_sim.py:862-873 -> motion_model_manager.py:552-563) + imitation_learning_step (social_nav_gym.py:252-274): every one of
@@ -1033,7 +1112,7 @@ GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
               g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
               g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45, g14_rk45_more=gen_g14_rk45_more,
-              g13_block_sizes=gen_g13_block_sizes, g15_imitation_rk45=gen_g15_imitation_rk45)
+              g13_block_sizes=gen_g13_block_sizes, g15_imitation_rk45=gen_g15_imitation_rk45, g16_policy=gen_g16_policy)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
