@@ -523,7 +523,7 @@ int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen);
  *   1 "fast":  v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp each);
  *   2 "fma":   fast, and determinants / dot products as mul + fma.
  * The mode holds for the process from the call on (-1 = back to CROWDSTEP_ORCA_MATH=exact|fast|fma, else the library default;
- * DESIGN.md 4.2a).  North-star parity for ORCA is 1e-5 per step on positions / velocities, not bits.  The generic ORCA builds
+ * DESIGN.md 4.2).  North-star parity for ORCA is 1e-5 per step on positions / velocities, not bits.  The generic ORCA builds
  * (other maxNeighbors, static obstacles, per-agent parameters, the grid path, the robot's own ORCA model) are always exact. */
 int cs_orca_set_math(int mode);
 int cs_orca_get_math(void);

@@ -113,7 +113,7 @@ __device__ __forceinline__ float ieee_sqrt(float x)
 // FM = 2: "fast + fma": and the 2 x 2 determinants, dot products and point + t * direction as mul + fma (one rounding less).
 // north_star asks for 1e-5 on positions / velocities per step, not for bits, and the restatement cannot be pinned on rvo2 anyway;
 // tests/test_gpu_orca_fast.py measures the fast builds per substep from re-synchronised state against the exact restatement and
-// accounts for every agent-substep beyond 1e-5 (DESIGN.md 4.2a).
+// accounts for every agent-substep beyond 1e-5 (DESIGN.md 4.2).
 template <int FM> __device__ __forceinline__ float odiv(float a, float b)
 {
     if constexpr (FM != 0) return a * __builtin_amdgcn_rcpf(b); else return ieee_div(a, b);
@@ -1505,9 +1505,9 @@ int big_world_min_rows(int dflt)
 
 // The arithmetic of the register-resident build (k_orca_step<FAST10 = true>): 0 exact (bit-identical to the restatement), 1 fast
 // (v_rcp / v_sqrt / v_rsq), 2 fast + fma.  cs_orca_set_math() sets it for the process; CROWDSTEP_ORCA_MATH=exact|fast|fma is read
-// once, at the first ORCA launch, when nobody has set it.  DESIGN.md 4.2a says which one is the default and why.
+// once, at the first ORCA launch, when nobody has set it.  DESIGN.md 4.2 says which one is the default and why.
 static int g_orca_math = -1;
-constexpr int ORCA_MATH_DEFAULT = 2;   // "fma": DESIGN.md 4.2a (profiles/r5c_orca_fast_parity.txt)
+constexpr int ORCA_MATH_DEFAULT = 2;   // "fma": DESIGN.md 4.2 (profiles/r5c_orca_fast_parity.txt)
 int orca_math()
 {
     if (g_orca_math < 0) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (CPU, restatement): how many agents of the dense phase of the cfg4 crossing violate a line in linearProgram2, how many
-linearProgram1 calls each makes and how long their inner loops are -- the numbers behind DESIGN.md 4.2 (lp2 on lane groups: rejected)."""
+linearProgram1 calls each makes and how long their inner loops are -- the numbers behind HISTORY.md Part II 4.2 (lp2 on lane groups: rejected)."""
 import sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import crowd_oracle as orc

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (CPU, restatement): linearProgram3 of the dense cfg4 crossing replayed per wavefront (two worlds) under two schedules of the
 lane groups -- the kernel's (one level per agent and round; a pass runs until its slowest group is through) and re-dealing the agents after
-every linearProgram1 call -- with instruction estimates per round / pass / iteration: DESIGN.md 4.2 (the second schedule is no gain)."""
+every linearProgram1 call -- with instruction estimates per round / pass / iteration: HISTORY.md Part II 4.2 (the second schedule is no gain)."""
 import sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import crowd_oracle as orc

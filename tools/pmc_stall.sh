@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage (GPU box): tools/pmc_stall.sh TAG [bench.py arguments]
 # Two SQ passes (8 slots each) of one bench workload with the LDS / wait split of the step kernel: where a wavefront's cycles go
-# (VALU issue, LDS issue stall, parked on s_waitcnt) -- the question behind DESIGN.md 4.1d (cfg5's wall pass is not issue-bound).
+# (VALU issue, LDS issue stall, parked on s_waitcnt) -- the question behind HISTORY.md Part II 4.1d (cfg5's wall pass is not issue-bound).
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/stall_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $R
