@@ -300,6 +300,7 @@ def orca_step_block(S, goals, margin, dt, n_substeps, robot_visible=False, robot
     ap = None if agent_params is None else np.ascontiguousarray(np.broadcast_to(np.asarray(agent_params, dtype=f), (W, rows, 4)))
     fn = lib().orc_orca_step_block_batched_pa
     fn.restype = None
+    threads = int(threads) or effective_cores()   # (an OpenMP team of the box's 256 logical CPUs under a 16-CPU quota costs ~0.1 s per call)
     fn(C.c_int(W), _ptr(S, C.c_float), _ptr(goals, C.c_float), C.c_int(G), C.c_int(rows), C.c_int(int(robot_visible)),
        _ptr(margin, C.c_float), _ptr(robot, C.c_float), _ptr(action, C.c_float), C.c_float(dt), C.c_int(n_substeps),
        C.c_float(neighbor_dist), C.c_int(max_nb), C.c_float(time_horizon), C.c_int(int(respawn)),
@@ -324,6 +325,7 @@ def orca_step_block_f64(S, goals, margin, dt, n_substeps, neighbor_dist=10.0, ma
     margin = np.ascontiguousarray(np.broadcast_to(np.asarray(margin, dtype=np.float64), (W, rows)))
     fn = lib().orc64_orca_step_block_batched_pa
     fn.restype = None
+    threads = int(threads) or effective_cores()
     fn(C.c_int(W), _ptr(S, C.c_double), _ptr(goals, C.c_double), C.c_int(G), C.c_int(rows), C.c_int(0), _ptr(margin, C.c_double), None, None,
        C.c_double(dt), C.c_int(n_substeps), C.c_double(neighbor_dist), C.c_int(max_nb), C.c_double(time_horizon), C.c_int(0),
        C.c_double(0.0), C.c_double(0.0), C.c_int(threads), C.c_double(5.0), None, C.c_int(0), None)
