@@ -524,6 +524,9 @@ __device__ __forceinline__ void lp3_fast10(const float4 (&Lr)[10], const Lines& 
 // Rows talk through LDS inside ONE wavefront (in-order LDS, compiler-only fences): the agents' lines L[10][TL] (stored by the
 // owners), the projected lines P[9][TL], one (result, maxSpeed, distance) record and one ticket per agent.
 #define ORCA_LDS_FENCE() asm volatile("" ::: "memory")
+typedef unsigned long long mask64;
+// LLVM's compare predicates, as __builtin_amdgcn_fcmpf / sicmp / uicmp take them (llvm/IR/InstrTypes.h CmpInst::Predicate)
+enum { FCMP_OGT = 2, FCMP_OGE = 3, FCMP_OLT = 4, FCMP_OLE = 5, ICMP_NE = 33, ICMP_SGT = 38, ICMP_SLT = 40 };
 // P [9][8] projected lines of the eight rows in flight, A [9][8] their chords on the speed circle (tL0, tR0; (+inf, -inf) when
 // the line misses the circle, which fails linearProgram1 through its own tL > tR test), q [T] agent records, sel [T] tickets
 struct RowLds { float4* P; float2* A; float4* q; int* sel; };
@@ -531,7 +534,9 @@ struct RowLds { float4* P; float2* A; float4* q; int* sel; };
 // min and max over the 16-lane row of the calling lane, left in every lane of the row: four rotate-and-combine steps
 // (row_ror 8, 4, 2, 1) with the DPP operand fused into v_min_f32 / v_max_f32 -- the two chains alternate, one wait state
 // covers the VALU-write -> DPP-read hazard.  The operands are finite or +-inf, never NaN.
-__device__ __forceinline__ void row_minmax16(float& mn, float& mx)
+// then the interval of linearProgram1: tR <- min(tR, row min), tL <- max(tL, row max) -- inside the block, as the two instructions
+// themselves (fminf / fmaxf on values the compiler cannot see through would each be preceded by a quieting v_max x, x, x)
+__device__ __forceinline__ void row_minmax16(float& mn, float& mx, float& tR, float& tL)
 {
     asm volatile("s_nop 1\n\t"
                  "v_min_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -545,13 +550,15 @@ __device__ __forceinline__ void row_minmax16(float& mn, float& mx)
                  "s_nop 0\n\t"
                  "v_min_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
                  "v_max_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(mn), "+v"(mx));
+                 "s_nop 1\n\t"
+                 "v_min_f32 %2, %2, %0\n\t"
+                 "v_max_f32 %3, %3, %1"
+                 : "+v"(mn), "+v"(mx), "+v"(tR), "+v"(tL));
 }
 
 // min and max over the 8-lane half row of the calling lane, left in every lane of it: neighbour swap, quad swap, half-row mirror
 // (quad_perm:[1,0,3,2], quad_perm:[2,3,0,1], row_half_mirror) -- three steps instead of four.
-__device__ __forceinline__ void row_minmax8(float& mn, float& mx)
+__device__ __forceinline__ void row_minmax8(float& mn, float& mx, float& tR, float& tL)
 {
     asm volatile("s_nop 1\n\t"
                  "v_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -562,8 +569,10 @@ __device__ __forceinline__ void row_minmax8(float& mn, float& mx)
                  "s_nop 0\n\t"
                  "v_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                  "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1"
-                 : "+v"(mn), "+v"(mx));
+                 "s_nop 1\n\t"
+                 "v_min_f32 %2, %2, %0\n\t"
+                 "v_max_f32 %3, %3, %1"
+                 : "+v"(mn), "+v"(mx), "+v"(tR), "+v"(tL));
 }
 
 // One sub-phase of a round of lp3_rows: the `npend` agents ticketed in R.sel (their records in R.q) are served 64 / RW at a time,
@@ -612,42 +621,50 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
         const float ox = -li.w, oy = li.z;
         float qx = ox * vm, qy = oy * vm;
         int k = -1;
-        bool fail2 = false, done = !rowvalid;
+        // The walk's lane conditions are kept as wave masks (one bit per lane, scalar registers): every compare below writes its mask
+        // directly (v_cmp -> SGPR pair), the logic between them is scalar, and a mask goes back into a select as it is
+        // (inverse ballot).  Written on bools the vote was `v_cndmask 0 / 1, v_cmp_ne` on top of the compares, and the interval's
+        // fminf / fmaxf quieted their operands first (they come from LDS and from the DPP block: four v_max x, x, x per trip).
+        const mask64 live_m = __builtin_amdgcn_ballot_w64(live);
+        mask64 fail_m = 0, done_m = ~__builtin_amdgcn_ballot_w64(rowvalid);
         ORCA_LDS_FENCE();
 #pragma nounroll
         for (int it = 0; it < 9; ++it) {
-            const bool viol = live && !done && (j > k) && (odet<FM>(pr.z, pr.w, pr.x - qx, pr.y - qy) > 0.0f);
-            const unsigned long long vmask = __builtin_amdgcn_ballot_w64(viol);
+            const mask64 vmask = __builtin_amdgcn_fcmpf(odet<FM>(pr.z, pr.w, pr.x - qx, pr.y - qy), 0.0f, FCMP_OGT) & __builtin_amdgcn_sicmp(j, k, ICMP_SGT) & live_m & ~done_m;
             if (vmask == 0) break;
             const unsigned rb = (unsigned)(vmask >> grp_sh) & ((1u << RW) - 1u);
-            const bool any = rb != 0;
-            const int kk = any ? (int)__builtin_ctz(rb) : 0;    // first violated line of my group
-            done = done || !any;                                // no line violated: linearProgram2 succeeded
+            const mask64 any_m = __builtin_amdgcn_uicmp(rb, 0u, ICMP_NE);
+            // first violated line of my group (a group without one is done -- linearProgram2 succeeded -- and reads some valid slot)
+            int kk;
+            if constexpr (RW == 8) kk = (int)__builtin_ctz(rb | 0x100u) & 7; else kk = __builtin_amdgcn_inverse_ballot_w64(any_m) ? (int)__builtin_ctz(rb) : 0;
             const float4 lk = R.P[kk * 8 + slot];
             const float2 ak = R.A[kk * 8 + slot];
             // linearProgram1(projLines, kk, ...): lane j < kk evaluates line j against line kk
-            const bool in = live && (j < kk);
+            const mask64 in_m = live_m & __builtin_amdgcn_sicmp(j, kk, ICMP_SLT);
             const float den = odet<FM>(lk.z, lk.w, pr.z, pr.w);
             const float num = odet<FM>(pr.z, pr.w, lk.x - pr.x, lk.y - pr.y);
             const float t = odiv<FM>(num, den);
-            const bool parl = fabsf(den) <= RVO_EPSILON;
+            const mask64 parl_m = __builtin_amdgcn_fcmpf(fabsf(den), RVO_EPSILON, FCMP_OLE);
             // a parallel earlier line with this line on its wrong side fails linearProgram1 outright: it enters the
             // reduction as the empty interval (tR = -inf, tL = +inf), which the tL > tR test below turns into the failure
-            const bool failp = in && parl && (num < 0.0f);
-            float rmin = failp ? -INFINITY : ((in && !parl && (den >= 0.0f)) ? t : INFINITY);
-            float rmax = failp ? INFINITY : ((in && !parl && !(den >= 0.0f)) ? t : -INFINITY);
-            if constexpr (RW == 16) row_minmax16(rmin, rmax); else row_minmax8(rmin, rmax);
-            const float tR = fminf(ak.y, rmin), tL = fmaxf(ak.x, rmax);
-            const bool ok = !(tL > tR);
+            const mask64 failp_m = in_m & parl_m & __builtin_amdgcn_fcmpf(num, 0.0f, FCMP_OLT);
+            const mask64 ge_m = __builtin_amdgcn_fcmpf(den, 0.0f, FCMP_OGE);
+            const bool failp = __builtin_amdgcn_inverse_ballot_w64(failp_m);
+            float rmin = failp ? -INFINITY : (__builtin_amdgcn_inverse_ballot_w64(in_m & ~parl_m & ge_m) ? t : INFINITY);
+            float rmax = failp ? INFINITY : (__builtin_amdgcn_inverse_ballot_w64(in_m & ~parl_m & ~ge_m) ? t : -INFINITY);
+            float tR = ak.y, tL = ak.x;
+            if constexpr (RW == 16) row_minmax16(rmin, rmax, tR, tL); else row_minmax8(rmin, rmax, tR, tL);   // tR = min(chord, row's min), tL = max(chord, row's max)
+            const mask64 ok_m = ~__builtin_amdgcn_fcmpf(tL, tR, FCMP_OGT);
             const float tt = (odot<FM>(ox, oy, lk.z, lk.w) > 0.0f) ? tR : tL;
-            const bool run = any && !done;
-            const bool set = run && ok, bad = run && !ok;
+            const mask64 set_m = any_m & ok_m, bad_m = any_m & ~ok_m;   // (a group with a violated line is not done: any implies !done)
+            const bool set = __builtin_amdgcn_inverse_ballot_w64(set_m);
             qx = set ? omad<FM>(tt, lk.z, lk.x) : qx;
             qy = set ? omad<FM>(tt, lk.w, lk.y) : qy;
             k = set ? kk : k;
-            fail2 = fail2 || bad;                               // linearProgram2 failed: LP3 keeps the old result
-            done = done || bad;
+            fail_m |= bad_m;                                    // linearProgram2 failed: LP3 keeps the old result
+            done_m |= ~any_m | bad_m;                           // no line violated: linearProgram2 succeeded
         }
+        const bool fail2 = __builtin_amdgcn_inverse_ballot_w64(fail_m);
         const bool take = rowvalid && !fail2;
         const float nrx = take ? qx : qa.x, nry = take ? qy : qa.y;
         const float ndist = odet<FM>(li.z, li.w, li.x - nrx, li.y - nry);
@@ -671,17 +688,12 @@ __device__ __forceinline__ void lp3_rows(const float4 (&Lr)[10], const Lines& L,
     const int me = L.tid;
     const int wbase = threadIdx.x & ~63;
     float distance = 0.0f;
-    int next_i = failed;
+    // the first violated line is the one linearProgram2 failed on: it tested det(dir, point - result) > 0 on this very result and
+    // left the result where it was (RVO2 walks i upwards from there; distance starts at 0).  The scan for the NEXT violated line
+    // closes a round, so a wavefront runs one scan per round it serves, not one more to find out that nothing is left.
+    int lvl = failed < cnt ? failed : -1;
 #pragma nounroll
     for (int round = 0; round < 10; ++round) {
-        // owner: my next violated line at or behind next_i, with the current result and distance (RVO2 walks i upwards)
-        int lvl = -1;
-#pragma unroll
-        for (int i = 9; i >= 0; --i) {
-            const float4 li = Lr[i];
-            const bool v = (i >= next_i) && (i < cnt) && (odet<FM>(li.z, li.w, li.x - rx, li.y - ry) > distance);
-            lvl = v ? i : lvl;
-        }
         const bool pending = lvl >= 0;
         if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
         if (pending) R.q[me] = make_float4(rx, ry, vmax, distance);
@@ -705,12 +717,21 @@ __device__ __forceinline__ void lp3_rows(const float4 (&Lr)[10], const Lines& L,
             ORCA_LDS_FENCE();
             lp3_serve<16, FM>(L, R, __builtin_popcountll(mb));
         }
+        int next_i = 10;
         if (pending) {
             const float4 qo = R.q[me];
             rx = qo.x; ry = qo.y; distance = qo.w;
             next_i = lvl + 1;
         }
         ORCA_LDS_FENCE();
+        // owner: my next violated line at or behind next_i, with the current result and distance
+        lvl = -1;
+#pragma unroll
+        for (int i = 9; i >= 1; --i) {
+            const float4 li = Lr[i];
+            const bool v = (i >= next_i) && (i < cnt) && (odet<FM>(li.z, li.w, li.x - rx, li.y - ry) > distance);
+            lvl = v ? i : lvl;
+        }
     }
 }
 
@@ -724,17 +745,21 @@ __device__ __forceinline__ void lp3_rows(const float4 (&Lr)[10], const Lines& L,
 //  * linearProgram3 (infeasible programme: about a third of the agents of a circular crossing, every substep) stays in
 //    registers too (lp3_fast10).
 // insertion of one candidate into the ten sorted (distSq, row) keys
+// compare-exchange of two keys: a <- min, b <- max.  The keys are bit patterns assembled from (float bits, row), never NaN; written as
+// fmin / fmax the compiler cannot know that and quiets every key first (v_max_f64 x, x, x: one more 4-cycle instruction per candidate).
+__device__ __forceinline__ void key_ce(double& a, double& b)
+{
+    double lo, hi;
+    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=v"(hi) : "v"(a), "v"(b));
+    a = lo; b = hi;
+}
 __device__ __forceinline__ void key_insert10(double (&key)[10], double x)
 {
 #pragma unroll
-    for (int s = 0; s < 10; ++s) {
-        const double lo = fmin(key[s], x);
-        x = fmax(key[s], x);
-        key[s] = lo;
-    }
+    for (int s = 0; s < 10; ++s) key_ce(key[s], x);
 }
 __device__ __forceinline__ double key_sentinel() { return __hiloint2double(0x7F7FFFFF, (int)0xFFFFFFFFu); }
-#define ORCA_CE(a, b) { const double ce_lo_ = fmin(a, b); b = fmax(a, b); a = ce_lo_; }
+#define ORCA_CE(a, b) key_ce(a, b);
 
 // From the ten neighbour keys on: ORCA lines, linearProgram2, linearProgram3.  fetch(b, q, rad): (x, y, vx, vy) and radius +
 // margin of row b (LDS rows of the world in the crowd kernel, global rows found through the grid in the big-world kernel).
@@ -749,8 +774,11 @@ __device__ __forceinline__ void orca_solve_fast10(bool active, bool lp3_static, 
     for (int s = 0; s < KF; ++s) cnt += (__double2hiint(key[s]) != 0x7F7FFFFF) ? 1 : 0;
     OSTAMP(1);
 
-    const float invT = 1.0f / time_horizon;
-    const float invDt = 1.0f / dt;
+    // (opaque: left visible, `coll ? 1 / dt : 1 / T` is rewritten as 1 / (coll ? dt : T) -- an IEEE division per LINE, twelve instructions
+    //  each, where two per launch do; same bits either way)
+    float invT = 1.0f / time_horizon;
+    float invDt = 1.0f / dt;
+    asm("" : "+v"(invT), "+v"(invDt));
     float4 Lr[KF];
 #pragma unroll
     for (int k = 0; k < KF; ++k) {
@@ -850,12 +878,19 @@ __device__ __forceinline__ void orca_velocity_fast10(bool active, bool lp3_stati
     OSTAMP(0);
     double key[10];
     const float range2 = neighbor_dist * neighbor_dist;
-    auto candidate = [&](int b) -> double {   // row b's key, or the sentinel (out of range, myself, a lane without an agent)
+    // (row, opaque per substep: the 25 lane masks `b != row` are loop-invariant, the compiler keeps them in 50 SGPRs across the substep
+    //  loop, runs out, spills them to VGPR lanes and pays two v_readlane per candidate to get them back; one v_cmp per candidate is cheaper)
+    int row_o = row;
+    asm volatile("" : "+v"(row_o));
+    const float range2_l = active ? range2 : -1.0f;                      // a lane without an agent has nobody in range
+    auto candidate = [&](int b) -> double {   // row b's key, or a sentinel (out of range, myself, a lane without an agent)
         const float4 q = pv[b];
         const float ddx = px - q.x, ddy = py - q.y;
         const float dsq = ddx * ddx + ddy * ddy;
-        const bool in = active && (dsq < range2) && (b != row);
-        return in ? __hiloint2double((int)__float_as_uint(dsq), b) : key_sentinel();
+        const bool in = (dsq < range2_l) & (b != row_o);                 // (no short circuit: the row is read by every lane, nothing to branch around)
+        // a sentinel is any key whose high word is 0x7F7FFFFF (no distance below neighborDist^2 has these bits); its low word is never
+        // read (slots k >= cnt), so it can be b as well: one select per key, the row index a constant
+        return __hiloint2double(in ? (int)__float_as_uint(dsq) : 0x7F7FFFFF, b);
     };
     // The ten smallest keys in order are a function of the key SET: rows are taken eight at a time through a 19-comparator sorting
     // network and merged into the list by a pruned odd-even merge (25 comparators; orca_sortnet.h, generated and checked by
