@@ -410,7 +410,7 @@ __device__ __forceinline__ float4 orca_line(float px, float py, float vx, float 
     const float wx = rvx - kT * rpx, wy = rvy - kT * rpy;
     const float wLenSq = wx * wx + wy * wy;
     const float dot1 = wx * rpx + wy * rpy;
-    const bool circ = coll || (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq);
+    const bool circ = coll | ((dot1 < 0.0f) & (dot1 * dot1 > RSq * wLenSq));   // (no short circuit: three compares, no branch per line)
     const float root = osqrt<FM>(circ ? wLenSq : distSq - RSq);   // |w|  or  the leg length
     const float den = circ ? root : distSq;
     float inv;
@@ -595,8 +595,8 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
         const int e = rowvalid ? R.sel[wbase + idx] : 0;
         const int a = e & 0xFFFF, lv = e >> 16;
         const float4 qa = R.q[a];
-        const float4 li = L.p[lv * TL + a];
-        const float4 lj = L.p[jj * TL + a];
+        const float4 li = L.p[__umul24(lv, TL) + a];              // (24-bit multiplies: full rate, v_mul_lo_u32 is not)
+        const float4 lj = L.p[__umul24(jj, TL) + a];
         const bool task = rowvalid && j < lv;
         // RVO2 linearProgram3: line j projected on line i
         const float d = odet<FM>(li.z, li.w, lj.z, lj.w);
@@ -616,7 +616,9 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
         const float disc = dot * dot + vm * vm - odot<FM>(pr.x, pr.y, pr.x, pr.y);
         const float sq = osqrt<FM>(fmaxf(disc, 0.0f));
         const float2 aux = (disc < 0.0f) ? make_float2(INFINITY, -INFINITY) : make_float2(-dot - sq, -dot + sq);
-        if (task) { R.P[jj * 8 + slot] = pr; R.A[jj * 8 + slot] = aux; }
+        // (half rows: lane j's slot is its own and slots j >= lv are never read -- every lane stores, nothing to branch around; whole rows
+        //  share slot 8 among the lanes j >= 8)
+        if (RW == 8 || task) { R.P[jj * 8 + slot] = pr; R.A[jj * 8 + slot] = aux; }
         // linearProgram2(projLines, radius, (-dir.y, dir.x), directionOpt = true) starts on the circle
         const float ox = -li.w, oy = li.z;
         float qx = ox * vm, qy = oy * vm;
@@ -643,7 +645,8 @@ __device__ __forceinline__ void lp3_serve(const Lines& L, const RowLds& R, int n
             const mask64 in_m = live_m & __builtin_amdgcn_sicmp(j, kk, ICMP_SLT);
             const float den = odet<FM>(lk.z, lk.w, pr.z, pr.w);
             const float num = odet<FM>(pr.z, pr.w, lk.x - pr.x, lk.y - pr.y);
-            const float t = odiv<FM>(num, den);
+            float t = odiv<FM>(num, den);
+            asm("" : "+v"(t));                                   // (evaluated by every lane: the compiler would branch around the reciprocal of the lanes that select it)
             const mask64 parl_m = __builtin_amdgcn_fcmpf(fabsf(den), RVO_EPSILON, FCMP_OLE);
             // a parallel earlier line with this line on its wrong side fails linearProgram1 outright: it enters the
             // reduction as the empty interval (tR = -inf, tL = +inf), which the tL > tR test below turns into the failure
@@ -696,7 +699,7 @@ __device__ __forceinline__ void lp3_rows(const float4 (&Lr)[10], const Lines& L,
     for (int round = 0; round < 10; ++round) {
         const bool pending = lvl >= 0;
         if (__builtin_amdgcn_ballot_w64(pending) == 0) break;
-        if (pending) R.q[me] = make_float4(rx, ry, vmax, distance);
+        R.q[me] = make_float4(rx, ry, vmax, distance);          // (every lane: a lane that is not pending reads its own record back below)
         // sub-phase A: levels 0 .. 8 on 8-lane groups; sub-phase B: level 9 on 16-lane rows
         const bool pa = pending && lvl <= 8, pb = pending && lvl == 9;
         const unsigned long long ma = __builtin_amdgcn_ballot_w64(pa), mb = __builtin_amdgcn_ballot_w64(pb);
@@ -717,12 +720,9 @@ __device__ __forceinline__ void lp3_rows(const float4 (&Lr)[10], const Lines& L,
             ORCA_LDS_FENCE();
             lp3_serve<16, FM>(L, R, __builtin_popcountll(mb));
         }
-        int next_i = 10;
-        if (pending) {
-            const float4 qo = R.q[me];
-            rx = qo.x; ry = qo.y; distance = qo.w;
-            next_i = lvl + 1;
-        }
+        const float4 qo = R.q[me];
+        rx = qo.x; ry = qo.y; distance = qo.w;
+        const int next_i = pending ? lvl + 1 : 10;
         ORCA_LDS_FENCE();
         // owner: my next violated line at or behind next_i, with the current result and distance
         lvl = -1;
