@@ -521,6 +521,13 @@ def roofline_block(spec, W, kern_ms, copy_gbs, cw, window=None):
             out["valu_issue_cycles_per_inst_model"] = cyc / insts
             out["valu_frac"] = cyc / simd_cycles
             out["valu_frac_floor"] = ((fma + other) * VALU_CLASS_CYCLES["fma"] + trans * VALU_CLASS_CYCLES["trans"]) / simd_cycles
+            # the same model against the cycles the wavefronts really lived (SQ_WAVE_CYCLES of the same passes) instead of kernel time x
+            # 2.4 GHz: independent of the shader clock, which drops under a long vector-heavy kernel (ORCA: ~1.8 GHz by this very ratio)
+            wq, wps = out["valu"].get("wave_quadcycles_per_substep"), out["valu"].get("waves_per_simd")
+            if wq and wps and wps <= 2.0:     # (every wavefront of the launch resident at once: every build here holds two per SIMD)
+                per_wave = cyc / (out["valu"]["waves_per_launch"] * n_sub * (W / float(pm.get("worlds", W))))
+                out["valu_frac_wave_cycles"] = per_wave * float(wps) / (4.0 * wq)
+                out["shader_clock_ghz_est"] = 4.0 * wq * n_sub / (k_avg * 1e-3) / 1e9   # (a lower bound: the launch is longer than its wavefronts live)
         else:     # no class counters for this configuration yet: every instruction at the 4.1 of the compare / select / min-max class
             out["valu_frac"] = insts * VALU_CLASS_CYCLES["other"] / simd_cycles
         out["valu_cycles_per_inst_achieved"] = simd_cycles / insts
