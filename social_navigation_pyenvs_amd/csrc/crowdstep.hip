@@ -380,7 +380,6 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     const long seg_tab = (long)w->O * w->Smax * ((w->flags & CS_OBSTACLES_SHARED) ? 1 : g.wpb);
     a.seg_tab = (seg_tab > 0 && seg_tab * 20 <= 16 * 1024) ? (int)seg_tab : 0;
     shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float)) + 16 + (size_t)(a.seg_tab > 0 ? a.seg_tab / w->Smax : 0) * sizeof(float4);
-    shmem += 128 * sizeof(int) + 130 * sizeof(float2) + sizeof(float4);   // wall pairs (sfmstep_kernel.h): the pairs' records and forces, the wall law
     {
         // one (agent, polygon) pair per lane: Helbing-type walls (no tangential term outside a contact), at most 4 polygons staged in LDS, no
         // respawn rule (the only way an agent jumps); CROWDSTEP_WALL_PAIRS=0 keeps every launch on the all-lanes pass (A/B)
@@ -388,6 +387,9 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
         const bool guo_walls = w->type == 1 || w->type == 4 || w->type == 7;
         a.wall_pairs = (wp_env && peq && a.seg_tab > 0 && a.seg_tab < 4096 && w->O > 0 && w->O <= 4 && !guo_walls && !(w->flags & CS_RESPAWN) && g.block == 64) ? 1 : 0;
     }
+    // wall pairs (sfmstep_kernel.h): the pairs' records and forces, the wall law -- the LAST region of the block's LDS, only where it is used
+    // (on every launch it cost the 25-row build its sixteenth block per CU: 8192 worlds 51 -> 60 us, 32768 worlds 160 -> 181 us)
+    if (a.wall_pairs) shmem += 128 * sizeof(int) + 130 * sizeof(float2) + sizeof(float4);
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     // two one-wavefront blocks per SIMD (the benchmark's 4096 x 25): the second half of the grid shares each SIMD with an older wavefront
