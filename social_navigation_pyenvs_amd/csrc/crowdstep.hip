@@ -316,6 +316,40 @@ GymHead gym_head(float* d_out, const float* d_global_time, float T, const float*
     return g;
 }
 
+// Dynamic LDS of a k_sfm_step block, and the two kernel arguments that follow from it (one function for the launch and for
+// cs_step_variant, which reports the figure: the blocks a CU holds are decided by it -- sixteen of the 25-row build, twelve of the 50-row
+// wall build -- and a region added for one build on every launch costs the others a block without any test noticing; tests/test_gpu_parity.py
+// asserts the figures of the benched builds).
+size_t step_lds_bytes(const cs_worlds* w, const Geometry& g, bool peq, int* seg_tab_out, int* wall_pairs_out)
+{
+    struct { int seg_tab, wall_pairs; } a = {0, 0};
+    // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
+    // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
+    size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
+                   2 * PADR * (sizeof(float4) + sizeof(float2)) +
+                   ((peq && g.block == 64) ? (size_t)UA * ACC_PITCH * sizeof(float2) : 0);
+    // per-agent parameters on the pair-once loop (Helbing / Guo, block of one wavefront): reaction accumulators + the partners' parameter rows
+    if (!peq && g.block == 64 && w->type % 3 != 2)
+        shmem += (size_t)UA * ACC_PITCH * sizeof(float2) + (size_t)(2 * g.block + PADR) * sizeof(float4);
+    // wall segment table (x1, y1, e, 1/|e|^2), shared or one per world of the block, when it is small enough
+    const long seg_tab = (long)w->O * w->Smax * ((w->flags & CS_OBSTACLES_SHARED) ? 1 : g.wpb);
+    a.seg_tab = (seg_tab > 0 && seg_tab * 20 <= 16 * 1024) ? (int)seg_tab : 0;
+    shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float)) + 16 + (size_t)(a.seg_tab > 0 ? a.seg_tab / w->Smax : 0) * sizeof(float4);
+    {
+        // one (agent, polygon) pair per lane: Helbing-type walls (no tangential term outside a contact), at most 4 polygons staged in LDS, no
+        // respawn rule (the only way an agent jumps); CROWDSTEP_WALL_PAIRS=0 keeps every launch on the all-lanes pass (A/B)
+        static const bool wp_env = []{ const char* e = std::getenv("CROWDSTEP_WALL_PAIRS"); return !(e && e[0] == '0'); }();
+        const bool guo_walls = w->type == 1 || w->type == 4 || w->type == 7;
+        a.wall_pairs = (wp_env && peq && a.seg_tab > 0 && a.seg_tab < 4096 && w->O > 0 && w->O <= 4 && !guo_walls && !(w->flags & CS_RESPAWN) && g.block == 64) ? 1 : 0;
+    }
+    // wall pairs (sfmstep_kernel.h): the pairs' records and forces, the wall law -- the LAST region of the block's LDS, only where it is used
+    // (on every launch it cost the 25-row build its sixteenth block per CU: 8192 worlds 51 -> 60 us, 32768 worlds 160 -> 181 us)
+    if (a.wall_pairs) shmem += 128 * sizeof(int) + 130 * sizeof(float2) + sizeof(float4);
+    if (seg_tab_out) *seg_tab_out = a.seg_tab;
+    if (wall_pairs_out) *wall_pairs_out = a.wall_pairs;
+    return shmem;
+}
+
 int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, const float* d_action,
                 float* d_peek, hipStream_t stream, float4* d_snap = nullptr, float* d_trace = nullptr, const RobotModel* rm = nullptr,
                 float* d_obs = nullptr, int obs_cols = 0, const GymHead* gym = nullptr)
@@ -368,28 +402,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     if (v.maxt == 16) return csimpl::row16_launch(a, stream);
     const kfn fn = variant_kernel(v, w->type);
     if (!fn) return fail(CS_ERR_ARG, "no kernel build for this variant");
-    // lds_p [2][2T+PADR] float4, lds_v [2][2T+PADR] float2, lds_vr [2][T] float2, respawn scratch 2 x [T] x 4 B,
-    // reaction accumulators [UA][2T] float2 (pair-once loop: all_params_equal, block of one wavefront)
-    size_t shmem = (size_t)g.block * (4 * sizeof(float4) + 4 * sizeof(float2) + 2 * sizeof(float2) + 2 * sizeof(float)) +
-                   2 * PADR * (sizeof(float4) + sizeof(float2)) +
-                   ((peq && g.block == 64) ? (size_t)UA * ACC_PITCH * sizeof(float2) : 0);
-    // per-agent parameters on the pair-once loop (Helbing / Guo, block of one wavefront): reaction accumulators + the partners' parameter rows
-    if (!peq && g.block == 64 && w->type % 3 != 2)
-        shmem += (size_t)UA * ACC_PITCH * sizeof(float2) + (size_t)(2 * g.block + PADR) * sizeof(float4);
-    // wall segment table (x1, y1, e, 1/|e|^2), shared or one per world of the block, when it is small enough
-    const long seg_tab = (long)w->O * w->Smax * ((w->flags & CS_OBSTACLES_SHARED) ? 1 : g.wpb);
-    a.seg_tab = (seg_tab > 0 && seg_tab * 20 <= 16 * 1024) ? (int)seg_tab : 0;
-    shmem += (size_t)a.seg_tab * (sizeof(float4) + sizeof(float)) + 16 + (size_t)(a.seg_tab > 0 ? a.seg_tab / w->Smax : 0) * sizeof(float4);
-    {
-        // one (agent, polygon) pair per lane: Helbing-type walls (no tangential term outside a contact), at most 4 polygons staged in LDS, no
-        // respawn rule (the only way an agent jumps); CROWDSTEP_WALL_PAIRS=0 keeps every launch on the all-lanes pass (A/B)
-        static const bool wp_env = []{ const char* e = std::getenv("CROWDSTEP_WALL_PAIRS"); return !(e && e[0] == '0'); }();
-        const bool guo_walls = w->type == 1 || w->type == 4 || w->type == 7;
-        a.wall_pairs = (wp_env && peq && a.seg_tab > 0 && a.seg_tab < 4096 && w->O > 0 && w->O <= 4 && !guo_walls && !(w->flags & CS_RESPAWN) && g.block == 64) ? 1 : 0;
-    }
-    // wall pairs (sfmstep_kernel.h): the pairs' records and forces, the wall law -- the LAST region of the block's LDS, only where it is used
-    // (on every launch it cost the 25-row build its sixteenth block per CU: 8192 worlds 51 -> 60 us, 32768 worlds 160 -> 181 us)
-    if (a.wall_pairs) shmem += 128 * sizeof(int) + 130 * sizeof(float2) + sizeof(float4);
+    const size_t shmem = step_lds_bytes(w, g, peq, &a.seg_tab, &a.wall_pairs);
     if (shmem > 64 * 1024) // one world per block with > ~600 rows
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     // two one-wavefront blocks per SIMD (the benchmark's 4096 x 25): the second half of the grid shares each SIMD with an older wavefront
@@ -778,8 +791,9 @@ int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)
         std::snprintf(buf, buflen, "k_sfm_step_row16<SOC=%d,HEADED=%d,ROWS=%d> grid=%d block=64 wpb=4", w->type % 3, w->type / 3, v.rows_ct, (w->W + 3) / 4);
         return CS_OK;
     }
-    std::snprintf(buf, buflen, "k_sfm_step<SOC=%d,HEADED=%d,PEQ=%d,MAXT=%d,OCC=%d,ROWS_CT=%d,LEAN=%d> grid=%d block=%d wpb=%d",
-                  w->type % 3, w->type / 3, v.peq ? 1 : 0, v.maxt, v.occ, v.rows_ct, v.lean, g.grid, g.block, g.wpb);
+    std::snprintf(buf, buflen, "k_sfm_step<SOC=%d,HEADED=%d,PEQ=%d,MAXT=%d,OCC=%d,ROWS_CT=%d,LEAN=%d> grid=%d block=%d wpb=%d lds=%d",
+                  w->type % 3, w->type / 3, v.peq ? 1 : 0, v.maxt, v.occ, v.rows_ct, v.lean, g.grid, g.block, g.wpb,
+                  (int)step_lds_bytes(w, g, v.peq, nullptr, nullptr));
     return CS_OK;
 }
 

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     // twelve blocks per CU at 10.5 KB each: 4 KB more per block cost it one of them (measured: 208 -> 260 us), so the agents' radii live in
     // lds_vr (written by the per-agent-parameter builds only) and the contact velocities in the respawn scratch (idle without the rule)
     constexpr int WP_MAX = 128;
+    constexpr int WP_NW = 4;                                        // segments of a pair's polygon per trip of its closest-point loop
     int* lds_wrec = reinterpret_cast<int*>(lds_poly + (a.Smax > 0 ? a.seg_tab / a.Smax : 0));   // [WP_MAX] pair: agent's row in lds_p | first segment << 8 | agent lane << 20
     float2* lds_wres = reinterpret_cast<float2*>(lds_wrec + WP_MAX);                             // [WP_MAX + 1] the pairs' forces ([WP_MAX]: the zero of "no pair")
     float4* lds_wlaw = reinterpret_cast<float4*>(lds_wres + WP_MAX + 2);                         // [1] the wall law A, log2 e / B, k1, k2 (all_params_equal)

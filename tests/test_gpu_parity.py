@@ -160,6 +160,12 @@ G13_VARIANT = {"n10": "k_sfm_step_row16<SOC=%d,HEADED=%d,ROWS=10>", "n25_traffic
                "n50": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=1", "n50_walls_static": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=2"}
 
 
+# ... and the dynamic LDS a block of each may take (reported by cs_step_variant): what decides how many blocks a CU holds on grids of more
+# than two wavefronts per SIMD -- 160 KB / 16 blocks for the builds without walls, / 12 for the 50-row wall build (three wavefronts per
+# SIMD by its registers).  Round 5 added a region for the wall pairs to every launch: 8192 worlds 51 -> 60 us, and no test noticed.
+G13_LDS_MAX = {"n25_traffic": 160 * 1024 // 16, "n50": 160 * 1024 // 16, "n50_walls_static": 160 * 1024 // 12}
+
+
 @pytest.mark.parametrize("group", ["g2_block", "g13_block_sizes"])
 def test_block_of_20_substeps(group):
     """20 fused substeps (cs_step, the lean / shape-specialised builds included) against the golden blocks the reference
@@ -225,6 +231,11 @@ def test_every_substep_inside_the_fused_block(group):
             want = G13_VARIANT[c["kind"]]
             want = want % (c["type"] % 3, c["type"] // 3) if "%d" in want else want
             assert want in cw.step_variant(), (c["kind"], cw.step_variant())
+            if c["kind"] in G13_LDS_MAX:
+                import re
+
+                lds = int(re.search(r"lds=(\d+)", cw.step_variant()).group(1))
+                assert 0 < lds <= G13_LDS_MAX[c["kind"]], (c["kind"], cw.step_variant())
         fam = "Moussaid" if c["type"] % 3 == 2 else "Helbing / Guo"
         res = fused_substeps_vs_oracle(cw, c["type"], c["in_states"], c["in_goals"], c["in_params"], c["in_safety"], c.get("in_obstacles"),
                                        c["dt"], c["n_substeps"], c["all_params_equal"], respawn=c["respawn"],
