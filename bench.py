@@ -69,7 +69,7 @@ SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 # v_min / v_max / v_max3 / v_cmp / v_cndmask (VOP3 or fed by a compare) / DPP / f64 min-max 4.1; v_exp / v_rcp / v_rsq / v_sqrt 8.2.
 # One wavefront ALONE on a SIMD issues no faster than one instruction per 4.4 - 5.6 cycles whatever the class.
 VALU_CLASS_CYCLES = {"fma": 2.2, "other": 4.1, "trans": 8.2}
-CPU_ROWS = ("cfg2", "cfg4_first20", "cfg4_dense", "cfg5_shard", "moussaid")   # other_configs rows that get their own CPU figure
+CPU_ROWS = ("cfg2", "cfg4_first20", "cfg4_dense", "cfg5_shard", "moussaid", "cfg3_new_guo", "robot26", "n30", "peragent")   # other_configs rows that get their own CPU figure (cfg5 = 8 x its shard)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 
 
@@ -284,9 +284,13 @@ def cpu_baseline(spec, seconds=12.0, single_seconds=4.0):
             idx = np.arange(sel)
             groups = [(idx, respawn)] if host["respawn_worlds"] is None else \
                 [(idx[host["respawn_worlds"][idx] == 1], True), (idx[host["respawn_worlds"][idx] == 0], False)]
-            runners = [orc.StepBlockRunner(type_id, host["S"][g_], host["goals"][g_], host["walls"], host["P"],
-                                           np.zeros((g_.size, host["S"].shape[1])), True, respawn=rs, respawn_par=rp,
-                                           dtype=np.float64, threads=threads) for g_, rs in groups if g_.size]
+            peq = bool(host.get("all_params_equal", True))
+            P_of = (lambda g_: host["P"]) if np.asarray(host["P"]).ndim == 2 else (lambda g_: np.asarray(host["P"])[g_])
+            runners = [orc.StepBlockRunner(type_id, host["S"][g_], host["goals"][g_], host["walls"], P_of(g_),
+                                           np.zeros((g_.size, host["S"].shape[1])), peq, respawn=rs, respawn_par=rp,
+                                           dtype=np.float64, threads=threads,
+                                           robot=None if host.get("robot") is None else host["robot"][g_],
+                                           action=None if host.get("action") is None else host["action"][g_]) for g_, rs in groups if g_.size]
             done, reps, t0 = 0, 0, time.perf_counter()
             while True:
                 for r in runners:

@@ -125,11 +125,15 @@ class StepBlockRunner:
     """In-place, copy-free repeated calls of orc_step_block_batched (for timing the CPU baseline)."""
 
     def __init__(self, type_, S, goals, obstacles, P, safety, all_params_equal, respawn=False,
-                 respawn_par=(0.0, 0.0, 0.0), dtype=np.float64, threads=0):
+                 respawn_par=(0.0, 0.0, 0.0), dtype=np.float64, threads=0, robot=None, action=None):
+        """``robot`` [W, 13] + ``action`` [W, 2]: a visible robot as the last state row of every world (the reference's robot_visible
+        branch: the humans see it, its own row is moved by the action)."""
         self.sfx, self.ct = _suffix(dtype)
         self.S = np.ascontiguousarray(S, dtype=dtype).copy()
         self.W, self.rows = self.S.shape[0], self.S.shape[1]
-        self.n = self.rows
+        self.robot = None if robot is None else np.ascontiguousarray(robot, dtype=dtype).copy()
+        self.action = None if action is None else np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=dtype), (self.W, 2)))
+        self.n = self.rows - (0 if self.robot is None else 1)
         self.goals = np.ascontiguousarray(goals, dtype=dtype).copy().reshape(self.W, self.n, -1, 2)
         self.G = self.goals.shape[2]
         P = np.ascontiguousarray(P, dtype=dtype)
@@ -149,7 +153,7 @@ class StepBlockRunner:
         rc = self.fn(C.c_int(self.W), C.c_int(self.type_), _ptr(self.S, ct), _ptr(self.goals, ct), C.c_int(self.G),
                      _ptr(self.obs, ct), C.c_size_t(self.obs_stride), C.c_int(self.O), C.c_int(self.Smax),
                      _ptr(self.P, ct), C.c_size_t(self.n * 20), ct(dt), C.c_int(n_substeps), _ptr(self.safety, ct),
-                     C.c_int(int(self.peq)), C.c_int(0), C.c_int(self.rows), None, None, C.c_int(0),
+                     C.c_int(int(self.peq)), C.c_int(0 if self.robot is None else 1), C.c_int(self.rows), _ptr(self.robot, ct), _ptr(self.action, ct), C.c_int(0),
                      C.c_int(int(self.respawn)), _ptr(self.rp, ct), C.c_int(self.threads))
         if rc != 0:
             raise ValueError(f"oracle step_block failed rc={rc}")

@@ -186,3 +186,31 @@ def test_line_is_relayed_at_once_and_a_rank_hanging_in_its_teardown_is_ended(tmp
     assert time.time() - t0 < 30
     assert json.loads(r.stdout.strip())["n_gpus"] == 2          # the measurement survived
     assert r.returncode == 9 and "did not exit within" in r.stderr
+
+
+def test_cpu_baseline_runner_covers_the_robot_and_per_agent_rows():
+    """bench.py times the oracle through StepBlockRunner (in place, copy-free): with a visible robot row and with per-agent parameters
+    it must step exactly what orc.step_block steps (the function the parity tests use)."""
+    import numpy as np
+
+    import bench
+    from oracle import crowd_oracle as orc
+    from social_navigation_pyenvs_amd.batched import HUMAN_MODELS
+
+    args = bench.parse([])
+    for name in ("robot26", "peragent"):
+        spec = next(s for s in bench.other_config_specs(args) if s["name"] == name)
+        host = bench.host_worlds(dict(spec, worlds=6, total_worlds=None, device_generator=False), 0, 1)
+        sel = np.nonzero(host["respawn_worlds"] == 0)[0] if host["respawn_worlds"] is not None else np.arange(6)
+        t = HUMAN_MODELS.index(spec["model"])
+        P = host["P"] if np.asarray(host["P"]).ndim == 2 else np.asarray(host["P"])[sel]
+        peq = bool(host["all_params_equal"])
+        rob = None if host["robot"] is None else host["robot"][sel]
+        act = None if host["action"] is None else host["action"][sel]
+        r = orc.StepBlockRunner(t, host["S"][sel], host["goals"][sel], host["walls"], P, np.zeros((sel.size, host["S"].shape[1])), peq,
+                                threads=1, robot=rob, action=act)
+        r.run(spec["dt"], 7)
+        S, g, _ = orc.step_block(t, host["S"][sel], host["goals"][sel], host["walls"], P, spec["dt"], 7, np.zeros((sel.size, host["S"].shape[1])), peq,
+                                 robot_visible=rob is not None, robot=rob, action=act, threads=1)
+        np.testing.assert_array_equal(r.S, S)
+        assert not np.array_equal(r.S, host["S"][sel])
