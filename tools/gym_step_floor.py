@@ -31,26 +31,26 @@ for nsub in (1, 5, 10, 20, 40):
     env.reset(phase="train", first_case=0, device=True)
     buf = env.action_buffer()
     buf.zero_()
+    # a crowd's cost follows its state (contacts, respawns): the two loops alternate in blocks of 25 steps over the same stretch of the episode
     with torch.cuda.stream(env.device_stream()):
-        for _ in range(30):
-            env.step_device(buf, auto_reset=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            env.step_device(buf, auto_reset=False)
-        torch.cuda.synchronize()
-        gym_us = (time.perf_counter() - t0) / steps * 1e6
         cw = env.cw
         for _ in range(30):
-            cw.step(0.0125, nsub)
-        cw.sync()
+            env.step_device(buf, auto_reset=False)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            cw.step(0.0125, nsub)
-        cw.sync()
-        torch.cuda.synchronize()
-        bare_us = (time.perf_counter() - t0) / steps * 1e6
+        gym_t = bare_t = 0.0
+        for _ in range(steps // 25):
+            t0 = time.perf_counter()
+            for _ in range(25):
+                env.step_device(buf, auto_reset=False)
+            torch.cuda.synchronize()
+            gym_t += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for _ in range(25):
+                cw.step(0.0125, nsub)
+            cw.sync()
+            torch.cuda.synchronize()
+            bare_t += time.perf_counter() - t0
+        gym_us, bare_us = gym_t / (steps // 25 * 25) * 1e6, bare_t / (steps // 25 * 25) * 1e6
     rows.append((nsub, gym_us, bare_us))
     print(f"substeps {nsub:3d} | Gym step {gym_us:7.2f} us | bare cs_step (plain launches) {bare_us:7.2f} us | difference {gym_us - bare_us:6.2f} us", flush=True)
     env.close()
