@@ -407,6 +407,17 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
         HIP_TRY(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     // two one-wavefront blocks per SIMD (the benchmark's 4096 x 25): the second half of the grid shares each SIMD with an older wavefront
     a.young_from = (g.block == 64 && g.grid == 2 * csimpl::device_simds()) ? g.grid / 2 : 0x7fffffff;
+    a.wg_waves = 1; a.lds_per_wave = 0;
+    if (g.block == 64) {
+        // one-wavefront builds: wg_waves independent wavefronts per workgroup (sfmstep_kernel.h); CROWDSTEP_WG_WAVES = 1 / 2 / 4 / 8 for A/B
+        static const int wg_env = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int v = e ? std::atoi(e) : 4; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }();
+        a.wg_waves = wg_env;
+        a.lds_per_wave = (int)((shmem + 15) & ~(size_t)15);
+        while (a.wg_waves > 1 && (size_t)a.lds_per_wave * a.wg_waves > 64 * 1024) a.wg_waves /= 2;   // (stay within the default dynamic-LDS limit of a workgroup)
+        hipLaunchKernelGGL(fn, dim3((g.grid + a.wg_waves - 1) / a.wg_waves), dim3(64 * a.wg_waves), (size_t)a.lds_per_wave * a.wg_waves, stream, a);
+        HIP_TRY(hipGetLastError());
+        return CS_OK;
+    }
     hipLaunchKernelGGL(fn, dim3(g.grid), dim3(g.block), shmem, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -791,9 +802,9 @@ int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)
         std::snprintf(buf, buflen, "k_sfm_step_row16<SOC=%d,HEADED=%d,ROWS=%d> grid=%d block=64 wpb=4", w->type % 3, w->type / 3, v.rows_ct, (w->W + 3) / 4);
         return CS_OK;
     }
-    std::snprintf(buf, buflen, "k_sfm_step<SOC=%d,HEADED=%d,PEQ=%d,MAXT=%d,OCC=%d,ROWS_CT=%d,LEAN=%d> grid=%d block=%d wpb=%d lds=%d",
+    std::snprintf(buf, buflen, "k_sfm_step<SOC=%d,HEADED=%d,PEQ=%d,MAXT=%d,OCC=%d,ROWS_CT=%d,LEAN=%d> grid=%d block=%d wpb=%d lds=%d%s",
                   w->type % 3, w->type / 3, v.peq ? 1 : 0, v.maxt, v.occ, v.rows_ct, v.lean, g.grid, g.block, g.wpb,
-                  (int)step_lds_bytes(w, g, v.peq, nullptr, nullptr));
+                  (int)step_lds_bytes(w, g, v.peq, nullptr, nullptr), g.block == 64 ? " (one-wavefront blocks, four to a workgroup)" : "");
     return CS_OK;
 }
 

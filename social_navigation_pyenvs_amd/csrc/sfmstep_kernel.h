@@ -56,10 +56,22 @@ constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one 
 //            does not need them and the goal switch is predicated; 4 = 3 + the robot follows a HUMAN motion model of its own
 //            (imitation learning, social_nav_gym.py:252-274): update_robot runs inside the substep loop (robot_model.h);
 //            5 = 3 with the walls kept (a Gym with a visible robot in a walled scene)
+constexpr int WG_WAVES_MAX = 8;   // (launch bound of the one-wavefront builds: up to eight independent wavefronts per workgroup, four by default)
 template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, int LEAN>
-__global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
+// One-wavefront builds (MAXT = 64) are launched as workgroups of a.wg_waves INDEPENDENT wavefronts (four by default), each the "block" the
+// rest of this file talks about -- its own worlds, its own slice of the dynamic LDS, no barrier with the others.  The dispatcher starts
+// workgroups at a fixed rate whatever their size: cfg3's 2048 one-wavefront workgroups took 2.8 us to start (s_memrealtime stamps of the
+// diagnostic build), 512 workgroups of four take a quarter of it -- 29.1 -> 27.8 us per launch, 7.3 -> 6.0 us for a launch of one substep.
+__global__ __launch_bounds__(MAXT == 64 ? 64 * WG_WAVES_MAX : MAXT, OCC) void k_sfm_step(const KArgs a)
 {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
+    extern __shared__ __align__(16) unsigned char smem_raw0[];
+    const int wave_in_wg = MAXT == 64 ? (int)(threadIdx.x >> 6) : 0;
+    unsigned char* smem_raw = smem_raw0 + (MAXT == 64 ? (size_t)wave_in_wg * a.lds_per_wave : 0);
+    const int vblock = MAXT == 64 ? (int)blockIdx.x * a.wg_waves + wave_in_wg : (int)blockIdx.x;   // the one-wavefront block this wavefront is
+#ifdef CS_STAMPS
+    unsigned long long pst_first, pst_first_rt;   // the wavefront's first instruction (shader clock, and the 100 MHz wall clock all wavefronts share)
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst_first), "=s"(pst_first_rt)::"memory");
+#endif
     // all_params_equal, whole worlds inside one wavefront: every unordered pair is evaluated ONCE (as the reference
     // does, forces_parallel.py:100-131: F[i,j] = f, F[j,i] = -f) and the reaction handed over through LDS.
     // Per-agent parameters (forces_parallel.py:43-84, :261: F_i = sum_j f(P_i; i, j), no antisymmetry) take the same loop for the Helbing /
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     // transcendentals per unordered pair instead of 2 x (12 + 2) (the peragent bench entry: 443 -> 35x VALU per wavefront-substep).
     constexpr bool N3L = MAXT == 64 && (PEQ || SOC != 2);
     constexpr bool PP = N3L && !PEQ;
-    const int T = blockDim.x;
+    const int T = MAXT == 64 ? 64 : blockDim.x;
     // Every world's rows are stored TWICE, back to back ([w][2][rows]): lane i then reads its partners
     // i+1 .. i+rows-1 at constant offsets from one base address -- no own-row slot, no modulo, no
     // per-partner compare (v_cmp + v_cndmask costs as much as a transcendental on this SIMD).
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     float4* lds_wlaw = reinterpret_cast<float4*>(lds_wres + WP_MAX + 2);                         // [1] the wall law A, log2 e / B, k1, k2 (all_params_equal)
     float2* lds_wrs = lds_vr;                                                                    // [WP_MAX] pair: the agent's radius, safety space
     float2* lds_wcv = reinterpret_cast<float2*>(lds_g0x);                                        // [T] the agents' refreshed linear velocities (contact terms)
-    const int tid = threadIdx.x;
+    const int tid = MAXT == 64 ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     static_assert(!LEAN || (PEQ && MAXT == 64), "the lean build is a pair-once build");
     constexpr bool LEAN_ROBOT = LEAN == 3 || LEAN == 4 || LEAN == 5;   // the robot is the last row (5: with walls)
     constexpr bool IMIT = LEAN == 4;                       // ... and follows its own human motion model
@@ -104,7 +116,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
     const int kmode = LEAN_ROBOT ? ((int)M_COMMIT_GOALS | (a.mode & (int)M_ROBOT_FROM_ARRAY)) : (LEAN ? (int)M_COMMIT_GOALS : a.mode);
     const int lw = tid / rows;
     const int row = tid - lw * rows;
-    const int w = blockIdx.x * a.wpb + lw;
+    const int w = vblock * a.wpb + lw;
     const bool valid = (lw < a.wpb) && (w < a.W);
     const bool robot_row = LEAN_ROBOT ? true : (LEAN ? false : (a.flags & CS_ROBOT_ROW) != 0);
     const bool human = valid && row < n;
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
 #include "sfmstep_load.inc"
     // the prologue: per-launch constants, wall segments and polygon circles staged in LDS, the Gym step's head (cs_gym_step), substep-0 rows published, the (agent, polygon) pairs of the wall pass numbered (LEAN = 2)
 #include "sfmstep_prologue.inc"
-    const bool prio_young = MAXT == 64 && (int)blockIdx.x >= a.young_from;
+    const bool prio_young = MAXT == 64 && vblock >= a.young_from;
     // base priority 1: above the generator's wavefronts of a refill pass on the side stream (priority 0, and OLDER than any of mine, so a tie
     // would go to them): the Gym step in NEXT_STEP mode 43.3 -> 41.5 us, a plain launch unchanged
     if constexpr (MAXT == 64) __builtin_amdgcn_s_setprio(1);
@@ -138,10 +150,7 @@ __global__ __launch_bounds__(MAXT, OCC) void k_sfm_step(const KArgs a)
         cur = nxt;
     }
 #ifdef CS_STAMPS
-    if (a.stamps != nullptr && (threadIdx.x & 63) == 0) {
-        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 12;
-        for (int k = 0; k < 12; ++k) o[k] = st_acc[k];
-    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst_loop_end)::"memory");
 #endif
 
     if (a.trace != nullptr && (human || is_robot) && a.nsub > 0)

@@ -51,6 +51,8 @@ struct KArgs {
     const float* rm_hmargin; // [W][rows] the humans' safety space as the robot's model sees it
     float* rm_memory;      // [W][2] robot.desired_force between substeps
     float rm_P[20];        // the robot's parameters
+    int wg_waves;          // one-wavefront builds (MAXT = 64): independent wavefronts per workgroup (each a virtual block of its own); 1 elsewhere
+    int lds_per_wave;      // ... and the bytes of dynamic LDS each of them owns
     int young_from;        // blocks from this index on are the YOUNGER wavefront of their SIMD (a grid of exactly two wavefronts per SIMD), INT_MAX: no such split
     float wall_efolds;     // a polygon farther than (this many e-folding lengths of the wall force) from every agent of a wavefront is skipped
     int wall_pairs;        // LEAN = 2 builds: the (agent, polygon) pairs within reach over the whole launch are numbered ONCE in the prologue and a

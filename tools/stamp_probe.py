@@ -64,7 +64,7 @@ else:
     cw = CrowdWorlds(S, goals, P, None, sc.polygon_walls() if (len(sys.argv) > 4 and sys.argv[4] == "hybridwalls") else None, type=model, all_params_equal=True, respawn_bounds=rb,
                      respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), layout="soa")
 g, b, wpb = cw.launch_geometry()
-buf = _lib.DeviceBuffer((g * (b // 64), 12), np.uint64)
+buf = _lib.DeviceBuffer((g * (b // 64), 20), np.uint64)
 lib = _lib.load()
 lib.cs_debug_set_stamp_buffer(C.c_void_p(buf.ptr))
 # STAMP_WARMUP Gym steps first, then the stamps of STAMP_STEPS launches summed (the kernel overwrites its buffer: one download per launch)
@@ -72,7 +72,7 @@ warm, steps = int(os.environ.get("STAMP_WARMUP", "0")), int(os.environ.get("STAM
 for _ in range(warm):
     cw.step(0.0125, 20)
 cw.sync()
-st = np.zeros((g * (b // 64), 12), np.float64)
+st = np.zeros((g * (b // 64), 20), np.float64)
 for _ in range(steps):
     cw.step(0.0125, 20)
     cw.sync()
@@ -80,10 +80,21 @@ for _ in range(steps):
 st /= steps
 names = ["goal switch", "rot+desired+walls", "pair-once: contact pass/ballot", "torque+euler+lds write", "barrier", "respawn check", "all-partners pair loop (not pair-once)", "loop top",
          "pair-once: zero accumulators", "pair-once: partner groups", "pair-once: reaction sum", "contact passes per 1000 wavefront-substeps (a count, not cycles)"]
-tot = st.sum(1).mean()
+tot = st[:, :11].sum(1).mean()
 print(f"N={n} {model}, Gym steps {warm}..{warm + steps}: mean wave cycles in loop = {tot:.0f} (per substep {tot / 20:.0f})")
 for k, nm in enumerate(names):
     print(f"  {nm:28s} {st[:, k].mean() / 20:9.1f} cyc/substep  {100 * st[:, k].mean() / tot:5.1f} %")
+fixed = ["entry -> every load of the load phase returned", "-> first substep (prologue arithmetic, LDS publication)", "last substep -> stores issued (epilogue)",
+         "-> stores acknowledged (not waited for by the wavefront)"]
+if st[:, 18].mean() > 0:   # slots 16 / 17 / 18 of the last launch (not summed): wall clock of each wavefront's first / last instruction, its wait for the kernel arguments
+    last = buf.download().astype(np.float64)
+    t0, t1 = last[:, 17], last[:, 18]
+    print(f"  last launch, wall clock (s_memrealtime, 10 ns ticks): first wavefront starts at 0, the last one {10e-3 * (t0.max() - t0.min()):.2f} us later; "
+          f"a wavefront lives {10e-3 * (t1 - t0).mean():.2f} us (min {10e-3 * (t1 - t0).min():.2f}, max {10e-3 * (t1 - t0).max():.2f}); first start -> last end {10e-3 * (t1.max() - t0.min()):.2f} us")
+    print(f"  first instruction -> kernel arguments loaded: {last[:, 16].mean():.0f} shader clocks (max {last[:, 16].max():.0f})")
+print("  around the substeps (shader clocks per launch, mean over the wavefronts):")
+for k, nm in enumerate(fixed):
+    print(f"    {nm:62s} {st[:, 12 + k].mean():9.0f} cycles  ({st[:, 12 + k].mean() / 2.4e3:5.2f} us at 2.4 GHz)")
 per_wave = st[:, :11].sum(1)
 print(f"  the launch waits for its slowest wavefront: slowest / mean wavefront = {per_wave.max() / per_wave.mean():.3f}, 99th percentile / mean = {np.percentile(per_wave, 99) / per_wave.mean():.3f}")
 print(f"  second half of the grid (the younger wavefront of each SIMD) / first half: {per_wave[len(per_wave) // 2:].mean() / per_wave[:len(per_wave) // 2].mean():.3f}")
