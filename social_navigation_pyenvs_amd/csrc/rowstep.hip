@@ -18,6 +18,7 @@
 //
 // gfx950 only: no portability macros, no CPU fallback.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstring>
 #include <type_traits>
@@ -59,7 +60,7 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
 }
 
 template <int SOC, int HEADED, int ROWS>
-__global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
+__global__ __launch_bounds__(512, 2) void k_sfm_step_row16(const KArgs a)   // (up to eight independent wavefronts per workgroup: row16_launch)
 {
     static_assert(ROWS >= 2 && ROWS <= 11, "ROWS + ROWS / 2 - 1 must stay inside the 16-lane row");
     constexpr int HF = (ROWS - 1) / 2;            // ring distances whose pairs are evaluated once (by the lower end)
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64, 2) void k_sfm_step_row16(const KArgs a)
     constexpr int KMAX = EVEN ? ROWS / 2 : HF;
     const int tid = threadIdx.x, r = tid & 15;
     __builtin_amdgcn_s_setprio(1);   // (base priority 1: above the generator's wavefronts of a refill pass, sfmstep_kernel.h)
-    const int w = blockIdx.x * 4 + (tid >> 4);
+    const int w = blockIdx.x * (blockDim.x >> 4) + (tid >> 4);   // four worlds per wavefront, blockDim.x / 64 independent wavefronts per workgroup
     const bool inw = w < a.W;
     const bool human = inw && r < ROWS;
     const bool mirror = r >= ROWS;                // lanes ROWS .. 15 carry copies of agents 0 .. (positions, Moussaid: velocities)
@@ -350,8 +351,12 @@ int row16_launch(const cstep::KArgs& a, hipStream_t stream)
 {
     kfn fn = a.rows == 10 ? pick_row16<10>(a.type) : (a.rows == 5 ? pick_row16<5>(a.type) : nullptr);
     if (!fn) return fail(CS_ERR_ARG, "no DPP-row build for this row count / type");
-    const int grid = (a.W + 3) / 4;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), 0, stream, a);
+    // wavefronts share nothing (no LDS, no barrier): four to a workgroup, because the dispatcher starts workgroups at a fixed rate whatever
+    // their size (sfmstep_kernel.h; CROWDSTEP_WG_WAVES = 1 / 2 / 4 / 8 for A/B)
+    static const int wgw = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int v = e ? std::atoi(e) : 4; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }();
+    const int wpg = 4 * wgw;                        // worlds per workgroup
+    const int grid = (a.W + wpg - 1) / wpg;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * wgw), 0, stream, a);
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }
