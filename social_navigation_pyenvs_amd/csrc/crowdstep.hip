@@ -409,8 +409,8 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.young_from = (g.block == 64 && g.grid == 2 * csimpl::device_simds()) ? g.grid / 2 : 0x7fffffff;
     a.wg_waves = 1; a.lds_per_wave = 0;
     if (g.block == 64) {
-        // one-wavefront builds: wg_waves independent wavefronts per workgroup (sfmstep_kernel.h); CROWDSTEP_WG_WAVES = 1 / 2 / 4 / 8 for A/B
-        static const int wg_env = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int v = e ? std::atoi(e) : 4; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }();
+        // one-wavefront builds: wg_waves independent wavefronts per workgroup (sfmstep_kernel.h); CROWDSTEP_WG_WAVES = 1 / 2 / 4 for A/B
+        static const int wg_env = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int v = e ? std::atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
         a.wg_waves = wg_env;
         a.lds_per_wave = (int)((shmem + 15) & ~(size_t)15);
         while (a.wg_waves > 1 && (size_t)a.lds_per_wave * a.wg_waves > 64 * 1024) a.wg_waves /= 2;   // (stay within the default dynamic-LDS limit of a workgroup)

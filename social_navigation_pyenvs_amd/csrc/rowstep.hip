@@ -60,7 +60,7 @@ __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, I..
 }
 
 template <int SOC, int HEADED, int ROWS>
-__global__ __launch_bounds__(512, 2) void k_sfm_step_row16(const KArgs a)   // (up to eight independent wavefronts per workgroup: row16_launch)
+__global__ __launch_bounds__(256, 2) void k_sfm_step_row16(const KArgs a)   // (up to four independent wavefronts per workgroup: row16_launch)
 {
     static_assert(ROWS >= 2 && ROWS <= 11, "ROWS + ROWS / 2 - 1 must stay inside the 16-lane row");
     constexpr int HF = (ROWS - 1) / 2;            // ring distances whose pairs are evaluated once (by the lower end)
@@ -352,8 +352,8 @@ int row16_launch(const cstep::KArgs& a, hipStream_t stream)
     kfn fn = a.rows == 10 ? pick_row16<10>(a.type) : (a.rows == 5 ? pick_row16<5>(a.type) : nullptr);
     if (!fn) return fail(CS_ERR_ARG, "no DPP-row build for this row count / type");
     // wavefronts share nothing (no LDS, no barrier): four to a workgroup, because the dispatcher starts workgroups at a fixed rate whatever
-    // their size (sfmstep_kernel.h; CROWDSTEP_WG_WAVES = 1 / 2 / 4 / 8 for A/B)
-    static const int wgw = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int v = e ? std::atoi(e) : 4; return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 4; }();
+    // their size (sfmstep_kernel.h; CROWDSTEP_WG_WAVES = 1 / 2 / 4 for A/B)
+    static const int wgw = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int v = e ? std::atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
     const int wpg = 4 * wgw;                        // worlds per workgroup
     const int grid = (a.W + wpg - 1) / wpg;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * wgw), 0, stream, a);

@@ -56,7 +56,8 @@ constexpr int ACC_PITCH = 128; // float2 slots per accumulator row (block = one 
 //            does not need them and the goal switch is predicated; 4 = 3 + the robot follows a HUMAN motion model of its own
 //            (imitation learning, social_nav_gym.py:252-274): update_robot runs inside the substep loop (robot_model.h);
 //            5 = 3 with the walls kept (a Gym with a visible robot in a walled scene)
-constexpr int WG_WAVES_MAX = 8;   // (launch bound of the one-wavefront builds: up to eight independent wavefronts per workgroup, four by default)
+constexpr int WG_WAVES_MAX = 4;   // (launch bound of the one-wavefront builds: four independent wavefronts per workgroup; a bound of eight -- which measures the same as
+                                  //  four -- makes the compiler allocate the Moussaid builds ten registers fewer and their launches 2 us longer)
 template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, int LEAN>
 // One-wavefront builds (MAXT = 64) are launched as workgroups of a.wg_waves INDEPENDENT wavefronts (four by default), each the "block" the
 // rest of this file talks about -- its own worlds, its own slice of the dynamic LDS, no barrier with the others.  The dispatcher starts
