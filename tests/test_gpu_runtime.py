@@ -69,3 +69,36 @@ def test_bench_launches_its_own_ranks_and_prints_one_parsable_line():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True,
                            timeout=300, env=env)
         assert r.returncode == 3 and r.stdout.strip() == "" and "needs 2 visible" in r.stderr
+
+
+WG_CHILD = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from social_navigation_pyenvs_amd import scenarios as sc
+from social_navigation_pyenvs_amd.batched import CrowdWorlds
+out = []
+for model, W, n in (("hsfm_farina", 37, 25), ("sfm_helbing", 45, 10), ("hsfm_new_moussaid", 9, 17)):
+    S, goals, P, rb = sc.hybrid_worlds(W, n, model)
+    cw = CrowdWorlds(S, goals, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
+                     respawn_worlds=(np.arange(W) %% 2 == 1).astype(np.int32), layout="soa")
+    for _ in range(6):
+        cw.step(0.0125, 20)
+    out.append(hashlib.sha256(np.ascontiguousarray(cw.get_states()).tobytes() + np.ascontiguousarray(cw.get_goals()).tobytes()).hexdigest())
+print("WGHASH " + " ".join(out))
+"""
+
+
+def test_one_wavefront_blocks_step_the_same_bits_however_many_share_a_workgroup():
+    """The one-wavefront step kernels (k_sfm_step MAXT = 64, the DPP-row kernel) go to the dispatcher four independent wavefronts to a
+    workgroup (sfmstep_kernel.h; CROWDSTEP_WG_WAVES = 1 / 2 / 4 is read once per process): the stepped worlds are the same bits whatever the
+    width -- grids that are not a multiple of it included (37 x 25: 19 blocks; 45 x 10: 12 DPP-row wavefronts; 9 x 17: 3 blocks)."""
+    hashes = {}
+    for wg in ("1", "2", "4"):
+        env = dict(os.environ, CROWDSTEP_WG_WAVES=wg)
+        r = subprocess.run([sys.executable, "-c", WG_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("WGHASH ")]
+        assert line, r.stdout[-500:]
+        hashes[wg] = line[-1]
+    assert hashes["1"] == hashes["2"] == hashes["4"], hashes
