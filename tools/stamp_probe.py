@@ -91,6 +91,16 @@ if st[:, 18].mean() > 0:   # slots 16 / 17 / 18 of the last launch (not summed):
     t0, t1 = last[:, 17], last[:, 18]
     print(f"  last launch, wall clock (s_memrealtime, 10 ns ticks): first wavefront starts at 0, the last one {10e-3 * (t0.max() - t0.min()):.2f} us later; "
           f"a wavefront lives {10e-3 * (t1 - t0).mean():.2f} us (min {10e-3 * (t1 - t0).min():.2f}, max {10e-3 * (t1 - t0).max():.2f}); first start -> last end {10e-3 * (t1.max() - t0.min()):.2f} us")
+    q = [0, 10, 50, 90, 99, 100]
+    print("  start of the wavefronts after the first one, percentiles " + str(q) + ": " + " ".join(f"{10e-3 * v:.2f}" for v in np.percentile(t0 - t0.min(), q)) + " us")
+    print("  end of the wavefronts before the last one,   percentiles " + str(q) + ": " + " ".join(f"{10e-3 * v:.2f}" for v in np.percentile(t1.max() - t1, q)) + " us")
+    wgw = int(os.environ.get("CROWDSTEP_WG_WAVES", "4"))
+    xcd = (np.arange(len(t0)) // wgw) % 8          # workgroups go to the eight XCDs in turn
+    print("  median start per XCD (workgroup index mod 8): " + " ".join(f"{10e-3 * (np.median(t0[xcd == k]) - t0.min()):.2f}" for k in range(8)) + " us;  spread inside an XCD (90th - 10th percentile): "
+          + " ".join(f"{10e-3 * (np.percentile(t0[xcd == k], 90) - np.percentile(t0[xcd == k], 10)):.2f}" for k in range(8)) + " us")
+    print("  wavefront life per XCD (median): " + " ".join(f"{10e-3 * np.median((t1 - t0)[xcd == k]):.2f}" for k in range(8)) + " us")
+    h = len(t0) // 2
+    print(f"  first half of the grid starts {10e-3 * (np.median(t0[:h]) - t0.min()):.2f} us after the first wavefront (median), the second half {10e-3 * (np.median(t0[h:]) - t0.min()):.2f} us")
     print(f"  first instruction -> kernel arguments loaded: {last[:, 16].mean():.0f} shader clocks (max {last[:, 16].max():.0f})")
 print("  around the substeps (shader clocks per launch, mean over the wavefronts):")
 for k, nm in enumerate(fixed):
