@@ -513,8 +513,8 @@ int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_pe
 /* Name of the kernel build the library runs for `w` (diagnostics; the parity tests assert through it that the build a
  * published number comes from is the build they compared with the oracle).  entry: 0 = cs_step, 1 = cs_update_humans_parallel
  * with d_out != d_state, 2 = cs_peek.  buf receives e.g. "k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2
- * lds=10128" (lds: the dynamic LDS of a block in bytes -- what decides how many blocks a CU holds; the ORCA builds also name their arithmetic,
- * "math=exact|fast|fma"). */
+ * lds=10128 wg=4" (lds: the dynamic LDS of a block in bytes -- what decides how many blocks a CU holds; wg: how many one-wavefront blocks go to the
+ * dispatcher as one workgroup; the ORCA builds also name their arithmetic, "math=exact|fast|fma"). */
 int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen);
 
 /* The arithmetic of the register-resident ORCA build (k_orca_step<FAST10>: maxNeighbors = 10, no static obstacles, one RVO2

@@ -320,6 +320,13 @@ GymHead gym_head(float* d_out, const float* d_global_time, float T, const float*
 // cs_step_variant, which reports the figure: the blocks a CU holds are decided by it -- sixteen of the 25-row build, twelve of the 50-row
 // wall build -- and a region added for one build on every launch costs the others a block without any test noticing; tests/test_gpu_parity.py
 // asserts the figures of the benched builds).
+// independent one-wavefront blocks per workgroup of the step kernels (sfmstep_kernel.h); CROWDSTEP_WG_WAVES = 1 / 2 / 4 for A/B, read once
+int step_wg_waves()
+{
+    static const int v = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int x = e ? std::atoi(e) : 4; return (x == 1 || x == 2 || x == 4) ? x : 4; }();
+    return v;
+}
+
 size_t step_lds_bytes(const cs_worlds* w, const Geometry& g, bool peq, int* seg_tab_out, int* wall_pairs_out)
 {
     struct { int seg_tab, wall_pairs; } a = {0, 0};
@@ -409,9 +416,8 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.young_from = (g.block == 64 && g.grid == 2 * csimpl::device_simds()) ? g.grid / 2 : 0x7fffffff;
     a.wg_waves = 1; a.lds_per_wave = 0;
     if (g.block == 64) {
-        // one-wavefront builds: wg_waves independent wavefronts per workgroup (sfmstep_kernel.h); CROWDSTEP_WG_WAVES = 1 / 2 / 4 for A/B
-        static const int wg_env = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int v = e ? std::atoi(e) : 4; return (v == 1 || v == 2 || v == 4) ? v : 4; }();
-        a.wg_waves = wg_env;
+        // one-wavefront builds: wg_waves independent wavefronts per workgroup (sfmstep_kernel.h)
+        a.wg_waves = step_wg_waves();
         a.lds_per_wave = (int)((shmem + 15) & ~(size_t)15);
         while (a.wg_waves > 1 && (size_t)a.lds_per_wave * a.wg_waves > 64 * 1024) a.wg_waves /= 2;   // (stay within the default dynamic-LDS limit of a workgroup)
         hipLaunchKernelGGL(fn, dim3((g.grid + a.wg_waves - 1) / a.wg_waves), dim3(64 * a.wg_waves), (size_t)a.lds_per_wave * a.wg_waves, stream, a);
@@ -804,7 +810,7 @@ int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)
     }
     std::snprintf(buf, buflen, "k_sfm_step<SOC=%d,HEADED=%d,PEQ=%d,MAXT=%d,OCC=%d,ROWS_CT=%d,LEAN=%d> grid=%d block=%d wpb=%d lds=%d%s",
                   w->type % 3, w->type / 3, v.peq ? 1 : 0, v.maxt, v.occ, v.rows_ct, v.lean, g.grid, g.block, g.wpb,
-                  (int)step_lds_bytes(w, g, v.peq, nullptr, nullptr), g.block == 64 ? " (one-wavefront blocks, four to a workgroup)" : "");
+                  (int)step_lds_bytes(w, g, v.peq, nullptr, nullptr), g.block == 64 ? (step_wg_waves() == 4 ? " wg=4" : (step_wg_waves() == 2 ? " wg=2" : " wg=1")) : "");
     return CS_OK;
 }
 

@@ -60,9 +60,11 @@ constexpr int WG_WAVES_MAX = 4;   // (launch bound of the one-wavefront builds: 
                                   //  four -- makes the compiler allocate the Moussaid builds ten registers fewer and their launches 2 us longer)
 template <int SOC, int HEADED, bool PEQ, int MAXT, int OCC, int ROWS_CT, int LEAN>
 // One-wavefront builds (MAXT = 64) are launched as workgroups of a.wg_waves INDEPENDENT wavefronts (four by default), each the "block" the
-// rest of this file talks about -- its own worlds, its own slice of the dynamic LDS, no barrier with the others.  The dispatcher starts
-// workgroups at a fixed rate whatever their size: cfg3's 2048 one-wavefront workgroups took 2.8 us to start (s_memrealtime stamps of the
-// diagnostic build), 512 workgroups of four take a quarter of it -- 29.1 -> 27.8 us per launch, 7.3 -> 6.0 us for a launch of one substep.
+// rest of this file talks about -- its own worlds, its own slice of the dynamic LDS, no barrier with the others.  Measured (tools/ab_wg_waves.sh):
+// cfg3 29.3 -> 28.2 us per launch, a launch of one substep 7.3 -> 6.1 us, with 512 workgroups of four instead of 2048 of one; inside an XCD the
+// wavefronts then start within 0.04 us instead of 0.24 (wall-clock stamps of the diagnostic build), the rest of the gain is per-workgroup work of
+// the dispatcher no wavefront sees.  (The 2 - 5 us between the first and the last wavefront's start that the same stamps show are offsets between
+// the eight XCDs, whatever the workgroup size: HISTORY.md.)
 __global__ __launch_bounds__(MAXT == 64 ? 64 * WG_WAVES_MAX : MAXT, OCC) void k_sfm_step(const KArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem_raw0[];
