@@ -137,9 +137,9 @@ __device__ __forceinline__ bool gym_head_world(const GymHead& g, int w, int n, c
     return bk.mode != 2 && bk.auto_reset && done;      // same-step rules: the world that ends NOW is replaced before the observation is returned
 }
 
-// The head's second half under cs_gym_step_staged, by the lane that ran gym_head_world: `take` = its verdict.  Leaves the launch's code in
-// pending[w] (read back by the whole wavefront in the epilogue with a device-scope load).
-__device__ __forceinline__ void gym_fold_decide(const GymHead& g, int w, bool take, bool ended_now, const GymPre pre)
+// The head's second half under cs_gym_step_staged, by the lane that ran gym_head_world: `take` = its verdict.  Returns the launch's code for the
+// world (the wavefront's epilogue acts on it) and leaves it in pending[w] for the launches to come (1: deferred).
+__device__ __forceinline__ int gym_fold_decide(const GymHead& g, int w, bool take, bool ended_now, const GymPre pre)
 {
     const GymFold& f = g.fold;
     int code = 0;
@@ -150,6 +150,7 @@ __device__ __forceinline__ void gym_fold_decide(const GymHead& g, int w, bool ta
         code = tag == want ? (int)slot + 2 : 1;
     }
     if (code != 0 || pre.pending != 0) __hip_atomic_store(f.pending + w, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return code;   // (the launch's own epilogue takes it from here, through LDS: no round trip to pending[w])
 }
 
 } // namespace cstep
