@@ -563,6 +563,14 @@ def _r(x, sig=5):
     return x
 
 
+def _wg_of(variant: str) -> int:
+    """one-wavefront blocks per workgroup as cs_step_variant names it (" wg=4"); 1 where the block is the workgroup"""
+    import re
+
+    m = re.search(r"\bwg=(\d+)", variant or "")
+    return int(m.group(1)) if m else 1
+
+
 def short_variant(v: str) -> str:
     """'k_sfm_step<SOC=0,HEADED=1,PEQ=1,MAXT=64,OCC=1,ROWS_CT=25,LEAN=1> grid=2048 block=64 wpb=2' -> 'sfm<0,1,1,64,1,25,1>g2048'"""
     import re
@@ -894,7 +902,8 @@ def main(argv=None):
                             f"{n_sub} fused substeps of {args.dt} s per step (one Gym step), state resident in HBM ({args.layout})",
                 "worlds_per_gpu": W, "worlds_total": total_worlds, "agents": args.agents, "substeps_per_step": n_sub,
                 "motion_model": args.model, "scenario": args.scenario, "parallelism": f"worlds sharded x{world_size}, no collective",
-                "launch": {"grid": g, "block": b, "worlds_per_block": wpb},
+                # (blocks of one wavefront go to the dispatcher several to a workgroup -- wg= in the variant string: grid / wg workgroups of block x wg threads)
+                "launch": {"grid": g, "block": b, "worlds_per_block": wpb, "blocks_per_workgroup": _wg_of(cw.step_variant())},
                 "timed_region": "eager launches, one HIP event pair per launch" if args.eager else
                                 "[untimed: worlds restored to the post-warm-up snapshot] barrier + sync | ONE replay of a HIP graph holding exactly K "
                                 "cs_step launches | sync + barrier; repeated R times on the SAME trajectory segment (Gym steps W .. W+K), median reported",
