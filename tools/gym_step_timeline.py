@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The device-resident Gym step as the GPU sees it.
-   run:      rocprofv3 --kernel-trace -d gpurun_out/tl -o tl -- python3 tools/gym_step_timeline.py run [same_step|next_step|none]
+   run:      rocprofv3 --kernel-trace -d gpurun_out/tl -o tl -- python3 tools/gym_step_timeline.py run [same_step|next_step|none] [gaps]
    analyse:  python3 tools/gym_step_timeline.py show gpurun_out/tl
    -> per kernel mean duration, and the idle time of the step stream between consecutive launches (step -> consume -> next step)"""
 import csv, glob, os, sys
@@ -28,8 +28,11 @@ if sys.argv[1] == "run":
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     buf.copy_(torch.randn(4096, 2, device="cuda", generator=g) * 0.5)
     with torch.cuda.stream(env.device_stream()):
+        gaps = len(sys.argv) > 3 and sys.argv[3] == "gaps"      # a host synchronisation after every step: every kernel starts on an idle GPU
         for _ in range(360):
             env.step_device(buf, auto_reset=mode)
+            if gaps:
+                torch.cuda.synchronize()
         torch.cuda.synchronize()
     sys.exit(0)
 
