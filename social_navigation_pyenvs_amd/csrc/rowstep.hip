@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_sfm_step_row16(const KArgs a)   // (
         const float xe = ext(px), ye = ext(py);
         float vxe = 0.0f, vye = 0.0f;
         if constexpr (SOC == 2) { vxe = ext(vx); vye = ext(vy); }
-        float ex = 0.0f, ey = 0.0f, rx = 0.0f, ry = 0.0f, rdmax = -1.0f;
+        float ex = 0.0f, ey = 0.0f, rx = 0.0f, ry = 0.0f, rdm = -1.0f;   // rdm: max over my partners of r_ij - d (masked by `human` once, behind the loop)
         static_for([&](auto kt) {
             constexpr int k = decltype(kt)::value;
             const float dx = px - shl<k>(xe), dy = py - shl<k>(ye);
@@ -178,22 +178,25 @@ __global__ __launch_bounds__(256, 2) void k_sfm_step_row16(const KArgs a)   // (
                 const float d2 = fmaf(dx, dx, dy * dy);
                 const float inv = rsq_fast(d2);
                 const float rd = fmaf(-d2, inv, rsum[k]);
-                const float ga = exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv;
+                // lanes without an agent hand exact zeros to the row shifts: their magnitude is the zero (one select; the displacement is finite)
+                const float ga = human ? exp2_fast(fmaf(rd, sp.cB, sp.lA)) * inv : 0.0f;
                 fx = ga * dx; fy = ga * dy;
                 if constexpr (SOC == 1) {
-                    const float gc = exp2_fast(fmaf(rd, sp.cD, sp.lC)) * (inv * sp.sAC);
+                    const float gc = human ? exp2_fast(fmaf(rd, sp.cD, sp.lC)) * (inv * sp.sAC) : 0.0f;
                     fx = fmaf(-gc, dy, fx); fy = fmaf(gc, dx, fy);
                 }
-                rdmax = human ? fmaxf(rdmax, rd) : rdmax;
+                rdm = fmaxf(rdm, rd);
             }
-            fx = human ? fx : 0.0f; fy = human ? fy : 0.0f;    // lanes without an agent hand exact zeros to the row shifts
-            ex += fx; ey += fy;
+            if constexpr (SOC == 2) { fx = human ? fx : 0.0f; fy = human ? fy : 0.0f; }   // (Moussaid: the pair force as a whole)
+            // (the first partner starts the sums: `0 + x` is an instruction the compiler must keep -- it turns -0 into +0)
+            if constexpr (k == 1) { ex = fx; ey = fy; } else { ex += fx; ey += fy; }
             if constexpr (k <= HF) {
                 // the partner's share -f: from the evaluator k lanes below, or from the one that wrapped around the ring
-                rx += shr<k>(fx) + shl<ROWS - k>(fx);
-                ry += shr<k>(fy) + shl<ROWS - k>(fy);
+                const float sx = shr<k>(fx) + shl<ROWS - k>(fx), sy = shr<k>(fy) + shl<ROWS - k>(fy);
+                if constexpr (k == 1) { rx = sx; ry = sy; } else { rx += sx; ry += sy; }
             }
         }, std::make_integer_sequence<int, KMAX>{});
+        const float rdmax = human ? rdm : -1.0f;
         float fsx = ex - rx, fsy = ey - ry;
         if constexpr (SOC != 2) {
             fsx *= sp.sA; fsy *= sp.sA;
