@@ -336,6 +336,34 @@ def orca_step_block_f64(S, goals, margin, dt, n_substeps, neighbor_dist=10.0, ma
     return (S[0], goals[0]) if single else (S, goals)
 
 
+ORCA_DECISION_KINDS = ["", "neighbour in range", "neighbour order", "colliding or not", "cut-off circle: side", "cut-off circle: cone", "which leg",
+                       "LP2: preferred velocity clipped", "LP2: line violated", "LP1: line misses the speed circle", "LP1: parallel lines",
+                       "LP1: parallel lines, side", "LP1: sign of the denominator", "LP1: empty interval", "LP1: direction optimum", "LP1: clamp left",
+                       "LP1: clamp right", "LP3: line violated", "LP3: parallel lines", "LP3: same direction", "LP2 failed -> LP3", "LP3: inner LP2 failed"]
+
+
+def orca_probe_agent(S_w, margin_w, agent, dt, k_ulps=4.0, probes=65, seed=1, neighbor_dist=10.0, max_nb=10, time_horizon=5.0, cap=4096):
+    """The PROBE instantiation of the ORCA restatement (oracle/orca_oracle_probe.c) for ONE agent of ONE world given as rows [n, 13]
+    (+ margins [n]): its new velocity `probes` times -- probe 0 unperturbed (== orca_step_block's velocity, bit for bit), the others with
+    every division / square root / two-term product sum perturbed by <= k_ulps float32 ulps -- and the ordered decision trace of each.
+    Returns (vel [probes, 2] float32, traces: list of (kind [m], outcome [m], margin [m]) arrays)."""
+    f = np.float32
+    S_w = np.ascontiguousarray(S_w, dtype=f)
+    n = S_w.shape[0]
+    pos = np.ascontiguousarray(S_w[:, 0:2]); vel = np.ascontiguousarray(S_w[:, 3:5]); pref = np.ascontiguousarray(S_w[:, 5:7])
+    rad = np.ascontiguousarray(S_w[:, 8] + np.asarray(margin_w, dtype=f)); vmax = np.ascontiguousarray(S_w[:, 12])
+    out = np.zeros((probes, 2), f)
+    kind = np.zeros((probes, cap), np.int32); outc = np.zeros((probes, cap), np.int32); marg = np.zeros((probes, cap), f)
+    nt = np.zeros(probes, np.int32)
+    fn = lib().orcp_probe_agent
+    fn.restype = None
+    fn(C.c_int(n), _ptr(pos, C.c_float), _ptr(vel, C.c_float), _ptr(pref, C.c_float), _ptr(rad, C.c_float), _ptr(vmax, C.c_float),
+       C.c_float(neighbor_dist), C.c_int(max_nb), C.c_float(time_horizon), C.c_float(dt), C.c_int(int(agent)), C.c_uint64(int(seed)), C.c_float(k_ulps),
+       C.c_int(probes), _ptr(out, C.c_float), _ptr(kind, C.c_int), _ptr(outc, C.c_int), _ptr(marg, C.c_float), C.c_int(cap), _ptr(nt, C.c_int))
+    traces = [(kind[p, :min(nt[p], cap)], outc[p, :min(nt[p], cap)], marg[p, :min(nt[p], cap)]) for p in range(probes)]
+    return out, traces
+
+
 def effective_cores() -> int:
     """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box shows 256 logical CPUs
     and grants 16 through cpu.max: an OpenMP team of 256 only gets throttled, and costs ~0.1 s to spin up per call)."""

@@ -44,36 +44,57 @@
 
 typedef struct { float px, py, dx, dy; } orca_line;
 
-static inline float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
+/* Hooks of the PROBE instantiation (oracle/orca_oracle_probe.c: the same statements with every division, square root and two-term
+ * product sum perturbed by a few ulps and every decision recorded -- a classification aid for tests/orca_fast_parity.py).  Here they
+ * are the plain float32 operations and comparisons, so this file's arithmetic is exactly what it was without them. */
+#ifndef O_HOOKS
+#define O_DIV(a, b) ((a) / (b))
+#define O_SQRT(x) sqrtf(x)
+#define O_DET(ax, ay, bx, by) ((ax) * (by) - (ay) * (bx))
+#define O_DOT(ax, ay, bx, by) ((ax) * (bx) + (ay) * (by))
+#define O_MAD(p, t, d) ((p) + (t) * (d))
+#define O_GT(kind, a, b) ((a) > (b))
+#define O_LT(kind, a, b) ((a) < (b))
+#define O_GE(kind, a, b) ((a) >= (b))
+#define O_LE(kind, a, b) ((a) <= (b))
+#define O_NOTE(kind, flag)
+#define O_AGENT_BEGIN(a)
+#endif
+/* decision kinds (the probe's trace) */
+enum { OD_NB_RANGE = 1, OD_NB_ORDER, OD_COLLIDING, OD_CIRCLE_SIDE, OD_CIRCLE_CONE, OD_WHICH_LEG, OD_LP2_CLIP, OD_LP2_VIOLATED, OD_LP1_DISC,
+       OD_LP1_PARALLEL, OD_LP1_PARALLEL_SIDE, OD_LP1_DEN_SIGN, OD_LP1_EMPTY, OD_LP1_DIROPT, OD_LP1_CLAMP_L, OD_LP1_CLAMP_R, OD_LP3_VIOLATED,
+       OD_LP3_PARALLEL, OD_LP3_SAME_DIR, OD_LP2_FAILED, OD_LP3_LP2_FAILED, OD_KINDS };
+
+static inline float det2(float ax, float ay, float bx, float by) { return O_DET(ax, ay, bx, by); }
 
 /* RVO2 linearProgram1 */
 static int lp1(const orca_line* L, int lineNo, float radius, float ox, float oy, int dirOpt, float* rx, float* ry)
 {
-    const float dot = L[lineNo].px * L[lineNo].dx + L[lineNo].py * L[lineNo].dy;
-    const float disc = dot * dot + radius * radius - (L[lineNo].px * L[lineNo].px + L[lineNo].py * L[lineNo].py);
-    if (disc < 0.0f) return 0;
-    const float sq = sqrtf(disc);
+    const float dot = O_DOT(L[lineNo].px, L[lineNo].py, L[lineNo].dx, L[lineNo].dy);
+    const float disc = dot * dot + radius * radius - O_DOT(L[lineNo].px, L[lineNo].py, L[lineNo].px, L[lineNo].py);
+    if (O_LT(OD_LP1_DISC, disc, 0.0f)) return 0;
+    const float sq = O_SQRT(disc);
     float tL = -dot - sq, tR = -dot + sq;
     for (int i = 0; i < lineNo; ++i) {
         const float den = det2(L[lineNo].dx, L[lineNo].dy, L[i].dx, L[i].dy);
         const float num = det2(L[i].dx, L[i].dy, L[lineNo].px - L[i].px, L[lineNo].py - L[i].py);
-        if (fabsf(den) <= RVO_EPSILON) {
-            if (num < 0.0f) return 0;
+        if (O_LE(OD_LP1_PARALLEL, fabsf(den), RVO_EPSILON)) {
+            if (O_LT(OD_LP1_PARALLEL_SIDE, num, 0.0f)) return 0;
             continue;
         }
-        const float t = num / den;
-        if (den >= 0.0f) tR = fminf(tR, t); else tL = fmaxf(tL, t);
-        if (tL > tR) return 0;
+        const float t = O_DIV(num, den);
+        if (O_GE(OD_LP1_DEN_SIGN, den, 0.0f)) tR = fminf(tR, t); else tL = fmaxf(tL, t);
+        if (O_GT(OD_LP1_EMPTY, tL, tR)) return 0;
     }
     float t;
     if (dirOpt) {
-        t = (ox * L[lineNo].dx + oy * L[lineNo].dy > 0.0f) ? tR : tL;
+        t = O_GT(OD_LP1_DIROPT, O_DOT(ox, oy, L[lineNo].dx, L[lineNo].dy), 0.0f) ? tR : tL;
     } else {
-        t = L[lineNo].dx * (ox - L[lineNo].px) + L[lineNo].dy * (oy - L[lineNo].py);
-        if (t < tL) t = tL; else if (t > tR) t = tR;
+        t = O_DOT(L[lineNo].dx, L[lineNo].dy, ox - L[lineNo].px, oy - L[lineNo].py);
+        if (O_LT(OD_LP1_CLAMP_L, t, tL)) t = tL; else if (O_GT(OD_LP1_CLAMP_R, t, tR)) t = tR;
     }
-    *rx = L[lineNo].px + t * L[lineNo].dx;
-    *ry = L[lineNo].py + t * L[lineNo].dy;
+    *rx = O_MAD(L[lineNo].px, t, L[lineNo].dx);
+    *ry = O_MAD(L[lineNo].py, t, L[lineNo].dy);
     return 1;
 }
 
@@ -81,13 +102,13 @@ static int lp1(const orca_line* L, int lineNo, float radius, float ox, float oy,
 static int lp2(const orca_line* L, int nl, float radius, float ox, float oy, int dirOpt, float* rx, float* ry)
 {
     if (dirOpt) { *rx = ox * radius; *ry = oy * radius; }
-    else if (ox * ox + oy * oy > radius * radius) {
-        const float nrm = sqrtf(ox * ox + oy * oy);
-        const float inv = 1.0f / nrm;             /* RVO2's Vector2 / float multiplies by the reciprocal (Vector2.h) */
+    else if (O_GT(OD_LP2_CLIP, O_DOT(ox, oy, ox, oy), radius * radius)) {
+        const float nrm = O_SQRT(O_DOT(ox, oy, ox, oy));
+        const float inv = O_DIV(1.0f, nrm);       /* RVO2's Vector2 / float multiplies by the reciprocal (Vector2.h) */
         *rx = ox * inv * radius; *ry = oy * inv * radius;
     } else { *rx = ox; *ry = oy; }
     for (int i = 0; i < nl; ++i) {
-        if (det2(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry) > 0.0f) {
+        if (O_GT(OD_LP2_VIOLATED, det2(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry), 0.0f)) {
             const float tx = *rx, ty = *ry;
             if (!lp1(L, i, radius, ox, oy, dirOpt, rx, ry)) { *rx = tx; *ry = ty; return i; }
         }
@@ -101,27 +122,29 @@ static void lp3(const orca_line* L, int nl, int numObst, int begin, float radius
     float distance = 0.0f;
     orca_line proj[ORCA_MAX_LINES];
     for (int i = begin; i < nl; ++i) {
-        if (det2(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry) > distance) {
+        if (O_GT(OD_LP3_VIOLATED, det2(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry), distance)) {
             int np = 0;
             for (int j = 0; j < numObst; ++j) proj[np++] = L[j];
             for (int j = numObst; j < i; ++j) {
                 orca_line ln;
                 const float d = det2(L[i].dx, L[i].dy, L[j].dx, L[j].dy);
-                if (fabsf(d) <= RVO_EPSILON) {
-                    if (L[i].dx * L[j].dx + L[i].dy * L[j].dy > 0.0f) continue;
+                if (O_LE(OD_LP3_PARALLEL, fabsf(d), RVO_EPSILON)) {
+                    if (O_GT(OD_LP3_SAME_DIR, O_DOT(L[i].dx, L[i].dy, L[j].dx, L[j].dy), 0.0f)) continue;
                     ln.px = 0.5f * (L[i].px + L[j].px); ln.py = 0.5f * (L[i].py + L[j].py);
                 } else {
-                    const float s = det2(L[j].dx, L[j].dy, L[i].px - L[j].px, L[i].py - L[j].py) / d;
-                    ln.px = L[i].px + s * L[i].dx; ln.py = L[i].py + s * L[i].dy;
+                    const float s = O_DIV(det2(L[j].dx, L[j].dy, L[i].px - L[j].px, L[i].py - L[j].py), d);
+                    ln.px = O_MAD(L[i].px, s, L[i].dx); ln.py = O_MAD(L[i].py, s, L[i].dy);
                 }
                 const float ex = L[j].dx - L[i].dx, ey = L[j].dy - L[i].dy;
-                const float en = sqrtf(ex * ex + ey * ey);
-                const float inv = 1.0f / en;
+                const float en = O_SQRT(O_DOT(ex, ey, ex, ey));
+                const float inv = O_DIV(1.0f, en);
                 ln.dx = ex * inv; ln.dy = ey * inv;
                 proj[np++] = ln;
             }
             const float tx = *rx, ty = *ry;
-            if (lp2(proj, np, radius, -L[i].dy, L[i].dx, 1, rx, ry) < np) { *rx = tx; *ry = ty; }
+            const int lp2_failed = lp2(proj, np, radius, -L[i].dy, L[i].dx, 1, rx, ry) < np;
+            O_NOTE(OD_LP3_LP2_FAILED, lp2_failed);
+            if (lp2_failed) { *rx = tx; *ry = ty; }
             distance = det2(L[i].dx, L[i].dy, L[i].px - *rx, L[i].py - *ry);
         }
     }
@@ -313,6 +336,7 @@ void orc_orca_new_velocities_pa(int na, const float* pos, const float* vel, cons
     const orca_vertex* V = (const orca_vertex*)verts;
     if (max_nb_all > ORCA_MAX_NEIGHBORS) max_nb_all = ORCA_MAX_NEIGHBORS;
     for (int a = 0; a < na; ++a) {
+        O_AGENT_BEGIN(a);
         float neighbor_dist = neighbor_dist_all, time_horizon = time_horizon_all, time_horizon_obst = time_horizon_obst_all;
         int max_nb = max_nb_all;
         if (agent_params) {
@@ -336,55 +360,55 @@ void orc_orca_new_velocities_pa(int na, const float* pos, const float* vel, cons
             for (int b = 0; b < na; ++b) {
                 if (b == a) continue;
                 const float ddx = pos[2 * a] - pos[2 * b], ddy = pos[2 * a + 1] - pos[2 * b + 1];
-                const float dsq = ddx * ddx + ddy * ddy;
-                if (dsq < rangeSq) {
+                const float dsq = O_DOT(ddx, ddy, ddx, ddy);
+                if (O_LT(OD_NB_RANGE, dsq, rangeSq)) {
                     if (cnt < max_nb) ++cnt;
                     int i = cnt - 1;
-                    while (i != 0 && dsq < nd[i - 1]) { nd[i] = nd[i - 1]; ni[i] = ni[i - 1]; --i; }
+                    while (i != 0 && O_LT(OD_NB_ORDER, dsq, nd[i - 1])) { nd[i] = nd[i - 1]; ni[i] = ni[i - 1]; --i; }
                     nd[i] = dsq; ni[i] = b;
                     if (cnt == max_nb) rangeSq = nd[cnt - 1];
                 }
             }
         }
         /* Agent::computeNewVelocity, agent lines (appended behind the obstacle lines) */
-        const float invT = 1.0f / time_horizon;
+        const float invT = O_DIV(1.0f, time_horizon);
         const float vx = vel[2 * a], vy = vel[2 * a + 1];
         for (int k = 0; k < cnt; ++k) {
             const int b = ni[k];
             const float rpx = pos[2 * b] - pos[2 * a], rpy = pos[2 * b + 1] - pos[2 * a + 1];
             const float rvx = vx - vel[2 * b], rvy = vy - vel[2 * b + 1];
-            const float distSq = rpx * rpx + rpy * rpy;
+            const float distSq = O_DOT(rpx, rpy, rpx, rpy);
             const float R = radius[a] + radius[b];
             const float RSq = R * R;
             float dx, dy, ux, uy;
-            if (distSq > RSq) {
+            if (O_GT(OD_COLLIDING, distSq, RSq)) {
                 const float wx = rvx - invT * rpx, wy = rvy - invT * rpy;
-                const float wLenSq = wx * wx + wy * wy;
-                const float dot1 = wx * rpx + wy * rpy;
-                if (dot1 < 0.0f && dot1 * dot1 > RSq * wLenSq) {
-                    const float wLen = sqrtf(wLenSq);
-                    const float inv = 1.0f / wLen;
+                const float wLenSq = O_DOT(wx, wy, wx, wy);
+                const float dot1 = O_DOT(wx, wy, rpx, rpy);
+                if (O_LT(OD_CIRCLE_SIDE, dot1, 0.0f) && O_GT(OD_CIRCLE_CONE, dot1 * dot1, RSq * wLenSq)) {
+                    const float wLen = O_SQRT(wLenSq);
+                    const float inv = O_DIV(1.0f, wLen);
                     const float uwx = wx * inv, uwy = wy * inv;
                     dx = uwy; dy = -uwx;
                     const float s = R * invT - wLen;
                     ux = s * uwx; uy = s * uwy;
                 } else {
-                    const float leg = sqrtf(distSq - RSq);
-                    if (det2(rpx, rpy, wx, wy) > 0.0f) {
-                        const float inv = 1.0f / distSq;
+                    const float leg = O_SQRT(distSq - RSq);
+                    if (O_GT(OD_WHICH_LEG, det2(rpx, rpy, wx, wy), 0.0f)) {
+                        const float inv = O_DIV(1.0f, distSq);
                         dx = (rpx * leg - rpy * R) * inv; dy = (rpx * R + rpy * leg) * inv;
                     } else {
-                        const float inv = 1.0f / distSq;
+                        const float inv = O_DIV(1.0f, distSq);
                         dx = -(rpx * leg + rpy * R) * inv; dy = -(-rpx * R + rpy * leg) * inv;
                     }
-                    const float dot2 = rvx * dx + rvy * dy;
+                    const float dot2 = O_DOT(rvx, rvy, dx, dy);
                     ux = dot2 * dx - rvx; uy = dot2 * dy - rvy;
                 }
             } else {
-                const float invDt = 1.0f / time_step;
+                const float invDt = O_DIV(1.0f, time_step);
                 const float wx = rvx - invDt * rpx, wy = rvy - invDt * rpy;
-                const float wLen = sqrtf(wx * wx + wy * wy);
-                const float inv = 1.0f / wLen;
+                const float wLen = O_SQRT(O_DOT(wx, wy, wx, wy));
+                const float inv = O_DIV(1.0f, wLen);
                 const float uwx = wx * inv, uwy = wy * inv;
                 dx = uwy; dy = -uwx;
                 const float s = R * invDt - wLen;
@@ -395,6 +419,7 @@ void orc_orca_new_velocities_pa(int na, const float* pos, const float* vel, cons
         const int total = numObst + cnt;
         float rx, ry;
         const int failed = lp2(L, total, maxspeed[a], pref[2 * a], pref[2 * a + 1], 0, &rx, &ry);
+        O_NOTE(OD_LP2_FAILED, failed < total);
         if (failed < total) lp3(L, total, numObst, failed, maxspeed[a], &rx, &ry);
         out_vel[2 * a] = rx; out_vel[2 * a + 1] = ry;
         if (lines_out) {

@@ -17,7 +17,14 @@ restatement is therefore classified, in this order:
   edge1  the exact restatement's own answer moves >= bar when the world's input rows move by ONE float32 ulp (random probes):
          a decision edge of the reference function at this input;
   edge4 / edge16  the same with up to 4 / 16 ulps (what a few roundings inside the programme amount to);
+  op4    the exact restatement's own answer moves >= bar when each of its divisions, square roots and two-term product sums is perturbed
+         by <= 4 float32 ulps (oracle/orca_oracle_probe.c, 128 random probes) -- what v_rcp / v_sqrt / v_rsq and mul + fma change;
   unexplained     none of these.
+Every agent-substep the double evaluation does not explain is ALSO named by the probe (`decisions`): the first decision of RVO2's
+computeNeighbors / computeNewVelocity / linearProgram1-3 that flips in a probe whose answer moved (e.g. "LP1: empty interval" = an LP2 -> LP3
+feasibility flip, "LP2: line violated" = a constraint entering the active set), or "ill-conditioned intersection" when the answer moves with every
+decision unchanged (the optimum is the intersection of two nearly parallel lines, or of a line and the speed circle it nearly touches);
+`probe_reproduces_build` counts those on which some probe lands within the bar of the build's own answer.
 Reported beside it: on the disagreeing agent-substeps, which of the two float32 answers is closer to the double one (a build that
 were WORSE than float32 RVO2 would lose that vote), and the share of ALL agent-substeps beyond the bar from the double evaluation
 for the build and for the exact restatement (the build is as far from real arithmetic as RVO2's own float32, no farther).
@@ -65,10 +72,42 @@ def edge_spread(orc, rng, S_w, g_w, margin_w, dt, probes, ulps=1):
     return np.abs(res[:, :, 3:5].astype(np.float64) - base[0][None, :, 3:5].astype(np.float64)).max(axis=(0, 2))
 
 
-def substeps_vs_restatement(cw, S0, g0, margin, dt, n_substeps, *, bar=BAR, probes=48, seed=0, progress=None, max_examined=6000):
+PROBE_ULPS, PROBE_COUNT = 4.0, 129
+OD_LP2_CLIP = 7     # |prefVel|^2 > maxSpeed^2 with a unit preferred velocity and maxSpeed 1: a coin toss whose two branches agree to an ulp
+
+
+def probe_classify(orc, S_w, margin_w, agent, dt, got_v, bar=BAR, seed=7):
+    """(sensitive, label, reproduced): does the exact restatement's new velocity of `agent` move >= bar under <= PROBE_ULPS-ulp operation noise,
+    the first decision that flips in such a probe (module docstring), and does some probe land within the bar of the build's answer got_v"""
+    vel, tr = orc.orca_probe_agent(S_w, margin_w, agent, dt, k_ulps=PROBE_ULPS, probes=PROBE_COUNT, seed=seed)
+    d = np.abs(vel[1:].astype(np.float64) - vel[0].astype(np.float64)).max(axis=1)
+    moved = np.nonzero(d >= bar)[0]
+    reproduced = bool((np.abs(vel[1:].astype(np.float64) - np.asarray(got_v, np.float64)).max(axis=1) < bar).any())
+    if len(moved) == 0:
+        return False, "not sensitive", reproduced
+    votes = {}
+    for p_ in moved + 1:
+        k0, o0, _ = tr[0]; k1, o1, _ = tr[p_]
+        L = min(len(k0), len(k1))
+        label = "ill-conditioned intersection"
+        for j in np.nonzero((k0[:L] != k1[:L]) | (o0[:L] != o1[:L]))[0]:
+            if k0[j] != k1[j]:
+                label = "trace diverged"; break
+            if k0[j] == OD_LP2_CLIP:
+                continue
+            label = orc.ORCA_DECISION_KINDS[k0[j]]; break
+        else:
+            if len(k0) != len(k1):
+                label = "trace diverged"
+        votes[label] = votes.get(label, 0) + 1
+    return True, max(votes, key=votes.get), reproduced
+
+
+def substeps_vs_restatement(cw, S0, g0, margin, dt, n_substeps, *, bar=BAR, probes=48, seed=0, progress=None, max_examined=6000, collect=None):
     """Run the protocol above on the batch `cw` (a CrowdWorlds of type "orca" created from S0 / g0 / margin, any arithmetic mode).
     Returns a dict of figures.  Every agent-substep beyond the bar is classified, in this order:
-    f64 / edge1 / edge4 / edge16 / unexplained (module docstring)."""
+    f64 / edge1 / edge4 / edge16 / unexplained (module docstring).  `collect` (a list): every beyond-bar agent-substep the double evaluation
+    does not explain is appended as a record (substep, world, agent, the world's input rows / goals / margins, both results, its class)."""
     from oracle import crowd_oracle as orc
 
     rng = np.random.default_rng(seed)
@@ -76,7 +115,7 @@ def substeps_vs_restatement(cw, S0, g0, margin, dt, n_substeps, *, bar=BAR, prob
     ref, rg = S0.copy(), g0.copy()
     dt32 = np.float32(dt)
     out = {"worlds": W, "agents": n, "substeps": n_substeps, "agent_substeps": 0, "beyond_bar": 0, "class_f64": 0, "class_edge1": 0, "class_edge4": 0, "class_edge16": 0,
-           "unexplained": 0, "worst": 0.0, "worst_within": 0.0, "worst_unexplained": 0.0, "bit_identical_agent_substeps": 0, "goal_column_flips": 0,
+           "class_op4": 0, "decisions": {}, "probe_reproduces_build": 0, "unexplained": 0, "worst": 0.0, "worst_within": 0.0, "worst_unexplained": 0.0, "bit_identical_agent_substeps": 0, "goal_column_flips": 0,
            "pref_velocity_worst": 0.0, "bar": bar, "probes": probes, "examined": 0, "not_examined": 0,
            "beyond_bar_vs_f64_build": 0, "beyond_bar_vs_f64_exact": 0, "disagree_build_closer_to_f64": 0, "disagree_exact_closer_to_f64": 0}
     hist = []
@@ -124,21 +163,38 @@ def substeps_vs_restatement(cw, S0, g0, margin, dt, n_substeps, *, bar=BAR, prob
                 spread = edge_spread(orc, rng, ref[w_], rg[w_], margin[w_], dt, probes, 1)
                 left = [a_ for a_ in agents if spread[a_] < bar]
                 out["class_edge1"] += len(agents) - len(left)
+                cls = {int(a_): "edge1" for a_ in agents}
+                probe = {int(a_): probe_classify(orc, ref[w_], margin[w_], int(a_), dt, got[w_, a_, 3:5], bar) for a_ in agents}
+                for a_ in agents:
+                    lab = probe[int(a_)][1]
+                    out["decisions"][lab] = out["decisions"].get(lab, 0) + 1
+                    out["probe_reproduces_build"] += int(probe[int(a_)][2])
                 if left:
                     spread4 = edge_spread(orc, rng, ref[w_], rg[w_], margin[w_], dt, probes, 4)
                     left16 = [a_ for a_ in left if spread4[a_] < bar]
                     out["class_edge4"] += len(left) - len(left16)
+                    for a_ in left:
+                        cls[int(a_)] = "edge4"
                     if left16:
                         spread16 = edge_spread(orc, rng, ref[w_], rg[w_], margin[w_], dt, probes, 16)
                         for a_ in left16:
                             if spread16[a_] >= bar:
                                 out["class_edge16"] += 1
+                                cls[int(a_)] = "edge16"
+                            elif probe[int(a_)][0]:
+                                out["class_op4"] += 1
+                                cls[int(a_)] = "op4"
                             else:
                                 out["unexplained"] += 1
+                                cls[int(a_)] = "unexplained"
                                 out["worst_unexplained"] = max(out["worst_unexplained"], float(err[w_, a_]))
+                if collect is not None:
+                    for a_ in agents:
+                        collect.append(dict(substep=k, world=int(w_), agent=int(a_), cls=cls[int(a_)], decision=probe[int(a_)][1], err=float(err[w_, a_]), S=ref[w_].copy(), g=rg[w_].copy(),
+                                            margin=margin[w_].copy(), got=got[w_, a_].copy(), exact=nxt[w_, a_].copy(), f64=n64[w_, a_].copy()))
         ref, rg = nxt, ng
         if progress and (k + 1) % progress == 0:
-            print(f"  substep {k + 1}/{n_substeps}: beyond bar {out['beyond_bar']} (f64 {out['class_f64']}, edge1 {out['class_edge1']}, edge4 {out['class_edge4']}, edge16 {out['class_edge16']}, "
+            print(f"  substep {k + 1}/{n_substeps}: beyond bar {out['beyond_bar']} (f64 {out['class_f64']}, edge1 {out['class_edge1']}, edge4 {out['class_edge4']}, edge16 {out['class_edge16']}, op4 {out['class_op4']}, "
                   f"unexplained {out['unexplained']}), worst {out['worst']:.2e}", flush=True)
     allerr = np.concatenate(hist)
     out["p50"], out["p99"], out["p9999"] = (float(np.quantile(allerr, q)) for q in (0.5, 0.99, 0.9999))
