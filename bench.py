@@ -92,6 +92,7 @@ def parse(argv=None):
     ap.add_argument("--device-generator", action="store_true", help="worlds from cs_generate_worlds (generators.static_obstacle_crossing: circle crossing R=14, seed 1000 + global id): what the cfg5 entry of other_configs runs")
     ap.add_argument("--robot", action="store_true", help="a visible robot as the last state row of every world (rows = agents + 1), driven by a constant action")
     ap.add_argument("--per-agent-params", action="store_true", help="every human its own (jittered) parameter row: all_params_equal = False")
+    ap.add_argument("--orca-math", default="default", choices=["default", "exact", "fast", "fma"], help="cs_worlds.orca_math of ORCA worlds (default: CROWDSTEP_ORCA_MATH, else exact -- the build that equals the restatement bit for bit)")
     ap.add_argument("--no-restore", action="store_true", help="let the worlds evolve from replay to replay (the round-2 protocol) instead of restoring the snapshot")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python (default: one HIP graph of K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -110,13 +111,14 @@ def spec_key(spec) -> str:
     W = spec["worlds"]
     return (f"{spec['model']}_{spec['agents']}_{spec['scenario']}" + ("_walls" if spec["walls"] else "") + ("_static" if spec["static"] else "")
             + ("_robot" if spec.get("robot") else "") + ("_peragent" if spec.get("per_agent") else "")
-            + (f"_{spec['phase_key']}" if spec.get("phase_key") else "") + ("" if W in (4096, 8192) else f"_{W}"))
+            + (f"_{spec['phase_key']}" if spec.get("phase_key") else "") + (f"_{spec['orca_math']}" if spec.get("orca_math") not in (None, "default", "exact") else "")
+            + ("" if W in (4096, 8192) else f"_{W}"))
 
 
 def workload_spec(args) -> dict:
     # ORCA's cost follows the crossing: the two named phases of other_configs keep their PMC entries when they are run on their own
     phase = {(0, 20): "first20", (25, 20): "dense"}.get((args.warmup, args.steps)) if (args.model == "orca" and args.scenario == "circle") else None
-    return dict(phase_key=phase, name="main", device_generator=bool(args.device_generator), model=args.model, agents=args.agents, scenario=args.scenario, walls=bool(args.walls),
+    return dict(phase_key=phase, orca_math=args.orca_math, name="main", device_generator=bool(args.device_generator), model=args.model, agents=args.agents, scenario=args.scenario, walls=bool(args.walls),
                 static=int(args.static), substeps=args.substeps, dt=args.dt, layout=args.layout, robot=bool(args.robot),
                 per_agent=bool(args.per_agent_params), worlds=args.worlds, total_worlds=args.total_worlds)
 
@@ -133,6 +135,12 @@ def other_config_specs(args) -> list[dict]:
              title="4096 worlds/GPU x 25-agent ORCA circle crossing, Gym steps 0-20 from the reset (agents still near the rim)"),
         dict(base, name="cfg4_dense", model="orca", scenario="circle", warmup=25, steps=20, phase_key="dense",
              title="4096 worlds/GPU x 25-agent ORCA circle crossing, Gym steps 25-45 (the crowd meets at the centre: the dense phase)"),
+        # (the two rows above: the library's default arithmetic, EXACT -- every substep equals oracle/orca_oracle.c bit for bit; below: the opt-in
+        # "fma" arithmetic, within 1e-5 per substep except where float32 does not determine RVO2's answer, tests/test_gpu_orca_fast.py)
+        dict(base, name="cfg4_first20_fma", model="orca", scenario="circle", warmup=0, steps=20, phase_key="first20", orca_math="fma",
+             title="cfg4_first20 with cs_worlds.orca_math = CS_ORCA_MATH_FMA (opt-in: v_rcp / v_sqrt / v_rsq, mul + fma)"),
+        dict(base, name="cfg4_dense_fma", model="orca", scenario="circle", warmup=25, steps=20, phase_key="dense", orca_math="fma",
+             title="cfg4_dense with cs_worlds.orca_math = CS_ORCA_MATH_FMA (opt-in)"),
         dict(base, name="cfg5", agents=50, scenario="circle", walls=True, static=3, worlds=8192, total_worlds=65536, device_generator=True,
              title="65536 worlds (whole job, strong split) x 50-agent HSFM circle crossing R=14 (generators.static_obstacle_crossing: "
                    "the worlds tests/test_gpu_fullsize.py checks), 3 immobile humans + 3 polygon walls"),
@@ -217,7 +225,7 @@ def build_worlds(spec, rank, world_size):
     h = host_worlds(spec, rank, world_size)
     cw = CrowdWorlds(h["S"], h["goals"], h["P"], h["margin"], h["walls"], type=model, all_params_equal=h["all_params_equal"],
                      respawn_bounds=h["respawn_bounds"], respawn_worlds=h["respawn_worlds"], layout=spec["layout"],
-                     robot_row=h["robot"] is not None, robot=h["robot"])
+                     robot_row=h["robot"] is not None, robot=h["robot"], orca_math=spec.get("orca_math") or "default")
     cw.bench_action = None if h["action"] is None else DeviceBuffer.from_numpy(h["action"])
     return cw, h, h["W"]
 
@@ -926,7 +934,11 @@ def main(argv=None):
             out["gpu_over_cpu"] = value / world_size / out["cpu_baseline"]["value"]
             # the other configurations the oracle covers, each beside its own row (3 s of CPU work per row)
             for o in others:
-                if o["name"] in CPU_ROWS:
+                if o["name"].endswith("_fma") and o["name"][:-4] in CPU_ROWS:   # same worlds, same window: the CPU figure of the exact row
+                    twin = next((x for x in others if x["name"] == o["name"][:-4] and x.get("cpu_value")), None)
+                    if twin:
+                        o["cpu_value"] = twin["cpu_value"]; o["gpu_over_cpu"] = o["value"] / twin["cpu_value"]
+                elif o["name"] in CPU_ROWS:
                     try:
                         ospec = next(x for x in other_config_specs(args) if x["name"] == o["name"])
                         cb = cpu_baseline(ospec, seconds=3.0, single_seconds=0.0)

@@ -101,13 +101,28 @@ typedef struct cs_worlds {
      * where the reference passes ORCA_DEFAULTS for everyone).  [W][rows][4] floats in that order, or NULL = the four scalars above for
      * every agent.  With it, orca_max_neighbors must be the LARGEST maxNeighbors and orca_neighbor_dist the largest neighborDist. */
     const float* d_orca_agent_params;
+    /* ORCA only (ABI 4): the arithmetic of the register-resident build for THESE worlds -- CS_ORCA_MATH_* below.  0 (a zeroed struct) = the
+     * process default: CROWDSTEP_ORCA_MATH=exact|fast|fma if set, else exact.  A field of the context, not a process-wide switch: two
+     * environments of one process may differ, and the mode is part of what a captured HIP graph froze. */
+    int32_t orca_math;
 } cs_worlds;
+
+/* cs_worlds.orca_math: how the register-resident ORCA build (k_orca_step<FAST10>: maxNeighbors = 10, no static obstacles, one RVO2
+ * parameter set -- what motion_model_manager.py:14, 237-246 always creates) divides and takes square roots in RVO2's linearProgram1 / 2 / 3
+ * and line construction (reached through rvo2.PyRVOSimulator.doStep, motion_model_manager.py:387; float32 like RVO2):
+ *   EXACT  correctly rounded divide / sqrt, no FMA contraction: bit-identical to oracle/orca_oracle.c.  THE DEFAULT.
+ *   FAST   v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp each);
+ *   FMA    fast, and determinants / dot products / point + t * direction as mul + fma.
+ * FAST / FMA are opt-in: they stay within north_star's 1e-5 per step except on the agent-substeps float32 does not determine (a decision
+ * edge of the linear programme or an ill-conditioned intersection; tests/test_gpu_orca_fast.py classifies every one).  The generic ORCA
+ * builds (other maxNeighbors, static obstacles, per-agent parameters, the grid path, the robot's own ORCA model) are always exact. */
+enum { CS_ORCA_MATH_DEFAULT = 0, CS_ORCA_MATH_EXACT = 1, CS_ORCA_MATH_FAST = 2, CS_ORCA_MATH_FMA = 3 };
 
 /* ---------------------------------------------------------------- runtime / memory helpers */
 const char* cs_last_error(void);
 /* The ABI this header describes.  A host binding must refuse a library whose cs_abi_version() differs: struct layouts (cs_worlds,
  * cs_gym_book, cs_stage_book) and argument lists change between versions (social_navigation_pyenvs_amd/_lib.py load() does). */
-#define CS_ABI_VERSION 3
+#define CS_ABI_VERSION 4
 int cs_abi_version(void);
 int cs_device_count(int* count);
 int cs_set_device(int device);
@@ -517,18 +532,8 @@ int cs_launch_geometry(const cs_worlds* w, int* grid, int* block, int* worlds_pe
  * dispatcher as one workgroup; the ORCA builds also name their arithmetic, "math=exact|fast|fma"). */
 int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen);
 
-/* The arithmetic of the register-resident ORCA build (k_orca_step<FAST10>: maxNeighbors = 10, no static obstacles, one RVO2
- * parameter set -- what motion_model_manager.py:14, 237-246 always creates).  RVO2's linearProgram1 / 2 / 3 (reached through
- * rvo2.PyRVOSimulator.doStep, motion_model_manager.py:387) divide and take square roots in float32:
- *   0 "exact": correctly rounded divide / sqrt, no FMA contraction: bit-identical to oracle/orca_oracle.c (the reference build
- *              of the bit-identity tests);
- *   1 "fast":  v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp each);
- *   2 "fma":   fast, and determinants / dot products as mul + fma.
- * The mode holds for the process from the call on (-1 = back to CROWDSTEP_ORCA_MATH=exact|fast|fma, else the library default;
- * DESIGN.md 4.2).  North-star parity for ORCA is 1e-5 per step on positions / velocities, not bits.  The generic ORCA builds
- * (other maxNeighbors, static obstacles, per-agent parameters, the grid path, the robot's own ORCA model) are always exact. */
-int cs_orca_set_math(int mode);
-int cs_orca_get_math(void);
+/* What CS_ORCA_MATH_DEFAULT resolves to in this process (CS_ORCA_MATH_EXACT unless CROWDSTEP_ORCA_MATH=fast|fma is set; read once). */
+int cs_orca_default_math(void);
 
 /* Diagnostic: the ORCA kernels' correctly rounded divide / square root sequences (csrc/orca.hip ieee_div, ieee_sqrt: the
  * compiler's FMA sequences without the exponent-range handling) against the compiler's operators on n_pairs random operand

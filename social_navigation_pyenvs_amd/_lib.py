@@ -26,7 +26,10 @@ CS_ROBOT_UNICYCLE = 1 << 5
 CS_ORCA = 9
 CS_SOCIAL_MOMENTUM = 10
 
-ABI_VERSION = 3   # include/crowdstep.h CS_ABI_VERSION
+ABI_VERSION = 4   # include/crowdstep.h CS_ABI_VERSION
+# cs_worlds.orca_math
+CS_ORCA_MATH_DEFAULT, CS_ORCA_MATH_EXACT, CS_ORCA_MATH_FAST, CS_ORCA_MATH_FMA = 0, 1, 2, 3
+ORCA_MATH_NAMES = {"default": 0, "exact": 1, "fast": 2, "fma": 3}
 
 # every symbol include/crowdstep.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -40,7 +43,7 @@ ABI_SYMBOLS = [
     "cs_update_humans_rk45", "cs_gym_bookkeeping", "cs_step_variant", "cs_debug_divsqrt_check", "cs_gym_observe", "cs_copy_worlds_masked", "cs_imitation_block", "cs_gym_bookkeeping_next_step", "cs_robot_model_velocities",
     "cs_step_trace", "cs_reserve_scratch", "cs_release_scratch", "cs_complete_rk45_simulation", "cs_robot_model_rk45", "cs_copy_worlds_masked_status",
     "cs_collision_reward_gym", "cs_step_observe", "cs_copy_worlds_masked_observe", "cs_refill_staged_worlds", "cs_consume_staged_worlds", "cs_gym_step",
-    "cs_orca_set_math", "cs_orca_get_math", "cs_gym_step_is_one_launch", "cs_gym_step_staged",
+    "cs_orca_default_math", "cs_gym_step_is_one_launch", "cs_gym_step_staged",
 ]
 
 
@@ -75,6 +78,7 @@ class cs_worlds(C.Structure):
         ("orca_max_neighbors", C.c_int32), ("sm_n_actions", C.c_int32),
         ("d_orca_vertices", C.c_void_p), ("orca_n_vertices", C.c_int32),
         ("d_orca_agent_params", C.c_void_p),
+        ("orca_math", C.c_int32),
     ]
 
 
@@ -180,8 +184,11 @@ def load():
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the crowd stepper.")
     _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
-    lib.cs_abi_version.restype = C.c_int
-    got = lib.cs_abi_version() if hasattr(lib, "cs_abi_version") else None
+    fn = getattr(lib, "cs_abi_version", None)     # (a stale or foreign CROWDSTEP_LIB may lack the symbol: report it as ABI None, not as a ctypes AttributeError)
+    got = None
+    if fn is not None:
+        fn.restype = C.c_int
+        got = fn()
     if got != ABI_VERSION:   # a stale or foreign build (CROWDSTEP_LIB): its structs and argument lists are not the ones bound here
         raise CrowdstepError(f"{LIB_PATH} speaks ABI {got}, this binding ABI {ABI_VERSION} (include/crowdstep.h CS_ABI_VERSION): rebuild the library")
     lib.cs_last_error.restype = C.c_char_p

@@ -46,7 +46,7 @@ class CrowdWorlds:
 
     def __init__(self, states, goals, params, safety=None, obstacles=None, *, type, all_params_equal=False,
                  robot_row=False, robot=None, respawn_bounds=None, respawn_worlds=None, layout="aos", device=None,
-                 stream=None, orca_vertices=None, orca_agent_params=None):
+                 stream=None, orca_vertices=None, orca_agent_params=None, orca_math="default"):
         _lib.require_gpu()
         if device is not None:
             _lib.set_device(device)
@@ -59,6 +59,7 @@ class CrowdWorlds:
         self.social_momentum = self.type == _lib.CS_SOCIAL_MOMENTUM
         self.sm_n_actions = 20  # motion_model_manager.py:249
         self.orca_params = dict(ORCA_DEFAULTS)
+        self.orca_math = orca_math   # cs_worlds.orca_math of THESE worlds: "default" (CROWDSTEP_ORCA_MATH, else exact) | "exact" | "fast" | "fma"
         self.stream = stream
         states = np.asarray(states, dtype=np.float32)
         if states.ndim == 2:
@@ -181,6 +182,9 @@ class CrowdWorlds:
         d.d_orca_vertices = _ptr(self.d_orca_vertices)
         d.orca_n_vertices = int(self.orca_n_vertices)
         d.d_orca_agent_params = _ptr(getattr(self, "d_orca_agent_params", None))
+        if self.orca_math not in _lib.ORCA_MATH_NAMES:
+            raise ValueError(f"orca_math must be one of {sorted(_lib.ORCA_MATH_NAMES)}, got {self.orca_math!r}")
+        d.orca_math = _lib.ORCA_MATH_NAMES[self.orca_math]
         return d
 
     # ------------------------------------------------------------------ hot path

@@ -437,7 +437,7 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
 extern "C" {
 
 const char* cs_last_error(void) { return g_err.c_str(); }
-int cs_abi_version(void) { return CS_ABI_VERSION; }   // 2: seed_stride in cs_gym_book / cs_gym_bookkeeping*, cs_stage_book, cs_event_query, cs_device_pci_bus_id; 3: cs_orca_set_math / cs_orca_get_math
+int cs_abi_version(void) { return CS_ABI_VERSION; }   // 2: seed_stride in cs_gym_book / cs_gym_bookkeeping*, cs_stage_book, cs_event_query, cs_device_pci_bus_id; 3: cs_orca_set_math / cs_orca_get_math; 4: cs_worlds.orca_math replaces them (cs_orca_default_math)
 
 int cs_device_count(int* count)
 {

@@ -108,7 +108,7 @@ __device__ __forceinline__ float ieee_sqrt(float x)
 
 // ---- the arithmetic the register-resident build is instantiated with (template parameter FM of everything below) -------------
 // FM = 0: "exact": IEEE divide / square root, no FMA contraction -- the restatement's operations on the restatement's operands,
-//         bit-identical to oracle/orca_oracle.c (the bit-identity reference; CROWDSTEP_ORCA_MATH=exact / cs_orca_set_math(0)).
+//         bit-identical to oracle/orca_oracle.c (the bit-identity reference; cs_worlds.orca_math = CS_ORCA_MATH_EXACT, the default).
 // FM = 1: "fast": v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (1 ulp each) instead of the 8- and 9-instruction correctly rounded sequences.
 // FM = 2: "fast + fma": and the 2 x 2 determinants, dot products and point + t * direction as mul + fma (one rounding less).
 // north_star asks for 1e-5 on positions / velocities per step, not for bits, and the restatement cannot be pinned on rvo2 anyway;
@@ -1538,26 +1538,23 @@ int big_world_min_rows(int dflt)
     return v < dflt ? (v < 1 ? 1 : v) : dflt;
 }
 
-// The arithmetic of the register-resident build (k_orca_step<FAST10 = true>): 0 exact (bit-identical to the restatement), 1 fast
-// (v_rcp / v_sqrt / v_rsq), 2 fast + fma.  cs_orca_set_math() sets it for the process; CROWDSTEP_ORCA_MATH=exact|fast|fma is read
-// once, at the first ORCA launch, when nobody has set it.  DESIGN.md 4.2 says which one is the default and why.
-static int g_orca_math = -1;
-constexpr int ORCA_MATH_DEFAULT = 2;   // "fma": DESIGN.md 4.2 (profiles/r5c_orca_fast_parity.txt)
-int orca_math()
+// The arithmetic of the register-resident build (k_orca_step<FAST10 = true>) is a field of the context (cs_worlds.orca_math, ABI 4): exact
+// (bit-identical to the restatement; THE DEFAULT), fast (v_rcp / v_sqrt / v_rsq) or fast + fma.  CS_ORCA_MATH_DEFAULT resolves to
+// CROWDSTEP_ORCA_MATH=exact|fast|fma (read once) else exact.  Returns the template parameter FM: 0 exact, 1 fast, 2 fma.
+int orca_default_math()
 {
-    if (g_orca_math < 0) {
+    static const int dflt = [] {
         const char* e = std::getenv("CROWDSTEP_ORCA_MATH");
-        int m = ORCA_MATH_DEFAULT;
-        if (e) m = std::strcmp(e, "exact") == 0 ? 0 : (std::strcmp(e, "fast") == 0 ? 1 : (std::strcmp(e, "fma") == 0 ? 2 : ORCA_MATH_DEFAULT));
-        g_orca_math = m;
-    }
-    return g_orca_math;
+        if (e && std::strcmp(e, "fast") == 0) return (int)CS_ORCA_MATH_FAST;
+        if (e && std::strcmp(e, "fma") == 0) return (int)CS_ORCA_MATH_FMA;
+        return (int)CS_ORCA_MATH_EXACT;
+    }();
+    return dflt;
 }
-int orca_set_math(int mode)
+static int orca_math_of(const cs_worlds* w)
 {
-    if (mode < -1 || mode > 2) return fail(CS_ERR_ARG, "ORCA arithmetic: 0 exact, 1 fast, 2 fast + fma (-1: back to the environment / default)");
-    g_orca_math = mode;
-    return CS_OK;
+    const int m = w->orca_math == CS_ORCA_MATH_DEFAULT ? orca_default_math() : w->orca_math;
+    return m - CS_ORCA_MATH_EXACT;
 }
 
 // dynamic LDS of the one-block kernel (k_orca_step) for these worlds: [2][T] rows + radii / respawn scratch, and either the
@@ -1660,6 +1657,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
     if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
+    if (w->orca_math < CS_ORCA_MATH_DEFAULT || w->orca_math > CS_ORCA_MATH_FMA) return fail(CS_ERR_ARG, "cs_worlds.orca_math: CS_ORCA_MATH_DEFAULT / EXACT / FAST / FMA");
     if (orca_uses_grid(w)) return orca_big_launch(w, dt, n_substeps, d_action, d_peek, stream);
     OArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -1695,7 +1693,7 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
         return CS_OK;
     };
     int rc;
-    const int fm = fast10 ? orca_math() : 0;   // the generic build (other maxNeighbors, static obstacles, per-agent parameters) is always exact
+    const int fm = fast10 ? orca_math_of(w) : 0;   // the generic build (other maxNeighbors, static obstacles, per-agent parameters) is always exact
     if (T == 64) {
         if (!fast10) rc = launch(k_orca_step<false, 64>);
         else rc = fm == 0 ? launch(k_orca_step<true, 64, 0>) : (fm == 1 ? launch(k_orca_step<true, 64, 1>) : launch(k_orca_step<true, 64, 2>));
@@ -1722,7 +1720,7 @@ int orca_variant(const cs_worlds* w, char* buf, size_t buflen)
         return CS_OK;
     }
     std::snprintf(buf, buflen, "k_orca_step<FAST10=%d,MAXT=%d> grid=%d block=%d wpb=%d math=%s", fast10 ? 1 : 0, T, (w->W + wpb - 1) / wpb, T, wpb,
-                  !fast10 ? "exact" : (orca_math() == 0 ? "exact" : (orca_math() == 1 ? "fast" : "fma")));
+                  !fast10 ? "exact" : (orca_math_of(w) == 0 ? "exact" : (orca_math_of(w) == 1 ? "fast" : "fma")));
     return CS_OK;
 }
 
@@ -1763,8 +1761,7 @@ int orca_robot_launch(const cs_worlds* w, float robot_margin, const float* d_hum
 
 } // namespace csimpl
 
-extern "C" int cs_orca_set_math(int mode) { return csimpl::orca_set_math(mode); }
-extern "C" int cs_orca_get_math(void) { return csimpl::orca_math(); }
+extern "C" int cs_orca_default_math(void) { return csimpl::orca_default_math(); }
 
 extern "C" int cs_debug_divsqrt_check(unsigned long long n_pairs, unsigned seed, unsigned long long* h_out, void* stream)
 {

@@ -1,4 +1,4 @@
-"""Per-substep accounting of the ORCA kernel's fast arithmetic (cs_orca_set_math 1 / 2: v_rcp / v_sqrt / v_rsq, mul + fma) against the
+"""Per-substep accounting of the ORCA kernel's fast arithmetic (cs_worlds.orca_math = CS_ORCA_MATH_FAST / FMA: v_rcp / v_sqrt / v_rsq, mul + fma) against the
 exact restatement (oracle/orca_oracle.c, float32 like RVO2; its own parity with rvo2 is UNPINNED -- the library is absent).
 
 Protocol (the one `parity_util.fused_substeps_vs_oracle` uses for the force models): the trajectory is advanced by the EXACT

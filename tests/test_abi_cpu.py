@@ -21,9 +21,9 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libcrowdstep.so does not export {name}"
     assert set(_lib.ABI_SYMBOLS) == declared
-    assert lib.cs_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.cs_abi_version() == _lib.ABI_VERSION == 4
     hdr = open(os.path.join(ROOT, "include", "crowdstep.h")).read()
-    assert "#define CS_ABI_VERSION 3" in hdr          # header, library and binding name one ABI
+    assert "#define CS_ABI_VERSION 4" in hdr          # header, library and binding name one ABI
 
 
 def test_library_on_disk_was_built_from_the_sources_on_disk():
@@ -52,9 +52,10 @@ def test_struct_layout_matches_header():
 
     from social_navigation_pyenvs_amd._lib import cs_worlds
 
-    # 8 int32 + 7 pointers + 5 floats + 2 int32 (+4 padding) + 1 pointer + 1 int32 (+4 padding) + 1 pointer
-    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 2 * 4 + 4 + 8 + 4 + 4 + 8
+    # 8 int32 + 7 pointers + 5 floats + 2 int32 (+4 padding) + 1 pointer + 1 int32 (+4 padding) + 1 pointer + 1 int32 (+4 padding)
+    assert C.sizeof(cs_worlds) == 8 * 4 + 7 * 8 + 5 * 4 + 2 * 4 + 4 + 8 + 4 + 4 + 8 + 4 + 4
     assert cs_worlds.d_state.offset == 32
+    assert cs_worlds.orca_math.offset == C.sizeof(cs_worlds) - 8        # ABI 4: the ORCA arithmetic is a field of the context
 
 
 def test_product_fails_loudly_without_gpu():

@@ -9,16 +9,17 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def exact_orca_arithmetic():
-    """This module is the BIT-IDENTITY suite: the register-resident ORCA build runs in its exact arithmetic (cs_orca_set_math(0):
-    correctly rounded divide / square root, no FMA contraction) and must equal oracle/orca_oracle.c bit for bit.  The library's
-    default arithmetic ("fma") is measured per substep in tests/test_gpu_orca_fast.py."""
+def exact_orca_arithmetic(monkeypatch):
+    """This module is the BIT-IDENTITY suite: the register-resident ORCA build in the library's DEFAULT arithmetic (cs_worlds.orca_math =
+    CS_ORCA_MATH_DEFAULT -> exact: correctly rounded divide / square root, no FMA contraction) must equal oracle/orca_oracle.c bit for bit.
+    The opt-in fast / fma arithmetic is measured per substep in tests/test_gpu_orca_fast.py.  (The default follows CROWDSTEP_ORCA_MATH, read
+    once per process: the suite refuses to run under a non-exact one rather than silently testing another build.)"""
+    import os
+
     from social_navigation_pyenvs_amd import _lib
 
-    lib = _lib.load()
-    _lib.check(lib.cs_orca_set_math(0))
+    assert os.environ.get("CROWDSTEP_ORCA_MATH", "exact") == "exact" and _lib.load().cs_orca_default_math() == _lib.CS_ORCA_MATH_EXACT
     yield
-    _lib.check(lib.cs_orca_set_math(-1))
 
 
 def make_worlds(rng, W, n, robot=False, traffic=False):

@@ -1,4 +1,4 @@
-"""GPU: the ORCA kernel's DEFAULT arithmetic ("fma": v_rcp / v_sqrt / v_rsq, determinants as mul + fma) and the "fast" one, per substep
+"""GPU: the ORCA kernel's OPT-IN arithmetics ("fma": v_rcp / v_sqrt / v_rsq, determinants as mul + fma; "fast": the first three only), per substep
 from re-synchronised state against the exact restatement, every agent-substep beyond north_star's 1e-5 accounted for
 (tests/orca_fast_parity.py; the full-size run is tools/orca_fast_parity.py -> profiles/r5c_orca_fast_parity.txt).
 The bit-identity suite of the exact arithmetic is tests/test_gpu_orca.py.  ORCA's parity with rvo2 itself is UNPINNED (library absent)."""
@@ -11,34 +11,37 @@ import parity_util
 pytestmark = pytest.mark.gpu
 
 
-def _set_math(mode):
-    from social_navigation_pyenvs_amd import _lib
-
-    _lib.check(_lib.load().cs_orca_set_math(mode))
-
-
-def test_default_arithmetic_is_fma_and_the_switch_works():
+def test_the_arithmetic_is_a_field_of_the_context_and_exact_is_the_default():
     import os
 
     from social_navigation_pyenvs_amd import _lib
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
     lib = _lib.load()
-    _set_math(-1)
     S, g, margin = ofp.crossing(8, 25, 7.0, 5)
     cw = CrowdWorlds(S, g, None, margin, None, type="orca")
-    if "CROWDSTEP_ORCA_MATH" not in os.environ:
-        assert lib.cs_orca_get_math() == 2 and "math=fma" in cw.step_variant(), cw.step_variant()
-    for mode, name in ((0, "exact"), (1, "fast"), (2, "fma")):
-        _set_math(mode)
-        assert lib.cs_orca_get_math() == mode and f"math={name}" in cw.step_variant()
+    if os.environ.get("CROWDSTEP_ORCA_MATH", "exact") == "exact":
+        assert lib.cs_orca_default_math() == _lib.CS_ORCA_MATH_EXACT and "math=exact" in cw.step_variant(), cw.step_variant()
+    # two environments of one process differ, and neither changes the other (ABI 4: cs_worlds.orca_math; there is no process-wide switch)
+    others = {name: CrowdWorlds(S, g, None, margin, None, type="orca", orca_math=name) for name in ("exact", "fast", "fma")}
+    for name, c in others.items():
+        assert f"math={name}" in c.step_variant()
+    for c in (cw, *others.values()):
+        c.step(0.0125, 3)
+    assert np.array_equal(cw.get_states(), others["exact"].get_states())
+    assert "math=exact" in cw.step_variant() and "math=fma" in others["fma"].step_variant()
+    cw.orca_math = "bogus"
     with pytest.raises(ValueError):
-        _set_math(7)
+        cw.step(0.0125, 1)
+    # an out-of-range field is refused by the library itself
+    cw.orca_math = "default"
+    d = cw.descriptor(); d.orca_math = 7
+    import ctypes as C
+    assert lib.cs_step(C.byref(d), C.c_float(0.0125), C.c_int(1), None, None) != 0
     # the generic builds (other maxNeighbors, per-agent parameters, obstacles) are always exact
-    cw5 = CrowdWorlds(S, g, None, margin, None, type="orca")
+    cw5 = CrowdWorlds(S, g, None, margin, None, type="orca", orca_math="fma")
     cw5.orca_params = dict(cw5.orca_params, max_neighbors=5)
     assert "FAST10=0" in cw5.step_variant() and "math=exact" in cw5.step_variant(), cw5.step_variant()
-    _set_math(-1)
 
 
 @pytest.mark.parametrize("mode,name", [(2, "fma"), (1, "fast")])
@@ -51,13 +54,9 @@ def test_fast_arithmetic_per_substep_against_the_exact_restatement(mode, name, W
     from social_navigation_pyenvs_amd.batched import CrowdWorlds
 
     S, g, margin = ofp.crossing(W, n, R, 4242 + n)
-    _set_math(mode)
-    try:
-        cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa")
-        assert f"math={name}" in cw.step_variant()
-        res = ofp.substeps_vs_restatement(cw, S, g, margin, 0.0125, nsub, seed=mode)
-    finally:
-        _set_math(-1)
+    cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa", orca_math=name)
+    assert f"math={name}" in cw.step_variant()
+    res = ofp.substeps_vs_restatement(cw, S, g, margin, 0.0125, nsub, seed=mode)
     parity_util.REPORT[f"ORCA {name} build per substep, {W}x{n}"] = {k: res[k] for k in (
         "agent_substeps", "bit_identical_agent_substeps", "beyond_bar", "beyond_bar_share", "class_f64", "class_edge1", "class_edge4", "class_edge16", "class_op4", "decisions", "probe_reproduces_build", "unexplained",
         "unexplained_share", "worst_unexplained", "disagree_build_closer_to_f64", "disagree_exact_closer_to_f64", "beyond_bar_vs_f64_build_share",
@@ -88,12 +87,8 @@ def test_fast_arithmetic_free_running_crowd_is_as_healthy_as_the_exact_one():
     W, n = 512, 25
     S, g, margin = ofp.crossing(W, n, 7.0, 777)
     h = {}
-    try:
-        for mode in (0, 1, 2):
-            _set_math(mode)
-            h[mode] = ofp.free_run_health(lambda: CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa"), S, g, margin, 0.0125, 700)
-    finally:
-        _set_math(-1)
+    for mode, name in enumerate(("exact", "fast", "fma")):
+        h[mode] = ofp.free_run_health(lambda: CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa", orca_math=name), S, g, margin, 0.0125, 700)
     for mode in (1, 2):
         assert h[mode]["worst_overlap_m"] < h[0]["worst_overlap_m"] + 5e-3, h
         assert h[mode]["max_speed_over_vmax"] < 5e-2, h

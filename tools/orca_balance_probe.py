@@ -31,5 +31,5 @@ for name, perm in orders.items():
         c.set_states(S1[perm]); c.set_goals(g1[perm]); c.sync()
         ev0.record(c.stream); c.step(0.0125, 20); ev1.record(c.stream); c.sync()
         best.append(ev0.elapsed_ms(ev1) * 1e3)
-    print(f"{name:32s} {np.median(best):8.1f} us (min {min(best):.1f})  math={_lib.load().cs_orca_get_math()}", flush=True)
+    print(f"{name:32s} {np.median(best):8.1f} us (min {min(best):.1f})  default math={_lib.load().cs_orca_default_math()}", flush=True)
 print("crowding proxy: min %.0f median %.0f max %.0f" % (cost.min(), np.median(cost), cost.max()))

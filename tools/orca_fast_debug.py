@@ -10,8 +10,7 @@ from social_navigation_pyenvs_amd import _lib
 from social_navigation_pyenvs_amd.batched import CrowdWorlds
 W, n, R, mode, thr = 4096, 25, 7.0, int(sys.argv[1]) if len(sys.argv) > 1 else 1, float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
 S, g, margin = ofp.crossing(W, n, R, 31337 + n)
-_lib.check(_lib.load().cs_orca_set_math(mode))
-cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa")
+cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa", orca_math=("exact", "fast", "fma")[mode])
 ref, rg = S.copy(), g.copy()
 dump = []
 for k in range(700):

@@ -1,4 +1,4 @@
-"""Diagnostic / evidence: the ORCA kernel's arithmetic modes (exact / fast / fma, cs_orca_set_math) per substep against the exact
+"""Diagnostic / evidence: the ORCA kernel's arithmetic modes (exact / fast / fma, cs_worlds.orca_math) per substep against the exact
 restatement, with every agent-substep beyond 1e-5 examined for a decision edge (tests/orca_fast_parity.py), the free-running
 health of each build, and the kernel time per mode.
   python tools/orca_fast_parity.py [worlds=4096] [substeps=700] [out.json]
@@ -47,8 +47,7 @@ for n, R, Wn, nsub in ((25, 7.0, W, NSUB), (10, 3.0, max(256, W // 4), min(NSUB,
     key = f"{Wn}x{n}_R{R:g}"
     report["shapes"][key] = {}
     for mode in (0, 1, 2):
-        _lib.check(lib.cs_orca_set_math(mode))
-        cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa")
+        cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa", orca_math=MODES[mode])
         t0 = time.time()
         res = ofp.substeps_vs_restatement(cw, S, g, margin, 0.0125, nsub, progress=100 if mode else None, seed=mode)
         res["variant"] = cw.step_variant()
@@ -58,21 +57,19 @@ for n, R, Wn, nsub in ((25, 7.0, W, NSUB), (10, 3.0, max(256, W // 4), min(NSUB,
         report["shapes"][key][MODES[mode]] = res
         print(f"[{key}] {MODES[mode]:5s}: {res['agent_substeps']:.3g} agent-substeps, bit-identical {res['bit_identical_agent_substeps'] / res['agent_substeps']:.4f}, "
               f"p50 {res['p50']:.1e} p99 {res['p99']:.1e} p99.99 {res['p9999']:.1e} worst {res['worst']:.2e}; beyond {ofp.BAR:g} vs exact f32: {res['beyond_bar']} "
-              f"({res['beyond_bar_share']:.2e} of all) = f64 {res['class_f64']} + edge1 {res['class_edge1']} + edge4 {res['class_edge4']} + edge16 {res['class_edge16']} + unexplained {res['unexplained']} "
+              f"({res['beyond_bar_share']:.2e} of all) = f64 {res['class_f64']} + edge1 {res['class_edge1']} + edge4 {res['class_edge4']} + edge16 {res['class_edge16']} + op4 {res['class_op4']} + unexplained {res['unexplained']} "
               f"(worst {res['worst_unexplained']:.2e}) + not examined {res['not_examined']}; of these closer to f64: build {res['disagree_build_closer_to_f64']} / exact {res['disagree_exact_closer_to_f64']}; "
               f"beyond bar vs f64: build {res['beyond_bar_vs_f64_build_share']:.2e}, exact f32 {res['beyond_bar_vs_f64_exact_share']:.2e}; goal flips {res['goal_column_flips']}; "
-              f"pref velocity worst {res['pref_velocity_worst']:.1e}  ({res['seconds']} s)", flush=True)
+              f"pref velocity worst {res['pref_velocity_worst']:.1e}; decisions {res['decisions']}; probe reproduces the build's answer on {res['probe_reproduces_build']}  ({res['seconds']} s)", flush=True)
     # free-running health and kernel time per mode (same worlds, same launch shape as bench.py's cfg4: 20 fused substeps)
     for mode in (0, 1, 2):
-        _lib.check(lib.cs_orca_set_math(mode))
-        h = ofp.free_run_health(lambda: CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa"), S, g, margin, 0.0125, nsub)
-        cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa")
+        h = ofp.free_run_health(lambda: CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa", orca_math=MODES[mode]), S, g, margin, 0.0125, nsub)
+        cw = CrowdWorlds(S, g, None, margin, None, type="orca", layout="soa", orca_math=MODES[mode])
         for _ in range(25):
             cw.step(0.0125, 20)          # into the dense phase
         h["dense_launch_us"] = round(timed_launch(cw, 0.0125, 20), 1)
         report["shapes"][key][MODES[mode]]["free_run"] = h
         print(f"[{key}] {MODES[mode]:5s} free run: {h}", flush=True)
-_lib.check(lib.cs_orca_set_math(-1))
 os.makedirs(os.path.dirname(OUT), exist_ok=True)
 with open(OUT, "w") as f:
     json.dump(report, f, indent=1)
