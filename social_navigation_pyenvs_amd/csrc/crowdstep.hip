@@ -127,13 +127,14 @@ using namespace cstep;
 __global__ void k_collision_reward(int W, int n, int rows, const float* S, long as, long fs, const float* robot,
                                    const float* action, float T, const float* gtime, float time_limit,
                                    float success_reward, float collision_penalty, float discomfort_dist,
-                                   float discomfort_factor, float* out)
+                                   float discomfort_factor, float* out, int unicycle)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= W) return;
     const float* rb = robot + (long)w * 13;
     const float rpx = rb[0], rpy = rb[1], rr = rb[8], rgx = rb[10], rgy = rb[11];
-    const float ax = action[(long)w * 2], ay = action[(long)w * 2 + 1];
+    float ax = action[(long)w * 2], ay = action[(long)w * 2 + 1];
+    gym_action_velocity(unicycle, rb[2], ax, ay);
     float dmin = INFINITY;
     int collision = 0;
     for (int i = 0; i < n; ++i) {
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(64) void k_collision_reward_wave(int W, int n, int 
         const float* rb = robot + (long)w * 13;
         rpx = rb[0]; rpy = rb[1]; rr = rb[8]; rgx = rb[10]; rgy = rb[11];
         ax = action[(long)w * 2]; ay = action[(long)w * 2 + 1];
+        gym_action_velocity(g.unicycle, rb[2], ax, ay);
         const float* s = S + ((long)w * rows + i) * as;
         closest = gym_swept_closest(s[0], s[fs], s[3 * fs], s[4 * fs], s[8 * fs], rpx, rpy, rr, ax, ay, g.T);
     }
@@ -298,10 +300,11 @@ kfn variant_kernel(const Variant& v, int type)
 }
 
 // the Gym head's arguments from the C ABI's (book == nullptr: reward row only)
-GymHead gym_head(float* d_out, const float* d_global_time, float T, const float* reward_cfg, const cs_gym_book* book, int W)
+GymHead gym_head(float* d_out, const float* d_global_time, float T, const float* reward_cfg, const cs_gym_book* book, int W, int flags)
 {
     GymHead g;
     std::memset(&g, 0, sizeof(g));
+    g.unicycle = (flags & CS_ROBOT_UNICYCLE) ? 1 : 0;
     g.out = d_out; g.gtime = d_global_time; g.T = T;
     g.time_limit = reward_cfg[0]; g.success_reward = reward_cfg[1]; g.collision_penalty = reward_cfg[2];
     g.discomfort_dist = reward_cfg[3]; g.discomfort_factor = reward_cfg[4];
@@ -588,7 +591,7 @@ int cs_gym_step(const cs_worlds* w, float dt, int n_substeps, const float* d_act
         return fail(CS_ERR_ARG, "null buffer in cs_gym_book");
     int mode = M_COMMIT_GOALS;
     if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
-    const GymHead gh = gym_head(d_out, d_global_time, T, reward_cfg, book, w->W);
+    const GymHead gh = gym_head(d_out, d_global_time, T, reward_cfg, book, w->W, w->flags);
     return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, d_obs,
                        theta_and_omega_visible ? 7 : 5, &gh);
 }
@@ -609,7 +612,7 @@ int cs_gym_step_staged(const cs_worlds* w, float dt, int n_substeps, const float
     if (book->d_seeds != stage_book->d_seeds) return fail(CS_ERR_ARG, "cs_gym_book.d_seeds and cs_stage_book.d_seeds must be one buffer");
     int mode = M_COMMIT_GOALS;
     if ((w->flags & CS_ROBOT_ROW) && w->d_robot) mode |= M_ROBOT_FROM_ARRAY;
-    GymHead gh = gym_head(d_out, d_global_time, T, reward_cfg, book, w->W);
+    GymHead gh = gym_head(d_out, d_global_time, T, reward_cfg, book, w->W, w->flags);
     const int rc = csimpl::stage_fold(gen, staging, w, stage_book, theta_and_omega_visible ? 7 : 5, d_obs, gh.fold);
     if (rc) return rc;
     return launch_step(w, dt, n_substeps, mode, nullptr, d_action, nullptr, (hipStream_t)stream, nullptr, nullptr, nullptr, d_obs,
@@ -654,12 +657,12 @@ int cs_collision_reward(const cs_worlds* w, const float* d_action, float T, cons
         const int wpb = 64 / w->n, grid = (w->W + wpb - 1) / wpb;
         hipLaunchKernelGGL(k_collision_reward_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w->W, w->n, rows, wpb,
                            (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action,
-                           gym_head(d_out, d_global_time, T, reward_cfg, nullptr, w->W));
+                           gym_head(d_out, d_global_time, T, reward_cfg, nullptr, w->W, w->flags));
     } else {
         const int block = 64, grid = (w->W + block - 1) / block;
         hipLaunchKernelGGL(k_collision_reward, dim3(grid), dim3(block), 0, (hipStream_t)stream, w->W, w->n, rows,
                            (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action, T, d_global_time,
-                           reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out);
+                           reward_cfg[0], reward_cfg[1], reward_cfg[2], reward_cfg[3], reward_cfg[4], d_out, (w->flags & CS_ROBOT_UNICYCLE) ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     return CS_OK;
@@ -691,7 +694,7 @@ int cs_collision_reward_gym(const cs_worlds* w, const float* d_action, float T, 
     const int wpb = 64 / w->n, grid = (w->W + wpb - 1) / wpb;
     hipLaunchKernelGGL(k_collision_reward_wave, dim3(grid), dim3(64), 0, (hipStream_t)stream, w->W, w->n, rows, wpb,
                        (const float*)w->d_state, as, fs, (const float*)w->d_robot, d_action,
-                       gym_head(d_out, d_global_time, T, reward_cfg, book, w->W));
+                       gym_head(d_out, d_global_time, T, reward_cfg, book, w->W, w->flags));
     HIP_TRY(hipGetLastError());
     return CS_OK;
 }

@@ -39,12 +39,26 @@ struct GymBook {
 };
 
 struct GymHead {
+    int unicycle;            // the action rows are ActionRot (v, r) (CS_ROBOT_UNICYCLE): the robot's velocity over the swept test is v (cos, sin)(r + yaw)
     float* out;              // [W][7] collision, dmin, reaching_goal, reward, terminated, truncated, info; nullptr: no head in this launch
     const float* gtime;      // [W] global time read for the time limit (== bk.gtime when the bookkeeping runs)
     float T, time_limit, success_reward, collision_penalty, discomfort_dist, discomfort_factor;
     GymBook bk;
     GymFold fold;
 };
+
+// The robot's velocity over the swept test's horizon for its action (social_nav_sim.py:968-973): an ActionXY is the velocity; an ActionRot (v, r)
+// gives v (cos, sin)(r + yaw) -- the reference reads a `robot.theta` no agent has there, the yaw is what it means; golden G17 holds
+// the reference's values with that attribute provided.  Hardware sin / cos in revolutions (stepcommon.h sincos_fast: 2.7e-7), both call sites alike.
+__device__ __forceinline__ void gym_action_velocity(int unicycle, float yaw, float& ax, float& ay)
+{
+#pragma clang fp contract(off)
+    if (unicycle) {
+        const float rev = (ay + yaw) * 0.15915494309189535f, v = ax;
+        ax = v * __builtin_amdgcn_cosf(rev);
+        ay = v * __builtin_amdgcn_sinf(rev);
+    }
+}
 
 // closest approach of one human to the robot over [0, T] with both velocities held (utils.py:22-36), minus the two radii
 __device__ __forceinline__ float gym_swept_closest(float hx, float hy, float hvx, float hvy, float hr, float rpx, float rpy, float rr,

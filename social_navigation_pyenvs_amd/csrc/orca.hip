@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "orca_sortnet.h"
+#include "robotstep.h"
 
 #pragma clang fp contract(off)
 
@@ -984,10 +985,10 @@ __global__ __launch_bounds__(MAXT) ORCA_WPE_ATTR void k_orca_step(const OArgs a)
     // the true robot (moves with the action); the simulator's copy is the state row
     const bool has_robot = a.robot != nullptr;
     const bool robot_moves = a.action != nullptr && has_robot;
-    float rbx = 0, rby = 0, rbvx = 0, rbvy = 0, ax = 0, ay = 0;
+    float rbx = 0, rby = 0, rbt = 0, rbvx = 0, rbvy = 0, ax = 0, ay = 0;
     if (valid && has_robot) {
         const float* rb = a.robot + (long)w * 13;
-        rbx = rb[0]; rby = rb[1]; rbvx = rb[3]; rbvy = rb[4];
+        rbx = rb[0]; rby = rb[1]; rbt = rb[2]; rbvx = rb[3]; rbvy = rb[4];
         if (robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
     }
 
@@ -1009,9 +1010,8 @@ __global__ __launch_bounds__(MAXT) ORCA_WPE_ATTR void k_orca_step(const OArgs a)
     for (int sub = 0; sub < a.nsub; ++sub) {
         if constexpr (MAXT == 64) { if (prio_young) { if (sub & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); } }
         const int nxt = cur ^ 1;
-        if (valid && robot_moves && (is_robot || (!robot_row && row == 0))) { // robot.step(action, dt) (holonomic)
-            rbx += ax * dt; rby += ay * dt; rbvx = ax; rbvy = ay;
-        }
+        if (valid && robot_moves && (is_robot || (!robot_row && row == 0)))   // robot.step(action, dt): holonomic or unicycle (robotstep.h)
+            csimpl::robot_action_step(a.flags, rbx, rby, rbt, rbvx, rbvy, ax, ay, dt);
         float nvx = 0.0f, nvy = 0.0f;
         if constexpr (FAST10) {
             // every lane of the wavefront takes part (linearProgram3 re-deals the lanes); lanes without a human carry no lines
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(MAXT) ORCA_WPE_ATTR void k_orca_step(const OArgs a)
         if (human) { srow[5 * fs] = pvx; srow[6 * fs] = pvy; srow[10 * fs] = g0x; srow[11 * fs] = g0y; }
         if (robot_moves && (is_robot || (!robot_row && row == 0))) {
             float* rb = a.robot + (long)w * 13;
-            rb[0] = rbx; rb[1] = rby; rb[3] = rbvx; rb[4] = rbvy;
+            rb[0] = rbx; rb[1] = rby; rb[2] = rbt; rb[3] = rbvx; rb[4] = rbvy;
         }
     }
 }
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(64) void k_orca_robot_step_fast(const ORArgs a)
 // neighbour list, the ORCA lines and the solve are bit-identical to the restatement's index-order walk.  State is double-buffered
 // in HBM (every agent reads the old rows, RVO2's doStep is a Jacobi update), one launch per substep.
 struct BigArgs {
-    int W, n, rows, G, NB, robot_row;
+    int W, n, rows, G, NB, robot_row, flags;
     int K, KO, nv;         // generic build: maxNeighbors, obstacle neighbours kept, obstacle vertices
     float dt, neighbor_dist, time_horizon, time_horizon_obst, inv_cell;
     const float* Sin; float* Sout; long as, fs;
@@ -1454,8 +1454,9 @@ __global__ __launch_bounds__(64) void k_bw_orca_step(const BigArgs a)
             rbx = rb[0]; rby = rb[1]; rbvx = rb[3]; rbvy = rb[4];
             if (a.action != nullptr) {
                 const float ax = a.action[(long)w * 2], ay = a.action[(long)w * 2 + 1];
-                rbx += ax * a.dt; rby += ay * a.dt; rbvx = ax; rbvy = ay;
-                rb[0] = rbx; rb[1] = rby; rb[3] = rbvx; rb[4] = rbvy;
+                float rbt = rb[2];
+                csimpl::robot_action_step(a.flags, rbx, rby, rbt, rbvx, rbvy, ax, ay, a.dt);
+                rb[0] = rbx; rb[1] = rby; rb[2] = rbt; rb[3] = rbvx; rb[4] = rbvy;
             }
         }
         if (is_robot) {
@@ -1603,7 +1604,7 @@ static int orca_big_launch(const cs_worlds* w, float dt, int n_substeps, const f
     }
     BigArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.W = W; a.n = n; a.rows = rows; a.robot_row = robot_row ? 1 : 0; a.G = w->G; a.NB = NB; a.dt = dt;
+    a.W = W; a.n = n; a.rows = rows; a.robot_row = robot_row ? 1 : 0; a.flags = w->flags; a.G = w->G; a.NB = NB; a.dt = dt;
     a.neighbor_dist = w->orca_neighbor_dist; a.time_horizon = w->orca_time_horizon;
     // cell edge = neighborDist (a floor keeps a degenerate neighborDist = 0 from dividing by zero: nobody is a neighbour then)
     a.inv_cell = 1.0f / (w->orca_neighbor_dist > 1e-3f ? w->orca_neighbor_dist : 1e-3f);
@@ -1653,7 +1654,6 @@ int orca_launch(const cs_worlds* w, float dt, int n_substeps, const float* d_act
                                               "(cs_worlds.d_orca_vertices), not as the SFM segment array");
     if (w->orca_n_vertices < 0 || (w->orca_n_vertices > 0 && !w->d_orca_vertices)) return fail(CS_ERR_ARG, "bad ORCA obstacle vertices");
     if (w->orca_n_vertices > 0 && !(w->orca_time_horizon_obst > 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");
-    if (w->flags & CS_ROBOT_UNICYCLE) return fail(CS_ERR_ARG, "ORCA step supports holonomic robot actions only");
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     if (w->orca_max_neighbors < 0 || w->orca_max_neighbors > KMAX) return fail(CS_ERR_ARG, "orca_max_neighbors must be in 0..16");
     if (!(w->orca_time_horizon > 0.0f) || !(w->orca_neighbor_dist >= 0.0f)) return fail(CS_ERR_ARG, "bad ORCA parameters");

@@ -20,6 +20,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "robotstep.h"
 
 #pragma clang fp contract(off)
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64) void k_sm_step(const MArgs a)
         r = srow[8 * fs]; vd = srow[12 * fs];
         if (is_robot && a.robot != nullptr) { // the true robot
             const float* rb = a.robot + (long)w * 13;
-            px = rb[0]; py = rb[1]; vx = rb[3]; vy = rb[4]; r = rb[8];
+            px = rb[0]; py = rb[1]; th = rb[2]; vx = rb[3]; vy = rb[4]; r = rb[8];
         }
         rs = r + a.safety[(long)w * rows + row];
     }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64) void k_sm_step(const MArgs a)
     float ax = 0, ay = 0;
     if (valid && robot_moves) { ax = a.action[(long)w * 2]; ay = a.action[(long)w * 2 + 1]; }
 
-    if (is_robot && robot_moves) { px += ax * dt; py += ay * dt; vx = ax; vy = ay; } // robot.step before the first update
+    if (is_robot && robot_moves) csimpl::robot_action_step(a.flags, px, py, th, vx, vy, ax, ay, dt); // robot.step before the first update (robotstep.h)
     if (valid) { lds_pv[0][tid] = make_float4(px, py, vx, vy); lds_rs[tid] = rs; }
     __syncthreads();
 
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(64) void k_sm_step(const MArgs a)
             vx = bax; vy = bay;
             lds_pv[nxt][tid] = make_float4(px, py, vx, vy);
         } else if (is_robot) {
-            if (robot_moves && sub + 1 < a.nsub) { px += ax * dt; py += ay * dt; vx = ax; vy = ay; } // next substep's robot.step
+            if (robot_moves && sub + 1 < a.nsub) csimpl::robot_action_step(a.flags, px, py, th, vx, vy, ax, ay, dt); // next substep's robot.step
             lds_pv[nxt][tid] = make_float4(px, py, vx, vy);
         }
         __syncthreads();
@@ -200,13 +201,13 @@ __global__ __launch_bounds__(64) void k_sm_step(const MArgs a)
         if (human) { srow[10 * fs] = g0x; srow[11 * fs] = g0y; }
         if (is_robot && robot_moves && a.robot != nullptr) {
             float* rb = a.robot + (long)w * 13;
-            rb[0] = px; rb[1] = py; rb[3] = vx; rb[4] = vy;
+            rb[0] = px; rb[1] = py; rb[2] = th; rb[3] = vx; rb[4] = vy;
         }
         if (!robot_row && row == 0 && robot_moves && a.robot != nullptr) { // invisible robot: advanced by the lane of row 0
             float* rb = a.robot + (long)w * 13;
-            float qx = rb[0], qy = rb[1];
-            for (int sub = 0; sub < a.nsub; ++sub) { qx += ax * dt; qy += ay * dt; }
-            rb[0] = qx; rb[1] = qy; rb[3] = ax; rb[4] = ay;
+            float qx = rb[0], qy = rb[1], qt = rb[2], qvx = rb[3], qvy = rb[4];
+            for (int sub = 0; sub < a.nsub; ++sub) csimpl::robot_action_step(a.flags, qx, qy, qt, qvx, qvy, ax, ay, dt);
+            rb[0] = qx; rb[1] = qy; rb[2] = qt; rb[3] = qvx; rb[4] = qvy;
         }
     }
 }
@@ -220,7 +221,6 @@ int social_momentum_launch(const cs_worlds* w, float dt, int n_substeps, const f
     if (!w) return fail(CS_ERR_ARG, "null cs_worlds");
     if (w->W <= 0 || w->n <= 0 || w->G <= 0) return fail(CS_ERR_ARG, "W, n, G must be positive");
     if (!w->d_state || !w->d_goals || !w->d_safety) return fail(CS_ERR_ARG, "null device buffer in cs_worlds");
-    if (w->flags & CS_ROBOT_UNICYCLE) return fail(CS_ERR_ARG, "the social-momentum step supports holonomic robot actions only");
     const int rows = w->n + ((w->flags & CS_ROBOT_ROW) ? 1 : 0);
     if (rows > 64) return fail(CS_ERR_ARG, "the social-momentum step supports up to 64 rows per world");
     const int A = w->sm_n_actions > 0 ? w->sm_n_actions : 20; // motion_model_manager.py:249

@@ -25,6 +25,9 @@ reference produced) is written to the ``.npz`` fixtures.  Groups (SURVEY.md §8c
   g16_policy  CADRL.predict / SARL.predict of the reference (crowd_nav/policy/cadrl.py:235-291, multi_human_rl.py:12-88, sarl.py) with
               seeded weights over Gym episodes of the reference env: weights, joint states, the peeked next human states, the 81 action
               values and the chosen action of every decision (the policy seam, SURVEY.md §8 rows b + f1)
+  g17_unicycle  the unicycle robot: RobotAgent.step(ActionRot(v, r), dt) (robot_agent.py:119-136) inside the Gym's substep loop
+              (social_nav_gym.py:240-245) run directly on the reference's objects, robot pose + crowd rows per substep; the Gym head for
+              that action with robot.theta provided
   g10_social_momentum  MotionModelManager("social_momentum").update_humans single steps (motion_model_manager.py:395-404,
               social_gym/src/social_momentum.py)
 """
@@ -1108,11 +1111,91 @@ def gen_g15_imitation_rk45():
     print("g15_imitation_rk45:", len(cases), "cases ->", save_cases("g15_imitation_rk45", cases))
 
 
+def gen_g17_unicycle():
+    """the unicycle robot (RobotAgent.step / compute_position with ActionRot, robot_agent.py:119-136) inside the Gym's
+    substep loop (social_nav_gym.py:240-245: robot.step(action, dt); update_humans(t, dt) -- time_step_factor times, the SAME (v, r) every
+    substep, so the robot turns by r per SUBSTEP).  The reference's own step() cannot take an ActionRot (social_nav_sim.py:973 reads
+    robot.theta, which no agent has), so the loop of :240-245 is run here directly on the reference's objects; every substep's robot pose and
+    crowd rows are recorded.  Also recorded, with the attribute the reference reads provided (robot.theta := robot.yaw): what
+    collision_detection_and_reaching_goal + compute_reward_and_infos return for that action (the Gym head's swept test, :949-1029)."""
+    cases = []
+    seed = 0
+    for model, scen, hn, visible in (("sfm_helbing", "circle_crossing", 5, True), ("sfm_helbing", "circle_crossing", 5, False),
+                                     ("hsfm_farina", "circle_crossing", 10, True), ("hsfm_new_guo", "parallel_traffic", 10, True),
+                                     ("hsfm_farina", "hybrid_scenario", 25, True), ("hsfm_farina", "hybrid_scenario", 25, False),
+                                     ("hsfm_new_guo", "circle_crossing", 25, True), ("sfm_guo", "parallel_traffic", 25, True),
+                                     ("hsfm_new_moussaid", "circle_crossing", 10, True)):
+        for rep in range(2):
+            seed += 1
+            rng = np.random.default_rng(170_000 + seed)
+            env, _ = make_env(model, scen, hn, visible, False, "unicycle")
+            if seed % 3 == 0:
+                env.set_safety_space(0.1)
+            test_case = int(rng.integers(0, 90))
+            env.reset(phase="test", test_case=test_case)
+            mm = env.motion_model_manager
+            robot = env.robot
+            if rep == 1:       # a heading that is not a multiple of pi / 2, a robot inside the crowd's reach
+                robot.yaw = float(rng.uniform(-np.pi, np.pi))
+                robot.position = np.array(robot.position, dtype=np.float64) * 0.5
+            if model.endswith("moussaid"):   # everybody at rest: sign(theta_ij ~ 0) follows float64 noise in the reference (SURVEY.md App. F.9) -> record a moving crowd
+                for _ in range(env.time_step_factor):
+                    robot.step(ns.action.ActionRot(0.6, 0.03), env.time_step)
+                    mm.update_humans(env.global_time, env.time_step)
+                    env.global_time += env.time_step
+            rec = dict(model=model, scenario=scen, human_num=hn, robot_visible=visible, safety_space=float(env.safety_space), test_case=test_case, rep=rep,
+                       global_time0=float(env.global_time), respawn=bool(mm.parallel_traffic_humans_respawn), all_params_equal=bool(mm.all_equal_humans),
+                       dt=float(env.time_step), n_substeps=int(env.time_step_factor), T=float(env.robot_time_step),
+                       mm_safety=mm.safety_space.copy(), params=mm.params.copy(),
+                       respawn_bounds=np.array(getattr(env, "respawn_bounds", None) or (0.0, 0.0), dtype=np.float64),
+                       robot_radius=float(robot.radius), robot_safety_space=float(getattr(robot, "safety_space", 0.0)), sfm_type=int(mm.sfm_type), robot_goal=np.array(robot.get_goal_position(), dtype=np.float64))
+            actions, robots, states, goals, heads = [], [], [], [], []
+            robot0 = robot.get_safe_state().copy()
+            states0, goals0 = mm.states.copy(), mm.goals.copy()
+            n_steps = 3
+            for k in range(n_steps):
+                v = float(rng.uniform(0.3, 1.0))
+                r = float(rng.uniform(-0.08, 0.08)) if k else float(rng.choice([-1.0, 1.0]) * rng.uniform(0.02, 0.08))
+                action = ns.action.ActionRot(v, r)
+                actions.append([v, r])
+                # the Gym head for this action (social_nav_gym.py:229-233) with the attribute :973 reads
+                robot.theta = robot.yaw
+                col, dmin, reach = env.collision_detection_and_reaching_goal(action, env.robot_time_step)
+                reward, term, trunc, info = env.compute_reward_and_infos(col, dmin, reach, env.global_time, env.robot_time_step)
+                del robot.theta
+                heads.append([float(col), float(dmin), float(reach), float(reward), float(term), float(trunc)])
+                rec.setdefault("infos", []).append(type(info).__name__)
+                rr, ss, gg = [], [], []
+                for _ in range(env.time_step_factor):        # social_nav_gym.py:240-245
+                    robot.step(action, env.time_step)
+                    mm.update_humans(env.global_time, env.time_step)
+                    env.global_time += env.time_step
+                    rr.append(robot.get_safe_state().copy()); ss.append(mm.states.copy()); gg.append(mm.goals.copy())
+                robots.append(rr); states.append(ss); goals.append(gg)
+            rec.update(robot0=robot0, states0=states0, goals0=goals0, actions=np.array(actions), heads=np.array(heads),
+                       robots=np.array(robots), states=np.array(states), goals=np.array(goals))
+            cases.append(rec)
+            env.parallel_traffic_humans_respawn = False
+    # RobotAgent.step called on its own (no crowd): 200 substeps of one action -- the yaw wraps through 2 pi (python's % keeps it in [0, 2 pi))
+    env, _ = make_env("sfm_helbing", "circle_crossing", 5, False, False, "unicycle")
+    env.reset(phase="test", test_case=3)
+    for v, r, yaw0 in ((0.8, 0.11, 1.5), (0.5, -0.07, -3.0), (1.0, 0.0, 0.3), (0.0, 0.2, 6.0)):
+        robot = env.robot
+        robot.position = np.array([0.3, -0.2]); robot.yaw = yaw0; robot.linear_velocity = np.zeros(2)
+        robot0 = robot.get_safe_state().copy()
+        rr = []
+        for _ in range(200):
+            robot.step(ns.action.ActionRot(v, r), 0.0125)
+            rr.append(robot.get_safe_state().copy())
+        cases.append(dict(model="none", robot_only=True, robot0=robot0, actions=np.array([[v, r]]), robots=np.array([rr]), dt=0.0125, n_substeps=200))
+    print("g17_unicycle:", len(cases), "cases ->", save_cases("g17_unicycle", cases))
+
+
 GROUPS = dict(g1_direct=gen_g1_direct, g1_episode=gen_g1_episode, g2_block=gen_g2_block, g3_gym=gen_g3_gym,
               g4_peek=gen_g4_peek, g5_reward=gen_g5_reward, g6_generators=gen_g6_generators,
               g7_respawn=gen_g7_respawn, g8_lookahead=gen_g8_lookahead, g9_laser=gen_g9_laser,
               g10_social_momentum=gen_g10_social_momentum, g11_imitation=gen_g11_imitation, g12_rk45=gen_g12_rk45, g14_rk45_more=gen_g14_rk45_more,
-              g13_block_sizes=gen_g13_block_sizes, g15_imitation_rk45=gen_g15_imitation_rk45, g16_policy=gen_g16_policy)
+              g13_block_sizes=gen_g13_block_sizes, g15_imitation_rk45=gen_g15_imitation_rk45, g16_policy=gen_g16_policy, g17_unicycle=gen_g17_unicycle)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -151,13 +151,27 @@ def moussaid_sign_ambiguous(Sw, P0, n, tol=2e-6):
     return amb
 
 
+def _unicycle(rb, A, dt):
+    """robot.step(ActionRot(v, r), dt) (robot_agent.py:119-136) on [w, 13] rows in float64"""
+    rb = np.array(rb, dtype=np.float64, copy=True)
+    v, r = A[:, 0], A[:, 1]
+    rb[:, 0] += np.cos(rb[:, 2] + r) * v * dt
+    rb[:, 1] += np.sin(rb[:, 2] + r) * v * dt
+    rb[:, 2] = np.mod(rb[:, 2] + r, 2 * np.pi)
+    rb[:, 3] = np.cos(rb[:, 2]) * v
+    rb[:, 4] = np.sin(rb[:, 2]) * v
+    return rb
+
+
 def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, nsub, peq, *, respawn=None, respawn_bounds=None,
-                             robot_row=False, robot=None, action=None, worlds=None, group=None, what="", bar=1e-5, omega_rtol=2e-4):
+                             robot_row=False, robot=None, action=None, worlds=None, group=None, what="", bar=1e-5, omega_rtol=2e-4, kinematics=0):
     """Run cw.step_trace(dt, nsub) (cs_step's kernel build, state updated in place) and check EVERY substep of the fused
     launch: record k + 1 against orc.step_block(1 substep, respawn rule included) from the GPU's record k (float32 rows
     read as float64).  S0 [W, rows, 13], goals0 [W, n, G, 2] = what the batch was created from; `worlds` = the worlds to
     check (default all).  `robot` [W, 13] + `action` [W, 2] (with robot_row): the visible robot of a Gym step, moved by its action
-    before every substep (social_nav_gym.py:240-243) and handed to the crowd as the last state row.
+    before every substep (social_nav_gym.py:240-243) and handed to the crowd as the last state row.  `kinematics` = 1: the action rows are
+    ActionRot (v, r) (the batch has cw.unicycle set; robot_agent.py:119-136) and the ROBOT's own records are checked too: record k against one
+    float64 unicycle step from record k - 1 (positions / velocities 2e-6, the yaw 1e-6: one float32 step with the hardware sin / cos).
     Returns a dict of figures; asserts the bar described above on every substep of every checked world."""
     from oracle import crowd_oracle as orc
 
@@ -181,8 +195,11 @@ def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, ns
         S[:, n] = R
         if action is not None:
             A = np.ascontiguousarray(np.broadcast_to(np.asarray(action, dtype=np.float32), (W, 2)))[sel].astype(np.float64)
-            S[:, n, 0:2] = (R[:, 0:2] + A * float(np.float32(dt))).astype(np.float32)
-            S[:, n, 3:5] = A
+            if kinematics == 0:
+                S[:, n, 0:2] = (R[:, 0:2] + A * float(np.float32(dt))).astype(np.float32)
+                S[:, n, 3:5] = A
+            else:
+                S[:, n] = _unicycle(R, A, float(np.float32(dt))).astype(np.float32)
     headed = type_ >= 3
     out = {"substeps": 0, "within": 0, "worst": 0.0, "worst_f32_oracle": 0.0, "ill_conditioned": 0, "goal_flips": 0, "lost_heading_rows": 0}
     for k in range(nsub):
@@ -244,6 +261,14 @@ def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, ns
         S[:, :n, 0:8] = got[..., 0:8]
         S[:, :n, 10:12] = got[..., 8:10]
         if robot_row and trace.shape[2] > n:
+            if kinematics == 1 and R is not None and action is not None:
+                # the robot's record k = the robot as substep k + 2 sees it (after its next move), the last one as it stands at the end
+                want = _unicycle(S[:, n], A, float(np.float32(dt))) if k + 1 < nsub else S[:, n]
+                rgot = trace[k][sel][:, n].astype(np.float64)
+                assert np.abs(rgot[:, [0, 1, 3, 4]] - want[:, [0, 1, 3, 4]]).max() < 2e-6, f"{what}: substep {k + 1}: the unicycle robot's record"
+                dyaw = np.abs(rgot[:, 2] - want[:, 2]); dyaw = np.minimum(dyaw, 2 * np.pi - dyaw)
+                assert dyaw.max() < 1e-6 and np.all((rgot[:, 2] >= 0) & (rgot[:, 2] < 2 * np.pi + 1e-6)), f"{what}: substep {k + 1}: the unicycle robot's yaw"
+                out["robot_records"] = out.get("robot_records", 0) + len(sel)
             S[:, n, 0:8] = trace[k][sel][:, n, 0:8]                       # the robot as the next substep sees it (GPU record)
         goals = gnext
         keep = ~np.isnan(goals[:, :, 0, 0])

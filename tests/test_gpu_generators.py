@@ -769,13 +769,16 @@ def test_one_launch_gym_step_defers_a_take_over_whose_episode_is_not_staged_yet(
     assert np.array_equal(env._dl["seeds"].cpu().numpy().astype(np.int64) - env._dl["base_seed"].cpu().numpy().astype(np.int64), ends * W)
 
 
-@pytest.mark.parametrize("n,model,robot_row,next_step", [(25, "hsfm_farina", False, False), (25, "hsfm_farina", True, True), (17, "sfm_guo", False, True),
-                                                         (10, "sfm_helbing", False, False), (50, "hsfm_new_guo", True, False), (7, "orca", False, False)])
-def test_gym_step_is_the_head_and_the_body_in_one_launch(n, model, robot_row, next_step):
+@pytest.mark.parametrize("n,model,robot_row,next_step,unicycle", [(25, "hsfm_farina", False, False, False), (25, "hsfm_farina", True, True, False), (17, "sfm_guo", False, True, False),
+                                                                  (10, "sfm_helbing", False, False, False), (50, "hsfm_new_guo", True, False, False), (7, "orca", False, False, False),
+                                                                  (25, "hsfm_farina", True, False, True), (25, "hsfm_farina", False, True, True), (10, "sfm_helbing", False, False, True),
+                                                                  (7, "orca", False, False, True)])
+def test_gym_step_is_the_head_and_the_body_in_one_launch(n, model, robot_row, next_step, unicycle):
     """cs_gym_step (the step kernel's prologue does the reward / termination of the incoming state and the episode bookkeeping, then the
     fused substeps, then the observation) == cs_collision_reward_gym ; cs_step_observe -- reward rows, typed results, counters, clocks,
     masks, seeds, state rows, goal lists, robot rows and observations, bit for bit, over several steps (so that robots collide, reach
-    goals and time out on the way); worlds the LDS kernel does not step (10-row worlds on the DPP-row kernel, ORCA) take the two launches."""
+    goals and time out on the way); worlds the LDS kernel does not step (10-row worlds on the DPP-row kernel, ORCA) take the two launches.
+    `unicycle`: the action rows are ActionRot (v, r) (CS_ROBOT_UNICYCLE, robot_agent.py:119-136): both heads turn them into the same velocity."""
     import ctypes as C
 
     from social_navigation_pyenvs_amd import _lib, scenarios as sc
@@ -799,6 +802,15 @@ def test_gym_step_is_the_head_and_the_body_in_one_launch(n, model, robot_row, ne
         mk = lambda: CrowdWorlds(St, g, P, None, None, type=model, all_params_equal=True, respawn_bounds=rb,
                                  respawn_worlds=(np.arange(W) % 2 == 1).astype(np.int32), robot_row=robot_row, robot=R)
     act = rng.uniform(-0.5, 0.5, (W, 2)).astype(np.float32)
+    if unicycle:
+        act = np.stack([rng.uniform(0.1, 0.9, W), rng.uniform(-0.1, 0.1, W)], -1).astype(np.float32)
+        R[:, 2] = rng.uniform(-np.pi, np.pi, W)
+        mk0 = mk
+
+        def mk():
+            c = mk0()
+            c.unicycle = True
+            return c
     clock = np.concatenate([[np.float32(0)], np.cumsum(np.full(240, 0.25, np.float32), dtype=np.float32)]).astype(np.float32)
     counter0 = rng.integers(0, 190, W).astype(np.int32); counter0[::9] = 197
     cfg = (C.c_float * 5)(50.0, 1.0, -0.25, 0.2, 0.5)
