@@ -17,7 +17,8 @@ namespace cstep {
 // code in `pending[w]`; the epilogue of the wavefront that stepped the world copies the slot over it instead of writing the stepped rows.
 //   pending[w]  between launches: 1 = the world's episode is over but its slot was not staged yet (the take-over is DEFERRED: the world
 //               is between episodes -- reward 0, no flags, as a NEXT_STEP world after its terminal step -- until a later launch finds
-//               the slot), 0 otherwise.  Inside a launch: 0 = keep stepping, 1 = deferred, 2 + slot = copy that slot.
+//               the slot), 0 otherwise.  Inside a launch: 0 = keep stepping, 1 = deferred, 2 + slot = copy that slot, -(2 + slot) = that slot's
+//               episode could not be generated (status != 0): nothing is copied, the stepped rows are written, the slot's turn is used up.
 // Ordering (no acquire / release pair, as in k_consume_staged): the tag is written LAST by the refill, behind a release of the slot's
 // words; it is read here with a device-scope relaxed load, the words ~30 us later with device-scope relaxed loads under a control
 // dependency on it (a slot whose tag is this world's next seed is not rewritten before the world's epoch moves); the epoch is stored
@@ -162,6 +163,10 @@ __device__ __forceinline__ int gym_fold_decide(const GymHead& g, int w, bool tak
         const long slot = (long)((pre.epoch + 1u) & (unsigned)(f.depth - 1)) * f.W + w;
         const unsigned tag = __hip_atomic_load(f.staged_seed + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         code = tag == want ? (int)slot + 2 : 1;
+        // a staged episode the generator could not build (its bounded rejection sampling gave up: status != 0, stored before the tag's release)
+        // is NOT taken over: the world keeps its stepped rows and a fresh observation -- what cs_gym_step + cs_consume_staged_worlds leave -- and
+        // only the slot's turn is consumed (epoch, failed).  Code -(slot + 2): the wavefront writes its rows as usual.
+        if (code >= 2 && __hip_atomic_load(f.staged_status + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) code = -code;
     }
     if (code != 0 || pre.pending != 0) __hip_atomic_store(f.pending + w, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return code;   // (the launch's own epilogue takes it from here, through LDS: no round trip to pending[w])

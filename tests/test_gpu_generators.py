@@ -684,12 +684,15 @@ def test_step_device_is_the_same_whatever_the_refill_cadence():
 
 
 @pytest.mark.parametrize("mode", [True, "next_step"])
-@pytest.mark.parametrize("W,n,steps", [(96, 6, 90), (4096, 25, 130)])
-def test_one_launch_gym_step_equals_the_two_launches(mode, W, n, steps):
+@pytest.mark.parametrize("W,n,steps,max_tries", [(96, 6, 90, None), (4096, 25, 130, None), (96, 6, 90, 1)])
+def test_one_launch_gym_step_equals_the_two_launches(mode, W, n, steps, max_tries):
     """cs_gym_step_staged (reward + bookkeeping, substeps, observation AND the take-over of the staged episodes in one launch) against
     cs_gym_step + cs_consume_staged_worlds, bit for bit: observations, rewards, flags, info codes of every step, the state rows, goal
     lists, robot rows, seeds, epochs and clocks at the end -- same-step and NEXT_STEP rules, a small batch of short episodes (the robots
-    run into the nearest human: worlds end again and again) and the benchmark's 4096 x 25 hybrid batch."""
+    run into the nearest human: worlds end again and again) and the benchmark's 4096 x 25 hybrid batch.
+    `max_tries`: the generator's bounded rejection sampling gives up on part of the staged episodes (status != 0): such a slot is NOT taken
+    over on either path -- the world keeps its stepped rows and a fresh observation, the slot's turn is used up, failed[w] = 1 (round 5's
+    one-launch step rewound such a world to its pre-step rows)."""
     torch = pytest.importorskip("torch")
     from social_navigation_pyenvs_amd.social_gym.social_nav_gym import BatchedSocialNavGym
 
@@ -698,6 +701,9 @@ def test_one_launch_gym_step_equals_the_two_launches(mode, W, n, steps):
     two.FOLD_RESET = False
     for e in (one, two):
         e.reset(phase="train", first_case=11, device=True)
+        if max_tries is not None:
+            e._gen_kw = dict(e._gen_kw, max_tries=max_tries)      # (before the device loop's generator is built, at the first step_device)
+    failed_seen = 0
     ended = np.zeros(W, int)
     gen = torch.Generator(device="cuda"); gen.manual_seed(5)
     for k in range(steps):
@@ -713,6 +719,10 @@ def test_one_launch_gym_step_equals_the_two_launches(mode, W, n, steps):
         for x, y in zip(o1, o2):
             assert torch.equal(x, y), k
         ended += (o1[2] | o1[3]).cpu().numpy().astype(int)
+        if max_tries is not None:
+            f1, f2 = one.reset_failed_mask(), two.reset_failed_mask()
+            assert torch.equal(f1, f2), k
+            failed_seen += int((f1 == 1).sum())
     assert one._dl[("pieces", 0, "next_step" if mode == "next_step" else "same_step")]["fold"] is not None
     assert (ended >= 1).sum() >= W // 8, ended.sum()
     np.testing.assert_array_equal(one.cw.get_states(), two.cw.get_states())
@@ -720,7 +730,12 @@ def test_one_launch_gym_step_equals_the_two_launches(mode, W, n, steps):
     np.testing.assert_array_equal(one.cw.get_robot(), two.cw.get_robot())
     for key in ("seeds", "epoch", "counter", "gtime", "failed"):
         assert torch.equal(one._dl[key], two._dl[key]), key
-    assert int(one._dl["pending"].sum()) == 0 and one.failed_resets() == 0
+    assert int(one._dl["pending"].sum()) == 0
+    if max_tries is None:
+        assert one.failed_resets() == 0
+    else:
+        fine = int(((one._dl["epoch"] > 0) & (one.reset_failed_mask() == 0)).sum())
+        assert failed_seen > 0 and fine > 0, (failed_seen, fine)   # some staged episodes could not be generated, others could
 
 
 def test_one_launch_gym_step_defers_a_take_over_whose_episode_is_not_staged_yet():
