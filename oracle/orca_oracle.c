@@ -499,24 +499,30 @@ void orc_orca_step_block_pa(float* S, float* goals, int G, int rows, int robot_v
             r[0] = robot[0]; r[1] = robot[1]; r[3] = robot[3]; r[4] = robot[4];
         }
         if (respawn) {
+            /* motion_model_manager.py:407-422, Python glue in float64: the flagged humans in index order, each behind everybody else -- the c-th
+             * lands at max(max_x + 2 max_r, bound) + c * 2 max_r (the (c-1)-th is the rightmost by then); RVO2's float32 sees the result once
+             * (:416 setAgentPosition).  The sum is formed in double and rounded once.
+             * h.radius + h.safety_space: set_safety_space() only resizes the RVO agents for ORCA (mmm.py:154-158), the humans' safety_space
+             * attribute stays 0 -> plain radii */
+            double mx = S[0], mr = S[8];
+            for (int j = 1; j < n; ++j) {
+                if (S[13 * j] > mx) mx = S[13 * j];
+                if (S[13 * j + 8] > mr) mr = S[13 * j + 8];
+            }
+            if (robot_visible && robot) {
+                if (robot[0] > mx) mx = robot[0];
+                if (robot[8] > mr) mr = robot[8];
+            }
+            int c = 0;
             for (int i = 0; i < n; ++i) {
                 float* r = S + 13 * i;
                 float* gi = goals + (size_t)i * G * 2;
                 const float ddx = r[0] - gi[0], ddy = r[1] - gi[1];
                 if (sqrtf(ddx * ddx + ddy * ddy) < 3.0f) {
-                    /* h.radius + h.safety_space: set_safety_space() only resizes the RVO agents for ORCA
-                       (mmm.py:154-158), the humans' safety_space attribute stays 0 -> plain radii */
-                    float mx = S[0], mr = S[8];
-                    for (int j = 1; j < n; ++j) {
-                        if (S[13 * j] > mx) mx = S[13 * j];
-                        if (S[13 * j + 8] > mr) mr = S[13 * j + 8];
-                    }
-                    if (robot_visible && robot) {
-                        if (robot[0] > mx) mx = robot[0];
-                        if (robot[8] > mr) mr = robot[8];
-                    }
-                    const float x = mx + mr * 2.0f;
-                    r[0] = x > bound_x ? x : bound_x;
+                    double x0 = mx + mr * 2.0;
+                    if (!(x0 > (double)bound_x)) x0 = (double)bound_x;
+                    r[0] = (float)(x0 + (double)c * (mr * 2.0));
+                    ++c;
                     if (r[1] >= 0) r[1] = r[1] < bound_y ? r[1] : bound_y; else r[1] = r[1] > -bound_y ? r[1] : -bound_y;
                     const float gx = gi[0], gy = r[1];
                     for (int g = 0; g < G; ++g) { gi[2 * g] = gx; gi[2 * g + 1] = gy; }

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "orca_sortnet.h"
 #include "robotstep.h"
+#include "respawnx.h"
 
 #pragma clang fp contract(off)
 
@@ -1115,14 +1116,16 @@ __global__ __launch_bounds__(MAXT) ORCA_WPE_ATTR void k_orca_step(const OArgs a)
                 if (valid && row == 0) {
                     float4* pvn = lds_pv + nxt * T + base;
                     const float* rp = lds_rp + base;
+                    // h.radius + h.safety_space with safety_space == 0 for ORCA humans (mmm.py:154-158); the maxima of the world as the first
+                    // respawned human finds it: the c-th lands c steps behind (respawnx.h: the reference's float64 sum, rounded once at :416)
+                    float mx = pvn[0].x, mr = rp[0];
+                    for (int j = 1; j < n; ++j) { mx = fmaxf(mx, pvn[j].x); mr = fmaxf(mr, rp[j]); }
+                    if (robot_row) { mx = fmaxf(mx, pvn[n].x); mr = fmaxf(mr, rp[n]); }
+                    int c = 0;
                     for (int i = 0; i < n; ++i) {
                         if (!lds_flag[base + i]) continue;
-                        // h.radius + h.safety_space with safety_space == 0 for ORCA humans (mmm.py:154-158)
-                        float mx = pvn[0].x, mr = rp[0];
-                        for (int j = 1; j < n; ++j) { mx = fmaxf(mx, pvn[j].x); mr = fmaxf(mr, rp[j]); }
-                        if (robot_row) { mx = fmaxf(mx, pvn[n].x); mr = fmaxf(mr, rp[n]); }
                         float4 q = pvn[i];
-                        q.x = fmaxf(mx + mr * 2.0f, a.bx);
+                        q.x = csimpl::respawn_x(mx, mr, a.bx, c++);
                         q.y = (q.y >= 0.0f) ? fminf(q.y, a.by) : fmaxf(q.y, -a.by);
                         pvn[i] = q;
                     }

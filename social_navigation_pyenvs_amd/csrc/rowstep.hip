@@ -279,8 +279,7 @@ __global__ __launch_bounds__(256, 2) void k_sfm_step_row16(const KArgs a)   // (
                 const float mr = row_max(human ? my_rs : 0.0f);
                 const unsigned rb = (unsigned)(fm >> (tid & 48)) & 0xFFFFu;
                 const int cnt_below = __builtin_popcount(rb & ((1u << r) - 1u));
-                float x = fmaxf(mx + mr * 2.0f, a.bx);
-                for (int t = 0; t < ROWS; ++t) x = (t < cnt_below) ? fmaxf(x + mr * 2.0f, a.bx) : x;
+                const float x = csimpl::respawn_x(mx, mr, a.bx, cnt_below);   // (respawnx.h: the reference's float64 sum, rounded once)
                 if (flag) {
                     px = x;
                     py = (py >= 0.0f) ? fminf(py, a.by) : fmaxf(py, -a.by);

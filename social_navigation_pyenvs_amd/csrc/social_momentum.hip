@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "robotstep.h"
+#include "respawnx.h"
 
 #pragma clang fp contract(off)
 
@@ -175,9 +176,7 @@ __global__ __launch_bounds__(64) void k_sm_step(const MArgs a)
                 float mx = pvn[0].x, mr = lds_rs[base];
                 for (int j = 1; j < n; ++j) { mx = fmaxf(mx, pvn[j].x); mr = fmaxf(mr, lds_rs[base + j]); }
                 if (robot_row) { mx = fmaxf(mx, lds_pv[cur][base + n].x); mr = fmaxf(mr, lds_rs[base + n]); }
-                float x = fmaxf(mx + mr * 2.0f, a.bx);
-                for (int t = 0; t < c; ++t) x = fmaxf(x + mr * 2.0f, a.bx);
-                px = x;
+                px = csimpl::respawn_x(mx, mr, a.bx, c);   // (respawnx.h: the reference's float64 sum, rounded once)
                 py = (py >= 0.0f) ? fminf(py, a.by) : fmaxf(py, -a.by);
                 lds_pv[nxt][tid] = make_float4(px, py, vx, vy);
                 g0y = py;

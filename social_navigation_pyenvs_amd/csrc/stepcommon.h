@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "gymhead.h"
+#include "respawnx.h"
 
 namespace cstep {
 
