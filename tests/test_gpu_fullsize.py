@@ -25,7 +25,11 @@ def _worlds(cfg):
         from social_navigation_pyenvs_amd import generators as gen
 
         W, n, model = 8192, 50, "hsfm_farina"  # (hsfm_new* blows up |omega| to 1e108 in the f64 reference itself here)
-        cw0 = gen.static_obstacle_crossing(W, n, model, first_world=0, radius=14.0, n_static=3, walls=True)
+        # "cfg5shard" = the worlds rank 0 owns; "cfg5shard@3" / "@7" = the worlds ranks 3 and 7 of the 8-GPU run own (global ids 24576.. and 57344..:
+        # worlds are functions of (seed, GLOBAL id), sharding.world_shard) -- no 8-GPU node has been available to any round, so the other ranks'
+        # worlds are stepped under the parity check here
+        first = 8192 * int(cfg.split("@")[1]) if "@" in cfg else 0
+        cw0 = gen.static_obstacle_crossing(W, n, model, first_world=first, radius=14.0, n_static=3, walls=True)
         S, goals, P, walls = cw0.get_states(), cw0.get_goals(), np.tile(sc.default_params(model), (n, 1)), sc.polygon_walls()
         rb, rw = None, None
     return W, n, model, S.astype(np.float32), goals.astype(np.float32), P.astype(np.float32), rb, rw, walls
@@ -35,6 +39,7 @@ def _worlds(cfg):
 # silently un-test a build
 VARIANT = {"cfg2": "k_sfm_step_row16<SOC=0,HEADED=0,ROWS=10>", "cfg3": "MAXT=64,OCC=1,ROWS_CT=25,LEAN=1",
            "cfg3x4": "MAXT=64,OCC=4,ROWS_CT=25,LEAN=1", "cfg5shard": "MAXT=64,OCC=3,ROWS_CT=50,LEAN=2"}
+VARIANT["cfg5shard@3"] = VARIANT["cfg5shard@7"] = VARIANT["cfg5shard"]
 
 
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg3x4", "cfg5shard"])
@@ -110,7 +115,7 @@ def test_full_size_properties(cfg):
         record(f"full size {cfg} 20 substeps from the evolved state (GPU vs f64 oracle)", err)
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg3x4", "cfg5shard"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg3x4", "cfg5shard", "cfg5shard@3", "cfg5shard@7"])
 def test_full_size_every_substep_of_the_fused_launch(cfg):
     """north_star's 1e-5 per SUBSTEP inside the fused 20-substep launch at BASELINE.json's full sizes, for the very kernel
     builds the published numbers come from: cs_step_trace records every row after every fused substep of ALL worlds; 48 sampled
@@ -134,6 +139,10 @@ def test_full_size_every_substep_of_the_fused_launch(cfg):
         res = fused_substeps_vs_oracle(cw, t, S_k, g_k, P, None, walls, 0.0125, 20, True, respawn=rw, respawn_bounds=rb, worlds=sample,
                                        group=f"full size {cfg} per substep inside the fused launch, {phase}", what=f"{cfg} {phase}")
         assert res["within"] >= res["substeps"] - res["ill_conditioned"], (cfg, phase, res)
+        if phase == "initial state" and "@" in cfg:
+            # another rank's shard really holds other worlds than rank 0's
+            W0, _, _, S0, _, _, _, _, _ = _worlds("cfg5shard")
+            assert not np.array_equal(S0[:64], S[:64])
         if phase == "initial state":
             # the traced launch is cs_step's launch: same rows as an untraced batch, bit for bit
             ref = make(S, goals)
