@@ -767,7 +767,45 @@ def gym_step_figures(W, n, steps=150):
             except Exception:
                 pass
         del env
+    try:    # the drop-in single-environment facade: what ONE SocialNavGym.step() costs at W = 1 (tools/facade_latency.py has the split)
+        out.update(facade_w1_latency(cfg, n))
+    except Exception as e:
+        out["facade_w1_error"] = f"{type(e).__name__}: {e}"[:120]
     return out
+
+
+def facade_w1_latency(cfg, n, steps=200):
+    """us per SocialNavGym.step(ActionXY) and per MotionModelManager.get_next_human_observable_states() (the SARL-style peek) of the W = 1 facade
+    -- host Python, the uploads / downloads of the host mirrors and the launches included (social_nav_gym.py:227-250; BASELINE.md: 227 ms per
+    reference Gym step at N = 25)."""
+    import types
+
+    from social_navigation_pyenvs_amd.crowd_nav.utils.action import ActionXY
+    from social_navigation_pyenvs_amd.social_gym.social_nav_gym import SocialNavGym
+    from social_navigation_pyenvs_amd.social_gym.src.robot_agent import RobotAgent
+
+    env = SocialNavGym()
+    env.configure(cfg)
+    robot = RobotAgent(env)
+    robot.visible, robot.desired_speed, robot.radius, robot.sensor = False, 1.0, 0.3, "coordinates"
+    robot.policy = types.SimpleNamespace(multiagent_training=True, with_theta_and_omega_visible=False, kinematics="holonomic", name="bench", query_env=True, time_step=None)
+    robot.kinematics = "holonomic"
+    env.set_robot(robot)
+    env.reset(phase="test", test_case=1)
+    rng = np.random.default_rng(n)
+    t_step = t_peek = 0.0
+    for k in range(steps + 20):
+        if k % 60 == 0:
+            env.reset(phase="test", test_case=1 + k // 60)
+        a = rng.uniform(-0.5, 0.5, 2)
+        t0 = time.perf_counter()
+        env.motion_model_manager.get_next_human_observable_states(env.robot_time_step)
+        t1 = time.perf_counter()
+        env.step(ActionXY(float(a[0]), float(a[1])))
+        t2 = time.perf_counter()
+        if k >= 20:
+            t_peek += t1 - t0; t_step += t2 - t1
+    return {"facade_w1_step": t_step / steps * 1e6, "facade_w1_peek": t_peek / steps * 1e6}
 
 
 def gym_step_child(W, n, timeout_s=240.0) -> dict:
