@@ -411,8 +411,7 @@ __global__ void k_bw_robot(const GArgs a, float* S)
             float c, sn;
             sincos_fast(rb[2] + ay, sn, c);
             rb[0] += c * ax * a.dt; rb[1] += sn * ax * a.dt;
-            float th = fmodf(rb[2] + ay, 6.283185307179586f);
-            if (th < 0) th += 6.283185307179586f;
+            const float th = mod_two_pi(rb[2] + ay);
             rb[2] = th;
             sincos_fast(th, sn, c);
             rb[3] = c * ax; rb[4] = sn * ax;

@@ -13,6 +13,9 @@ namespace csimpl {
 #define CS_RESPAWNX 1
 #endif
 
+// FAST0: a uniform early way out for c == 0 (the usual case: one human of a world respawns in a substep -- a single rounding as it is).  The DPP row
+// kernel instantiates the straight form: with the branch compiled in, its launch was 2 % slower whether anybody respawns or not (same-box A/B).
+template <bool FAST0 = true>
 __device__ __forceinline__ float respawn_x(float max_x, float max_r, float bound_x, int c)
 {
 #if CS_RESPAWNX == 0
@@ -22,9 +25,11 @@ __device__ __forceinline__ float respawn_x(float max_x, float max_r, float bound
     return (float)(x0 + (double)c * step);
 #else
     // the same sum in float32 pairs (hi + lo, error-free transformations: Knuth's TwoSum, an FMA for the product's error): the hot kernels carry
-    // no float64 code (the DPP row kernel lost 0.7 us per launch of 10.4 with the double form compiled in beside its substep loop, branch never taken)
+    // no float64 arithmetic (the DPP row kernel lost 0.7 us per launch of 10.4 with the double form compiled in beside its substep loop, in a branch
+    // cfg2 never takes: same-box A/B, tools/ab_vs_prev.sh; HISTORY.md)
 #pragma clang fp contract(off)
     const float step = 2.0f * max_r;                          // exact
+    if constexpr (FAST0) { if (c == 0) return fmaxf(max_x + step, bound_x); }
     float s = max_x + step;                                   // TwoSum(max_x, step) -> s + e
     float bb = s - max_x;
     float e = (max_x - (s - bb)) + (step - bb);

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void k_sfm_step_row16(const KArgs a)   // (
                 const float mr = row_max(human ? my_rs : 0.0f);
                 const unsigned rb = (unsigned)(fm >> (tid & 48)) & 0xFFFFu;
                 const int cnt_below = __builtin_popcount(rb & ((1u << r) - 1u));
-                const float x = csimpl::respawn_x(mx, mr, a.bx, cnt_below);   // (respawnx.h: the reference's float64 sum, rounded once)
+                const float x = csimpl::respawn_x<false>(mx, mr, a.bx, cnt_below);   // (respawnx.h: the reference's float64 sum, rounded once)
                 if (flag) {
                     px = x;
                     py = (py >= 0.0f) ? fminf(py, a.by) : fmaxf(py, -a.by);
@@ -316,8 +316,7 @@ __global__ __launch_bounds__(256, 2) void k_sfm_step_row16(const KArgs a)   // (
             if (a.flags & CS_ROBOT_UNICYCLE) {
                 const float c = cosf(qt + ay), s = sinf(qt + ay);
                 qx += c * ax * dt; qy += s * ax * dt;
-                qt = fmodf(qt + ay, 6.283185307179586f);
-                if (qt < 0) qt += 6.283185307179586f;
+                qt = mod_two_pi(qt + ay);
                 qvx = cosf(qt) * ax; qvy = sinf(qt) * ax;
             } else {
                 qx += ax * dt; qy += ay * dt; qvx = ax; qvy = ay;

@@ -124,6 +124,18 @@ __device__ __forceinline__ void sincos_fast(float x, float& s, float& c)
     c = __builtin_amdgcn_cosf(rev);
 }
 
+// python's x % (2 pi) of a float32 heading (robot_agent.py:131: yaw = (yaw + r) % (2 * np.pi), in [0, 2 pi)): x - floor(x / 2 pi) * 2 pi with a
+// two-term 2 pi (more exact than fmodf by fl32(2 pi), which is 1.7e-7 off 2 pi per wrap), a dozen instructions instead of ocml's fmodf loop.
+__device__ __forceinline__ float mod_two_pi(float x)
+{
+    const float k = floorf(x * 0.15915494309189535f);
+    float t = fmaf(-k, 6.2831855f, x);            // 6.2831855f = fl32(2 pi) = 2 pi + 1.7484555e-7
+    t = fmaf(k, 1.7484555e-7f, t);
+    if (t < 0.0f) t += 6.2831855f;
+    if (t >= 6.2831855f) t -= 6.2831855f;
+    return t;
+}
+
 // social_gym/src/utils.py:7-13 (Python % == fmod for the operand signs reaching each branch)
 __device__ __forceinline__ float bound_angle(float a)
 {
