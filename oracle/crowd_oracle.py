@@ -225,8 +225,74 @@ def process_obstacle(vertices) -> np.ndarray:
     return out
 
 
-def process_obstacles(polygons) -> np.ndarray:
-    """All polygons of a scene in one vertex table (next / prev become global indices)."""
+def split_obstacles(records) -> np.ndarray:
+    """KdTree::buildObstacleTreeRecursive of RVO2 v2.0.x, the part that changes the obstacle set: every edge straddling the line of a node's
+    splitting edge is cut at the intersection (new convex vertex with the cut edge's direction).  Written with an explicit work list (RVO2
+    recurses left then right: the list is a stack that pops the left child first, so new vertices get RVO2's indices).  float32.  UNPINNED."""
+    f = np.float32
+    eps = f(1e-5)
+    V = np.asarray(records, dtype=np.float32).reshape(-1, 8).copy()
+    px, py = list(V[:, 0]), list(V[:, 1])
+    ux, uy, cv = list(V[:, 2]), list(V[:, 3]), list(V[:, 4])
+    nxt, prv = [int(x) for x in V[:, 5]], [int(x) for x in V[:, 6]]
+
+    def side(i1, i2, j):          # leftOf(point[i1], point[i2], point[j]) = det(p1 - pj, p2 - p1)
+        return f(f(f(px[i1] - px[j]) * f(py[i2] - py[i1])) - f(f(py[i1] - py[j]) * f(px[i2] - px[i1])))
+
+    stack = [list(range(len(px)))]
+    while stack:
+        obst = stack.pop()
+        m = len(obst)
+        if m == 0:
+            continue
+        best_key, best = (m, m), 0
+        for i, i1 in enumerate(obst):
+            i2 = nxt[i1]
+            l = r = 0
+            for j, j1 in enumerate(obst):
+                if j == i:
+                    continue
+                a, b = side(i1, i2, j1), side(i1, i2, nxt[j1])
+                if a >= -eps and b >= -eps:
+                    l += 1
+                elif a <= eps and b <= eps:
+                    r += 1
+                else:
+                    l += 1; r += 1
+            key = (max(l, r), min(l, r))
+            if key < best_key:
+                best_key, best = key, i
+        i1 = obst[best]; i2 = nxt[i1]
+        L, R = [], []
+        for j, j1 in enumerate(obst):
+            if j == best:
+                continue
+            j2 = nxt[j1]
+            a, b = side(i1, i2, j1), side(i1, i2, j2)
+            if a >= -eps and b >= -eps:
+                L.append(j1)
+            elif a <= eps and b <= eps:
+                R.append(j1)
+            else:
+                ex, ey = f(px[i2] - px[i1]), f(py[i2] - py[i1])
+                num = f(f(ex * f(py[j1] - py[i1])) - f(ey * f(px[j1] - px[i1])))
+                den = f(f(ex * f(py[j1] - py[j2])) - f(ey * f(px[j1] - px[j2])))
+                t = f(num / den)
+                k = len(px)
+                px.append(f(px[j1] + f(t * f(px[j2] - px[j1])))); py.append(f(py[j1] + f(t * f(py[j2] - py[j1]))))
+                ux.append(ux[j1]); uy.append(uy[j1]); cv.append(f(1.0)); nxt.append(j2); prv.append(j1)
+                nxt[j1] = k; prv[j2] = k
+                (L if a > 0 else R).append(j1)
+                (R if a > 0 else L).append(k)
+        stack.append(R)           # popped second
+        stack.append(L)           # popped first: RVO2 builds the left subtree (and numbers its new vertices) before the right one
+    out = np.zeros((len(px), 8), np.float32)
+    out[:, 0], out[:, 1], out[:, 2], out[:, 3], out[:, 4], out[:, 5], out[:, 6] = px, py, ux, uy, cv, nxt, prv
+    return out
+
+
+def process_obstacles(polygons, kdtree_split=True) -> np.ndarray:
+    """All polygons of a scene in one vertex table (next / prev become global indices), then processObstacles()' edge splitting."""
     recs, base = [], 0
     for poly in polygons:
         r = process_obstacle(poly)
@@ -234,7 +300,8 @@ def process_obstacles(polygons) -> np.ndarray:
         r[:, 6] += base
         base += len(r)
         recs.append(r)
-    return np.concatenate(recs) if recs else np.zeros((0, 8), np.float32)
+    out = np.concatenate(recs) if recs else np.zeros((0, 8), np.float32)
+    return split_obstacles(out) if (kdtree_split and len(out)) else out
 
 
 def orca_new_velocities_obst(pos, vel, pref, radius, maxspeed, verts, neighbor_dist=10.0, max_nb=10, time_horizon=5.0,

@@ -24,10 +24,11 @@
  * order instead of a kd-tree (same set; only the order of exactly tied distances could differ, for
  * N <= 10 = MAX_LEAF_SIZE even that is identical).
  * Static obstacles (motion_model_manager.py:244-246 addObstacle / processObstacles): the obstacle
- * ORCA lines of Agent::computeNewVelocity and linearProgram3 with numObstLines are restated below; the obstacle
- * neighbours are found by brute force over the polygon edges (RVO2's obstacle kd-tree may SPLIT an edge into collinear
- * pieces -- the pieces give the same half-planes except where a piece boundary decides which end vertex defines the
- * velocity obstacle; that splitting is not modelled).  No Gym scenario has walls (social_nav_sim.py:296,355,428).
+ * ORCA lines of Agent::computeNewVelocity and linearProgram3 with numObstLines are restated below.  processObstacles() =
+ * KdTree::buildObstacleTree SPLITS every edge that straddles the line of a node's splitting edge into collinear pieces: that part is
+ * restated on the host (oracle/crowd_oracle.py split_obstacles; the package's own: rvo2.split_obstacles_kdtree), so the vertex records this
+ * file is given already hold the pieces; the obstacle neighbours are then found by brute force over them (the kd-tree is a search
+ * structure: same set; only the order of exactly tied distances could differ).  No Gym scenario has walls (social_nav_sim.py:296,355,428).
  */
 #include <math.h>
 #include <stddef.h>

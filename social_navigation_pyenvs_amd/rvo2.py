@@ -18,8 +18,8 @@ and per-agent ``neighborDist`` / ``maxNeighbors`` (<= 16) / ``timeHorizon`` / ``
 agent (motion_model_manager.py:14, :241), which keeps the register-resident ten-neighbour solve.  Static obstacles: ``addObstacle(vertices)`` (counter-clockwise
 polygons, or two vertices for a one-sided wall) + ``processObstacles()`` build RVO2's vertex records (point, unit direction
 to the next vertex, convexity, links); the kernel restates the obstacle ORCA lines and the hard-constraint form of
-linearProgram3.  The obstacle kd-tree's edge splitting is not modelled and each agent keeps its 16
-nearest edges.
+linearProgram3.  ``processObstacles()`` also performs the edge SPLITTING of RVO2's obstacle kd-tree
+(``split_obstacles_kdtree``: the pieces are what agents meet as obstacle neighbours); each agent keeps its 16 nearest edges.
 """
 from __future__ import annotations
 
@@ -51,8 +51,82 @@ def process_obstacle(vertices) -> np.ndarray:
     return out
 
 
-def process_obstacles(polygons) -> np.ndarray:
-    """All polygons of a scene in one vertex table (next / prev become table indices)."""
+def split_obstacles_kdtree(records: np.ndarray) -> np.ndarray:
+    """RVOSimulator::processObstacles = KdTree::buildObstacleTree (RVO2 v2.0.x KdTree.cpp buildObstacleTreeRecursive): while it builds the obstacle
+    kd-tree RVO2 SPLITS every edge that straddles the line of a node's splitting edge -- a new vertex at the intersection (convex, the direction
+    of the edge it cuts, linked between the edge's two ends) -- so the edges an agent later meets as obstacle neighbours are those PIECES.  The
+    pieces of an edge give the same ORCA half-planes as the edge except where a piece boundary decides which end vertex defines the velocity
+    obstacle.  Restated from the published algorithm in float32 like RVO2 (the library is absent: parity unpinned); the tree itself is
+    only a search structure -- the kernels find the pieces by brute force / the uniform grid, same neighbour set.
+    `records` [n, 8] as process_obstacle builds them with GLOBAL next / prev; returns [n + splits, 8]."""
+    f = np.float32
+    EPS = f(1e-5)
+    rec = [list(map(float, r)) for r in np.asarray(records, dtype=np.float32)]
+
+    def pt(i):
+        return f(rec[i][0]), f(rec[i][1])
+
+    def left_of(a, b, c):                       # det(a - c, b - a)
+        return f(f(f(a[0] - c[0]) * f(b[1] - a[1])) - f(f(a[1] - c[1]) * f(b[0] - a[0])))
+
+    def det(ax, ay, bx, by):
+        return f(f(ax * by) - f(ay * bx))
+
+    def build(obst):
+        if not obst:
+            return
+        n = len(obst)
+        best, split = (n, n), 0
+        for i in range(n):
+            i1 = obst[i]; i2 = int(rec[i1][5])
+            left = right = 0
+            for j in range(n):
+                if i == j:
+                    continue
+                j1 = obst[j]; j2 = int(rec[j1][5])
+                a = left_of(pt(i1), pt(i2), pt(j1)); b = left_of(pt(i1), pt(i2), pt(j2))
+                if a >= -EPS and b >= -EPS:
+                    left += 1
+                elif a <= EPS and b <= EPS:
+                    right += 1
+                else:
+                    left += 1; right += 1
+            cand = (max(left, right), min(left, right))
+            if cand < (max(best), min(best)):
+                best, split = (left, right), i
+        i1 = obst[split]; i2 = int(rec[i1][5])
+        lefts, rights = [], []
+        for j in range(n):
+            if j == split:
+                continue
+            j1 = obst[j]; j2 = int(rec[j1][5])
+            a = left_of(pt(i1), pt(i2), pt(j1)); b = left_of(pt(i1), pt(i2), pt(j2))
+            if a >= -EPS and b >= -EPS:
+                lefts.append(j1)
+            elif a <= EPS and b <= EPS:
+                rights.append(j1)
+            else:                                # the edge j1 -> j2 straddles the line of the splitting edge: cut it there
+                p1, p2, q1, q2 = pt(i1), pt(i2), pt(j1), pt(j2)
+                t = f(det(f(p2[0] - p1[0]), f(p2[1] - p1[1]), f(q1[0] - p1[0]), f(q1[1] - p1[1])) /
+                      det(f(p2[0] - p1[0]), f(p2[1] - p1[1]), f(q1[0] - q2[0]), f(q1[1] - q2[1])))
+                sx, sy = f(q1[0] + f(t * f(q2[0] - q1[0]))), f(q1[1] + f(t * f(q2[1] - q1[1])))
+                new = len(rec)
+                rec.append([float(sx), float(sy), rec[j1][2], rec[j1][3], 1.0, float(j2), float(j1), 0.0])
+                rec[j1][5] = float(new); rec[j2][6] = float(new)
+                if a > 0:
+                    lefts.append(j1); rights.append(new)
+                else:
+                    rights.append(j1); lefts.append(new)
+        build(lefts)
+        build(rights)
+
+    build(list(range(len(rec))))
+    return np.asarray(rec, dtype=np.float32).reshape(-1, 8)
+
+
+def process_obstacles(polygons, kdtree_split=True) -> np.ndarray:
+    """All polygons of a scene in one vertex table (next / prev become table indices), then RVO2's processObstacles(): the edge splitting of its
+    obstacle kd-tree (split_obstacles_kdtree; ``kdtree_split=False``: the polygons' own edges, what rounds 3-5 stepped)."""
     recs, base = [], 0
     for poly in polygons:
         r = process_obstacle(poly)
@@ -60,7 +134,8 @@ def process_obstacles(polygons) -> np.ndarray:
         r[:, 6] += base
         base += len(r)
         recs.append(r)
-    return np.concatenate(recs) if recs else np.zeros((0, 8), np.float32)
+    out = np.concatenate(recs) if recs else np.zeros((0, 8), np.float32)
+    return split_obstacles_kdtree(out) if (kdtree_split and len(out)) else out
 
 
 class PyRVOSimulator:

@@ -786,3 +786,46 @@ def test_rvo2_module_per_agent_parameters():
         np.testing.assert_array_equal(got_v, ref[0, :, 3:5])
         np.testing.assert_array_equal(got_p, ref[0, :, 0:2])
         p32, v32 = got_p, got_v
+
+
+def test_orca_obstacle_pieces_of_the_kdtree_split_bit_identical():
+    """processObstacles() cuts edges (RVO2's obstacle kd-tree, rvo2.split_obstacles_kdtree): a corridor scene whose long wall IS cut -- the
+    package's vertex table equals the oracle's restatement of the split, and crowds walking along the cut wall step bit-identically to the C
+    restatement on those records (one-block generic build and the grid path)."""
+    import os
+
+    from social_navigation_pyenvs_amd import rvo2
+    from social_navigation_pyenvs_amd.batched import CrowdWorlds
+
+    rect = lambda x0, y0, x1, y1: [[x0, y0], [x1, y0], [x1, y1], [x0, y1]]
+    polys = [rect(-6.0, -1.0, 6.0, 0.0), rect(-0.5, 1.6, 0.5, 7.0), rect(-9.0, -4.0, -7.0, 4.0), rect(7.0, -4.0, 9.0, 4.0)]
+    verts = rvo2.process_obstacles(polys)
+    np.testing.assert_array_equal(verts, orc.process_obstacles(polys))
+    assert len(verts) == 18 and len(rvo2.process_obstacles(polys, kdtree_split=False)) == 16
+    rng = np.random.default_rng(8)
+    W, n = 24, 9
+    S = np.zeros((W, n, 13), np.float32)
+    goals = np.full((W, n, 2, 2), np.nan, np.float32)
+    for w in range(W):
+        xs = np.linspace(-5.0, 5.0, n) + rng.uniform(-0.15, 0.15, n)
+        S[w, :, 0] = xs; S[w, :, 1] = rng.uniform(0.40, 1.1, n)          # in the corridor between the wall's top edge and the pillar
+        S[w, :, 3:5] = rng.normal(0, 0.3, (n, 2)); S[w, :, 8] = 0.3; S[w, :, 9] = 75; S[w, :, 12] = 1.0
+        goals[w, :, 0, 0] = -xs; goals[w, :, 0, 1] = -0.2                    # goals below the wall's top edge: everybody pushes against it
+        goals[w, :, 1] = S[w, :, 0:2]
+        d = goals[w, :, 0] - S[w, :, 0:2]
+        S[w, :, 5:7] = d / np.linalg.norm(d, axis=1, keepdims=True); S[w, :, 10:12] = goals[w, :, 0]
+    margin = np.full((W, n), 0.01, np.float32)
+    ref, rgoals, _ = orc.orca_step_block(S, goals, margin, 0.0125, 40, verts=verts)
+    for grid in (False, True):
+        if grid:
+            os.environ["CROWDSTEP_BIGWORLD_MIN_ROWS"] = "4"
+        try:
+            cw = CrowdWorlds(S, goals, None, margin, None, type="orca", orca_vertices=verts)
+            assert ("k_bw_orca_step" in cw.step_variant()) == grid, cw.step_variant()
+            cw.step(0.0125, 40)
+            got = cw.get_states()
+        finally:
+            os.environ.pop("CROWDSTEP_BIGWORLD_MIN_ROWS", None)
+        np.testing.assert_array_equal(got[..., [0, 1, 3, 4, 5, 6, 10, 11]], ref[..., [0, 1, 3, 4, 5, 6, 10, 11]])
+    assert np.abs(ref[..., 0:2] - S[..., 0:2]).max() > 0.2                      # they moved; nobody went through the wall
+    assert ref[..., 1].min() > 0.25
