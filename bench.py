@@ -69,7 +69,7 @@ SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 # v_min / v_max / v_max3 / v_cmp / v_cndmask (VOP3 or fed by a compare) / DPP / f64 min-max 4.1; v_exp / v_rcp / v_rsq / v_sqrt 8.2.
 # One wavefront ALONE on a SIMD issues no faster than one instruction per 4.4 - 5.6 cycles whatever the class.
 VALU_CLASS_CYCLES = {"fma": 2.2, "other": 4.1, "trans": 8.2}
-CPU_ROWS = ("cfg2", "cfg4_first20", "cfg4_dense", "cfg5_shard", "moussaid", "cfg3_new_guo", "robot26", "n30", "peragent")   # other_configs rows that get their own CPU figure (cfg5 = 8 x its shard)
+CPU_ROWS = ("cfg2", "cfg4_first20", "cfg4_dense", "cfg5_shard", "moussaid", "cfg3_new_guo", "robot26", "n30", "peragent", "n15", "n40")   # other_configs rows that get their own CPU figure (cfg5 = 8 x its shard)
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")
 
 
@@ -150,6 +150,9 @@ def other_config_specs(args) -> list[dict]:
         dict(base, name="cfg3_new_guo", model="hsfm_new_guo", title="4096 worlds/GPU x 25-agent hsfm_new_guo hybrid scenario (SURVEY.md §8d cfg3's second model)"),
         dict(base, name="robot26", robot=True, title="4096 worlds/GPU x 25-agent hsfm_farina hybrid scenario + a VISIBLE robot (26 rows per world), constant action"),
         dict(base, name="n30", agents=30, title="4096 worlds/GPU x 30-agent hsfm_farina hybrid scenario"),
+        # crowd sizes OFF the table of compile-time row counts (6, 10, 11, 20, 25, 26, 30, 50, 51): the run-time-row build
+        dict(base, name="n15", agents=15, title="4096 worlds/GPU x 15-agent hsfm_farina hybrid scenario (no shape-specialised build: run-time row count, 4 worlds per wavefront)"),
+        dict(base, name="n40", agents=40, title="4096 worlds/GPU x 40-agent hsfm_farina hybrid scenario (no shape-specialised build: run-time row count, 1 world per wavefront)"),
         dict(base, name="peragent", per_agent=True, title="4096 worlds/GPU x 25-agent hsfm_farina hybrid scenario, per-agent parameters (all_params_equal = False)"),
     ]
 

@@ -324,6 +324,16 @@ GymHead gym_head(float* d_out, const float* d_global_time, float T, const float*
 // wall build -- and a region added for one build on every launch costs the others a block without any test noticing; tests/test_gpu_parity.py
 // asserts the figures of the benched builds).
 // independent one-wavefront blocks per workgroup of the step kernels (sfmstep_kernel.h); CROWDSTEP_WG_WAVES = 1 / 2 / 4 for A/B, read once
+int step_wg_waves();
+// ... as launched for a block of `shmem` bytes of dynamic LDS: halved until the workgroup stays within the default 64 KB dynamic-LDS limit
+// (one helper for launch_step and cs_step_variant: the reported width is the launched one)
+int step_wg_waves_for(size_t shmem)
+{
+    int wg = step_wg_waves();
+    const size_t per_wave = (shmem + 15) & ~(size_t)15;
+    while (wg > 1 && per_wave * (size_t)wg > 64 * 1024) wg /= 2;
+    return wg;
+}
 int step_wg_waves()
 {
     static const int v = []{ const char* e = std::getenv("CROWDSTEP_WG_WAVES"); const int x = e ? std::atoi(e) : 4; return (x == 1 || x == 2 || x == 4) ? x : 4; }();
@@ -420,9 +430,8 @@ int launch_step(const cs_worlds* w, float dt, int nsub, int mode, float* d_out, 
     a.wg_waves = 1; a.lds_per_wave = 0;
     if (g.block == 64) {
         // one-wavefront builds: wg_waves independent wavefronts per workgroup (sfmstep_kernel.h)
-        a.wg_waves = step_wg_waves();
         a.lds_per_wave = (int)((shmem + 15) & ~(size_t)15);
-        while (a.wg_waves > 1 && (size_t)a.lds_per_wave * a.wg_waves > 64 * 1024) a.wg_waves /= 2;   // (stay within the default dynamic-LDS limit of a workgroup)
+        a.wg_waves = step_wg_waves_for(shmem);
         hipLaunchKernelGGL(fn, dim3((g.grid + a.wg_waves - 1) / a.wg_waves), dim3(64 * a.wg_waves), (size_t)a.lds_per_wave * a.wg_waves, stream, a);
         HIP_TRY(hipGetLastError());
         return CS_OK;
@@ -813,7 +822,8 @@ int cs_step_variant(const cs_worlds* w, int entry, char* buf, size_t buflen)
     }
     std::snprintf(buf, buflen, "k_sfm_step<SOC=%d,HEADED=%d,PEQ=%d,MAXT=%d,OCC=%d,ROWS_CT=%d,LEAN=%d> grid=%d block=%d wpb=%d lds=%d%s",
                   w->type % 3, w->type / 3, v.peq ? 1 : 0, v.maxt, v.occ, v.rows_ct, v.lean, g.grid, g.block, g.wpb,
-                  (int)step_lds_bytes(w, g, v.peq, nullptr, nullptr), g.block == 64 ? (step_wg_waves() == 4 ? " wg=4" : (step_wg_waves() == 2 ? " wg=2" : " wg=1")) : "");
+                  (int)step_lds_bytes(w, g, v.peq, nullptr, nullptr),
+                  g.block == 64 ? (step_wg_waves_for(step_lds_bytes(w, g, v.peq, nullptr, nullptr)) == 4 ? " wg=4" : (step_wg_waves_for(step_lds_bytes(w, g, v.peq, nullptr, nullptr)) == 2 ? " wg=2" : " wg=1")) : "");
     return CS_OK;
 }
 

@@ -138,7 +138,7 @@ def test_bench_argument_and_seed_plumbing_two_ranks():
     # (cfg5 -- the 65536-world job, strong split -- and cfg5_shard -- 8192 worlds per GPU, weak -- read the same PMC entry: the same kernel build
     #  on the same kind of worlds)
     assert r0["keys"] == ["sfm_helbing_10_circle", "orca_25_circle_first20", "orca_25_circle_dense", "orca_25_circle_first20_fma", "orca_25_circle_dense_fma", "hsfm_farina_50_circle_walls_static",
-                          "hsfm_farina_50_circle_walls_static", "hsfm_new_moussaid_25_hybrid", "hsfm_new_guo_25_hybrid", "hsfm_farina_25_hybrid_robot", "hsfm_farina_30_hybrid", "hsfm_farina_25_hybrid_peragent"]
+                          "hsfm_farina_50_circle_walls_static", "hsfm_new_moussaid_25_hybrid", "hsfm_new_guo_25_hybrid", "hsfm_farina_25_hybrid_robot", "hsfm_farina_30_hybrid", "hsfm_farina_15_hybrid", "hsfm_farina_40_hybrid", "hsfm_farina_25_hybrid_peragent"]
 
 
 class _HostOnlyEnv:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_summary.py DIR OUT.json -- per configuration of tools/profile_round2.sh: mean per dispatch of the rocprofv3 PMC
+"""tools/pmc_summary.py DIR OUT.json -- per configuration of tools/profile_round6.sh: mean per dispatch of the rocprofv3 PMC
 counters of the step kernel -> HBM-side bytes per agent and launch, VALU issue figures.  The result is committed as
 profiles/pmc_summary.json (bench.py reads it back and tags every figure with its source file)."""
 import csv
@@ -10,6 +10,8 @@ import sys
 
 SHAPES = {"cfg3": (4096, 25, "hsfm_farina_25_hybrid"), "cfg2": (4096, 10, "sfm_helbing_10_circle"), "cfg4": (4096, 25, "orca_25_circle"),
           "cfg4_first20": (4096, 25, "orca_25_circle_first20"), "cfg4_dense": (4096, 25, "orca_25_circle_dense"),
+          "cfg4_first20_fma": (4096, 25, "orca_25_circle_first20_fma"), "cfg4_dense_fma": (4096, 25, "orca_25_circle_dense_fma"),
+          "n15": (4096, 15, "hsfm_farina_15_hybrid"), "n40": (4096, 40, "hsfm_farina_40_hybrid"),
           "cfg5": (8192, 50, "hsfm_farina_50_circle_walls_static"), "cfg3x4": (16384, 25, "hsfm_farina_25_hybrid_16384"),
           "moussaid": (4096, 25, "hsfm_new_moussaid_25_hybrid"), "cfg3_new_guo": (4096, 25, "hsfm_new_guo_25_hybrid"),
           "robot26": (4096, 25, "hsfm_farina_25_hybrid_robot"), "n30": (4096, 30, "hsfm_farina_30_hybrid"),

@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage (GPU box): tools/profile_round4.sh TAG [config ...]
+# usage (GPU box): bash tools/profile_round6.sh TAG [config ...]      (supersedes profile_round{,2,3,4,5}.sh)
 # Per configuration: rocprofv3 kernel stats of bench.py (stationary protocol: every replay restored to the post-warm-up worlds) and
-# three PMC passes (FETCH_SIZE, WRITE_SIZE, SQ issue counters -- separate passes, never combined with a trace domain).
+# four PMC passes (FETCH_SIZE, WRITE_SIZE, SQ issue counters, SQ instruction classes -- separate passes, never combined with a trace domain).
 # tools/pmc_summary.py turns the counter CSVs into pmc_summary.json (stamped with the library build id), which bench.py reads back
 # from profiles/ (roofline.traffic / valu / valu_frac / pmc_build_matches).
 TAG=$1; shift
@@ -12,6 +12,10 @@ CFG[cfg3]=""
 CFG[cfg2]="--agents 10 --model sfm_helbing --scenario circle"
 CFG[cfg4_first20]="--model orca --scenario circle --warmup 0 --steps 20"
 CFG[cfg4_dense]="--model orca --scenario circle --warmup 25 --steps 20"
+CFG[cfg4_first20_fma]="--model orca --scenario circle --warmup 0 --steps 20 --orca-math fma"
+CFG[cfg4_dense_fma]="--model orca --scenario circle --warmup 25 --steps 20 --orca-math fma"
+CFG[n15]="--agents 15"
+CFG[n40]="--agents 40"
 CFG[cfg5]="--worlds 8192 --agents 50 --model hsfm_farina --scenario circle --walls --static 3 --device-generator"
 CFG[cfg3x4]="--worlds 16384"
 CFG[moussaid]="--model hsfm_new_moussaid"
@@ -20,7 +24,7 @@ CFG[robot26]="--robot"
 CFG[n30]="--agents 30"
 CFG[peragent]="--per-agent-params"
 CFG[cfg5_nowalls]="--worlds 8192 --agents 50 --model hsfm_farina --scenario circle --static 3 --device-generator"
-NAMES=${@:-cfg3 cfg2 cfg4_first20 cfg4_dense cfg5 cfg5_nowalls cfg3_new_guo robot26 n30 peragent}
+NAMES=${@:-cfg3 cfg2 cfg4_first20 cfg4_dense cfg4_first20_fma cfg4_dense_fma cfg5 moussaid cfg3_new_guo robot26 n30 peragent n15 n40}
 # the DRIVER's command (BENCH_rNN.json): python3 bench.py --gpus 1 --steps 20 --warmup 5 -- its line is the one quoted first in README / DESIGN
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_protocol_bench.json 2> $O/driver_protocol_bench.log || { echo "driver-protocol bench failed"; tail -5 $O/driver_protocol_bench.log; exit 1; }
 cp gpurun_out/bench_full.json $O/driver_protocol_bench_full.json
@@ -40,7 +44,8 @@ for name in $NAMES; do
   cp $(find $O/${name}_stats -name "*kernel_stats.csv" | head -1) $O/${name}_kernel_stats.csv && head -3 $O/${name}_kernel_stats.csv | cut -c1-160
   # (the counters are taken over the SAME window as the kernel time above: round 3 paired the instruction count of Gym steps 20-30 with
   #  the time of steps 20-70, which made cfg5's wall pass look stall-bound -- profiles/r4k_cfg5_wall_pass_counters_*.txt)
-  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+              "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64"; do
     p=$(echo $pass | cut -d' ' -f1)
     rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/${name}_pmc_$p -- python3 bench.py $A $S --repeats 1 > /dev/null 2> $O/${name}_pmc_$p.log || { echo "pmc $p failed"; tail -5 $O/${name}_pmc_$p.log; exit 1; }
     cp $(find $O/${name}_pmc_$p -name "*counter_collection.csv" | head -1) $O/${name}_pmc_$p.csv
@@ -48,13 +53,16 @@ for name in $NAMES; do
   done
   rm -rf $O/${name}_stats
 done
-# the SQ counters once more over the driver protocol's windows (instruction counts follow the crowd's state)
+# the SQ counters once more over the driver protocol's window of the HEADLINE (instruction counts follow the crowd's state; the other
+# configurations run over their own windows whatever --steps says)
 SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
-for pair in "cfg3_w5s20|--steps 20 --warmup 5" "cfg5_w20s20|${CFG[cfg5]} --steps 20 --warmup 20"; do
-  name=${pair%%|*}; A="${pair#*|} --no-cpu-baseline --no-other-configs"
-  rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/${name}_pmc_SQ_WAVES -- python3 bench.py $A --repeats 1 > /dev/null 2> $O/${name}_pmc_SQ_WAVES.log || { echo "pmc $name failed"; tail -5 $O/${name}_pmc_SQ_WAVES.log; exit 1; }
-  cp $(find $O/${name}_pmc_SQ_WAVES -name "*counter_collection.csv" | head -1) $O/${name}_pmc_SQ_WAVES.csv
-  rm -rf $O/${name}_pmc_SQ_WAVES
+MIX="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64"
+name=cfg3_w5s20; A="--steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"
+for pass in "$SQ" "$MIX"; do
+  p=$(echo $pass | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $O/${name}_pmc_$p -- python3 bench.py $A --repeats 1 > /dev/null 2> $O/${name}_pmc_$p.log || { echo "pmc $name failed"; tail -5 $O/${name}_pmc_$p.log; exit 1; }
+  cp $(find $O/${name}_pmc_$p -name "*counter_collection.csv" | head -1) $O/${name}_pmc_$p.csv
+  rm -rf $O/${name}_pmc_$p
 done
 python3 tools/pmc_summary.py $O $O/pmc_summary.json && python3 -c "
 import json; d=json.load(open('$O/pmc_summary.json'))
