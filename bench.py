@@ -64,7 +64,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3   # MI355X vector fp32 peak (MI355X_MICROARCH.md)
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 # What one SIMD needs per wave64 vector instruction when >= 2 wavefronts share it, MEASURED per instruction class on an MI355X
-# (tools/valu_issue_ceiling.hip, profiles/r5_valu_issue_ceiling.txt: independent streams in inline assembly at 1 / 2 / 4 / 8
+# (tools/valu_issue_ceiling.hip, profiles/archive/r5_valu_issue_ceiling.txt: independent streams in inline assembly at 1 / 2 / 4 / 8
 # wavefronts per SIMD, shader cycles by s_memtime; round 4 priced everything at 4): v_fma / v_mul / v_add / v_mov / v_and..xor 2.2;
 # v_min / v_max / v_max3 / v_cmp / v_cndmask (VOP3 or fed by a compare) / DPP / f64 min-max 4.1; v_exp / v_rcp / v_rsq / v_sqrt 8.2.
 # One wavefront ALONE on a SIMD issues no faster than one instruction per 4.4 - 5.6 cycles whatever the class.
@@ -547,7 +547,7 @@ def roofline_block(spec, W, kern_ms, copy_gbs, cw, window=None):
             out["valu_frac"] = insts * VALU_CLASS_CYCLES["other"] / simd_cycles
         out["valu_cycles_per_inst_achieved"] = simd_cycles / insts
         out["valu_frac_meaning"] = ("SIMD issue cycles the launch's vector instructions need (PMC instruction counts by class x the MEASURED cost of the class at >= 2 "
-                                    "wavefronts per SIMD: fma/mul/add 2.2, transcendental 8.2, everything else 4.1; profiles/r5_valu_issue_ceiling.txt) / (1024 SIMDs x kernel "
+                                    "wavefronts per SIMD: fma/mul/add 2.2, transcendental 8.2, everything else 4.1; profiles/archive/r5_valu_issue_ceiling.txt) / (1024 SIMDs x kernel "
                                     "time x 2.4 GHz).  valu_frac_floor prices every non-transcendental instruction at 2.2 (no SIMD can do better).  Without class "
                                     "counters: all at 4.1")
     return out

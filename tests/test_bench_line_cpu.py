@@ -16,7 +16,7 @@ import bench  # noqa: E402
 def canned_full(n_ranks=1):
     """A full result assembled from committed measurements: profiles/r3r_main_bench.json is the 22.6 KB line of round 3 -- the one
     the driver could not parse -- with the blocks this round added beside it."""
-    full = json.load(open(os.path.join(ROOT, "profiles", "r3r_main_bench.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "archive", "r3r_main_bench.json")))
     full["n_gpus"] = n_ranks
     full["dist"] = {"backend": "nccl" if n_ranks > 1 else None, "world_size": n_ranks, "launcher": "self", "rccl_version": "2.26.6"}
     full["ranks"] = [{"rank": r, "device": r, "pci": f"0000:{0x05 + 0x10 * r:02x}:00.0", "worlds": 4096, "kernel_us": 31.134706640243532 + r} for r in range(n_ranks)]

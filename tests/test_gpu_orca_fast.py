@@ -1,6 +1,6 @@
 """GPU: the ORCA kernel's OPT-IN arithmetics ("fma": v_rcp / v_sqrt / v_rsq, determinants as mul + fma; "fast": the first three only), per substep
 from re-synchronised state against the exact restatement, every agent-substep beyond north_star's 1e-5 accounted for
-(tests/orca_fast_parity.py; the full-size run is tools/orca_fast_parity.py -> profiles/r5c_orca_fast_parity.txt).
+(tests/orca_fast_parity.py; the full-size run is tools/orca_fast_parity.py -> profiles/archive/r5c_orca_fast_parity.txt).
 The bit-identity suite of the exact arithmetic is tests/test_gpu_orca.py.  ORCA's parity with rvo2 itself is UNPINNED (library absent)."""
 import numpy as np
 import pytest

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""usage (here, after a gpurun of tools/profile_round4.sh TAG): tools/collect_round4.py TAG
+"""usage (here, after the gpurun calls of tools/profile_round6.sh TAG have merged their files into gpurun_out/TAG): tools/pmc_summary.py gpurun_out/TAG gpurun_out/TAG/pmc_summary.json; tools/collect_profiles.py TAG
 Copies the judged summaries from gpurun_out/TAG (scratch) into profiles/ (tracked): kernel stats, the bench lines of the profiled
 commands, the PMC counter CSVs REDUCED to the step kernels' rows (dispatch, kernel, counter, value: 1 MB instead of 7), and
 pmc_summary.json (which bench.py reads back: roofline.traffic / valu / valu_frac / pmc_build_matches)."""
