@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# CROWDSTEP_LIB: another build of the library (same-box A/B of two kernel builds: tools/ab_lib.sh); never set in production
+# CROWDSTEP_LIB: another build of the library (same-box A/B of two kernel builds: tools/ab_libs.sh, tools/ab_vs_prev.sh); never set in production
 LIB_PATH = os.environ.get("CROWDSTEP_LIB") or os.path.join(_PKG, "libcrowdstep.so")
 
 CS_OK = 0
