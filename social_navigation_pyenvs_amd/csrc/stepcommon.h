@@ -186,6 +186,27 @@ __device__ __forceinline__ float atan2_fast(float y, float x)
     return copysignf(r, y);
 }
 
+// atan2(y, x) of a UNIT vector (x, y) -- Moussaid's theta_ij is the angle between two normalised vectors, (cross, dot) of them: the smaller of
+// |x|, |y| is then the sine of an angle in [0, pi / 4], and asin(s) = s P(s^2) on [0, 0.7072] (degree-6 minimax fit, 2e-7 rad) needs neither
+// the reciprocal nor the max of atan2_fast.  The norm of the argument is 1 to a few float32 ulps (v_rsq): 4e-7 rad at the octant's edge.
+__device__ __forceinline__ float atan2_unit(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float sn = fminf(ax, ay);
+    const float t = sn * sn;
+    float r = 0.1019788458943367f;
+    r = fmaf(r, t, -0.05660269409418106f);
+    r = fmaf(r, t, 0.06181516870856285f);
+    r = fmaf(r, t, 0.03858460113406181f);
+    r = fmaf(r, t, 0.07553976029157639f);
+    r = fmaf(r, t, 0.16664893925189972f);
+    r = fmaf(r, t, 1.0000001192092896f);
+    r *= sn;
+    if (ay > ax) r = 1.5707963267948966f - r;
+    if (x < 0.0f) r = 3.141592653589793f - r;
+    return copysignf(r, y);
+}
+
 // Social-force parameters used inside the pair loop (subset of the 20-vector, agent.py:268-388),
 // with the exponent scales pre-multiplied: exp(x / B) = exp2(x * (log2(e) / B))
 struct SocP {
@@ -239,45 +260,81 @@ __device__ __forceinline__ void pair_force_moussaid(const SocP& p, float pix, fl
     const float inorm = i2 * iinv;
     const float ix = ivx * iinv, iy = ivy * iinv;
     // theta_ij = wrap(angle(n) - angle(i) + pi) is the signed angle from i to -n (:124): one atan2 of (cross, dot)
-    const float th = atan2_fast(iy * nx - ix * ny, -(ix * nx + iy * ny));
+    const float th = atan2_unit(iy * nx - ix * ny, -(ix * nx + iy * ny));
     const float k = (th > 0.0f) ? 1.0f : ((th < 0.0f) ? -1.0f : 0.0f);
     const float hx = -iy, hy = ix;
     const float F = p.gam * inorm;
     const float dv = -(vdx * hx + vdy * hy);
-    const float e0 = p.Ei * exp2_fast(-dist * rcp_fast(F) * LOG2E);
+    const float w0 = -dist * rcp_fast(F) * LOG2E;                               // (two exponentials of summed exponents: see pair_force_moussaid_once)
     const float a1 = p.ns1 * F * th, a2 = p.ns * F * th;
-    const float e1 = exp2_fast(-(a1 * a1) * LOG2E), e2 = exp2_fast(-(a2 * a2) * LOG2E);
+    const float e1 = p.Ei * exp2_fast(fmaf(-(a1 * a1), LOG2E, w0)), e2 = p.Ei * exp2_fast(fmaf(-(a2 * a2), LOG2E, w0));
     const float sel = skip ? 0.0f : 1.0f;
     const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
-    fx -= sel * (e0 * (e1 * ix + k * e2 * hx) + kk * ix + kt * hx);
-    fy -= sel * (e0 * (e1 * iy + k * e2 * hy) + kk * iy + kt * hy);
+    fx -= sel * ((e1 + kk) * ix + (k * e2 + kt) * hx);
+    fy -= sel * ((e1 + kk) * iy + (k * e2 + kt) * hy);
 }
 
 // Same force, returned instead of accumulated (no own-row / padding slot): used by the pair-once loop, which
 // also hands -f to the partner (the reference's all_params_equal path does exactly that, :100-104).
+// CONTACT = false (round 6, the one-wavefront pair-once loop): without the k1 / k2 body-contact terms -- exact zeros unless the two bodies
+// overlap -- which a contact pass behind a wave vote adds for the rows that touch somebody (moussaid_contact_term below; the Helbing / Guo
+// loops have worked that way since round 1); rd_out = rij - dist, what the vote is taken on.
+template <bool CONTACT = true>
 __device__ __forceinline__ void pair_force_moussaid_once(const SocP& p, float dx, float dy, float vdx, float vdy,
-                                                         float rij, float& fx, float& fy)
+                                                         float rij, float& fx, float& fy, float* rd_out = nullptr)
 {
     const float d2 = fmaf(dx, dx, dy * dy);
     const float inv = rsq_fast(d2);
-    const float dist = dist_refined(d2, inv);
     const float nx = dx * inv, ny = dy * inv;
-    const float m0 = fmaxf(0.0f, rij - dist);
     const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);
     const float i2 = fmaxf(fmaf(ivx, ivx, ivy * ivy), 1e-30f);
     const float iinv = rsq_fast(i2);            // 1 / |w|: also 1 / F up to gamma (F = gamma |w|), no reciprocal of its own
     const float inorm = i2 * iinv;
     const float ix = ivx * iinv, iy = ivy * iinv;
-    const float th = atan2_fast(iy * nx - ix * ny, -(ix * nx + iy * ny));
+    const float th = atan2_unit(iy * nx - ix * ny, -(ix * nx + iy * ny));
+    const float hx = -iy, hy = ix;
+    // Ei e^{-dist / F} e^{-(ns1 F theta)^2} and Ei e^{-dist / F} e^{-(ns F theta)^2} as TWO exponentials of summed exponents (round 6: three, and
+    // two more products, until then; the sums differ from the products by a rounding of the exponent: < 1e-6 relative)
+    const float u = p.gam * inorm * th, u2 = u * u;                            // (F theta)^2 shared by the two Gaussians
+    if constexpr (CONTACT) {
+        const float dist = dist_refined(d2, inv);
+        const float m0 = fmaxf(0.0f, rij - dist);
+        const float dv = -(vdx * hx + vdy * hy);
+        const float w0 = -dist * iinv * p.cg;                                   // -dist / F in base-2 exponent units
+        const float e1 = p.Ei * exp2_fast(fmaf(u2, p.c1, w0)), e2 = p.Ei * exp2_fast(fmaf(u2, p.c2, w0));
+        const float e2s = (th == 0.0f) ? 0.0f : copysignf(e2, th);              // sign(theta) e2
+        const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
+        fx = -((e1 + kk) * ix + (e2s + kt) * hx);
+        fy = -((e1 + kk) * iy + (e2s + kt) * hy);
+        if (rd_out) *rd_out = rij - dist;
+    } else {
+        const float dist = d2 * inv;                                           // (the exponent does not need the refined root: 2.5 ulp of dist / F)
+        const float w0 = -dist * iinv * p.cg;
+        const float e1 = p.Ei * exp2_fast(fmaf(u2, p.c1, w0)), e2 = p.Ei * exp2_fast(fmaf(u2, p.c2, w0));
+        const float e2s = (th == 0.0f) ? 0.0f : copysignf(e2, th);
+        fx = -(e1 * ix + e2s * hx);
+        fy = -(e1 * iy + e2s * hy);
+        *rd_out = rij - dist;
+    }
+}
+
+// The body-contact part of the Moussaid force on (me) from a partner it may overlap (forces_parallel.py:130: k1 max(0, rd) i_ij + k2 max(0, rd) dv h_ij,
+// negated like the whole force): what pair_force_moussaid_once<false> leaves out.  (dx, dy) = p_me - p_j, (vdx, vdy) = v_me - v_j.
+__device__ __forceinline__ void moussaid_contact_term(const SocP& p, float dx, float dy, float vdx, float vdy, float rij, float& tx, float& ty)
+{
+    const float d2 = fmaf(dx, dx, dy * dy);
+    const float inv = rsq_fast(d2);
+    const float m0 = fmaxf(0.0f, rij - dist_refined(d2, inv));
+    const float nx = dx * inv, ny = dy * inv;
+    const float ivx = fmaf(p.lam, vdx, -nx), ivy = fmaf(p.lam, vdy, -ny);
+    const float i2 = fmaxf(fmaf(ivx, ivx, ivy * ivy), 1e-30f);
+    const float iinv = rsq_fast(i2);
+    const float ix = ivx * iinv, iy = ivy * iinv;
     const float hx = -iy, hy = ix;
     const float dv = -(vdx * hx + vdy * hy);
-    const float e0 = p.Ei * exp2_fast(-dist * iinv * p.cg);                   // Ei e^{-dist / F}
-    const float u = p.gam * inorm * th, u2 = u * u;                            // (F theta)^2 shared by the two Gaussians
-    const float e1 = exp2_fast(u2 * p.c1), e2 = exp2_fast(u2 * p.c2);           // e^{-(ns1 F theta)^2}, e^{-(ns F theta)^2}
-    const float e2s = (th == 0.0f) ? 0.0f : copysignf(e2, th);                  // sign(theta) e2
     const float kk = p.k1 * m0, kt = p.k2 * m0 * dv;
-    fx = -(e0 * (e1 * ix + e2s * hx) + kk * ix + kt * hx);
-    fy = -(e0 * (e1 * iy + e2s * hy) + kk * iy + kt * hy);
+    tx = -(kk * ix + kt * hx);
+    ty = -(kk * iy + kt * hy);
 }
 
 

@@ -104,10 +104,14 @@ def single_call_bar(ref32, ref64, omega_in, dt, headed, bar=1e-5):
     return max(bar, F32_SLACK * e32), e32
 
 
-def row_errors(got, ref, omega_in, dt, headed):
+def row_errors(got, ref, omega_in, dt, headed, theta_in=None):
     """Vectorised column rules of this module for rows [..., >= 8]: returns (err [...], omega_rel [...], lost [...] bool):
     err = worst of |d px|, |d py| (+ |d bvx|, |d bvy|, and theta / vx / vy minus what float32 holds of theta + omega_in dt when
-    headed); omega_rel = relative omega error; lost = rows whose heading float32 cannot hold at all."""
+    headed); omega_rel = relative omega error; lost = rows whose heading float32 cannot hold at all.
+    `theta_in` (headed models): the INCOMING headings.  The reference's bound_angle leaves every heading in [-pi, pi]; a float32 row whose
+    incoming heading lies outside lost it in an EARLIER substep (omega dt of 1e17 rad, hsfm_new* driven into contact: the reference's own
+    omega reaches 1e108 there) -- its rotation R(theta) is then only good to ulp(theta) ~ 5e-5 rad, and with it the body-frame
+    velocity: such a row is compared on its position only and counted as lost."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     with np.errstate(invalid="ignore", over="ignore"):
@@ -119,6 +123,9 @@ def row_errors(got, ref, omega_in, dt, headed):
         e = np.maximum(e, np.maximum(d[..., 5], d[..., 6]))
         swing = np.abs(np.asarray(omega_in, dtype=np.float64)) * abs(dt)
         lost = ~(swing <= 1e4)
+        gone = np.zeros(e.shape, bool) if theta_in is None else ~(np.abs(np.asarray(theta_in, dtype=np.float64)) <= np.pi * (1 + 1e-6))
+        e = np.where(gone, np.maximum(d[..., 0], d[..., 1]), e)
+        lost = lost | gone
         allow = 4.0 * EPS32 * np.where(lost, 0.0, swing)
         dth = np.minimum(d[..., 2], np.abs(d[..., 2] - 2.0 * np.pi))
         hv = np.maximum(np.maximum(d[..., 3], d[..., 4]), dth) - allow
@@ -220,8 +227,8 @@ def fused_substeps_vs_oracle(cw, type_, S0, goals0, P, safety, obstacles, dt, ns
             ref[m], ref32[m], gnext[m] = r64, r32, g64.reshape(-1, n, G, 2)
         got = trace[k][sel][:, :n].astype(np.float64)                    # [w, n, 12]
         om_in = S[:, :n, 7]
-        e_gpu, rel, lost = row_errors(got, ref[:, :n], om_in, dt, headed)
-        e_f32, _, _ = row_errors(ref32[:, :n], ref[:, :n], om_in, dt, headed)
+        e_gpu, rel, lost = row_errors(got, ref[:, :n], om_in, dt, headed, theta_in=S[:, :n, 2])
+        e_f32, _, _ = row_errors(ref32[:, :n], ref[:, :n], om_in, dt, headed, theta_in=S[:, :n, 2])
         if type_ % 3 == 2 and np.any(e_gpu >= bar):
             # Moussaid: a row that fails may sit on sign(theta_ij ~ 0) (also as the partner of such a pair: the reaction -f flips with it)
             for a_ in np.nonzero((e_gpu >= bar).any(axis=1))[0]:
