@@ -73,7 +73,7 @@ def test_full_size_properties(cfg):
     cw = make(np.arange(W))
     assert VARIANT[cfg] in cw.step_variant(), cw.step_variant()
     sample = rng.choice(W, 12, replace=False)
-    for nsub, tol in ((1, 1e-5), (20, 5e-5)):
+    for nsub, tol in ((1, 1e-5), (20, 1e-5)):      # (round 6: the 20-substep END state at 1e-5 too -- measured worst 3.6e-6; round 5 allowed 5e-5)
         cw = make(np.arange(W))
         cw.step(0.0125, nsub)
         out, gout = cw.get_states(), cw.get_goals()
@@ -111,7 +111,7 @@ def test_full_size_properties(cfg):
         ref20, _, _ = oracle_block(w, full, gfull, 20)
         err = np.max(np.abs(out20[w][:, [0, 1, 3, 4]] - ref20[:, [0, 1, 3, 4]]))
         respawned = rw is not None and bool(rw[w])
-        assert err < (3e-4 if respawned else 5e-5), (cfg, "evolved + 20", int(w), err)
+        assert err < 1e-5, (cfg, "evolved + 20", int(w), err, respawned)      # (round 6: 1e-5 for respawning worlds too -- measured worst 4.4e-6; round 5: 5e-5 / 3e-4)
         record(f"full size {cfg} 20 substeps from the evolved state (GPU vs f64 oracle)", err)
 
 
